@@ -1,0 +1,182 @@
+"""ctypes loader for the CPU oracle (oracle/libtaxor_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (taxor_amd) never does.  See oracle/taxor_oracle.h for scope and pinning status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtaxor_oracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("taxor_oracle.c", "taxor_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libtaxor_oracle.so"])
+    return _SO
+
+
+class _Ixf(C.Structure):
+    _fields_ = [("bins", C.c_uint64), ("stride", C.c_uint64), ("seg_len", C.c_uint64),
+                ("seed", C.c_uint64), ("data", C.c_void_p)]
+
+
+class _Hixf(C.Structure):
+    _fields_ = [("n_ixf", C.c_size_t), ("ixf", C.POINTER(_Ixf)),
+                ("next_ixf", C.POINTER(C.c_void_p)), ("fname_idx", C.POINTER(C.c_void_p))]
+
+
+class _Params(C.Structure):
+    _fields_ = [("k", C.c_int), ("s", C.c_int), ("t", C.c_int),
+                ("error_rate", C.c_double), ("percentage", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_wyhash_u64.restype = C.c_uint64
+        L.orc_wyhash_u64.argtypes = [C.c_uint64]
+        L.orc_dna4_normalise.restype = C.c_int
+        L.orc_dna4_normalise.argtypes = [C.c_void_p, C.c_size_t]
+        L.orc_seq_to_syncmers.restype = C.c_size_t
+        L.orc_seq_to_syncmers.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_syncmer_match_ratio.restype = C.c_double
+        L.orc_syncmer_match_ratio.argtypes = [C.c_size_t, C.c_double]
+        L.orc_threshold.restype = C.c_size_t
+        L.orc_threshold.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+        L.orc_ixf_seg_len.restype = C.c_uint64
+        L.orc_ixf_seg_len.argtypes = [C.c_uint64]
+        L.orc_ixf_probe.restype = None
+        L.orc_ixf_probe.argtypes = [C.POINTER(_Ixf), C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_ixf_bulk_count.restype = None
+        L.orc_ixf_bulk_count.argtypes = [C.POINTER(_Ixf), C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_bulk_contains.restype = C.c_size_t
+        L.orc_bulk_contains.argtypes = [C.POINTER(_Hixf), C.c_void_p, C.c_size_t, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_search_batch.restype = C.c_int
+        L.orc_search_batch.argtypes = [C.POINTER(_Hixf), C.POINTER(_Params), C.c_void_p, C.c_void_p,
+                                       C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_classify_filter.restype = None
+        L.orc_classify_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def wyhash(x):
+    return int(lib().orc_wyhash_u64(C.c_uint64(int(x) & (2**64 - 1))))
+
+
+def dna4_normalise(seq: bytes) -> bytes:
+    buf = np.frombuffer(seq, dtype=np.uint8).copy()
+    if lib().orc_dna4_normalise(_p(buf), buf.size) != 0:
+        raise ValueError("character outside the dna15 alphabet")
+    return buf.tobytes()
+
+
+def seq_to_syncmers(seq: bytes, k=22, s=12, t=5) -> np.ndarray:
+    cap = max(len(seq), 1)
+    out = np.empty(cap, dtype=np.uint64)
+    n = lib().orc_seq_to_syncmers(seq, len(seq), k, s, t, _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
+
+
+def syncmer_match_ratio(k, err):
+    return float(lib().orc_syncmer_match_ratio(k, err))
+
+
+def threshold(hash_count, k=22, err=0.04, percentage=-1.0):
+    return int(lib().orc_threshold(hash_count, k, err, percentage))
+
+
+def ixf_seg_len(max_bin_elements):
+    return int(lib().orc_ixf_seg_len(max_bin_elements))
+
+
+class Hixf:
+    """Host view of a HIXF for the oracle.
+
+    ixfs: list of dicts {bins, stride, seg_len, seed, data(np.uint8 1-D, rows*stride)}
+    next_ixf / fname_idx: list of np.int64 arrays (one per IXF, length bins)
+    """
+
+    def __init__(self, ixfs, next_ixf, fname_idx):
+        self.n = len(ixfs)
+        self._keep = []
+        arr = (_Ixf * self.n)()
+        for i, f in enumerate(ixfs):
+            d = np.ascontiguousarray(f["data"], dtype=np.uint8)
+            assert d.size == 3 * f["seg_len"] * f["stride"], "IXF data size mismatch"
+            self._keep.append(d)
+            arr[i] = _Ixf(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data)
+        self._ixf = arr
+        self._nx = [np.ascontiguousarray(a, dtype=np.int64) for a in next_ixf]
+        self._fn = [np.ascontiguousarray(a, dtype=np.int64) for a in fname_idx]
+        self._nxp = (C.c_void_p * self.n)(*[a.ctypes.data for a in self._nx])
+        self._fnp = (C.c_void_p * self.n)(*[a.ctypes.data for a in self._fn])
+        self.c = _Hixf(self.n, arr, self._nxp, self._fnp)
+        self.total_leaves = int(sum((a >= 0).sum() for a in self._fn))
+
+    def ixf_probe(self, i, key):
+        rows = np.zeros(3, dtype=np.uint64)
+        fp = np.zeros(1, dtype=np.uint8)
+        lib().orc_ixf_probe(C.byref(self._ixf[i]), C.c_uint64(int(key)), _p(rows), _p(fp))
+        return rows, int(fp[0])
+
+    def ixf_bulk_count(self, i, hashes):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.zeros(int(self._ixf[i].bins), dtype=np.uint32)
+        lib().orc_ixf_bulk_count(C.byref(self._ixf[i]), _p(h), h.size, _p(out))
+        return out
+
+    def bulk_contains(self, hashes, thr):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        cap = self.total_leaves + 1
+        ub = np.empty(cap, dtype=np.int64)
+        cnt = np.empty(cap, dtype=np.uint32)
+        vb = np.zeros(1, dtype=np.uint64)
+        n = lib().orc_bulk_contains(C.byref(self.c), _p(h), h.size, int(thr), _p(ub), _p(cnt), cap, _p(vb))
+        assert n <= cap
+        return ub[:n].copy(), cnt[:n].copy(), int(vb[0])
+
+    def search_batch(self, bases: np.ndarray, offsets: np.ndarray, k=22, s=12, t=5, err=0.04,
+                     percentage=-1.0, threads=1):
+        """bases: np.uint8 ASCII (already dna4-normalised), offsets: uint64[n+1].
+        Returns (n_hashes u32[n], out_off u64[n+1], user_bin i64[], count u32[], visited_bytes)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        prm = _Params(k, s, t, err, percentage)
+        nh = np.zeros(n, dtype=np.uint32)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        cap = max(4 * n, 1024)
+        vb = np.zeros(1, dtype=np.uint64)
+        while True:
+            ub = np.empty(cap, dtype=np.int64)
+            cnt = np.empty(cap, dtype=np.uint32)
+            rc = lib().orc_search_batch(C.byref(self.c), C.byref(prm), _p(bases), _p(offsets), n, threads,
+                                        _p(nh), _p(off), _p(ub), _p(cnt), cap, _p(vb))
+            if rc == 0:
+                tot = int(off[n])
+                return nh, off, ub[:tot].copy(), cnt[:tot].copy(), int(vb[0])
+            cap = int(off[n]) + 16
+
+
+def classify_filter(counts):
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    keep = np.zeros(c.size, dtype=np.uint8)
+    lib().orc_classify_filter(_p(c), c.size, _p(keep))
+    return keep.astype(bool)

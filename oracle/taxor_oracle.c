@@ -1,0 +1,434 @@
+/*
+ * taxor_oracle.c -- CPU ORACLE (test infrastructure, see taxor_oracle.h for scope and pinning status).
+ * Plain C restatement of the reference `taxor search` hot path; citations are file:line into
+ * /root/reference (JensUweUlrich/Taxor @ 2025-05-23).
+ */
+#include "taxor_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* =============================================================================================== */
+/* hashing                                                                                         */
+/* =============================================================================================== */
+
+/* martinus/unordered_dense v3.0.1, detail::wyhash: mum() = 128-bit product split into lo/hi,
+ * mix(a,b) = lo ^ hi, hash(uint64_t x) = mix(x, 0x9E3779B97F4A7C15).  [un-vendored; published algorithm] */
+uint64_t orc_wyhash_u64(uint64_t x)
+{
+    __uint128_t r = (__uint128_t)x * (__uint128_t)UINT64_C(0x9E3779B97F4A7C15);
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+
+int orc_dna4_normalise(char *seq, size_t len)
+{
+    /* rank_to_char of dna4 is "ACGT"; char_to_rank sends IUPAC codes to their first base, U to T and
+     * every other legal character (N) to rank 0 = 'A'.  [RECALL seqan3 alphabet/nucleotide/dna4.hpp] */
+    static char map[256];
+    static int init = 0;
+    if (!init) {
+        memset(map, 0, sizeof map);
+        const char *from = "ACGTURYSWKMBDHVN";
+        const char *to   = "ACGTTACCAGACAAAA";
+        for (int i = 0; from[i]; ++i) {
+            map[(unsigned char)from[i]] = to[i];
+            map[(unsigned char)(from[i] + 32)] = to[i];
+        }
+        init = 1;
+    }
+    for (size_t i = 0; i < len; ++i) {
+        char m = map[(unsigned char)seq[i]];
+        if (!m) return -1;
+        seq[i] = m;
+    }
+    return 0;
+}
+
+/* syncmer.cpp:53-70 -- A/a 0, C/c 1, G/g 2, T/t/U/u 3, bytes 0..3 map to themselves, else 4 */
+static unsigned char nt4(unsigned char c)
+{
+    switch (c) {
+    case 0: case 'A': case 'a': return 0;
+    case 1: case 'C': case 'c': return 1;
+    case 2: case 'G': case 'g': return 2;
+    case 3: case 'T': case 't': case 'U': case 'u': return 3;
+    default: return 4;
+    }
+}
+
+/* insertion-ordered set of uint64 (ankerl::unordered_dense::set<size_t> keeps a dense vector in
+ * insertion order; taxor_search.cpp:236 copies it out front to back) */
+typedef struct {
+    uint64_t *dense;
+    size_t n, dense_cap;
+    uint32_t *slots; /* index+1 into dense, 0 = empty */
+    size_t mask;
+} oset;
+
+static void oset_init(oset *s)
+{
+    s->dense_cap = 256;
+    s->dense = (uint64_t *)malloc(s->dense_cap * sizeof(uint64_t));
+    s->n = 0;
+    s->mask = 1023;
+    s->slots = (uint32_t *)calloc(s->mask + 1, sizeof(uint32_t));
+}
+
+static void oset_free(oset *s)
+{
+    free(s->dense);
+    free(s->slots);
+}
+
+static size_t oset_slot(uint64_t v, size_t mask)
+{
+    v ^= v >> 29;
+    v *= UINT64_C(0xBF58476D1CE4E5B9);
+    v ^= v >> 32;
+    return (size_t)v & mask;
+}
+
+static void oset_insert(oset *s, uint64_t v)
+{
+    size_t p = oset_slot(v, s->mask);
+    while (s->slots[p]) {
+        if (s->dense[s->slots[p] - 1] == v) return;
+        p = (p + 1) & s->mask;
+    }
+    if (s->n == s->dense_cap) {
+        s->dense_cap *= 2;
+        s->dense = (uint64_t *)realloc(s->dense, s->dense_cap * sizeof(uint64_t));
+    }
+    s->dense[s->n++] = v;
+    s->slots[p] = (uint32_t)s->n;
+    if (s->n * 2 > s->mask) { /* grow + rehash */
+        size_t nm = (s->mask + 1) * 4 - 1;
+        uint32_t *ns = (uint32_t *)calloc(nm + 1, sizeof(uint32_t));
+        for (size_t i = 0; i < s->n; ++i) {
+            size_t q = oset_slot(s->dense[i], nm);
+            while (ns[q]) q = (q + 1) & nm;
+            ns[q] = (uint32_t)(i + 1);
+        }
+        free(s->slots);
+        s->slots = ns;
+        s->mask = nm;
+    }
+}
+
+/* make_string_to_hashvalues_open_syncmers_canonical, syncmer.cpp:80-155.
+ * Positions are size_t in the reference and wrap (qs_min_pos = -1, i - k with i < k); uint64_t
+ * arithmetic reproduces that exactly. */
+static void syncmers_into(const char *seq, size_t len, uint64_t k, uint64_t s, uint64_t t, oset *set)
+{
+    const uint64_t kmask = (k < 32) ? ((UINT64_C(1) << (2 * k)) - 1) : UINT64_MAX;   /* :86 */
+    const uint64_t smask = (UINT64_C(1) << (2 * s)) - 1;                               /* :87 */
+    const uint64_t kshift = (k - 1) * 2, sshift = (s - 1) * 2;                        /* :88-89 */
+    const uint64_t w = k - s + 1;
+    uint64_t *qs = (uint64_t *)malloc((w + 2) * sizeof(uint64_t)); /* std::deque, :90 */
+    size_t q_head = 0, q_size = 0;
+    const size_t q_cap = (size_t)w + 2;
+    uint64_t qs_min_val = UINT64_MAX;                                                  /* :91 */
+    uint64_t qs_min_pos = (uint64_t)-1;                                                /* :92 */
+    uint64_t l = 0, xk[2] = {0, 0}, xs[2] = {0, 0};                                    /* :94-96 */
+
+    for (uint64_t i = 0; i < len; ++i) {
+        unsigned c = nt4((unsigned char)seq[i]);                                       /* :99 */
+        if (c < 4) {
+            xk[0] = (xk[0] << 2 | c) & kmask;                                          /* :101 */
+            xk[1] = xk[1] >> 2 | (uint64_t)(3 - c) << kshift;                          /* :102 */
+            xs[0] = (xs[0] << 2 | c) & smask;                                          /* :103 */
+            xs[1] = xs[1] >> 2 | (uint64_t)(3 - c) << sshift;                          /* :104 */
+            if (++l < s) continue;                                                     /* :105 */
+            uint64_t ys = xs[0] < xs[1] ? xs[0] : xs[1];                               /* :109 */
+            qs[(q_head + q_size) % q_cap] = ys;                                        /* :111 */
+            ++q_size;
+            if (q_size < w) continue;                                                  /* :113 */
+            if (q_size == w) {                                                         /* :116 */
+                for (uint64_t j = 0; j < q_size; ++j) {
+                    uint64_t v = qs[(q_head + j) % q_cap];
+                    if (v < qs_min_val) {                                              /* :118 */
+                        qs_min_val = v;
+                        qs_min_pos = i - k + j + 1;
+                    }
+                }
+            } else {
+                q_head = (q_head + 1) % q_cap;                                         /* :126 */
+                --q_size;
+                if (qs_min_pos == i - k) {                                             /* :128 */
+                    qs_min_val = UINT64_MAX;
+                    qs_min_pos = i - s + 1;
+                    for (int64_t j = (int64_t)q_size - 1; j >= 0; --j) {               /* :131 */
+                        uint64_t v = qs[(q_head + (size_t)j) % q_cap];
+                        if (v < qs_min_val) {
+                            qs_min_val = v;
+                            qs_min_pos = i - k + (uint64_t)j + 1;
+                        }
+                    }
+                } else if (ys < qs_min_val) {                                          /* :137 */
+                    qs_min_val = ys;
+                    qs_min_pos = i - s + 1;
+                }
+            }
+            if (qs_min_pos == i - k + t) {                                             /* :142 */
+                uint64_t yk = xk[0] < xk[1] ? xk[0] : xk[1];
+                oset_insert(set, orc_wyhash_u64(yk));                                  /* :145 */
+            }
+        } else {                                                                       /* :147-153 */
+            qs_min_val = UINT64_MAX;
+            qs_min_pos = (uint64_t)-1;
+            l = xs[0] = xs[1] = xk[0] = xk[1] = 0;
+            q_head = q_size = 0;
+        }
+    }
+    free(qs);
+}
+
+size_t orc_seq_to_syncmers(const char *seq, size_t len, int k, int s, int t, uint64_t *out, size_t cap)
+{
+    oset set;
+    oset_init(&set);
+    syncmers_into(seq, len, (uint64_t)k, (uint64_t)s, (uint64_t)t, &set);
+    size_t n = set.n;
+    memcpy(out, set.dense, (n < cap ? n : cap) * sizeof(uint64_t));
+    oset_free(&set);
+    return n;
+}
+
+/* =============================================================================================== */
+/* thresholds                                                                                      */
+/* =============================================================================================== */
+
+/* syncmer_model.hpp:14-36 -- rows: read accuracy 80..100 %, columns: k = 12,14,...,30 (data table) */
+static const double matching_ratios[21][10] = {
+    {0.552077, 0.195989, 0.151428, 0.118475, 0.0946177, 0.0797244, 0.0604658, 0.0480255, 0.0367569, 0.0252911},
+    {0.552385, 0.207533, 0.161204, 0.127368, 0.103704, 0.0881939, 0.0689396, 0.0556991, 0.044185, 0.0298818},
+    {0.552239, 0.220393, 0.17382, 0.139866, 0.113736, 0.0966358, 0.0783558, 0.0639223, 0.0523452, 0.0389549},
+    {0.552682, 0.236329, 0.188152, 0.152267, 0.126191, 0.106106, 0.0876917, 0.0730642, 0.0621864, 0.0489249},
+    {0.553172, 0.254091, 0.202686, 0.165344, 0.137087, 0.116649, 0.098822, 0.0831266, 0.0703342, 0.0582562},
+    {0.553716, 0.271183, 0.219848, 0.181959, 0.152163, 0.130048, 0.110622, 0.0942414, 0.0810792, 0.0688187},
+    {0.554532, 0.292154, 0.240059, 0.199738, 0.168952, 0.144956, 0.122726, 0.105878, 0.0940805, 0.0777557},
+    {0.557957, 0.313553, 0.260912, 0.220014, 0.186567, 0.16101, 0.137399, 0.119867, 0.10453, 0.0900014},
+    {0.563925, 0.338316, 0.283689, 0.2401, 0.206963, 0.179541, 0.155347, 0.135128, 0.121575, 0.104741},
+    {0.568519, 0.364594, 0.310373, 0.267578, 0.231083, 0.20088, 0.174376, 0.153111, 0.139339, 0.120042},
+    {0.579726, 0.395595, 0.338947, 0.295287, 0.258713, 0.22876, 0.200759, 0.175309, 0.161306, 0.139616},
+    {0.599258, 0.430241, 0.371291, 0.325596, 0.289651, 0.257329, 0.228011, 0.201799, 0.186956, 0.164794},
+    {0.611572, 0.468953, 0.410482, 0.363923, 0.325828, 0.293046, 0.26167, 0.235216, 0.216716, 0.192162},
+    {0.624341, 0.510411, 0.452122, 0.407016, 0.370022, 0.334601, 0.303413, 0.275232, 0.254563, 0.227871},
+    {0.655724, 0.555245, 0.498564, 0.453201, 0.416285, 0.381883, 0.352291, 0.322556, 0.299739, 0.271481},
+    {0.694872, 0.608367, 0.552085, 0.509395, 0.471692, 0.437803, 0.405938, 0.377117, 0.354352, 0.325132},
+    {0.742071, 0.669034, 0.613738, 0.57366, 0.539215, 0.50832, 0.476855, 0.449152, 0.42683, 0.397277},
+    {0.795543, 0.733694, 0.68341, 0.647737, 0.617382, 0.588448, 0.56083, 0.533714, 0.514757, 0.486399},
+    {0.853121, 0.802585, 0.763169, 0.733734, 0.708902, 0.684331, 0.660171, 0.637633, 0.621567, 0.596993},
+    {0.918163, 0.882314, 0.854479, 0.835831, 0.819643, 0.804269, 0.788526, 0.771895, 0.763059, 0.742114},
+    {1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0}};
+
+double orc_syncmer_match_ratio(size_t kmer_size, double error_rate)
+{
+    /* asserts at syncmer_model.hpp:40-44 are compiled out in the reference's Release build; fence them */
+    if (kmer_size % 2 != 0 || kmer_size < 12 || kmer_size > 30) return -1.0;
+    if (!(error_rate >= 0.0) || !(error_rate <= 0.2)) return -1.0;
+    size_t row_index = (size_t)ceil((1.0 - error_rate) * 100.0 - 80.0);               /* :47 */
+    size_t col_index = kmer_size - 10 - ((kmer_size - 10) / 2) - 1;                    /* :48 */
+    if (row_index > 20 || col_index > 9) return -1.0;
+    return matching_ratios[row_index][col_index];                                      /* :49 */
+}
+
+size_t orc_threshold(size_t hash_count, size_t kmer_size, double error_rate, double percentage)
+{
+    if (percentage > 0.0 && percentage <= 1.0)                                         /* threshold.hpp:27 */
+        return (size_t)((double)hash_count * percentage);                              /* :76-79 */
+    double ratio = orc_syncmer_match_ratio(kmer_size, error_rate);                     /* :59 */
+    return (size_t)((double)hash_count * ratio);                                       /* :60 */
+}
+
+/* =============================================================================================== */
+/* interleaved XOR filter  [un-vendored; restated from xorfilter.hpp + hashutil.hpp evidence]      */
+/* =============================================================================================== */
+
+static uint64_t murmur64(uint64_t h) /* hashutil.hpp:50-57 */
+{
+    h ^= h >> 33;
+    h *= UINT64_C(0xff51afd7ed558ccd);
+    h ^= h >> 33;
+    h *= UINT64_C(0xc4ceb9fe1a85ec53);
+    h ^= h >> 33;
+    return h;
+}
+
+static uint64_t rotl64(uint64_t n, unsigned c) /* xorfilter.hpp:22-28 */
+{
+    c &= 63;
+    return (n << c) | (n >> ((-c) & 63));
+}
+
+static uint32_t reduce32(uint32_t hash, uint32_t n) /* xorfilter.hpp:36-39 */
+{
+    return (uint32_t)(((uint64_t)hash * n) >> 32);
+}
+
+uint64_t orc_ixf_seg_len(uint64_t max_bin_elements)
+{
+    size_t array_len = (size_t)(32 + 1.23 * (double)max_bin_elements);                 /* xorfilter.hpp:67 */
+    return array_len / 3;                                                              /* :68 */
+}
+
+void orc_ixf_probe(const orc_ixf *f, uint64_t key, uint64_t rows[3], uint8_t *fp)
+{
+    uint64_t hash = murmur64(key + f->seed);                                           /* hashutil.hpp:59-61 */
+    *fp = (uint8_t)(hash ^ (hash >> 32));                                              /* xorfilter.hpp:60-62 */
+    for (int i = 0; i < 3; ++i) {                                                      /* :42-45,340-347 */
+        uint32_t r = (uint32_t)rotl64(hash, (unsigned)(21 * i));
+        rows[i] = (uint64_t)reduce32(r, (uint32_t)f->seg_len) + (uint64_t)i * f->seg_len;
+    }
+}
+
+void orc_ixf_bulk_count(const orc_ixf *f, const uint64_t *hashes, size_t n, uint32_t *counts)
+{
+    memset(counts, 0, f->bins * sizeof(uint32_t));
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t rows[3];
+        uint8_t fp;
+        orc_ixf_probe(f, hashes[i], rows, &fp);
+        const uint8_t *r0 = f->data + rows[0] * f->stride;
+        const uint8_t *r1 = f->data + rows[1] * f->stride;
+        const uint8_t *r2 = f->data + rows[2] * f->stride;
+        for (uint64_t j = 0; j < f->bins; ++j)
+            counts[j] += (uint32_t)(fp == (uint8_t)(r0[j] ^ r1[j] ^ r2[j]));           /* xorfilter.hpp:348-349 */
+    }
+}
+
+/* =============================================================================================== */
+/* hierarchical IXF traversal -- hierarchical_interleaved_xor_filter.hpp:303-340                   */
+/* =============================================================================================== */
+
+typedef struct {
+    int64_t *ub;
+    uint32_t *cnt;
+    size_t n, cap;
+    uint64_t bytes;
+} resbuf;
+
+static void bulk_contains_impl(const orc_hixf *h, const uint64_t *hashes, size_t n, int64_t ixf_idx,
+                               size_t threshold, resbuf *rb)
+{
+    const orc_ixf *f = &h->ixf[ixf_idx];
+    uint32_t *result = (uint32_t *)malloc((f->bins ? f->bins : 1) * sizeof(uint32_t)); /* :307 */
+    orc_ixf_bulk_count(f, hashes, n, result);                                          /* :309 */
+    rb->bytes += (uint64_t)n * 3u * f->bins;
+    uint32_t sum = 0;                                                                  /* :310 */
+    const int64_t *fname = h->fname_idx[ixf_idx];
+    for (size_t bin = 0; bin < f->bins; ++bin) {                                       /* :313 */
+        sum += result[bin];                                                            /* :315 */
+        int64_t cur = fname[bin];                                                      /* :317 */
+        if (cur < 0) {                                                                 /* :319 merged bin */
+            if ((size_t)sum >= threshold)                                              /* :321 */
+                bulk_contains_impl(h, hashes, n, h->next_ixf[ixf_idx][bin], threshold, rb);
+            sum = 0u;
+        } else if (bin + 1u == f->bins || cur != fname[bin + 1]) {                     /* :325-326 */
+            if ((size_t)sum >= threshold) {                                            /* :328 */
+                if (rb->n < rb->cap) {
+                    rb->ub[rb->n] = cur;                                               /* :330 */
+                    rb->cnt[rb->n] = sum;
+                }
+                rb->n++;
+            }
+            sum = 0u;
+        }
+    }
+    free(result);
+}
+
+size_t orc_bulk_contains(const orc_hixf *h, const uint64_t *hashes, size_t n, size_t threshold,
+                         int64_t *user_bin, uint32_t *count, size_t cap, uint64_t *visited_bytes)
+{
+    resbuf rb = {user_bin, count, 0, cap, 0};
+    bulk_contains_impl(h, hashes, n, 0, threshold, &rb);                               /* :391 */
+    if (visited_bytes) *visited_bytes = rb.bytes;
+    return rb.n;
+}
+
+/* =============================================================================================== */
+/* per-read driver -- taxor_search.cpp:196-313                                                     */
+/* =============================================================================================== */
+
+size_t orc_search_read(const orc_hixf *h, const orc_search_params *p, const char *seq, size_t len,
+                       uint32_t *n_hashes, int64_t *user_bin, uint32_t *count, size_t cap,
+                       uint64_t *visited_bytes)
+{
+    oset set;
+    oset_init(&set);
+    syncmers_into(seq, len, (uint64_t)p->k, (uint64_t)p->s, (uint64_t)p->t, &set);     /* :222 */
+    size_t hash_count = set.n;                                                         /* :261 */
+    size_t thr = orc_threshold(hash_count, (size_t)p->k, p->error_rate, p->percentage); /* :263 */
+    size_t n = orc_bulk_contains(h, set.dense, hash_count, thr, user_bin, count, cap, visited_bytes); /* :265 */
+    if (n_hashes) *n_hashes = (uint32_t)hash_count;
+    oset_free(&set);
+    return n;
+}
+
+int orc_search_batch(const orc_hixf *h, const orc_search_params *p, const char *bases,
+                     const uint64_t *offsets, uint64_t n_reads, int threads, uint32_t *n_hashes,
+                     uint64_t *out_off, int64_t *user_bin, uint32_t *count, uint64_t cap,
+                     uint64_t *visited_bytes)
+{
+    /* do_parallel.hpp:17-36 hands each of `threads` tasks one contiguous slice [start,end) of the
+     * chunk; each task here fills a private growing buffer (the reference's per-thread result_string),
+     * and the buffers are concatenated in task order, which is input order. */
+    if (threads < 1) threads = 1;
+    typedef struct { int64_t *ub; uint32_t *cnt; uint64_t n, cap, vbytes; } tbuf;
+    tbuf *tb = (tbuf *)calloc((size_t)threads, sizeof(tbuf));
+    uint64_t *sizes = (uint64_t *)calloc(n_reads + 1, sizeof(uint64_t));
+    const uint64_t per = (n_reads + (uint64_t)threads - 1) / (uint64_t)threads;
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int tsk = 0; tsk < threads; ++tsk) {
+        tbuf *b = &tb[tsk];
+        b->cap = 1024;
+        b->ub = (int64_t *)malloc(b->cap * sizeof(int64_t));
+        b->cnt = (uint32_t *)malloc(b->cap * sizeof(uint32_t));
+        uint64_t lo = per * (uint64_t)tsk, hi = lo + per > n_reads ? n_reads : lo + per;
+        for (uint64_t r = lo; r < hi; ++r) {
+            const char *seq = bases + offsets[r];
+            size_t len = (size_t)(offsets[r + 1] - offsets[r]);
+            uint32_t nh = 0;
+            uint64_t vb = 0;
+            for (;;) {
+                size_t n = orc_search_read(h, p, seq, len, &nh, b->ub + b->n, b->cnt + b->n,
+                                           (size_t)(b->cap - b->n), &vb);
+                if (b->n + n <= b->cap) { sizes[r] = n; b->n += n; break; }
+                while (b->n + n > b->cap) b->cap *= 2;      /* rare: re-run this read with room */
+                b->ub = (int64_t *)realloc(b->ub, b->cap * sizeof(int64_t));
+                b->cnt = (uint32_t *)realloc(b->cnt, b->cap * sizeof(uint32_t));
+            }
+            n_hashes[r] = nh;
+            b->vbytes += vb;
+        }
+    }
+    out_off[0] = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) out_off[r + 1] = out_off[r] + sizes[r];
+    int rc = out_off[n_reads] > cap ? -1 : 0;
+    uint64_t pos = 0, vsum = 0;
+    for (int tsk = 0; tsk < threads; ++tsk) {
+        if (rc == 0 && tb[tsk].n) {
+            memcpy(user_bin + pos, tb[tsk].ub, tb[tsk].n * sizeof(int64_t));
+            memcpy(count + pos, tb[tsk].cnt, tb[tsk].n * sizeof(uint32_t));
+        }
+        pos += tb[tsk].n;
+        vsum += tb[tsk].vbytes;
+        free(tb[tsk].ub);
+        free(tb[tsk].cnt);
+    }
+    if (visited_bytes) *visited_bytes = vsum;
+    free(tb);
+    free(sizes);
+    return rc;
+}
+
+void orc_classify_filter(const uint32_t *count, size_t n, uint8_t *keep)
+{
+    uint64_t max_count = 0;                                                            /* :275-280 */
+    for (size_t i = 0; i < n; ++i)
+        if (count[i] > max_count) max_count = count[i];
+    for (size_t i = 0; i < n; ++i)                                                     /* :285 */
+        keep[i] = !((double)count[i] < (double)max_count * 0.8);
+}
