@@ -1,0 +1,202 @@
+/*
+ * taxor_gpu.h -- C ABI of the MI355X-native `taxor search` hot path (libtaxor_gpu.so).
+ *
+ * The reference (JensUweUlrich/Taxor @ 2025-05-23) has no FFI; its seam for this path is the chunk loop
+ * of search_single():  hixf::do_parallel(worker, records.size(), threads, compute_time)
+ * (src/main/taxor_search.cpp:315-326, worker = :196-313).  A batch of (id, seq) records goes in, per-read
+ * (user_bin, count) tuples come out.  This header replaces exactly that seam; every entry point cites
+ * the reference interface it stands in for.  Plain pointers and sizes only, no C++/torch types, no
+ * exceptions: every function returns 0 on success or a negative taxor_status, and
+ * taxor_gpu_last_error() returns the message (the reference prints "[TAXOR SEARCH ERROR] ..." and
+ * returns -1, taxor_search.cpp:380-384).
+ *
+ * Threading: an index is immutable after creation and may be shared; a searcher is single-caller, like
+ * the reference's membership_agent (hierarchical_interleaved_xor_filter.hpp:371-379).  Result pointers
+ * returned by a searcher stay valid until the next call on that searcher (same convention as
+ * bulk_contains' reference return, :381-406).
+ */
+#ifndef TAXOR_GPU_H
+#define TAXOR_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TAXOR_OK = 0,
+    TAXOR_E_ARG = -1,       /* bad argument / unsupported parameter                          */
+    TAXOR_E_HIP = -2,       /* HIP runtime failure                                           */
+    TAXOR_E_ALPHABET = -3,  /* read character outside the dna15 alphabet                     */
+    TAXOR_E_INTERNAL = -4,  /* internal capacity invariant violated (never silent)           */
+    TAXOR_E_IO = -5,        /* file could not be read/written or is inconsistent             */
+    TAXOR_E_NOMEM = -6
+} taxor_status;
+
+const char *taxor_gpu_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index hand-off.  Replaces: taxor_index<hixf_t> loaded by cereal (src/main/load_index.hpp:27-38) and
+ * held by pointer in the agents (hierarchical_interleaved_xor_filter.hpp:300).
+ * The view is what a loader parsed from a .hixf: per IXF the interleaved fingerprint array plus the two
+ * bookkeeping vectors next_ixf_id[i] (:115-122) and ixf_bin_to_filename_position[i] (:172-178).
+ * The library copies everything into HBM; the caller keeps ownership of the host arrays.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t bins;            /* bin count == counting_vector size                                  */
+    uint64_t stride;          /* bytes per fingerprint row, multiple of 64, >= bins                 */
+    uint64_t seg_len;         /* rows per hash segment; the array has 3*seg_len rows                */
+    uint64_t seed;            /* per-IXF seed (src/hixf/build/construct_ixf.cpp:100-108 redraws it) */
+    const uint8_t *data;      /* host, 3*seg_len*stride bytes, data[row*stride+bin]; NULL = leave
+                                 the device rows uninitialised (use ..._fill_random / _upload_bin)  */
+    const int64_t *next_ixf;  /* [bins]                                                             */
+    const int64_t *fname_idx; /* [bins], -1 = merged bin                                            */
+} taxor_ixf_view;
+
+typedef struct {
+    uint64_t n_ixf;
+    const taxor_ixf_view *ixf;
+    uint64_t n_user_bins;
+    uint8_t kmer_size, syncmer_size, t_syncmer; /* src/main/index.hpp:219-221 */
+    uint8_t use_syncmer;                        /* :223; must be 1 (k-mer/minimiser mode is out of scope) */
+    uint16_t scaling;                           /* :224; must be 1 (FracMinHash down-scaling out of scope) */
+} taxor_hixf_view;
+
+typedef struct taxor_gpu_index taxor_gpu_index;
+
+int taxor_gpu_index_create(const taxor_hixf_view *view, int device, taxor_gpu_index **out);
+void taxor_gpu_index_destroy(taxor_gpu_index *idx);
+/* bytes of fingerprint data resident in HBM */
+uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx);
+/* number of leaf runs (= tuples a threshold-0 read produces) and IXF tree depth */
+uint64_t taxor_gpu_index_leaf_runs(const taxor_gpu_index *idx);
+uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx);
+/* Index construction helpers for synthetic / planted indexes (what a GPU builder would use):
+ * fill one IXF with seeded pseudo-random fingerprints (behaves like non-matching bins, FPR 2^-8),
+ * overwrite one bin column (rows = 3*seg_len bytes), read an IXF back (to hand the same bytes to a
+ * checker). */
+int taxor_gpu_index_fill_random(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed);
+int taxor_gpu_index_upload_bin(taxor_gpu_index *idx, uint64_t ixf, uint64_t bin, const uint8_t *column,
+                               uint64_t rows);
+int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8_t *data, uint64_t len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Searcher = one GPU-side "membership agent" + the per-read driver state.
+ * Replaces: the worker lambda's locals (taxor_search.cpp:198-203) and hixf::threshold::threshold
+ * (src/hixf/search/threshold.hpp:22-81): `ratio` is what threshold::get multiplies the hash count by --
+ * get_min_syncmer_match_ratio(k, error_rate) or --percentage; use taxor_threshold_ratio() to derive it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    double ratio;             /* threshold = (size_t)(n_hashes * ratio), threshold.hpp:60,76-79 */
+    uint32_t sub_batch_reads; /* reads per internal launch group (0 = default 32768)           */
+    uint64_t sub_batch_bases; /* bases per internal launch group (0 = default 2^29)            */
+    uint32_t time_kernels;    /* 1 = bracket the dominant kernel with HIP events               */
+} taxor_gpu_search_params;
+
+typedef struct taxor_gpu_searcher taxor_gpu_searcher;
+
+int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_search_params *prm,
+                              taxor_gpu_searcher **out);
+void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s);
+
+/* Per-read results, CSR: tuples of read r are [read_off[r], read_off[r+1]) in DFS order of the HIXF
+ * traversal (hierarchical_interleaved_xor_filter.hpp:313-338), BEFORE the 0.8*max filter of
+ * taxor_search.cpp:275-286 (apply taxor_classify_filter or the host formatter).  n_hashes[r] is
+ * QHASH_COUNT (taxor_search.cpp:261,298). */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_tuples;
+    const uint64_t *read_off; /* [n_reads+1] */
+    const int64_t *user_bin;  /* [n_tuples]  */
+    const uint32_t *count;    /* [n_tuples]  */
+    const uint32_t *n_hashes; /* [n_reads]   */
+} taxor_gpu_results;
+
+/* The drop-in batch call (host buffers in, host results out).  Replaces
+ * hixf::do_parallel(worker, n, threads, compute_time) for one chunk of records:
+ * bases = concatenated read sequences as read from FASTA/FASTQ (any dna15 character; the dna4 mapping of
+ * src/hixf/build/dna4_traits.hpp:15-18 is applied on the device), offsets[n_reads+1] into bases. */
+int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets,
+                           uint64_t n_reads, taxor_gpu_results *out);
+
+/* The same call split into its three phases so that a caller can keep a batch resident in HBM
+ * (upload once, run many times) and overlap transfers with compute:
+ *   upload : H2D of the ASCII bases + on-device dna4 mapping and 2-bit packing
+ *   run    : all kernels (syncmers -> dedup -> threshold -> level-synchronous HIXF query -> DFS order),
+ *            asynchronous on the searcher's stream
+ *   fetch  : wait + D2H of the CSR results */
+int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets,
+                           uint64_t n_reads);
+int taxor_gpu_batch_run(taxor_gpu_searcher *s);
+int taxor_gpu_batch_sync(taxor_gpu_searcher *s);
+int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *out);
+/* Device-resident results of the last run (for an RCCL gather): sizes, then D2D copy into caller-provided
+ * DEVICE buffers (read_off u64[n_reads+1], user_bin i64[n_tuples], count u32[n_tuples], n_hashes
+ * u32[n_reads]); any pointer may be NULL to skip it.  Synchronises the searcher's stream. */
+int taxor_gpu_batch_result_sizes(taxor_gpu_searcher *s, uint64_t *n_reads, uint64_t *n_tuples);
+int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read_off, void *d_user_bin, void *d_count,
+                                  void *d_n_hashes);
+
+/* Measurement of the last taxor_gpu_batch_run (valid after sync).  algorithmic_bytes follows SURVEY.md
+ * section 8(d): sum over reads of ceil(L/4) + sum over visited IXFs n_h*3*bins + 8 + 12*tuples;
+ * query_* are the dominant kernel (k_query_level) only: launches, HIP-event milliseconds on the searcher's
+ * stream (0 unless time_kernels), and its gather bytes sum n_h*3*bins. */
+typedef struct {
+    uint64_t n_reads, n_bases, n_hashes, n_tuples, n_work_items;
+    uint64_t algorithmic_bytes;
+    uint64_t query_bytes;
+    uint32_t query_launches;
+    float query_ms;
+    float syncmer_ms;
+    float finalize_ms;
+    float total_ms;
+} taxor_gpu_run_stats;
+int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stage entry points (used by the parity tests; each stage is checked on its own against the oracle).
+ * ---------------------------------------------------------------------------------------------- */
+/* hashing::seq_to_syncmers (src/hashing/syncmer.hpp:23) for a batch: distinct hashes of read r, in first-
+ * insertion order, at hashes[hash_off[r] .. hash_off[r+1]).  Pointers valid until the next call. */
+int taxor_gpu_syncmers(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                       const uint64_t **hash_off, const uint64_t **hashes);
+/* ixf.counting_agent<uint32_t>().bulk_count(values) for one IXF of the index
+ * (call site hierarchical_interleaved_xor_filter.hpp:307-309): counts[bins]. */
+int taxor_gpu_ixf_bulk_count(taxor_gpu_searcher *s, uint64_t ixf, const uint64_t *hashes, uint64_t n,
+                             uint32_t *counts);
+/* membership_agent::bulk_contains(values, threshold) (:381-406) for one hash list. */
+int taxor_gpu_bulk_contains(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, uint64_t threshold,
+                            taxor_gpu_results *out);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side scalars of the path (no GPU needed).
+ * ---------------------------------------------------------------------------------------------- */
+/* threshold::threshold + get(): ratio by which the hash count is multiplied.  percentage in (0,1] selects
+ * the percentage model (threshold.hpp:27-32), otherwise get_min_syncmer_match_ratio(k, error_rate)
+ * (syncmer_model.hpp:38-50).  Returns a negative value where the reference would read out of bounds. */
+double taxor_threshold_ratio(uint32_t kmer_size, double error_rate, double percentage);
+/* (size_t)(hash_count * ratio) */
+uint64_t taxor_threshold(uint64_t hash_count, double ratio);
+/* keep[i] = !(double(count[i]) < double(max)*0.8), taxor_search.cpp:275-286 */
+void taxor_classify_filter(const uint32_t *count, uint64_t n, uint8_t *keep);
+/* seg_len of an IXF sized for max_bin_elements keys per bin: (size_t)(32 + 1.23*n) / 3 */
+uint64_t taxor_ixf_seg_len(uint64_t max_bin_elements);
+/* XOR-filter construction of one bin column (3*seg_len bytes) for `keys` under (seed, seg_len); returns 0,
+ * or 1 if peeling failed for this seed (caller redraws the seed like construct_ixf.cpp:100-108). */
+int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint8_t *column);
+/* Seeded synthetic long reads: read i is drawn from genome g_i at a uniform start
+ * (reverse-complemented with probability frac_reverse) with ONT-like errors at rate e (40/30/30
+ * sub/ins/del), or uniformly random with probability frac_random.  Note: with the reference's
+ * t = ceil((k-s+1)/2) in INTEGER division (taxor_build.cpp:509-510; 5 at k22/s12) open-syncmer selection
+ * is not strand-symmetric, so a reverse-strand read shares no syncmers with a forward-indexed genome.  genomes = concatenated ACGT, genome_off[n_genomes+1].  Writes ASCII into bases (capacity
+ * cap) and offsets[n_reads+1]; origin[i] = genome index or -1.  Deterministic in (seed, i). */
+int taxor_synth_reads(const char *genomes, const uint64_t *genome_off, uint64_t n_genomes, uint64_t n_reads,
+                      uint32_t read_len, double error_rate, double frac_random, double frac_reverse,
+                      uint64_t seed, int threads, char *bases, uint64_t cap, uint64_t *offsets, int32_t *origin);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

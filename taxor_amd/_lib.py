@@ -1,0 +1,111 @@
+"""ctypes binding of libtaxor_gpu.so (include/taxor_gpu.h).  There is no fallback: if the HIP library is
+missing or does not load, importing anything that computes raises immediately."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtaxor_gpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+def build(force=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s"] + (["-B"] if force else [])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+class IxfView(C.Structure):
+    _fields_ = [("bins", C.c_uint64), ("stride", C.c_uint64), ("seg_len", C.c_uint64), ("seed", C.c_uint64),
+                ("data", C.c_void_p), ("next_ixf", C.c_void_p), ("fname_idx", C.c_void_p)]
+
+
+class HixfView(C.Structure):
+    _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
+                ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),
+                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("ratio", C.c_double), ("sub_batch_reads", C.c_uint32), ("sub_batch_bases", C.c_uint64),
+                ("time_kernels", C.c_uint32)]
+
+
+class Results(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_tuples", C.c_uint64), ("read_off", C.POINTER(C.c_uint64)),
+                ("user_bin", C.POINTER(C.c_int64)), ("count", C.POINTER(C.c_uint32)),
+                ("n_hashes", C.POINTER(C.c_uint32))]
+
+
+class RunStats(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_hashes", C.c_uint64),
+                ("n_tuples", C.c_uint64), ("n_work_items", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+                ("query_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
+                ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+# every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "taxor_gpu_last_error": (C.c_char_p, []),
+    "taxor_gpu_index_create": (C.c_int, [C.POINTER(HixfView), C.c_int, C.POINTER(_P)]),
+    "taxor_gpu_index_destroy": (None, [_P]),
+    "taxor_gpu_index_data_bytes": (C.c_uint64, [_P]),
+    "taxor_gpu_index_leaf_runs": (C.c_uint64, [_P]),
+    "taxor_gpu_index_depth": (C.c_uint32, [_P]),
+    "taxor_gpu_index_fill_random": (C.c_int, [_P, C.c_uint64, C.c_uint64]),
+    "taxor_gpu_index_upload_bin": (C.c_int, [_P, C.c_uint64, C.c_uint64, _P, C.c_uint64]),
+    "taxor_gpu_index_download_ixf": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64]),
+    "taxor_gpu_searcher_create": (C.c_int, [_P, C.POINTER(SearchParams), C.POINTER(_P)]),
+    "taxor_gpu_searcher_destroy": (None, [_P]),
+    "taxor_gpu_search_batch": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(Results)]),
+    "taxor_gpu_batch_upload": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "taxor_gpu_batch_run": (C.c_int, [_P]),
+    "taxor_gpu_batch_sync": (C.c_int, [_P]),
+    "taxor_gpu_batch_fetch": (C.c_int, [_P, C.POINTER(Results)]),
+    "taxor_gpu_batch_result_sizes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "taxor_gpu_batch_export_device": (C.c_int, [_P, _P, _P, _P, _P]),
+    "taxor_gpu_batch_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
+    "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
+                                     C.POINTER(C.POINTER(C.c_uint64))]),
+    "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),
+    "taxor_gpu_bulk_contains": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(Results)]),
+    "taxor_threshold_ratio": (C.c_double, [C.c_uint32, C.c_double, C.c_double]),
+    "taxor_threshold": (C.c_uint64, [C.c_uint64, C.c_double]),
+    "taxor_classify_filter": (None, [_P, C.c_uint64, _P]),
+    "taxor_ixf_seg_len": (C.c_uint64, [C.c_uint64]),
+    "taxor_ixf_build_bin": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, _P]),
+    "taxor_synth_reads": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_double, C.c_double,
+                                    C.c_double, C.c_uint64, C.c_int, _P, C.c_uint64, _P, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtaxor_gpu.so; raise loudly if it is absent (no CPU path exists in the product)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C taxor_amd/csrc).  taxor_amd has no CPU fallback.")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class TaxorError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[TAXOR SEARCH ERROR] {msg} (status {code})")
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise TaxorError(rc, lib().taxor_gpu_last_error().decode(errors="replace"))

@@ -1,0 +1,910 @@
+// api.hip -- C ABI of libtaxor_gpu.so (include/taxor_gpu.h): index residency in HBM, the per-GPU searcher,
+// the batch pipeline (upload -> syncmers -> level-synchronous HIXF query -> DFS-ordered CSR) and the stage
+// entry points the parity tests use.  No CPU fallback exists: every compute entry point runs HIP kernels.
+#include "../../include/taxor_gpu.h"
+#include "ixf_arith.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace taxor;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(TAXOR_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                              \
+    } while (0)
+
+// growable device buffer
+template <typename T> struct DBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 8 + 64;
+        HIP_TRY(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+inline uint64_t round_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+} // namespace
+
+struct taxor_gpu_index {
+    int device = 0;
+    uint8_t *d_slab = nullptr;
+    uint64_t slab_bytes = 0, data_bytes = 0;
+    IxfDesc *d_ixf = nullptr;
+    uint32_t *d_binfo = nullptr;
+    int64_t *d_ubin = nullptr;
+    uint32_t *d_dfs_key = nullptr;
+    std::vector<IxfDesc> h_ixf; // data pointers are device pointers
+    std::vector<uint64_t> rows;
+    uint64_t n_user_bins = 0, total_bins = 0, leaf_runs = 0;
+    uint32_t depth = 0, max_stride = 0;
+    int k = 0, s = 0, t = 0;
+};
+
+struct SubBatch {
+    uint32_t first, n;
+    uint64_t slots; // candidate/hash slots of this sub-batch
+};
+
+struct taxor_gpu_searcher {
+    taxor_gpu_index *idx = nullptr;
+    taxor_gpu_search_params prm{};
+    hipStream_t st = nullptr;
+    Counters *d_ctr = nullptr;
+    Counters h_ctr{};
+    int grid_sync = 0, grid_query = 0;
+    size_t lds_query = 0;
+
+    // batch-resident input
+    uint64_t n_reads = 0, n_bases = 0;
+    DBuf<uint8_t> d_ascii;
+    DBuf<uint64_t> d_aoff, d_poff, d_hoff;
+    DBuf<uint32_t> d_packed, d_rlen, d_hcap, d_nh;
+    DBuf<uint64_t> d_thr;
+    std::vector<SubBatch> subs;
+    uint64_t max_slots = 0, max_read_slots = 0;
+    uint32_t max_sub_reads = 0;
+    uint64_t packed_word_count = 0, packed_in_bytes = 0;
+
+    // per-sub-batch scratch
+    DBuf<uint64_t> d_cand, d_hashes;
+    DBuf<uint2> d_q[2];
+    DBuf<uint4> d_hits;
+    DBuf<uint32_t> d_read_hits, d_cursor, d_roff, d_biglist, d_gtab;
+    uint32_t q_cap = 0, hit_cap = 0, gtab_stride = 0;
+
+    // batch-resident output
+    DBuf<uint64_t> d_read_off;
+    DBuf<int64_t> d_out_ub;
+    DBuf<uint32_t> d_out_cnt, d_out_key;
+    uint64_t tuple_cap = 0;
+    bool ran = false, synced = false;
+
+    // host mirrors handed out through taxor_gpu_results
+    std::vector<uint64_t> h_read_off, h_hash_off, h_hashes;
+    std::vector<int64_t> h_ub;
+    std::vector<uint32_t> h_cnt, h_nh;
+
+    // timing
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, int>> ev_spans; // (start event index, kind 0=syncmer 1=query 2=finalize)
+    taxor_gpu_run_stats stats{};
+};
+
+extern "C" const char *taxor_gpu_last_error(void) { return g_err.c_str(); }
+
+// =========================================================================================================
+// index
+// =========================================================================================================
+extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
+{
+    if (!v || !out || v->n_ixf == 0 || !v->ixf) return fail(TAXOR_E_ARG, "index_create: empty view");
+    if (!v->use_syncmer)
+        return fail(TAXOR_E_ARG, "index_create: use_syncmer=false (k-mer/minimiser indexes) is out of scope");
+    if (v->scaling > 1) return fail(TAXOR_E_ARG, "index_create: scaling>1 (FracMinHash) is out of scope");
+    const int k = v->kmer_size, s = v->syncmer_size, t = v->t_syncmer;
+    if (k < 2 || k > 32 || s < 1 || s > 16 || s >= k || k - s + 1 > 32 || t < 1)
+        return fail(TAXOR_E_ARG, "index_create: unsupported k=%d s=%d t=%d (need k<=32, s<=16, s<k, t>=1)", k, s, t);
+    if (v->n_ixf >= (1u << 30)) return fail(TAXOR_E_ARG, "index_create: too many IXFs");
+    HIP_TRY(hipSetDevice(device));
+
+    auto idx = new taxor_gpu_index();
+    idx->device = device;
+    idx->k = k;
+    idx->s = s;
+    idx->t = t;
+    idx->n_user_bins = v->n_user_bins;
+    const uint64_t n = v->n_ixf;
+    idx->h_ixf.resize(n);
+    idx->rows.resize(n);
+    std::vector<uint64_t> slab_off(n);
+    uint64_t off = 0, tb = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const taxor_ixf_view &f = v->ixf[i];
+        if (f.bins == 0 || f.stride < f.bins || f.stride % 64 != 0 || f.seg_len == 0 || !f.next_ixf || !f.fname_idx) {
+            delete idx;
+            return fail(TAXOR_E_ARG, "index_create: IXF %llu malformed (bins=%llu stride=%llu seg_len=%llu)",
+                        (unsigned long long)i, (unsigned long long)f.bins, (unsigned long long)f.stride,
+                        (unsigned long long)f.seg_len);
+        }
+        if (3 * f.seg_len >= (1ull << 32) || f.stride > (1u << 20)) {
+            delete idx;
+            return fail(TAXOR_E_ARG, "index_create: IXF %llu too large (rows or stride)", (unsigned long long)i);
+        }
+        idx->rows[i] = 3 * f.seg_len;
+        slab_off[i] = off;
+        off += round_up(idx->rows[i] * f.stride, 4096);
+        idx->data_bytes += idx->rows[i] * f.stride;
+        IxfDesc &d = idx->h_ixf[i];
+        d.seed = f.seed;
+        d.seg_len = (uint32_t)f.seg_len;
+        d.bins = (uint32_t)f.bins;
+        d.stride = (uint32_t)f.stride;
+        d.units = (uint32_t)(f.stride / 16);
+        d.bin_base = (uint32_t)tb;
+        d.pad = 0;
+        tb += f.bins;
+        idx->max_stride = std::max(idx->max_stride, d.stride);
+    }
+    if (tb >= (1ull << 32)) {
+        delete idx;
+        return fail(TAXOR_E_ARG, "index_create: more than 2^32 technical bins");
+    }
+    idx->total_bins = tb;
+    idx->slab_bytes = off + 4096;
+
+    // per-bin tables + DFS keys + depth; validates that the IXFs form a tree rooted at 0
+    std::vector<uint32_t> binfo(tb), dfs(tb, 0);
+    std::vector<int64_t> ubin(tb, -1);
+    for (uint64_t i = 0; i < n; ++i) {
+        const taxor_ixf_view &f = v->ixf[i];
+        const uint32_t bb = idx->h_ixf[i].bin_base;
+        for (uint64_t b = 0; b < f.bins; ++b) {
+            const int64_t cur = f.fname_idx[b];
+            uint32_t info = 0;
+            if (cur < 0) { // merged bin (hixf.hpp:172-178); child = next_ixf_id[i][bin] (:115-122)
+                const int64_t ch = f.next_ixf[b];
+                if (ch <= 0 || (uint64_t)ch >= n || (uint64_t)ch == i) {
+                    delete idx;
+                    return fail(TAXOR_E_ARG, "index_create: IXF %llu bin %llu: bad child %lld", (unsigned long long)i,
+                                (unsigned long long)b, (long long)ch);
+                }
+                info = BINFO_MERGED | BINFO_END | (uint32_t)ch;
+            } else {
+                if ((uint64_t)cur >= v->n_user_bins) {
+                    delete idx;
+                    return fail(TAXOR_E_ARG, "index_create: IXF %llu bin %llu: user bin %lld out of range",
+                                (unsigned long long)i, (unsigned long long)b, (long long)cur);
+                }
+                ubin[bb + b] = cur;
+                if (b + 1 == f.bins || cur != f.fname_idx[b + 1]) { // hixf.hpp:325-326
+                    info = BINFO_END;
+                    idx->leaf_runs++;
+                }
+            }
+            binfo[bb + b] = info;
+        }
+    }
+    {
+        std::vector<uint8_t> seen(n, 0);
+        struct Frame { uint64_t ixf, bin; uint32_t depth; };
+        std::vector<Frame> stack;
+        stack.push_back({0, 0, 1});
+        seen[0] = 1;
+        uint32_t key = 0;
+        while (!stack.empty()) {
+            Frame &fr = stack.back();
+            const taxor_ixf_view &f = v->ixf[fr.ixf];
+            if (fr.bin == f.bins) { stack.pop_back(); continue; }
+            const uint64_t b = fr.bin++;
+            const uint32_t g = idx->h_ixf[fr.ixf].bin_base + (uint32_t)b;
+            dfs[g] = key++;
+            idx->depth = std::max(idx->depth, fr.depth);
+            if (binfo[g] & BINFO_MERGED) {
+                const uint64_t ch = binfo[g] & 0x3FFFFFFFu;
+                if (seen[ch]) {
+                    delete idx;
+                    return fail(TAXOR_E_ARG, "index_create: IXF %llu is referenced twice (not a tree)", (unsigned long long)ch);
+                }
+                seen[ch] = 1;
+                const uint32_t d = fr.depth + 1;
+                stack.push_back({ch, 0, d});
+            }
+        }
+        if (idx->depth >= (uint32_t)MAX_LEVELS - 1) {
+            delete idx;
+            return fail(TAXOR_E_ARG, "index_create: hierarchy deeper than %d levels", MAX_LEVELS - 2);
+        }
+    }
+
+    hipError_t e = hipMalloc((void **)&idx->d_slab, idx->slab_bytes);
+    if (e != hipSuccess) {
+        delete idx;
+        return fail(TAXOR_E_NOMEM, "index_create: hipMalloc of %llu bytes failed: %s", (unsigned long long)idx->slab_bytes,
+                    hipGetErrorString(e));
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        idx->h_ixf[i].data = idx->d_slab + slab_off[i];
+        if (v->ixf[i].data) {
+            e = hipMemcpy(idx->d_slab + slab_off[i], v->ixf[i].data, idx->rows[i] * v->ixf[i].stride, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                taxor_gpu_index_destroy(idx);
+                return fail(TAXOR_E_HIP, "index_create: upload of IXF %llu failed: %s", (unsigned long long)i, hipGetErrorString(e));
+            }
+        }
+    }
+    bool ok = hipMalloc((void **)&idx->d_ixf, n * sizeof(IxfDesc)) == hipSuccess &&
+              hipMalloc((void **)&idx->d_binfo, tb * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&idx->d_ubin, tb * sizeof(int64_t)) == hipSuccess &&
+              hipMalloc((void **)&idx->d_dfs_key, tb * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(idx->d_ixf, idx->h_ixf.data(), n * sizeof(IxfDesc), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(idx->d_binfo, binfo.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(idx->d_ubin, ubin.data(), tb * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(idx->d_dfs_key, dfs.data(), tb * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        taxor_gpu_index_destroy(idx);
+        return fail(TAXOR_E_HIP, "index_create: table upload failed");
+    }
+    *out = idx;
+    return TAXOR_OK;
+}
+
+extern "C" void taxor_gpu_index_destroy(taxor_gpu_index *idx)
+{
+    if (!idx) return;
+    (void)hipSetDevice(idx->device);
+    if (idx->d_slab) (void)hipFree(idx->d_slab);
+    if (idx->d_ixf) (void)hipFree(idx->d_ixf);
+    if (idx->d_binfo) (void)hipFree(idx->d_binfo);
+    if (idx->d_ubin) (void)hipFree(idx->d_ubin);
+    if (idx->d_dfs_key) (void)hipFree(idx->d_dfs_key);
+    delete idx;
+}
+
+extern "C" uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx) { return idx ? idx->data_bytes : 0; }
+extern "C" uint64_t taxor_gpu_index_leaf_runs(const taxor_gpu_index *idx) { return idx ? idx->leaf_runs : 0; }
+extern "C" uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx) { return idx ? idx->depth : 0; }
+
+extern "C" int taxor_gpu_index_fill_random(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed)
+{
+    if (!idx || ixf >= idx->h_ixf.size()) return fail(TAXOR_E_ARG, "fill_random: bad IXF id");
+    HIP_TRY(hipSetDevice(idx->device));
+    const uint64_t bytes = idx->rows[ixf] * idx->h_ixf[ixf].stride; // multiple of 64
+    launch_fill_random(const_cast<uint8_t *>(idx->h_ixf[ixf].data), bytes, seed, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_index_upload_bin(taxor_gpu_index *idx, uint64_t ixf, uint64_t bin, const uint8_t *column,
+                                          uint64_t rows)
+{
+    if (!idx || ixf >= idx->h_ixf.size() || bin >= idx->h_ixf[ixf].bins || rows != idx->rows[ixf] || !column)
+        return fail(TAXOR_E_ARG, "upload_bin: bad arguments");
+    HIP_TRY(hipSetDevice(idx->device));
+    uint8_t *d_col = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_col, rows));
+    hipError_t e = hipMemcpy(d_col, column, rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_scatter_column(const_cast<uint8_t *>(idx->h_ixf[ixf].data), idx->h_ixf[ixf].stride, bin, d_col, rows, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d_col);
+    if (e != hipSuccess) return fail(TAXOR_E_HIP, "upload_bin: %s", hipGetErrorString(e));
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8_t *data, uint64_t len)
+{
+    if (!idx || ixf >= idx->h_ixf.size() || !data || len != idx->rows[ixf] * idx->h_ixf[ixf].stride)
+        return fail(TAXOR_E_ARG, "download_ixf: bad arguments");
+    HIP_TRY(hipSetDevice(idx->device));
+    HIP_TRY(hipMemcpy(data, idx->h_ixf[ixf].data, len, hipMemcpyDeviceToHost));
+    return TAXOR_OK;
+}
+
+// =========================================================================================================
+// searcher
+// =========================================================================================================
+extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_search_params *prm,
+                                         taxor_gpu_searcher **out)
+{
+    if (!idx || !prm || !out) return fail(TAXOR_E_ARG, "searcher_create: null argument");
+    if (!(prm->ratio >= 0.0) || !(prm->ratio <= 1.0))
+        return fail(TAXOR_E_ARG, "searcher_create: threshold ratio %g outside [0,1] (error rate / k outside the model?)", prm->ratio);
+    HIP_TRY(hipSetDevice(idx->device));
+    auto s = new taxor_gpu_searcher();
+    s->idx = idx;
+    s->prm = *prm;
+    if (s->prm.sub_batch_reads == 0) s->prm.sub_batch_reads = 32768;
+    if (s->prm.sub_batch_bases == 0) s->prm.sub_batch_bases = 1ull << 29;
+    if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
+    hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
+    if (e != hipSuccess) {
+        delete s;
+        return fail(TAXOR_E_HIP, "searcher_create: %s", hipGetErrorString(e));
+    }
+    s->lds_query = 240 * 16 + 16 + (size_t)idx->max_stride * 4;
+    if (s->lds_query > 160 * 1024) {
+        taxor_gpu_searcher_destroy(s);
+        return fail(TAXOR_E_ARG, "searcher_create: an IXF with %u-byte rows does not fit the LDS tally", idx->max_stride);
+    }
+    s->grid_sync = syncmers_grid(idx->device);
+    s->grid_query = query_grid(idx->device, s->lds_query);
+    *out = s;
+    return TAXOR_OK;
+}
+
+extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->idx->device);
+    if (s->st) (void)hipStreamSynchronize(s->st);
+    s->d_ascii.release(); s->d_aoff.release(); s->d_poff.release(); s->d_hoff.release();
+    s->d_packed.release(); s->d_rlen.release(); s->d_hcap.release(); s->d_nh.release(); s->d_thr.release();
+    s->d_cand.release(); s->d_hashes.release(); s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
+    s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release();
+    s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
+    for (auto ev : s->ev) (void)hipEventDestroy(ev);
+    if (s->d_ctr) (void)hipFree(s->d_ctr);
+    if (s->st) (void)hipStreamDestroy(s->st);
+    delete s;
+}
+
+namespace {
+
+int ev_reserve(taxor_gpu_searcher *s)
+{
+    if (s->ev_used + 2 > s->ev.size()) {
+        for (int i = 0; i < 64; ++i) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            s->ev.push_back(ev);
+        }
+    }
+    return 0;
+}
+
+// bracket helpers: begin returns the index of the start event
+int ev_begin(taxor_gpu_searcher *s, int kind, size_t *slot)
+{
+    *slot = (size_t)-1;
+    if (!s->prm.time_kernels) return 0;
+    if (ev_reserve(s)) return TAXOR_E_HIP;
+    *slot = s->ev_used;
+    s->ev_used += 2;
+    s->ev_spans.push_back({*slot, kind});
+    HIP_TRY(hipEventRecord(s->ev[*slot], s->st));
+    return 0;
+}
+
+int ev_end(taxor_gpu_searcher *s, size_t slot)
+{
+    if (slot == (size_t)-1) return 0;
+    HIP_TRY(hipEventRecord(s->ev[slot + 1], s->st));
+    return 0;
+}
+
+// host-side layout of a batch: packed offsets, candidate slots, sub-batch partition
+int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_reads, std::vector<uint64_t> &poff,
+                 std::vector<uint32_t> &rlen, std::vector<uint64_t> &hoff, std::vector<uint32_t> &hcap)
+{
+    const taxor_gpu_index *idx = s->idx;
+    const int w = idx->k - idx->s + 1;
+    int gap = std::min(idx->t, w - idx->t + 1); // minimum distance between two open syncmers of one read
+    if (gap < 1) gap = 1;
+    poff.resize(n_reads);
+    rlen.resize(n_reads);
+    hoff.resize(n_reads);
+    hcap.resize(n_reads);
+    s->subs.clear();
+    s->max_slots = 0;
+    s->max_read_slots = 0;
+    s->max_sub_reads = 0;
+    uint64_t words = 0, sub_slots = 0, sub_bases = 0;
+    uint32_t sub_first = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        if (offsets[r + 1] < offsets[r]) return fail(TAXOR_E_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len >= (1ull << 31)) return fail(TAXOR_E_ARG, "read %llu longer than 2^31 bases", (unsigned long long)r);
+        const uint64_t nwin = len >= (uint64_t)idx->k ? len - idx->k + 1 : 0;
+        const uint64_t cap = round_up(nwin / gap + 2, 16); // 128-B aligned regions: no line shared between reads
+        if (r > sub_first && (r - sub_first >= s->prm.sub_batch_reads || sub_bases + len > s->prm.sub_batch_bases)) {
+            s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots});
+            s->max_slots = std::max(s->max_slots, sub_slots);
+            s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(r - sub_first));
+            sub_first = (uint32_t)r;
+            sub_slots = 0;
+            sub_bases = 0;
+        }
+        poff[r] = words;
+        rlen[r] = (uint32_t)len;
+        hoff[r] = sub_slots;
+        hcap[r] = (uint32_t)cap;
+        words += round_up((len + 15) / 16, 4);
+        sub_slots += cap;
+        sub_bases += len;
+        s->max_read_slots = std::max(s->max_read_slots, cap);
+    }
+    if (n_reads > sub_first) {
+        s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), sub_slots});
+        s->max_slots = std::max(s->max_slots, sub_slots);
+        s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(n_reads - sub_first));
+    }
+    s->packed_word_count = words + 16;
+    s->packed_in_bytes = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) s->packed_in_bytes += (rlen[r] + 3u) / 4u; // ceil(L/4), SURVEY 8(d)
+    return 0;
+}
+
+int ensure_scratch(taxor_gpu_searcher *s)
+{
+    const taxor_gpu_index *idx = s->idx;
+    const uint32_t R = std::max<uint32_t>(s->max_sub_reads, 1);
+    if (s->d_cand.reserve(s->max_slots + 64)) return TAXOR_E_HIP;
+    if (s->d_hashes.reserve(s->max_slots + 64)) return TAXOR_E_HIP;
+    const uint64_t qmin = std::max<uint64_t>(4ull * R, idx->h_ixf.size() + 64);
+    const uint64_t hmin = std::max<uint64_t>(4ull * R, idx->leaf_runs + 64);
+    if (s->q_cap < qmin) s->q_cap = (uint32_t)std::min<uint64_t>(qmin, 0x7FFFFFFFu);
+    if (s->hit_cap < hmin) s->hit_cap = (uint32_t)std::min<uint64_t>(hmin, 0x7FFFFFFFu);
+    if (s->d_q[0].reserve(s->q_cap) || s->d_q[1].reserve(s->q_cap)) return TAXOR_E_HIP;
+    if (s->d_hits.reserve(s->hit_cap)) return TAXOR_E_HIP;
+    if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R))
+        return TAXOR_E_HIP;
+    // dedup scratch for reads whose table does not fit LDS (8192 slots)
+    uint64_t ts = 64;
+    while (ts < 2 * s->max_read_slots) ts <<= 1;
+    if (ts > 8192) {
+        if (ts > (1ull << 31)) return fail(TAXOR_E_ARG, "read too long for the dedup table");
+        if (s->gtab_stride < ts) s->gtab_stride = (uint32_t)ts;
+        if (s->d_gtab.reserve((size_t)s->gtab_stride * (size_t)s->grid_sync)) return TAXOR_E_HIP;
+    }
+    const uint64_t tmin = std::max<uint64_t>(4 * s->n_reads + 1024, idx->leaf_runs + 64);
+    if (s->tuple_cap < tmin) s->tuple_cap = tmin;
+    if (s->d_out_ub.reserve(s->tuple_cap) || s->d_out_cnt.reserve(s->tuple_cap) || s->d_out_key.reserve(s->tuple_cap))
+        return TAXOR_E_HIP;
+    if (s->d_read_off.reserve(s->n_reads + 1)) return TAXOR_E_HIP;
+    return 0;
+}
+
+// level loop + CSR assembly for one group of reads whose hashes / thresholds are already on the device
+int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d_hoff, const uint32_t *d_nh,
+              const uint64_t *d_thr, uint32_t n_reads, uint64_t *d_read_off, int is_last, uint32_t *d_counts_out,
+              int only_ixf)
+{
+    const taxor_gpu_index *idx = s->idx;
+    HIP_TRY(hipMemsetAsync(s->d_read_hits.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
+    HIP_TRY(hipMemsetAsync(s->d_cursor.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
+    QueryArgs q{};
+    q.ixf = idx->d_ixf;
+    q.binfo = idx->d_binfo;
+    q.hashes = d_hashes;
+    q.hoff = d_hoff;
+    q.nh = d_nh;
+    q.thr = d_thr;
+    q.hits = s->d_hits.p;
+    q.read_hits = s->d_read_hits.p;
+    q.counts_out = d_counts_out;
+    q.ctr = s->d_ctr;
+    q.q_cap = s->q_cap;
+    q.hit_cap = s->hit_cap;
+    const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
+    for (uint32_t lvl = 0; lvl < levels; ++lvl) {
+        q.level = lvl;
+        q.q_in = (lvl == 0 && only_ixf < 0) ? nullptr : s->d_q[lvl & 1].p;
+        q.q_out = s->d_q[(lvl + 1) & 1].p;
+        q.n_level0 = n_reads;
+        size_t slot;
+        if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
+        launch_query_level(q, s->grid_query, s->lds_query, s->st);
+        if (ev_end(s, slot)) return TAXOR_E_HIP;
+        s->stats.query_launches++;
+    }
+    HIP_TRY(hipGetLastError());
+    if (d_counts_out) return 0;
+    FinalizeArgs f{};
+    f.hits = s->d_hits.p;
+    f.read_hits = s->d_read_hits.p;
+    f.cursor = s->d_cursor.p;
+    f.roff = s->d_roff.p;
+    f.biglist = s->d_biglist.p;
+    f.dfs_key = idx->d_dfs_key;
+    f.ubin = idx->d_ubin;
+    f.read_off = d_read_off;
+    f.out_ub = s->d_out_ub.p;
+    f.out_cnt = s->d_out_cnt.p;
+    f.out_key = s->d_out_key.p;
+    f.ctr = s->d_ctr;
+    f.n_reads = n_reads;
+    f.tuple_cap = s->tuple_cap;
+    f.is_last = is_last;
+    size_t slot;
+    if (ev_begin(s, 2, &slot)) return TAXOR_E_HIP;
+    launch_finalize(f, s->st);
+    if (ev_end(s, slot)) return TAXOR_E_HIP;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// zero the per-sub-batch part of the counters block, keep the running totals
+int reset_sub_counters(taxor_gpu_searcher *s, bool whole)
+{
+    const size_t n = whole ? sizeof(Counters) : offsetof(Counters, tuple_total);
+    // flags must survive across sub-batches: they sit first, so skip them unless the whole block is reset
+    if (whole) HIP_TRY(hipMemsetAsync(s->d_ctr, 0, n, s->st));
+    else HIP_TRY(hipMemsetAsync(reinterpret_cast<uint8_t *>(s->d_ctr) + sizeof(uint32_t), 0, n - sizeof(uint32_t), s->st));
+    return 0;
+}
+
+int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb)
+{
+    const taxor_gpu_index *idx = s->idx;
+    SyncmerArgs a{};
+    a.packed = s->d_packed.p;
+    a.poff = s->d_poff.p + sb.first;
+    a.rlen = s->d_rlen.p + sb.first;
+    a.hoff = s->d_hoff.p + sb.first;
+    a.hcap = s->d_hcap.p + sb.first;
+    a.cand = s->d_cand.p;
+    a.hashes = s->d_hashes.p;
+    a.nh = s->d_nh.p + sb.first;
+    a.thr = s->d_thr.p + sb.first;
+    a.ratio = s->prm.ratio;
+    a.gtab = s->d_gtab.p;
+    a.gtab_stride = s->gtab_stride;
+    a.ctr = s->d_ctr;
+    a.n_reads = sb.n;
+    a.k = idx->k;
+    a.s = idx->s;
+    a.t = idx->t;
+    size_t slot;
+    if (ev_begin(s, 0, &slot)) return TAXOR_E_HIP;
+    launch_syncmers(a, s->grid_sync, s->st);
+    if (ev_end(s, slot)) return TAXOR_E_HIP;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_flags(taxor_gpu_searcher *s, bool *rerun)
+{
+    *rerun = false;
+    HIP_TRY(hipMemcpyAsync(&s->h_ctr, s->d_ctr, sizeof(Counters), hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
+    const uint32_t f = s->h_ctr.flags;
+    if (f & FLAG_ALPHABET) return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet");
+    if (f & FLAG_CAND_OVERFLOW) return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated");
+    if (f & FLAG_DEDUP_OVERFLOW) return fail(TAXOR_E_INTERNAL, "dedup scratch too small");
+    if (f & FLAG_QUEUE_OVERFLOW) {
+        uint32_t need = 0;
+        for (int i = 0; i < MAX_LEVELS; ++i) need = std::max(need, s->h_ctr.q_n[i]);
+        s->q_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * s->q_cap, (uint64_t)need + 1024), 0x7FFFFFFFu);
+        *rerun = true;
+    }
+    if (f & FLAG_HITS_OVERFLOW) {
+        s->hit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * s->hit_cap, (uint64_t)s->h_ctr.n_hits + 1024), 0x7FFFFFFFu);
+        *rerun = true;
+    }
+    if (f & FLAG_TUPLE_OVERFLOW) {
+        s->tuple_cap = std::max<uint64_t>(2 * s->tuple_cap, s->h_ctr.tuple_total + 1024);
+        *rerun = true;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    if (!s || !offsets || (!bases && n_reads && offsets[n_reads] != offsets[0]))
+        return fail(TAXOR_E_ARG, "batch_upload: null argument");
+    if (n_reads >= (1ull << 32)) return fail(TAXOR_E_ARG, "batch_upload: more than 2^32 reads in one batch");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    s->ran = s->synced = false;
+    std::vector<uint64_t> poff, hoff;
+    std::vector<uint32_t> rlen, hcap;
+    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap)) return rc;
+    s->n_reads = n_reads;
+    const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
+    s->n_bases = nb;
+    if (s->d_ascii.reserve(nb + 64) || s->d_aoff.reserve(n_reads + 1) || s->d_poff.reserve(n_reads + 1) ||
+        s->d_hoff.reserve(n_reads + 1) || s->d_rlen.reserve(n_reads + 1) || s->d_hcap.reserve(n_reads + 1) ||
+        s->d_nh.reserve(n_reads + 1) || s->d_thr.reserve(n_reads + 1) || s->d_packed.reserve(s->packed_word_count))
+        return TAXOR_E_HIP;
+    std::vector<uint64_t> aoff(n_reads + 1);
+    for (uint64_t r = 0; r <= n_reads; ++r) aoff[r] = offsets[r] - a0;
+    HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(Counters), s->st));
+    if (nb) HIP_TRY(hipMemcpyAsync(s->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, s->st));
+    HIP_TRY(hipMemcpyAsync(s->d_aoff.p, aoff.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
+    if (n_reads) {
+        HIP_TRY(hipMemcpyAsync(s->d_poff.p, poff.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
+        HIP_TRY(hipMemcpyAsync(s->d_hoff.p, hoff.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
+        HIP_TRY(hipMemcpyAsync(s->d_rlen.p, rlen.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+        HIP_TRY(hipMemcpyAsync(s->d_hcap.p, hcap.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+    }
+    launch_pack_dna4(s->d_ascii.p, s->d_aoff.p, s->d_poff.p, s->d_packed.p, (uint32_t)n_reads, s->d_ctr, s->st);
+    HIP_TRY(hipGetLastError());
+    bool rerun;
+    if (int rc = check_flags(s, &rerun)) return rc; // synchronises; the pageable host vectors above may now die
+    return ensure_scratch(s);
+}
+
+extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
+{
+    if (!s) return fail(TAXOR_E_ARG, "batch_run: null searcher");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    if (int rc = ensure_scratch(s)) return rc;
+    s->ev_used = 0;
+    s->ev_spans.clear();
+    s->stats = taxor_gpu_run_stats{};
+    size_t tot_slot;
+    if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
+    if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
+    if (s->subs.empty()) { // zero reads: CSR = [0]
+        HIP_TRY(hipMemsetAsync(s->d_read_off.p, 0, sizeof(uint64_t), s->st));
+    }
+    for (size_t i = 0; i < s->subs.size(); ++i) {
+        const SubBatch &sb = s->subs[i];
+        if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
+        if (int rc = launch_syncmers_sub(s, sb)) return rc;
+        if (int rc = run_query(s, s->d_hashes.p, s->d_hoff.p + sb.first, s->d_nh.p + sb.first, s->d_thr.p + sb.first, sb.n,
+                               s->d_read_off.p + sb.first, i + 1 == s->subs.size(), nullptr, -1))
+            return rc;
+    }
+    if (ev_end(s, tot_slot)) return TAXOR_E_HIP;
+    s->ran = true;
+    s->synced = false;
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
+{
+    if (!s) return fail(TAXOR_E_ARG, "batch_sync: null searcher");
+    if (!s->ran) return fail(TAXOR_E_ARG, "batch_sync: no run in flight");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        bool rerun;
+        if (int rc = check_flags(s, &rerun)) return rc;
+        if (!rerun) {
+            s->synced = true;
+            // stats
+            taxor_gpu_run_stats &st = s->stats;
+            st.n_reads = s->n_reads;
+            st.n_bases = s->n_bases;
+            st.n_hashes = s->h_ctr.n_hashes;
+            st.n_tuples = s->h_ctr.tuple_total;
+            st.n_work_items = s->h_ctr.n_work;
+            st.query_bytes = s->h_ctr.query_bytes;
+            st.algorithmic_bytes = s->packed_in_bytes + st.query_bytes + 8 * st.n_reads + 12 * st.n_tuples;
+            st.query_ms = st.syncmer_ms = st.finalize_ms = st.total_ms = 0.f;
+            for (auto &sp : s->ev_spans) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, s->ev[sp.first], s->ev[sp.first + 1]) != hipSuccess) continue;
+                if (sp.second == 0) st.syncmer_ms += ms;
+                else if (sp.second == 1) st.query_ms += ms;
+                else if (sp.second == 2) st.finalize_ms += ms;
+                else st.total_ms += ms;
+            }
+            return TAXOR_OK;
+        }
+        if (int rc = taxor_gpu_batch_run(s)) return rc; // capacities were grown; everything is deterministic
+    }
+    return fail(TAXOR_E_INTERNAL, "batch_sync: buffers kept overflowing");
+}
+
+extern "C" int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out)
+{
+    if (!s || !out || !s->synced) return fail(TAXOR_E_ARG, "batch_stats: no completed run");
+    *out = s->stats;
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_batch_result_sizes(taxor_gpu_searcher *s, uint64_t *n_reads, uint64_t *n_tuples)
+{
+    if (!s) return fail(TAXOR_E_ARG, "result_sizes: null searcher");
+    if (!s->synced)
+        if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    if (n_reads) *n_reads = s->n_reads;
+    if (n_tuples) *n_tuples = s->h_ctr.tuple_total;
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read_off, void *d_user_bin, void *d_count,
+                                             void *d_n_hashes)
+{
+    if (!s) return fail(TAXOR_E_ARG, "export_device: null searcher");
+    if (!s->synced)
+        if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    const uint64_t nt = s->h_ctr.tuple_total, nr = s->n_reads;
+    if (d_read_off) HIP_TRY(hipMemcpyAsync(d_read_off, s->d_read_off.p, (nr + 1) * 8, hipMemcpyDeviceToDevice, s->st));
+    if (d_user_bin && nt) HIP_TRY(hipMemcpyAsync(d_user_bin, s->d_out_ub.p, nt * 8, hipMemcpyDeviceToDevice, s->st));
+    if (d_count && nt) HIP_TRY(hipMemcpyAsync(d_count, s->d_out_cnt.p, nt * 4, hipMemcpyDeviceToDevice, s->st));
+    if (d_n_hashes && nr) HIP_TRY(hipMemcpyAsync(d_n_hashes, s->d_nh.p, nr * 4, hipMemcpyDeviceToDevice, s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *out)
+{
+    if (!s || !out) return fail(TAXOR_E_ARG, "batch_fetch: null argument");
+    if (!s->synced)
+        if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    const uint64_t nt = s->h_ctr.tuple_total, nr = s->n_reads;
+    s->h_read_off.resize(nr + 1);
+    s->h_ub.resize(nt);
+    s->h_cnt.resize(nt);
+    s->h_nh.resize(nr);
+    HIP_TRY(hipMemcpyAsync(s->h_read_off.data(), s->d_read_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s->st));
+    if (nt) {
+        HIP_TRY(hipMemcpyAsync(s->h_ub.data(), s->d_out_ub.p, nt * 8, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(hipMemcpyAsync(s->h_cnt.data(), s->d_out_cnt.p, nt * 4, hipMemcpyDeviceToHost, s->st));
+    }
+    if (nr) HIP_TRY(hipMemcpyAsync(s->h_nh.data(), s->d_nh.p, nr * 4, hipMemcpyDeviceToHost, s->st));
+    HIP_TRY(hipStreamSynchronize(s->st));
+    out->n_reads = nr;
+    out->n_tuples = nt;
+    out->read_off = s->h_read_off.data();
+    out->user_bin = s->h_ub.data();
+    out->count = s->h_cnt.data();
+    out->n_hashes = s->h_nh.data();
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                                      taxor_gpu_results *out)
+{
+    if (int rc = taxor_gpu_batch_upload(s, bases, offsets, n_reads)) return rc;
+    if (int rc = taxor_gpu_batch_run(s)) return rc;
+    return taxor_gpu_batch_fetch(s, out);
+}
+
+// =========================================================================================================
+// stage entry points
+// =========================================================================================================
+extern "C" int taxor_gpu_syncmers(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
+                                  const uint64_t **hash_off, const uint64_t **hashes)
+{
+    if (!s || !hash_off || !hashes) return fail(TAXOR_E_ARG, "syncmers: null argument");
+    if (int rc = taxor_gpu_batch_upload(s, bases, offsets, n_reads)) return rc;
+    s->h_hash_off.assign(n_reads + 1, 0);
+    s->h_hashes.clear();
+    s->h_nh.resize(n_reads);
+    std::vector<uint64_t> tmp, hoff_h;
+    if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
+    for (size_t i = 0; i < s->subs.size(); ++i) {
+        const SubBatch &sb = s->subs[i];
+        if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
+        if (int rc = launch_syncmers_sub(s, sb)) return rc;
+        bool rerun;
+        if (int rc = check_flags(s, &rerun)) return rc;
+        tmp.resize(sb.slots);
+        hoff_h.resize(sb.n);
+        HIP_TRY(hipMemcpy(s->h_nh.data() + sb.first, s->d_nh.p + sb.first, sb.n * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(hoff_h.data(), s->d_hoff.p + sb.first, sb.n * 8, hipMemcpyDeviceToHost));
+        if (sb.slots) HIP_TRY(hipMemcpy(tmp.data(), s->d_hashes.p, sb.slots * 8, hipMemcpyDeviceToHost));
+        for (uint32_t r = 0; r < sb.n; ++r) {
+            const uint32_t nh = s->h_nh[sb.first + r];
+            s->h_hash_off[sb.first + r + 1] = s->h_hash_off[sb.first + r] + nh;
+            s->h_hashes.insert(s->h_hashes.end(), tmp.begin() + hoff_h[r], tmp.begin() + hoff_h[r] + nh);
+        }
+    }
+    *hash_off = s->h_hash_off.data();
+    *hashes = s->h_hashes.data();
+    return TAXOR_OK;
+}
+
+namespace {
+
+// stage a single pseudo-read whose hash list and threshold are given
+int stage_hash_list(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, uint64_t threshold)
+{
+    if (n >= (1ull << 32)) return fail(TAXOR_E_ARG, "hash list too long");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    s->ran = s->synced = false;
+    s->n_reads = 1;
+    s->n_bases = 0;
+    s->subs.clear();
+    s->max_slots = n + 64;
+    s->max_read_slots = 16;
+    s->max_sub_reads = 1;
+    if (s->d_hoff.reserve(2) || s->d_nh.reserve(2) || s->d_thr.reserve(2)) return TAXOR_E_HIP;
+    if (int rc = ensure_scratch(s)) return rc;
+    const uint64_t zero = 0;
+    const uint32_t nh = (uint32_t)n;
+    if (n) HIP_TRY(hipMemcpy(s->d_hashes.p, hashes, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_hoff.p, &zero, 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_nh.p, &nh, 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->d_thr.p, &threshold, 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+} // namespace
+
+extern "C" int taxor_gpu_ixf_bulk_count(taxor_gpu_searcher *s, uint64_t ixf, const uint64_t *hashes, uint64_t n,
+                                        uint32_t *counts)
+{
+    if (!s || !counts || (n && !hashes)) return fail(TAXOR_E_ARG, "ixf_bulk_count: null argument");
+    if (ixf >= s->idx->h_ixf.size()) return fail(TAXOR_E_ARG, "ixf_bulk_count: bad IXF id");
+    if (int rc = stage_hash_list(s, hashes, n, ~0ull)) return rc;
+    const uint32_t bins = s->idx->h_ixf[ixf].bins;
+    uint32_t *d_counts = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_counts, (size_t)bins * 4));
+    int rc = reset_sub_counters(s, true);
+    const uint2 item = make_uint2(0u, (uint32_t)ixf);
+    const uint32_t one = 1;
+    hipError_t e = hipMemcpyAsync(s->d_q[0].p, &item, sizeof item, hipMemcpyHostToDevice, s->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&s->d_ctr->q_n[0], &one, 4, hipMemcpyHostToDevice, s->st);
+    if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+    if (e != hipSuccess) rc = fail(TAXOR_E_HIP, "ixf_bulk_count: %s", hipGetErrorString(e));
+    s->ev_used = 0;
+    s->ev_spans.clear();
+    if (!rc) rc = run_query(s, s->d_hashes.p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, nullptr, 1, d_counts, (int)ixf);
+    if (!rc) {
+        e = hipStreamSynchronize(s->st);
+        if (e == hipSuccess) e = hipMemcpy(counts, d_counts, (size_t)bins * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TAXOR_E_HIP, "ixf_bulk_count: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(d_counts);
+    return rc;
+}
+
+extern "C" int taxor_gpu_bulk_contains(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, uint64_t threshold,
+                                       taxor_gpu_results *out)
+{
+    if (!s || !out || (n && !hashes)) return fail(TAXOR_E_ARG, "bulk_contains: null argument");
+    if (int rc = stage_hash_list(s, hashes, n, threshold)) return rc;
+    for (int attempt = 0; attempt < 40; ++attempt) {
+        if (int rc = ensure_scratch(s)) return rc;
+        if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
+        s->ev_used = 0;
+        s->ev_spans.clear();
+        if (int rc = run_query(s, s->d_hashes.p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, s->d_read_off.p, 1, nullptr, -1))
+            return rc;
+        bool rerun;
+        if (int rc = check_flags(s, &rerun)) return rc;
+        if (!rerun) {
+            s->ran = s->synced = true;
+            return taxor_gpu_batch_fetch(s, out);
+        }
+    }
+    return fail(TAXOR_E_INTERNAL, "bulk_contains: buffers kept overflowing");
+}

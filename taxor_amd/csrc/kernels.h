@@ -1,0 +1,124 @@
+// kernels.h -- device data layout + launch wrappers of the taxor search hot path (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace taxor {
+
+// ---- index layout in HBM --------------------------------------------------------------------------
+// One slab holds every IXF's fingerprint array, 4 KiB aligned: row r of IXF v at data + r*stride,
+// stride = bins rounded up to 64 B, so a probe (one hash, one IXF) is three contiguous rows and a lane
+// reads one aligned 16-B unit of 16 bins.
+struct IxfDesc {
+    const uint8_t *data;
+    uint64_t seed;
+    uint32_t seg_len;
+    uint32_t bins;
+    uint32_t stride;   // bytes per row
+    uint32_t units;    // stride / 16
+    uint32_t bin_base; // first entry of this IXF in the per-bin tables
+    uint32_t pad;
+};
+
+// per-bin tables, indexed by bin_base + bin:
+//   binfo   : bit31 = merged bin, bit30 = last technical bin of a (possibly split) user bin,
+//             bits 0..29 = child IXF id for merged bins
+//   ubin    : user bin (filename index) of a leaf bin
+//   dfs_key : rank of the bin in the full depth-first traversal of the hierarchy; sorting a read's
+//             tuples by it restores the reference's emission order
+static constexpr uint32_t BINFO_MERGED = 0x80000000u;
+static constexpr uint32_t BINFO_END = 0x40000000u;
+
+// ---- flags raised by kernels (never silent) ---------------------------------------------------------
+enum : uint32_t {
+    FLAG_ALPHABET = 1u,       // character outside dna15 in the input
+    FLAG_CAND_OVERFLOW = 2u,  // syncmer candidate capacity bound violated (internal invariant)
+    FLAG_QUEUE_OVERFLOW = 4u, // work queue too small  -> host grows and reruns
+    FLAG_HITS_OVERFLOW = 8u,  // hit buffer too small   -> host grows and reruns
+    FLAG_TUPLE_OVERFLOW = 16u,// batch tuple arrays too small -> host grows and reruns
+    FLAG_DEDUP_OVERFLOW = 32u // dedup scratch too small (internal invariant)
+};
+
+// counters block (one per searcher, u32 words unless noted)
+struct Counters {
+    uint32_t flags;
+    uint32_t cursor_sync;      // dynamic work cursor of k_syncmers
+    uint32_t n_hits;
+    uint32_t n_big;
+    uint32_t q_n[16];          // work items per level
+    uint32_t q_cursor[16];     // dynamic work cursor per level
+    uint32_t pad[2];
+    unsigned long long tuple_total;   // tuples emitted so far in this batch run
+    unsigned long long n_hashes;      // distinct hashes so far
+    unsigned long long query_bytes;   // sum n_h*3*bins over work items
+    unsigned long long n_work;        // work items processed
+};
+static constexpr int MAX_LEVELS = 16;
+
+struct SyncmerArgs {
+    const uint32_t *packed;   // 2-bit bases, 16 per word, first base in the top bits
+    const uint64_t *poff;     // word offset of read r
+    const uint32_t *rlen;     // bases in read r
+    const uint64_t *hoff;     // first candidate/hash slot of read r
+    const uint32_t *hcap;     // slots of read r
+    uint64_t *cand;           // selected syncmer hashes in window order (with duplicates)
+    uint64_t *hashes;         // distinct hashes, first-occurrence order
+    uint32_t *nh;             // distinct count per read
+    uint64_t *thr;            // (size_t)(nh * ratio)
+    double ratio;
+    uint32_t *gtab;           // per-block dedup scratch for reads whose table does not fit LDS
+    uint32_t gtab_stride;     // slots per block (power of two), 0 = none
+    Counters *ctr;
+    uint32_t n_reads;
+    int k, s, t;
+};
+
+struct QueryArgs {
+    const IxfDesc *ixf;
+    const uint32_t *binfo;
+    const uint64_t *hashes;
+    const uint64_t *hoff;
+    const uint32_t *nh;
+    const uint64_t *thr;
+    const uint2 *q_in;        // (read, ixf) work items; nullptr = level 0: item i is (i, 0)
+    uint2 *q_out;
+    uint4 *hits;              // (read, global bin, count, -)
+    uint32_t *read_hits;      // tuples per read
+    uint32_t *counts_out;     // optional: raw per-bin counts of the (single) work item
+    Counters *ctr;
+    uint32_t level;
+    uint32_t n_level0;        // number of items when q_in == nullptr
+    uint32_t q_cap, hit_cap;
+};
+
+struct FinalizeArgs {
+    const uint4 *hits;
+    uint32_t *read_hits;
+    uint32_t *cursor;          // zeroed scratch, per read
+    uint32_t *roff;            // exclusive scan of read_hits (sub-batch local)
+    uint32_t *biglist;
+    const uint32_t *dfs_key;
+    const int64_t *ubin;
+    uint64_t *read_off;        // batch CSR, at the sub-batch's first read
+    int64_t *out_ub;
+    uint32_t *out_cnt;
+    uint32_t *out_key;
+    Counters *ctr;
+    uint32_t n_reads;          // reads in this sub-batch
+    uint64_t tuple_cap;
+    int is_last;
+};
+
+// launch wrappers (all asynchronous on `st`)
+void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,
+                      uint32_t n_reads, Counters *ctr, hipStream_t st);
+void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st);
+int syncmers_grid(int device);
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
+int query_grid(int device, size_t lds_bytes);
+void launch_finalize(const FinalizeArgs &a, hipStream_t st);
+void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
+void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,
+                           hipStream_t st);
+
+} // namespace taxor

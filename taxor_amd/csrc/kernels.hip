@@ -1,0 +1,745 @@
+// kernels.hip -- hand-written gfx950 kernels of the `taxor search` hot path.
+//
+//   k_pack_dna4     ASCII -> dna4 mapping -> 2-bit packing              (dna4_traits.hpp:15-18)
+//   k_syncmers      open canonical syncmer selection + wyhash + per-read dedup + threshold
+//                   (src/hashing/syncmer.cpp:80-165, taxor_search.cpp:221-237,261-263)
+//   k_query_level   one level of the HIXF traversal: IXF bulk_count for every (read, IXF) work item of the
+//                   level, split-bin tally, threshold test, emission of child work items and tuples
+//                   (hierarchical_interleaved_xor_filter.hpp:303-340)
+//   k_scan/k_scatter/k_sort_*   CSR assembly in the reference's DFS emission order
+//
+// The path is integer hashing + row gathers + byte compares: HBM-bound, no MFMA.  Lanes run across the
+// bins of a fingerprint row (16 bins = one aligned 16-B unit per lane), so every probe is three coalesced
+// row segments; hashes run in the loop; per-bin counters live in registers as packed bytes.
+#include "kernels.h"
+#include "ixf_arith.h"
+
+namespace taxor {
+
+static constexpr int BLK = 256;
+
+// ------------------------------------------------------------------------------------------------------
+// small wave / block primitives (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if ((int)lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_incl_max(int v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d);
+        if ((int)lane_id() >= d) v = max(v, t);
+    }
+    return v;
+}
+
+// exclusive prefix sum over the 256 threads of a block; *total = block sum.  scratch: >= 4 words.
+__device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *scratch, uint32_t *total)
+{
+    const uint32_t incl = wave_incl_add(v);
+    const uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63) scratch[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BLK / 64; ++i) {
+        const uint32_t x = scratch[i];
+        if (i < w) off += x;
+        tot += x;
+    }
+    *total = tot;
+    return off + incl - v;
+}
+
+// exclusive prefix max over the 256 threads (identity -1)
+__device__ __forceinline__ int block_excl_max(int v, int *scratch)
+{
+    const int incl = wave_incl_max(v);
+    const uint32_t w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane_id() == 63) scratch[w] = incl;
+    __syncthreads();
+    int off = -1;
+#pragma unroll
+    for (uint32_t i = 0; i < BLK / 64; ++i)
+        if (i < w) off = max(off, scratch[i]);
+    int prev = __shfl_up(incl, 1);
+    if (lane_id() == 0) prev = -1;
+    return max(off, prev);
+}
+
+// append one record per participating lane with a single atomic per wave (ballot + popcount).
+// Returns the slot for lanes with pred, undefined otherwise.
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t *counter)
+{
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_pack_dna4 : one block per read (grid-stride), one thread per 16-base word
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t dna4_code(uint8_t c)
+{
+    // seqan3 dna4 char_to_rank: IUPAC codes -> first base, U -> T, N -> A; both cases. 0xFF = not dna15.
+    switch (c | 0x20) {
+    case 'a': case 'r': case 'w': case 'm': case 'd': case 'h': case 'v': case 'n': return 0;
+    case 'c': case 'y': case 's': case 'b': return 1;
+    case 'g': case 'k': return 2;
+    case 't': case 'u': return 3;
+    default: return 0xFFu;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_pack_dna4(const uint8_t *__restrict__ ascii,
+                                                   const uint64_t *__restrict__ aoff,
+                                                   const uint64_t *__restrict__ poff,
+                                                   uint32_t *__restrict__ packed, uint32_t n_reads,
+                                                   Counters *ctr)
+{
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t a0 = aoff[r];
+        const uint32_t len = (uint32_t)(aoff[r + 1] - a0);
+        const uint32_t nw = ((len + 15u) >> 4);
+        const uint32_t nw_pad = (nw + 3u) & ~3u; // reads start on a 4-word (64-base) boundary
+        uint32_t *dst = packed + poff[r];
+        bool bad = false;
+        for (uint32_t w = threadIdx.x; w < nw_pad; w += BLK) {
+            uint32_t word = 0;
+            if (w < nw) {
+                const uint32_t b0 = w << 4;
+#pragma unroll
+                for (uint32_t j = 0; j < 16; ++j) {
+                    uint32_t code = 0;
+                    if (b0 + j < len) {
+                        const uint8_t ch = ascii[a0 + b0 + j];
+                        code = dna4_code(ch);
+                        // reject anything that is not a letter of dna15 (digits etc. share no case bit trick)
+                        const bool letter = (uint8_t)((ch | 0x20) - 'a') < 26;
+                        if (code == 0xFFu || !letter) { bad = true; code = 0; }
+                    }
+                    word |= code << (30u - 2u * j);
+                }
+            }
+            dst[w] = word;
+        }
+        if (__any(bad) && lane_id() == 0) atomicOr(&ctr->flags, FLAG_ALPHABET);
+    }
+}
+
+void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,
+                      uint32_t n_reads, Counters *ctr, hipStream_t st)
+{
+    if (!n_reads) return;
+    const int grid = (int)(n_reads < 8192u ? n_reads : 8192u);
+    hipLaunchKernelGGL(k_pack_dna4, dim3(grid), dim3(BLK), 0, st, ascii, aoff, poff, packed, n_reads, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_syncmers
+//
+// The reference walks the read base by base with a deque and a stateful tie rule (syncmer.cpp:116-140):
+// first window -> leftmost minimum; when the tracked minimum leaves the window -> rescan from the right
+// (rightmost minimum); otherwise a new s-mer replaces it only if strictly smaller.  Parallel form used
+// here (exact, validated against the sequential code on tie-heavy reads): for window x over s-mer starts
+// [x, x+w-1] let Lm/Rm be the leftmost/rightmost argmin.  If the minimum is unique the tracked position
+// p_x is that argmin regardless of history.  Across a run of tied windows p only changes when it drops
+// out of the window, and then becomes Rm of the first window that no longer contains it, i.e. the chain
+// q -> Rm(q+1).  So p_x = walk that chain from the nearest earlier anchor (a unique-minimum window, or
+// window 0 with p = Lm) until q >= x.  A window is an open syncmer iff p_x == x + t - 1 (syncmer.cpp:142).
+// ------------------------------------------------------------------------------------------------------
+static constexpr int SY_C = 8;                 // consecutive windows per thread in the resolve pass
+static constexpr int SY_T = BLK * SY_C;        // windows per tile
+static constexpr int SY_WORDS = SY_T / 16 + 8; // packed words staged per tile
+static constexpr int SY_LDS_TAB = 8192;        // dedup slots held in LDS
+
+__device__ __forceinline__ uint32_t revcomp32(uint32_t x, int nb)
+{
+    x = __brev(~x);
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    return x >> (32 - 2 * nb);
+}
+
+__device__ __forceinline__ uint64_t revcomp64(uint64_t x, int nb)
+{
+    x = __brevll(~x);
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    return x >> (64 - 2 * nb);
+}
+
+// n-base value starting at base `pos` (tile-local word array W, wbase = first staged word), n <= 32
+__device__ __forceinline__ uint64_t extract_bases(const uint32_t *W, uint32_t pos_word, uint32_t o, int n)
+{
+    const uint64_t hi = ((uint64_t)W[pos_word] << 32) | W[pos_word + 1];
+    const int end = 2 * (int)o + 2 * n;
+    const uint64_t mask = (n < 32) ? ((1ull << (2 * n)) - 1ull) : ~0ull;
+    if (end <= 64) return (hi >> (64 - end)) & mask;
+    const int sh = end - 64; // 1..30
+    return ((hi << sh) | (uint64_t)(W[pos_word + 2] >> (32 - sh))) & mask;
+}
+
+__device__ __forceinline__ uint32_t dedup_slot(uint64_t h, uint32_t mask)
+{
+    h ^= h >> 31;
+    h *= 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(h >> 32) & mask;
+}
+
+__global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
+{
+    __shared__ uint32_t sW[SY_WORDS];
+    __shared__ uint32_t sV[SY_T + 32];
+    __shared__ uint8_t sLm[SY_T];
+    __shared__ uint8_t sRm[SY_T];
+    __shared__ uint32_t sTab[SY_LDS_TAB];
+    __shared__ uint32_t sScr[8];
+    __shared__ int sCarry;
+    __shared__ uint32_t sRead;
+
+    const int k = a.k, s = a.s, t = a.t;
+    const int w = k - s + 1;
+    const uint32_t smask = (s < 16) ? ((1u << (2 * s)) - 1u) : 0xFFFFFFFFu;
+    const uint32_t tid = threadIdx.x;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sRead = atomicAdd(&a.ctr->cursor_sync, 1u);
+        __syncthreads();
+        const uint32_t r = sRead;
+        if (r >= a.n_reads) break;
+
+        const uint32_t L = a.rlen[r];
+        const uint32_t *__restrict__ pk = a.packed + a.poff[r];
+        const uint32_t nwords = (((L + 15u) >> 4) + 3u) & ~3u;
+        uint64_t *__restrict__ cand = a.cand + a.hoff[r];
+        uint64_t *__restrict__ outh = a.hashes + a.hoff[r];
+        const uint32_t cap = a.hcap[r];
+        const int nwin = (int)L - k + 1; // number of k-mer windows (<= 0: none)
+        uint32_t n_sel = 0;              // block-uniform
+
+        if (tid == 0) sCarry = 0;
+        for (int x0 = 0; x0 < nwin; x0 += SY_T) {
+            __syncthreads();
+            // ---- stage packed words of the tile ---------------------------------------------------
+            const uint32_t wbase = (uint32_t)x0 >> 4;
+            for (uint32_t i = tid; i < (uint32_t)SY_WORDS; i += BLK) {
+                const uint32_t wi = wbase + i;
+                sW[i] = wi < nwords ? pk[wi] : 0u;
+            }
+            __syncthreads();
+            // ---- canonical s-mer values (syncmer.cpp:103-110; the s-mer "hash" is the raw 2-bit value)
+            const int nv = min(SY_T + w - 1, (int)L - s + 1 - x0); // valid s-mer starts in this tile
+            for (int i = (int)tid; i < SY_T + w - 1; i += BLK) {
+                uint32_t v = 0xFFFFFFFFu;
+                if (i < nv) {
+                    const uint32_t pos = (uint32_t)(x0 + i);
+                    const uint32_t f = (uint32_t)extract_bases(sW, (pos >> 4) - wbase, pos & 15u, s) & smask;
+                    const uint32_t rc = revcomp32(f, s);
+                    v = min(f, rc);
+                }
+                sV[i] = v;
+            }
+            __syncthreads();
+            // ---- per window: leftmost / rightmost argmin (interleaved assignment: conflict-free LDS)
+            const int nw_tile = min(SY_T, nwin - x0);
+#pragma unroll 2
+            for (int c = 0; c < SY_C; ++c) {
+                const int xl = c * BLK + (int)tid;
+                if (xl < nw_tile) {
+                    uint32_t m = sV[xl];
+                    int lm = 0, rm = 0;
+                    for (int j = 1; j < w; ++j) {
+                        const uint32_t v = sV[xl + j];
+                        if (v < m) { m = v; lm = j; rm = j; }
+                        else if (v == m) rm = j;
+                    }
+                    sLm[xl] = (uint8_t)lm;
+                    sRm[xl] = (uint8_t)rm;
+                }
+            }
+            __syncthreads();
+            // ---- resolve the tracked position per window (chunked assignment: SY_C consecutive windows)
+            const int xs = (int)tid * SY_C;
+            int last_anchor = -1;
+            for (int c = 0; c < SY_C; ++c) {
+                const int xl = xs + c;
+                if (xl < nw_tile && (sLm[xl] == sRm[xl] || x0 + xl == 0)) last_anchor = xl;
+            }
+            const int anchor = block_excl_max(last_anchor, (int *)sScr);
+            uint32_t selmask = 0;
+            int p; // tile-local s-mer start currently tracked (may be -1: last position of the previous tile)
+            if (xs < nw_tile) {
+                p = anchor >= 0 ? anchor + (int)sLm[anchor] : sCarry - x0;
+                while (p < xs) p = (p + 1) + (int)sRm[p + 1];
+                for (int c = 0; c < SY_C; ++c) {
+                    const int xl = xs + c;
+                    if (xl >= nw_tile) break;
+                    const int lm = sLm[xl], rm = sRm[xl];
+                    if (lm == rm || x0 + xl == 0) p = xl + lm;
+                    else if (p < xl) p = xl + rm;
+                    if (p == xl + t - 1) selmask |= 1u << c;
+                }
+            }
+            __syncthreads();
+            if (xs < nw_tile && xs + SY_C >= nw_tile) sCarry = p + x0; // owner of the tile's last window
+            // ---- emit wyhash(canonical k-mer) of the selected windows, in window order --------------
+            uint32_t tot;
+            uint32_t pos = n_sel + block_excl_add((uint32_t)__popc(selmask), sScr, &tot);
+            while (selmask) {
+                const int c = __ffs((int)selmask) - 1;
+                selmask &= selmask - 1;
+                const uint32_t x = (uint32_t)(x0 + xs + c);
+                const uint64_t f = extract_bases(sW, (x >> 4) - wbase, x & 15u, k);
+                const uint64_t rc = revcomp64(f, k);
+                const uint64_t h = wyhash_u64(f < rc ? f : rc); // syncmer.cpp:144-145
+                if (pos < cap) cand[pos] = h;
+                ++pos;
+            }
+            n_sel += tot;
+        }
+        __syncthreads();
+        if (n_sel > cap) { // capacity bound (nwin / min(t, w-t+1) + 2) violated: internal invariant
+            if (tid == 0) atomicOr(&a.ctr->flags, FLAG_CAND_OVERFLOW);
+            n_sel = cap;
+        }
+
+        // ---- per-read dedup (ankerl::unordered_dense::set semantics, syncmer.cpp:157-165): keep the first
+        //      occurrence of every hash, preserve first-insertion order -------------------------------
+        uint32_t n_dist = 0;
+        if (n_sel > 0) {
+            uint32_t ts = 64;
+            while (ts < 2u * n_sel) ts <<= 1;
+            uint32_t *tab;
+            if (ts <= (uint32_t)SY_LDS_TAB) tab = sTab;
+            else if (ts <= a.gtab_stride) tab = a.gtab + (size_t)blockIdx.x * a.gtab_stride;
+            else {
+                if (tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW);
+                tab = sTab;
+                ts = SY_LDS_TAB;
+                n_sel = min(n_sel, (uint32_t)SY_LDS_TAB / 2u);
+            }
+            const uint32_t mask = ts - 1u;
+            for (uint32_t i = tid; i < ts; i += BLK) tab[i] = 0xFFFFFFFFu;
+            __syncthreads();
+            for (uint32_t i = tid; i < n_sel; i += BLK) {
+                const uint64_t h = cand[i];
+                uint32_t q = dedup_slot(h, mask);
+                for (;;) {
+                    const uint32_t cur = atomicCAS(&tab[q], 0xFFFFFFFFu, i);
+                    if (cur == 0xFFFFFFFFu) break;
+                    if (cand[cur] == h) { atomicMin(&tab[q], i); break; }
+                    q = (q + 1u) & mask;
+                }
+            }
+            __syncthreads();
+            for (uint32_t base = 0; base < n_sel; base += BLK) {
+                const uint32_t i = base + tid;
+                uint64_t h = 0;
+                uint32_t first = 0;
+                if (i < n_sel) {
+                    h = cand[i];
+                    uint32_t q = dedup_slot(h, mask);
+                    for (;;) {
+                        const uint32_t cur = tab[q];
+                        if (cur == 0xFFFFFFFFu) break; // cannot happen for an inserted key
+                        if (cand[cur] == h) { first = (cur == i); break; }
+                        q = (q + 1u) & mask;
+                    }
+                }
+                uint32_t tot;
+                const uint32_t rank = block_excl_add(first, sScr, &tot);
+                if (first) outh[n_dist + rank] = h;
+                n_dist += tot;
+            }
+        }
+        if (tid == 0) {
+            a.nh[r] = n_dist;                                                   // taxor_search.cpp:261
+            a.thr[r] = (uint64_t)((double)n_dist * a.ratio);                    // threshold.hpp:60,76-79
+            atomicAdd(&a.ctr->n_hashes, (unsigned long long)n_dist);
+        }
+    }
+}
+
+int syncmers_grid(int device)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers, BLK, 0) != hipSuccess || per < 1) per = 2;
+    return p.multiProcessorCount * per;
+}
+
+void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
+{
+    if (!a.n_reads) return;
+    hipLaunchKernelGGL(k_syncmers, dim3(grid), dim3(BLK), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_query_level
+//
+// One work item = (read, IXF).  The block stages the read's probes (rows + fingerprint, per this IXF's seed
+// and segment length) in LDS a tile at a time; thread (u, g) owns the 16-B unit u of every row and the hash
+// subset g, g+G, ...; each hash costs the thread three 16-B loads (whole block: three contiguous row
+// segments), an XOR3, and an exact zero-byte test whose 0/1 bytes accumulate in packed byte counters.
+// Tiles are <= 255 hashes so the byte counters cannot overflow before they are widened.  Counters are
+// merged through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
+// ------------------------------------------------------------------------------------------------------
+static constexpr int Q_HT = 240; // hashes per probe tile
+
+__device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
+{
+    uint32_t t = (y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    t = ~(t | y | 0x7F7F7F7Fu); // 0x80 in every byte of y that is zero
+    return t >> 7;
+}
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+__device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, const uint4 &y, const uint4 &z,
+                                                 uint32_t fp4)
+{
+    acc8.x += zero_bytes01(x.x ^ y.x ^ z.x ^ fp4);
+    acc8.y += zero_bytes01(x.y ^ y.y ^ z.y ^ fp4);
+    acc8.z += zero_bytes01(x.z ^ y.z ^ z.z ^ fp4);
+    acc8.w += zero_bytes01(x.w ^ y.w ^ z.w ^ fp4);
+}
+
+__global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // all LDS in the dynamic region (keeps its base 16-B aligned): probes | work item | per-bin counts
+    uint4 *sProbe = reinterpret_cast<uint4 *>(smem);                                // Q_HT probes
+    uint32_t *sItemP = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4));   // 16 B
+    uint32_t *sC = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4) + 16);  // stride words
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lvl = a.level;
+    const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl], a.q_cap) : a.n_level0;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *sItemP = atomicAdd(&a.ctr->q_cursor[lvl], 1u);
+        __syncthreads();
+        const uint32_t item = *sItemP;
+        if (item >= n_items) break;
+        uint32_t r, v;
+        if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
+        else { r = item; v = 0; }
+
+        const IxfDesc D = a.ixf[v];
+        const uint32_t n = a.nh[r];
+        const uint64_t thr = a.thr[r];
+        const uint64_t *__restrict__ hp = a.hashes + a.hoff[r];
+        const uint32_t units = D.units, stride = D.stride;
+
+        for (uint32_t i = tid; i < stride; i += BLK) sC[i] = 0;
+
+        // column passes: 256 units (4096 bins) per pass; almost always exactly one
+        for (uint32_t u0 = 0; u0 < units; u0 += BLK) {
+            const uint32_t upass = min(units - u0, (uint32_t)BLK);
+            const uint32_t G = BLK / upass;           // hashes processed concurrently by the block
+            const uint32_t g = tid / upass;
+            const uint32_t u = u0 + (tid - g * upass);
+            const bool active = g < G;
+            const uint8_t *__restrict__ base = D.data + (size_t)u * 16u;
+            uint32_t acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0;
+
+            for (uint32_t t0 = 0; t0 < n; t0 += Q_HT) {
+                const uint32_t nt = min((uint32_t)Q_HT, n - t0);
+                __syncthreads();
+                if (tid < nt) {
+                    const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
+                    sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                }
+                __syncthreads();
+                if (active) {
+                    uint4 acc8 = make_uint4(0, 0, 0, 0);
+                    uint32_t i = g;
+                    for (; i + 3u * G < nt; i += 4u * G) {
+                        const uint4 p0 = sProbe[i], p1 = sProbe[i + G], p2 = sProbe[i + 2u * G],
+                                    p3 = sProbe[i + 3u * G];
+                        const uint4 a0 = ld16(base + (size_t)p0.x * stride), b0 = ld16(base + (size_t)p0.y * stride),
+                                    c0 = ld16(base + (size_t)p0.z * stride);
+                        const uint4 a1 = ld16(base + (size_t)p1.x * stride), b1 = ld16(base + (size_t)p1.y * stride),
+                                    c1 = ld16(base + (size_t)p1.z * stride);
+                        const uint4 a2 = ld16(base + (size_t)p2.x * stride), b2 = ld16(base + (size_t)p2.y * stride),
+                                    c2 = ld16(base + (size_t)p2.z * stride);
+                        const uint4 a3 = ld16(base + (size_t)p3.x * stride), b3 = ld16(base + (size_t)p3.y * stride),
+                                    c3 = ld16(base + (size_t)p3.z * stride);
+                        probe_accumulate(acc8, a0, b0, c0, p0.w);
+                        probe_accumulate(acc8, a1, b1, c1, p1.w);
+                        probe_accumulate(acc8, a2, b2, c2, p2.w);
+                        probe_accumulate(acc8, a3, b3, c3, p3.w);
+                    }
+                    for (; i < nt; i += G) {
+                        const uint4 p0 = sProbe[i];
+                        const uint4 a0 = ld16(base + (size_t)p0.x * stride), b0 = ld16(base + (size_t)p0.y * stride),
+                                    c0 = ld16(base + (size_t)p0.z * stride);
+                        probe_accumulate(acc8, a0, b0, c0, p0.w);
+                    }
+                    // widen the packed byte counters (<= 240 per byte) into 32-bit counters
+                    const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[4 * q + 0] += wv[q] & 0xFFu;
+                        acc[4 * q + 1] += (wv[q] >> 8) & 0xFFu;
+                        acc[4 * q + 2] += (wv[q] >> 16) & 0xFFu;
+                        acc[4 * q + 3] += wv[q] >> 24;
+                    }
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (acc[j]) atomicAdd(&sC[u * 16u + (uint32_t)j], acc[j]);
+            }
+        }
+        __syncthreads();
+
+        if (a.counts_out)
+            for (uint32_t b = tid; b < D.bins; b += BLK) a.counts_out[b] = sC[b];
+
+        // ---- tally: hierarchical_interleaved_xor_filter.hpp:313-338 --------------------------------------
+        const uint32_t *__restrict__ bi = a.binfo + D.bin_base;
+        const uint32_t nb_round = (D.bins + 63u) & ~63u;
+        for (uint32_t b = tid; b < nb_round; b += BLK) {
+            bool push_child = false, push_hit = false;
+            uint32_t sum = 0, info = 0;
+            if (b < D.bins) {
+                info = bi[b];
+                if (info & BINFO_MERGED) {
+                    sum = sC[b];                                   // merged bins are runs of their own
+                    push_child = (uint64_t)sum >= thr;             // :321
+                } else if (info & BINFO_END) {
+                    int bb = (int)b;
+                    sum = sC[bb];
+                    while (bb > 0 && (bi[bb - 1] >> 30) == 0u) sum += sC[--bb]; // split bin: :315,325-326
+                    push_hit = (uint64_t)sum >= thr;               // :328
+                }
+            }
+            const uint32_t qs = wave_append(push_child, &a.ctr->q_n[lvl + 1]);
+            if (push_child) {
+                if (qs < a.q_cap) a.q_out[qs] = make_uint2(r, info & 0x3FFFFFFFu);
+                else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+            }
+            const uint32_t hs = wave_append(push_hit, &a.ctr->n_hits);
+            if (push_hit) {
+                if (hs < a.hit_cap) {
+                    a.hits[hs] = make_uint4(r, D.bin_base + b, sum, 0u);
+                    atomicAdd(&a.read_hits[r], 1u);
+                } else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
+            }
+        }
+        if (tid == 0) {
+            atomicAdd(&a.ctr->query_bytes, (unsigned long long)n * 3ull * D.bins);
+            atomicAdd(&a.ctr->n_work, 1ull);
+        }
+    }
+}
+
+int query_grid(int device, size_t lds_bytes)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level, BLK, lds_bytes) != hipSuccess || per < 1)
+        per = 2;
+    if (per > 8) per = 8;
+    return p.multiProcessorCount * per;
+}
+
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_query_level, dim3(grid), dim3(BLK), lds_bytes, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// finalize: per-read tuple counts -> CSR offsets -> scatter -> sort each read's tuples by DFS key
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_offsets(const FinalizeArgs a)
+{
+    __shared__ uint32_t sW[16];
+    __shared__ uint32_t sCarry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) sCarry = 0;
+    const unsigned long long base = a.ctr->tuple_total;
+    for (uint32_t b0 = 0; b0 < a.n_reads; b0 += 1024) {
+        __syncthreads();
+        const uint32_t i = b0 + tid;
+        const uint32_t v = i < a.n_reads ? a.read_hits[i] : 0u;
+        const uint32_t incl = wave_incl_add(v);
+        if (lane_id() == 63) sW[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = sCarry, tot = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t x = sW[w];
+            if (w < (tid >> 6)) off += x;
+            tot += x;
+        }
+        if (i < a.n_reads) {
+            a.roff[i] = off + incl - v;
+            a.read_off[i] = base + off + incl - v;
+        }
+        __syncthreads();
+        if (tid == 0) sCarry += tot;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long total = base + sCarry;
+        a.roff[a.n_reads] = sCarry;
+        a.ctr->tuple_total = total;
+        if (total > a.tuple_cap) atomicOr(&a.ctr->flags, FLAG_TUPLE_OVERFLOW);
+        if (a.is_last) a.read_off[a.n_reads] = total;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_scatter_hits(const FinalizeArgs a)
+{
+    const uint32_t n = min(a.ctr->n_hits, 0xFFFFFFFFu);
+    const unsigned long long base = a.ctr->tuple_total - a.roff[a.n_reads]; // first tuple of this sub-batch
+    for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
+        const uint4 h = a.hits[i];
+        const uint32_t slot = atomicAdd(&a.cursor[h.x], 1u);
+        const unsigned long long pos = base + a.roff[h.x] + slot;
+        if (pos < a.tuple_cap) {
+            a.out_key[pos] = a.dfs_key[h.y];
+            a.out_ub[pos] = a.ubin[h.y];
+            a.out_cnt[pos] = h.z;
+        }
+    }
+}
+
+// one wave per read; reads with more than 64 tuples go to the block-wide sorter
+__global__ __launch_bounds__(BLK) void k_sort_small(const FinalizeArgs a)
+{
+    const uint32_t wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * BLK) >> 6;
+    const unsigned long long base0 = a.ctr->tuple_total - a.roff[a.n_reads];
+    if (a.ctr->tuple_total > a.tuple_cap) return;
+    for (uint32_t r = wave; r < a.n_reads; r += nwaves) {
+        const uint32_t n = a.read_hits[r];
+        if (n < 2) continue;
+        if (n > 64) {
+            if (lane_id() == 0) a.biglist[atomicAdd(&a.ctr->n_big, 1u)] = r;
+            continue;
+        }
+        const unsigned long long base = base0 + a.roff[r];
+        const uint32_t l = lane_id();
+        uint32_t key = 0xFFFFFFFFu, cnt = 0;
+        int64_t ub = 0;
+        if (l < n) { key = a.out_key[base + l]; ub = a.out_ub[base + l]; cnt = a.out_cnt[base + l]; }
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += (__shfl(key, (int)j) < key) ? 1u : 0u;
+        if (l < n) { a.out_key[base + rank] = key; a.out_ub[base + rank] = ub; a.out_cnt[base + rank] = cnt; }
+    }
+}
+
+// block per big read: sorting network with ascending comparators only (flip stage + half-cleaners);
+// elements past n act as +inf and are never touched
+__device__ __forceinline__ void sort_stage(const FinalizeArgs &a, unsigned long long base, uint32_t n, uint32_t N,
+                                           uint32_t x)
+{
+    for (uint32_t i = threadIdx.x; i < N; i += BLK) {
+        const uint32_t l = i ^ x;
+        if (l > i && l < n) {
+            const uint32_t ki = a.out_key[base + i], kl = a.out_key[base + l];
+            if (kl < ki) {
+                a.out_key[base + i] = kl;
+                a.out_key[base + l] = ki;
+                const int64_t ui = a.out_ub[base + i];
+                a.out_ub[base + i] = a.out_ub[base + l];
+                a.out_ub[base + l] = ui;
+                const uint32_t ci = a.out_cnt[base + i];
+                a.out_cnt[base + i] = a.out_cnt[base + l];
+                a.out_cnt[base + l] = ci;
+            }
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(BLK) void k_sort_big(const FinalizeArgs a)
+{
+    const uint32_t nbig = a.ctr->n_big;
+    const unsigned long long base0 = a.ctr->tuple_total - a.roff[a.n_reads];
+    if (a.ctr->tuple_total > a.tuple_cap) return;
+    for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const uint32_t r = a.biglist[bi];
+        const uint32_t n = a.read_hits[r];
+        const unsigned long long base = base0 + a.roff[r];
+        uint32_t N = 1;
+        while (N < n) N <<= 1;
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= N; kk <<= 1) {
+            sort_stage(a, base, n, N, kk - 1u);                       // mirror within blocks of kk
+            for (uint32_t j = kk >> 2; j > 0; j >>= 1) sort_stage(a, base, n, N, j);
+        }
+    }
+}
+
+void launch_finalize(const FinalizeArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_scan_offsets, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(k_scatter_hits, dim3(1024), dim3(BLK), 0, st, a);
+    const uint32_t waves_needed = a.n_reads;
+    uint32_t grid = (waves_needed + 3u) / 4u;
+    if (grid > 4096u) grid = 4096u;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_sort_small, dim3(grid), dim3(BLK), 0, st, a);
+    hipLaunchKernelGGL(k_sort_big, dim3(256), dim3(BLK), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// index construction helpers
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLK) void k_fill_random(uint4 *data, uint64_t n16, uint64_t seed)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * BLK) {
+        uint64_t z0 = murmur64(seed + 2ull * i + 1ull), z1 = murmur64(seed ^ (0x9E3779B97F4A7C15ull * (2ull * i + 2ull)));
+        data[i] = make_uint4((uint32_t)z0, (uint32_t)(z0 >> 32), (uint32_t)z1, (uint32_t)(z1 >> 32));
+    }
+}
+
+void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st)
+{
+    if (!n_bytes) return;
+    hipLaunchKernelGGL(k_fill_random, dim3(8192), dim3(BLK), 0, st, reinterpret_cast<uint4 *>(data), n_bytes / 16, seed);
+}
+
+__global__ __launch_bounds__(BLK) void k_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin,
+                                                        const uint8_t *col, uint64_t rows)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * BLK + threadIdx.x; i < rows; i += (uint64_t)gridDim.x * BLK)
+        data[i * stride + bin] = col[i];
+}
+
+void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,
+                           hipStream_t st)
+{
+    if (!rows) return;
+    uint64_t grid = (rows + BLK - 1) / BLK;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_scatter_column, dim3((uint32_t)grid), dim3(BLK), 0, st, data, stride, bin, col, rows);
+}
+
+} // namespace taxor

@@ -1,0 +1,209 @@
+"""Host-side mirror (Python) of the reference's search interface on top of the C ABI.
+
+Names follow the reference: GpuIndex stands where `taxor_index<hixf_t>` does (src/main/index.hpp:25-287),
+Searcher where the worker's `membership_agent` + `threshold` do (src/main/taxor_search.cpp:196-313,
+src/hixf/build/hierarchical_interleaved_xor_filter.hpp:290-413).  All computation happens in
+libtaxor_gpu.so; this module only marshals numpy arrays."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def threshold_ratio(kmer_size=22, error_rate=0.04, percentage=-1.0):
+    """hixf::threshold::threshold + get_min_syncmer_match_ratio (threshold.hpp:22-81, syncmer_model.hpp:38-50)"""
+    r = _lib.lib().taxor_threshold_ratio(int(kmer_size), float(error_rate), float(percentage))
+    if r < 0:
+        raise ValueError(f"no syncmer threshold model for k={kmer_size}, error_rate={error_rate}")
+    return r
+
+
+def threshold(hash_count, ratio):
+    return int(_lib.lib().taxor_threshold(int(hash_count), float(ratio)))
+
+
+def classify_filter(counts):
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    keep = np.zeros(c.size, dtype=np.uint8)
+    _lib.lib().taxor_classify_filter(_p(c), c.size, _p(keep))
+    return keep.astype(bool)
+
+
+@dataclass
+class SearchResults:
+    """CSR per-read tuples in the reference's DFS emission order, before the 0.8*max filter."""
+    read_off: np.ndarray   # uint64[n_reads+1]
+    user_bin: np.ndarray   # int64[n_tuples]
+    count: np.ndarray      # uint32[n_tuples]
+    n_hashes: np.ndarray   # uint32[n_reads]   (QHASH_COUNT)
+
+    def tuples(self, r):
+        lo, hi = int(self.read_off[r]), int(self.read_off[r + 1])
+        return [(int(a), int(b)) for a, b in zip(self.user_bin[lo:hi], self.count[lo:hi])]
+
+
+def _results(res: _lib.Results) -> SearchResults:
+    n, t = int(res.n_reads), int(res.n_tuples)
+    ro = np.ctypeslib.as_array(res.read_off, shape=(n + 1,)).copy()
+    ub = np.ctypeslib.as_array(res.user_bin, shape=(t,)).copy() if t else np.zeros(0, np.int64)
+    ct = np.ctypeslib.as_array(res.count, shape=(t,)).copy() if t else np.zeros(0, np.uint32)
+    nh = np.ctypeslib.as_array(res.n_hashes, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+    return SearchResults(ro, ub, ct, nh)
+
+
+class GpuIndex:
+    """A HIXF resident in one GPU's HBM."""
+
+    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1):
+        """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)}"""
+        L = _lib.lib()
+        self._keep = []
+        arr = (_lib.IxfView * len(ixfs))()
+        for i, f in enumerate(ixfs):
+            nx = np.ascontiguousarray(f["next_ixf"], dtype=np.int64)
+            fn = np.ascontiguousarray(f["fname_idx"], dtype=np.int64)
+            assert nx.size == f["bins"] and fn.size == f["bins"]
+            d = f.get("data")
+            if d is not None:
+                d = np.ascontiguousarray(d, dtype=np.uint8)
+                assert d.size == 3 * f["seg_len"] * f["stride"], "IXF data size mismatch"
+            self._keep += [nx, fn, d]
+            arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"],
+                                  d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data)
+        view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling)
+        h = C.c_void_p()
+        check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
+        self._h = h
+        self._keep = []          # the library copied everything into HBM
+        self.device = device
+        self.k, self.s, self.t = k, s, t
+        self.n_ixf = len(ixfs)
+        self.n_user_bins = n_user_bins
+        self.shapes = [(f["bins"], f["stride"], f["seg_len"]) for f in ixfs]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().taxor_gpu_index_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def data_bytes(self):
+        return int(_lib.lib().taxor_gpu_index_data_bytes(self._h))
+
+    @property
+    def leaf_runs(self):
+        return int(_lib.lib().taxor_gpu_index_leaf_runs(self._h))
+
+    @property
+    def depth(self):
+        return int(_lib.lib().taxor_gpu_index_depth(self._h))
+
+    def fill_random(self, ixf, seed):
+        check(_lib.lib().taxor_gpu_index_fill_random(self._h, ixf, seed))
+
+    def upload_bin(self, ixf, bin_, column):
+        col = np.ascontiguousarray(column, dtype=np.uint8)
+        check(_lib.lib().taxor_gpu_index_upload_bin(self._h, ixf, bin_, _p(col), col.size))
+
+    def download_ixf(self, ixf):
+        bins, stride, seg = self.shapes[ixf]
+        out = np.empty(3 * seg * stride, dtype=np.uint8)
+        check(_lib.lib().taxor_gpu_index_download_ixf(self._h, ixf, _p(out), out.size))
+        return out
+
+
+class Searcher:
+    """One GPU-side agent: syncmers -> dedup -> threshold -> HIXF query -> per-read tuples."""
+
+    def __init__(self, index: GpuIndex, error_rate=0.04, percentage=-1.0, ratio=None, sub_batch_reads=0,
+                 sub_batch_bases=0, time_kernels=False):
+        self.index = index
+        self.ratio = threshold_ratio(index.k, error_rate, percentage) if ratio is None else float(ratio)
+        prm = _lib.SearchParams(self.ratio, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0)
+        h = C.c_void_p()
+        check(_lib.lib().taxor_gpu_searcher_create(index._h, C.byref(prm), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().taxor_gpu_searcher_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @staticmethod
+    def _batch(bases, offsets):
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        return b, o
+
+    # --- the drop-in batch call ---------------------------------------------------------------------------
+    def search_batch(self, bases, offsets) -> SearchResults:
+        b, o = self._batch(bases, offsets)
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_search_batch(self._h, _p(b), _p(o), o.size - 1, C.byref(res)))
+        return _results(res)
+
+    # --- phases -------------------------------------------------------------------------------------------
+    def upload(self, bases, offsets):
+        b, o = self._batch(bases, offsets)
+        check(_lib.lib().taxor_gpu_batch_upload(self._h, _p(b), _p(o), o.size - 1))
+
+    def run(self):
+        check(_lib.lib().taxor_gpu_batch_run(self._h))
+
+    def sync(self):
+        check(_lib.lib().taxor_gpu_batch_sync(self._h))
+
+    def fetch(self) -> SearchResults:
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_batch_fetch(self._h, C.byref(res)))
+        return _results(res)
+
+    def stats(self):
+        st = _lib.RunStats()
+        check(_lib.lib().taxor_gpu_batch_stats(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in _lib.RunStats._fields_}
+
+    def result_sizes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(_lib.lib().taxor_gpu_batch_result_sizes(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def export_device(self, read_off_ptr=None, user_bin_ptr=None, count_ptr=None, n_hashes_ptr=None):
+        """D2D copy of the last run's results into caller-owned device buffers (raw device pointers)."""
+        check(_lib.lib().taxor_gpu_batch_export_device(self._h, read_off_ptr, user_bin_ptr, count_ptr, n_hashes_ptr))
+
+    # --- stage entry points ---------------------------------------------------------------------------------
+    def seq_to_syncmers(self, bases, offsets):
+        """hashing::seq_to_syncmers for a batch -> (hash_off uint64[n+1], hashes uint64[])"""
+        b, o = self._batch(bases, offsets)
+        ho, hs = C.POINTER(C.c_uint64)(), C.POINTER(C.c_uint64)()
+        n = o.size - 1
+        check(_lib.lib().taxor_gpu_syncmers(self._h, _p(b), _p(o), n, C.byref(ho), C.byref(hs)))
+        hoff = np.ctypeslib.as_array(ho, shape=(n + 1,)).copy()
+        tot = int(hoff[n])
+        hashes = np.ctypeslib.as_array(hs, shape=(tot,)).copy() if tot else np.zeros(0, np.uint64)
+        return hoff, hashes
+
+    def ixf_bulk_count(self, ixf, hashes):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        out = np.zeros(self.index.shapes[ixf][0], dtype=np.uint32)
+        check(_lib.lib().taxor_gpu_ixf_bulk_count(self._h, ixf, _p(h), h.size, _p(out)))
+        return out
+
+    def bulk_contains(self, hashes, thr):
+        h = np.ascontiguousarray(hashes, dtype=np.uint64)
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_bulk_contains(self._h, _p(h), h.size, int(thr), C.byref(res)))
+        r = _results(res)
+        return r.user_bin, r.count

@@ -1,0 +1,218 @@
+"""Synthetic, footprint-faithful HIXF layouts with planted genomes, and seeded synthetic long reads
+(SURVEY.md section 8(d)).  No published .hixf is available offline, so tests and the bench query indexes
+produced here: same k/s/t, uint8 fingerprints, a stated number of bins per IXF and hierarchy depth; planted
+genomes are inserted by real XOR-filter construction along full root->leaf paths (including a split user
+bin and a depth-3 merged chain); every other bin is seeded pseudo-random bytes, which behaves exactly like a
+non-matching bin (false-positive rate 2^-8 per hash and bin).
+
+All construction goes through libtaxor_gpu.so's host helpers; nothing here touches oracle/."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_SEED = 20250523
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def random_genomes(n, length, seed=DEFAULT_SEED):
+    """n random ACGT genomes -> (bases uint8[n*length], offsets uint64[n+1])"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    bases = acgt[rng.integers(0, 4, size=n * length, dtype=np.uint8)]
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length))
+    return bases, offs
+
+
+def synth_reads(genomes, genome_off, n_reads, read_len, error_rate=0.04, frac_random=0.1, seed=DEFAULT_SEED,
+                threads=8, frac_reverse=0.0):
+    """ONT-like reads (40/30/30 sub/ins/del) from the genomes + a fraction of uniform random reads.
+    Returns (bases uint8[n_reads*read_len], offsets uint64[n_reads+1], origin int32[n_reads])."""
+    g = np.ascontiguousarray(genomes, dtype=np.uint8)
+    go = np.ascontiguousarray(genome_off, dtype=np.uint64)
+    bases = np.empty(n_reads * read_len, dtype=np.uint8)
+    offs = np.empty(n_reads + 1, dtype=np.uint64)
+    origin = np.empty(n_reads, dtype=np.int32)
+    rc = _lib.lib().taxor_synth_reads(_p(g), _p(go), go.size - 1, n_reads, read_len, error_rate, frac_random,
+                                      frac_reverse, seed, threads, _p(bases), bases.size, _p(offs), _p(origin))
+    _lib.check(rc)
+    return bases, offs, origin
+
+
+def seg_len_for(max_bin_elements):
+    return int(_lib.lib().taxor_ixf_seg_len(int(max_bin_elements)))
+
+
+def build_columns(bin_keys, seg_len, seed0):
+    """XOR-filter columns for several bins of one IXF under a common seed; redraws the seed like the
+    reference's reseed loop (src/hixf/build/construct_ixf.cpp:100-108) until every bin peels."""
+    L = _lib.lib()
+    seed = int(seed0) & (2**64 - 1)
+    rows = 3 * seg_len
+    for _ in range(64):
+        cols = {}
+        ok = True
+        for b, keys in bin_keys.items():
+            k = np.ascontiguousarray(keys, dtype=np.uint64)
+            col = np.zeros(rows, dtype=np.uint8)
+            if L.taxor_ixf_build_bin(_p(k), k.size, seed, seg_len, _p(col)) != 0:
+                ok = False
+                break
+            cols[b] = col
+        if ok:
+            return seed, cols
+        seed = (seed * 6364136223846793005 + 1442695040888963407) & (2**64 - 1)
+    raise RuntimeError("XOR filter construction failed for 64 seeds (duplicate keys?)")
+
+
+def _stride(bins):
+    return ((bins + 63) // 64) * 64
+
+
+def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_elems=None,
+                child_max_elems=None, seed=DEFAULT_SEED, with_split=True, with_deep=True):
+    """Build a 2-3 level HIXF layout with the planted hash sets on full root->leaf paths.
+
+    planted: list of uint64 arrays (distinct syncmer hashes of genome i).  Returns a dict:
+      ixfs: [{bins, stride, seg_len, seed, next_ixf, fname_idx, columns{bin: uint8[rows]}, fill_seed}]
+      n_user_bins, planted_user_bin[i], depth
+    Root: planted[0] split over bins 0..2 (one user bin), planted[1] a single leaf at bin 3, bins
+    4..4+n_children-1 merged (children), the rest decoy leaves.  The other planted sets go round-robin into
+    the children; in child 0 one of them is split over two bins and, with_deep, another sits in a grandchild
+    reached through a merged bin of child 0 (depth-3 chain)."""
+    planted = [np.unique(np.ascontiguousarray(p, dtype=np.uint64)) for p in planted]
+    P = len(planted)
+    assert P >= 2 and root_bins >= 4 + n_children and child_bins >= 8
+    rng = np.random.default_rng(seed)
+    next_ub = [0]
+
+    def new_ub():
+        next_ub[0] += 1
+        return next_ub[0] - 1
+
+    planted_ub = [None] * P
+    ixfs = []
+
+    def new_ixf(bins, max_elems):
+        ixfs.append(dict(bins=bins, stride=_stride(bins), keys={}, next_ixf=None,
+                         fname_idx=np.full(bins, -2, dtype=np.int64), child_of={}, max_elems=max_elems))
+        return len(ixfs) - 1
+
+    root = new_ixf(root_bins, root_max_elems)
+    # --- root leaves ---
+    b = 0
+    if with_split:
+        ub = new_ub()
+        planted_ub[0] = ub
+        for j in range(3):
+            ixfs[root]["keys"][b] = planted[0][j::3]
+            ixfs[root]["fname_idx"][b] = ub
+            b += 1
+    else:
+        ub = new_ub()
+        planted_ub[0] = ub
+        ixfs[root]["keys"][b] = planted[0]
+        ixfs[root]["fname_idx"][b] = ub
+        b = 3
+    ub = new_ub()
+    planted_ub[1] = ub
+    ixfs[root]["keys"][3] = planted[1]
+    ixfs[root]["fname_idx"][3] = ub
+    # --- children ---
+    children = []
+    for c in range(n_children):
+        ci = new_ixf(child_bins, child_max_elems)
+        children.append(ci)
+        ixfs[root]["fname_idx"][4 + c] = -1
+        ixfs[root]["child_of"][4 + c] = ci
+    rest = list(range(2, P))
+    deep_member = rest.pop() if (with_deep and len(rest) >= 2) else None
+    slot = [1] * n_children      # next free bin per child (bin 0 stays a decoy)
+    for n_, pi in enumerate(rest):
+        c = n_ % n_children
+        ci = children[c]
+        ub = new_ub()
+        planted_ub[pi] = ub
+        if n_ == 0 and with_split:   # split over two technical bins of child 0
+            for j in range(2):
+                ixfs[ci]["keys"][slot[c]] = planted[pi][j::2]
+                ixfs[ci]["fname_idx"][slot[c]] = ub
+                slot[c] += 1
+        else:
+            ixfs[ci]["keys"][slot[c]] = planted[pi]
+            ixfs[ci]["fname_idx"][slot[c]] = ub
+            slot[c] += 1
+        slot[c] += 1                 # leave a decoy bin between planted ones
+        assert slot[c] < child_bins - 2, "child_bins too small for the planted genomes"
+    if deep_member is not None:
+        gi = new_ixf(child_bins, child_max_elems)
+        c0 = children[0]
+        mb = child_bins - 2
+        ixfs[c0]["fname_idx"][mb] = -1
+        ixfs[c0]["child_of"][mb] = gi
+        ub = new_ub()
+        planted_ub[deep_member] = ub
+        ixfs[gi]["keys"][2] = planted[deep_member]
+        ixfs[gi]["fname_idx"][2] = ub
+    # --- decoy leaves get their own user bins; merged bins hold the union of their child's keys ---
+    for f in ixfs:
+        for bb in range(f["bins"]):
+            if f["fname_idx"][bb] == -2:
+                f["fname_idx"][bb] = new_ub()
+
+    def all_keys(i):
+        parts = [k for k in ixfs[i]["keys"].values()]
+        for bb, ch in ixfs[i]["child_of"].items():
+            parts.append(all_keys(ch))
+        return np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+
+    for i in range(len(ixfs) - 1, -1, -1):
+        for bb, ch in ixfs[i]["child_of"].items():
+            ixfs[i]["keys"][bb] = all_keys(ch)
+    out = []
+    for i, f in enumerate(ixfs):
+        mx = max([len(k) for k in f["keys"].values()] + [1])
+        cap = f["max_elems"] if f["max_elems"] else mx
+        assert cap >= mx, f"IXF {i}: max_elems {cap} < largest bin {mx}"
+        seg = seg_len_for(cap)
+        nonempty = {bb: k for bb, k in f["keys"].items() if len(k)}   # empty bins stay random fill
+        sd, cols = build_columns(nonempty, seg, int(rng.integers(1, 2**63)))
+        nx = np.full(f["bins"], i, dtype=np.int64)       # next_ixf_id[i][b] == i  <=>  not merged
+        for bb, ch in f["child_of"].items():
+            nx[bb] = ch
+        out.append(dict(bins=f["bins"], stride=f["stride"], seg_len=seg, seed=sd, next_ixf=nx,
+                        fname_idx=f["fname_idx"], columns=cols, fill_seed=int(rng.integers(1, 2**63))))
+    depth = 3 if deep_member is not None else 2
+    return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth)
+
+
+def materialize_host(layout):
+    """Random-fill every IXF on the host and write the planted columns -> list usable by GpuIndex and by
+    a checker (small layouts only: allocates rows*stride bytes per IXF)."""
+    res = []
+    for f in layout["ixfs"]:
+        rows = 3 * f["seg_len"]
+        rng = np.random.default_rng(f["fill_seed"])
+        data = rng.integers(0, 256, size=(rows, f["stride"]), dtype=np.uint8)
+        for b, col in f["columns"].items():
+            data[:, b] = col
+        res.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"],
+                        next_ixf=f["next_ixf"], fname_idx=f["fname_idx"], data=data.reshape(-1)))
+    return res
+
+
+def device_index(layout, k=22, s=12, t=5, device=0):
+    """Create the index directly in HBM: rows are filled by a device kernel, planted columns uploaded."""
+    from .search import GpuIndex
+    ixfs = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"],
+                 next_ixf=f["next_ixf"], fname_idx=f["fname_idx"], data=None) for f in layout["ixfs"]]
+    idx = GpuIndex(ixfs, layout["n_user_bins"], k, s, t, device)
+    for i, f in enumerate(layout["ixfs"]):
+        idx.fill_random(i, f["fill_seed"])
+        for b, col in f["columns"].items():
+            idx.upload_bin(i, b, col)
+    return idx

@@ -1,0 +1,312 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+Bit-exact: everything on this path is integer / byte / index work."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from taxor_amd import GpuIndex, Searcher, synth
+from taxor_amd._lib import TaxorError
+
+pytestmark = pytest.mark.gpu
+
+
+def _dummy_index(k=22, s=12, t=5):
+    bins, stride, seg = 64, 64, 16
+    data = np.zeros(3 * seg * stride, dtype=np.uint8)
+    return GpuIndex([dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64),
+                          fname_idx=np.arange(bins), data=data)], bins, k, s, t)
+
+
+def _cat(reads):
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, np.uint8)
+    offs = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    return bases, offs
+
+
+def _load(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as f:
+        return json.load(f)
+
+
+# ------------------------------------------------------------------------------------------------ syncmers
+def test_syncmers_golden(golden_dir):
+    g = _load(golden_dir, "syncmers.json")
+    by_kst = {}
+    for c in g["cases"]:
+        if "N" in c["seq"]:
+            continue  # the search path never sees N: dna4 turns it into A before the selector (see dna4 case)
+        by_kst.setdefault((c.get("k", g["k"]), c.get("s", g["s"]), c.get("t", g["t"])), []).append(c)
+    for (k, s, t), cases in by_kst.items():
+        idx = _dummy_index(k, s, t)
+        sr = Searcher(idx, ratio=0.5)
+        bases, offs = _cat([c["seq"].encode() for c in cases])
+        hoff, hashes = sr.seq_to_syncmers(bases, offs)
+        for i, c in enumerate(cases):
+            got = hashes[int(hoff[i]):int(hoff[i + 1])].tolist()
+            assert got == [int(h) for h in c["hashes"]], (c["name"], k, s, t)
+        sr.close()
+        idx.close()
+
+
+def test_syncmers_dna4_mapping(golden_dir):
+    g = _load(golden_dir, "syncmers.json")
+    idx = _dummy_index()
+    sr = Searcher(idx, ratio=0.5)
+    for c in g["dna4"]:
+        hoff, hashes = sr.seq_to_syncmers(*_cat([c["raw"].encode()]))
+        assert hashes.tolist() == [int(h) for h in c["hashes"]]
+    # with_N through the search path == oracle on the dna4-normalised read
+    n_case = [c for c in g["cases"] if c["name"] == "with_N"][0]
+    hoff, hashes = sr.seq_to_syncmers(*_cat([n_case["seq"].encode()]))
+    assert hashes.tolist() == orc.seq_to_syncmers(orc.dna4_normalise(n_case["seq"].encode())).tolist()
+    with pytest.raises(TaxorError) as e:
+        sr.seq_to_syncmers(*_cat([b"ACGTACGTACGTACGTACGTACGTAC#GT"]))
+    assert e.value.code == -3
+    sr.close()
+    idx.close()
+
+
+def _lowcomplex(rng, n):
+    parts, tot = [], 0
+    while tot < n:
+        c = rng.random()
+        if c < 0.35:
+            p = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(5, 80))).astype(np.uint8))
+        elif c < 0.6:
+            p = bytes([int(rng.choice(list(b"ACGT")))]) * int(rng.integers(5, 120))
+        else:
+            u = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(2, 12))).astype(np.uint8))
+            p = u * int(rng.integers(3, 60))
+        parts.append(p)
+        tot += len(p)
+    return b"".join(parts)[:n]
+
+
+@pytest.mark.parametrize("kst", [(22, 12, 5), (16, 8, 4), (30, 12, 9), (28, 14, 7), (22, 12, 1), (22, 12, 11), (32, 16, 8)])
+def test_syncmers_vs_oracle_ragged_and_tie_heavy(kst):
+    k, s, t = kst
+    rng = np.random.default_rng(k * 100 + s)
+    reads = [b"", b"A", b"ACGT" * 5]
+    reads += [bytes(rng.choice(list(b"ACGT"), size=n).astype(np.uint8)) for n in
+              (k - 1, k, k + 1, 2 * k, 100, 2047, 2048, 2049, 2048 + k - 1, 2048 + k, 4096 + k - 1, 5000, 20011)]
+    reads += [_lowcomplex(rng, int(n)) for n in rng.integers(k, 9000, size=40)]
+    reads += [b"A" * 7000, b"AC" * 3000, b"TTAGGG" * 1500, (b"ACGTTGCA" * 2 + b"G") * 400]
+    idx = _dummy_index(k, s, t)
+    sr = Searcher(idx, ratio=0.5, sub_batch_reads=7)      # several sub-batches
+    hoff, hashes = sr.seq_to_syncmers(*_cat(reads))
+    for i, rd in enumerate(reads):
+        want = orc.seq_to_syncmers(rd, k, s, t)
+        got = hashes[int(hoff[i]):int(hoff[i + 1])]
+        assert got.tolist() == want.tolist(), (i, len(rd), got.size, want.size)
+    sr.close()
+    idx.close()
+
+
+def test_syncmers_long_reads_global_dedup_table():
+    """reads whose dedup table exceeds LDS (n_sel > 4096) take the global-memory table"""
+    rng = np.random.default_rng(11)
+    unit = bytes(rng.choice(list(b"ACGT"), size=30000).astype(np.uint8))
+    reads = [bytes(rng.choice(list(b"ACGT"), size=300000).astype(np.uint8)),
+             unit * 6,                                   # every hash occurs 6 times
+             bytes(rng.choice(list(b"ACGT"), size=70000).astype(np.uint8))]
+    idx = _dummy_index()
+    sr = Searcher(idx, ratio=0.5)
+    hoff, hashes = sr.seq_to_syncmers(*_cat(reads))
+    for i, rd in enumerate(reads):
+        want = orc.seq_to_syncmers(rd)
+        got = hashes[int(hoff[i]):int(hoff[i + 1])]
+        assert got.size == want.size and np.array_equal(got, want), (i, got.size, want.size)
+    sr.close()
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------------- bulk_count
+@pytest.mark.parametrize("bins", [1, 63, 64, 65, 192, 200, 1000, 1024, 4096, 5000])
+def test_ixf_bulk_count_vs_oracle(bins):
+    rng = np.random.default_rng(bins)
+    stride = ((bins + 63) // 64) * 64
+    planted = {b: np.unique(rng.integers(0, 2**63, size=500, dtype=np.uint64))
+               for b in sorted({0, bins // 2, bins - 1})}
+    seg = synth.seg_len_for(700)
+    seed, cols = synth.build_columns(planted, seg, 99 + bins)
+    data = rng.integers(0, 256, size=(3 * seg, stride), dtype=np.uint8)
+    for b, c in cols.items():
+        data[:, b] = c
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=seed, next_ixf=np.zeros(bins, np.int64),
+               fname_idx=np.arange(bins), data=data.reshape(-1))
+    idx = GpuIndex([ixf], bins)
+    sr = Searcher(idx, ratio=0.5)
+    h = orc.Hixf([ixf], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    for n in (0, 1, 2, 239, 240, 241, 481, 1500):
+        keys = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+        if n >= 240:
+            keys[: n // 2] = planted[0][: n // 2] if n // 2 <= planted[0].size else keys[: n // 2]
+        got = sr.ixf_bulk_count(0, keys)
+        want = h.ixf_bulk_count(0, keys)
+        assert np.array_equal(got, want), (bins, n)
+    for b, ks in planted.items():
+        assert sr.ixf_bulk_count(0, ks)[b] == ks.size
+    assert np.array_equal(idx.download_ixf(0), data.reshape(-1))
+    sr.close()
+    idx.close()
+
+
+# ------------------------------------------------------------------------------------------- bulk_contains
+def test_toy_hixf_golden(golden_dir):
+    g = _load(golden_dir, "toy_hixf.json")
+    hx = g["hixf"]
+    ixfs = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"],
+                 next_ixf=np.array(hx["next_ixf"][i]), fname_idx=np.array(hx["fname_idx"][i]),
+                 data=np.array(f["data"], dtype=np.uint8)) for i, f in enumerate(hx["ixfs"])]
+    idx = GpuIndex(ixfs, 6)
+    assert idx.depth == 3 and idx.leaf_runs == 9
+    sr = Searcher(idx, ratio=0.5)
+    for c in g["cases"]:
+        hoff, hashes = sr.seq_to_syncmers(*_cat([c["read"].encode()]))
+        assert hashes.size == c["n_hashes"]
+        ub, cnt = sr.bulk_contains(hashes, c["thr"])
+        assert [[int(a), int(b)] for a, b in zip(ub, cnt)] == c["result"]
+    # and the whole driver at the two error rates
+    for err in (0.04, 0.1):
+        cases = [c for c in g["cases"] if c["err"] == err]
+        s2 = Searcher(idx, error_rate=err, sub_batch_reads=5)
+        res = s2.search_batch(*_cat([c["read"].encode() for c in cases]))
+        for i, c in enumerate(cases):
+            assert res.n_hashes[i] == c["n_hashes"]
+            assert [list(x) for x in res.tuples(i)] == c["result"]
+        s2.close()
+    sr.close()
+    idx.close()
+
+
+def _planted_setup(seed, n_genomes=9, glen=30000, root_bins=70, child_bins=48, n_children=3):
+    g, go = synth.random_genomes(n_genomes, glen, seed=seed)
+    hidx = _dummy_index()
+    hs = Searcher(hidx, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(n_genomes)]
+    hs.close()
+    hidx.close()
+    lay = synth.make_layout(planted, root_bins=root_bins, child_bins=child_bins, n_children=n_children, seed=seed)
+    host = synth.materialize_host(lay)
+    return g, go, lay, host
+
+
+def _compare(res, oracle_out, n):
+    nh, off, ub, cnt, _ = oracle_out
+    assert np.array_equal(res.n_hashes, nh)
+    assert np.array_equal(res.read_off, off)
+    assert np.array_equal(res.user_bin, ub)
+    assert np.array_equal(res.count, cnt)
+
+
+def test_search_batch_vs_oracle_planted_hierarchy():
+    g, go, lay, host = _planted_setup(5)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, origin = synth.synth_reads(g, go, 600, 1800, error_rate=0.02, frac_random=0.15, seed=3)
+    # ragged extras: empty read, shorter than k (threshold 0 -> every leaf run reported), == k, IUPAC codes
+    extra = [b"", b"ACGTACGTAC", bytes(g[:22]), bytes(g[100:160]), b"ACGTNRYKMSWBDHVNacgtnn" * 20,
+             bytes(g[int(go[3]):int(go[3]) + 5000])]
+    all_reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(600)] + extra
+    B, O = _cat(all_reads)
+    Bn = np.frombuffer(orc.dna4_normalise(B.tobytes()), dtype=np.uint8)
+    for err, sub in ((0.04, 0), (0.04, 37), (0.1, 64), (0.2, 1000)):
+        sr = Searcher(idx, error_rate=err, sub_batch_reads=sub)
+        res = sr.search_batch(B, O)
+        want = h.search_batch(Bn, O, err=err, threads=4)
+        _compare(res, want, len(all_reads))
+        # positive control: reads drawn from a planted genome report that genome's user bin
+        hit = tot = 0
+        for i in range(600):
+            if origin[i] >= 0:
+                tot += 1
+                hit += lay["planted_user_bin"][origin[i]] in [u for u, _ in res.tuples(i)]
+        assert hit > 0.8 * tot, (err, hit, tot)
+        # the short reads report every leaf run of the hierarchy, count 0 or small
+        assert len(res.tuples(601)) == idx.leaf_runs
+        sr.close()
+    # percentage model
+    sr = Searcher(idx, percentage=0.3)
+    _compare(sr.search_batch(B, O), h.search_batch(Bn, O, percentage=0.3, threads=4), len(all_reads))
+    sr.close()
+    idx.close()
+
+
+def test_threshold_zero_flood_grows_buffers():
+    """many reads shorter than k: each reports every leaf run (taxor quirk) -> hit/queue/tuple
+    buffers overflow their first sizing and the library must grow and rerun, never truncate"""
+    g, go, lay, host = _planted_setup(8, n_genomes=5, glen=8000, root_bins=200, child_bins=64, n_children=40)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    reads = [b"ACGTACGTACGTACG"] * 300 + [bytes(g[:3000])] * 3
+    B, O = _cat(reads)
+    sr = Searcher(idx, sub_batch_reads=128)
+    res = sr.search_batch(B, O)
+    _compare(res, h.search_batch(B, O, threads=4), len(reads))
+    assert int(res.read_off[-1]) >= 300 * idx.leaf_runs
+    # idempotence: same batch again on the same searcher
+    res2 = sr.search_batch(B, O)
+    assert np.array_equal(res.user_bin, res2.user_bin) and np.array_equal(res.count, res2.count)
+    sr.close()
+    idx.close()
+
+
+def test_wide_ixf_many_tuples_sorted_segments():
+    """reads with > 64 tuples take the block-wide sorter; order must still be the reference's DFS order"""
+    rng = np.random.default_rng(2)
+    bins = 700
+    planted = {b: np.unique(rng.integers(0, 2**63, size=64, dtype=np.uint64)) for b in (3,)}
+    seg = synth.seg_len_for(100)
+    seed, cols = synth.build_columns(planted, seg, 7)
+    child_bins = 130
+    root = dict(bins=bins, stride=704, seg_len=seg, seed=seed, next_ixf=np.zeros(bins, np.int64),
+                fname_idx=np.arange(bins, dtype=np.int64),
+                data=rng.integers(0, 256, size=3 * seg * 704, dtype=np.uint8))
+    # two merged bins in the middle -> children with their own leaves
+    root["fname_idx"][100] = -1
+    root["next_ixf"][100] = 1
+    root["fname_idx"][400] = -1
+    root["next_ixf"][400] = 2
+    ch = [dict(bins=child_bins, stride=192, seg_len=seg, seed=5 + i, next_ixf=np.full(child_bins, i + 1, np.int64),
+               fname_idx=np.arange(bins + i * child_bins, bins + (i + 1) * child_bins, dtype=np.int64),
+               data=rng.integers(0, 256, size=3 * seg * 192, dtype=np.uint8)) for i in range(2)]
+    ixfs = [root] + ch
+    idx = GpuIndex(ixfs, bins + 2 * child_bins)
+    h = orc.Hixf(ixfs, [f["next_ixf"] for f in ixfs], [f["fname_idx"] for f in ixfs])
+    sr = Searcher(idx, ratio=0.5)
+    for n, thr in ((300, 0), (300, 1), (300, 2), (2000, 8), (2000, 9)):
+        keys = rng.integers(0, 2**63, size=n, dtype=np.uint64)
+        ub, cnt = sr.bulk_contains(keys, thr)
+        wub, wcnt, _ = h.bulk_contains(keys, thr)
+        assert np.array_equal(ub, wub) and np.array_equal(cnt, wcnt), (n, thr, ub.size, wub.size)
+    sr.close()
+    idx.close()
+
+
+def test_device_built_index_matches_host_copy():
+    """index created directly in HBM (fill kernel + column uploads) == what download hands to the oracle"""
+    g, go, lay, _ = _planted_setup(21, n_genomes=6, glen=12000)
+    idx = synth.device_index(lay)
+    host = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], next_ixf=f["next_ixf"],
+                 fname_idx=f["fname_idx"], data=idx.download_ixf(i)) for i, f in enumerate(lay["ixfs"])]
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, origin = synth.synth_reads(g, go, 300, 2500, error_rate=0.02, frac_random=0.1, seed=4)
+    sr = Searcher(idx, time_kernels=True)
+    sr.upload(bases, offs)
+    sr.run()
+    sr.sync()
+    res = sr.fetch()
+    want = h.search_batch(bases, offs, threads=4)
+    _compare(res, want, 300)
+    st = sr.stats()
+    assert st["n_reads"] == 300 and st["n_bases"] == 300 * 2500
+    assert st["n_hashes"] == int(want[0].sum()) and st["n_tuples"] == want[2].size
+    assert st["query_bytes"] == want[4]                       # algorithmic gather bytes, SURVEY 8(d)
+    assert st["algorithmic_bytes"] == want[4] + 300 * 625 + 8 * 300 + 12 * want[2].size
+    assert st["query_ms"] > 0 and st["query_launches"] == idx.depth
+    sr.close()
+    idx.close()
