@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- `taxor search` hot path on MI355X: Mbp/s classified against a GTDB-class k22/s12 HIXF.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path (syncmers -> dedup -> threshold -> level-synchronous HIXF query -> DFS
+ordered per-read tuples) over one batch of synthetic long reads that is already resident in HBM (2-bit
+packed); with N>1 every rank holds a replica of the index, classifies its own shard of reads (weak scaling)
+and the per-read results are gathered on rank 0 over RCCL inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : k_query_level (dominant kernel) algorithmic gather bytes / its HIP-event time vs 8 TB/s HBM
+  cpu_baseline : the CPU oracle (oracle/, a port of the reference path) timed on this box's host cores on a
+                 bounded sample of the same reads and index; also used to re-check parity on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: root_bins, child_bins, n_children, total index bytes, reads/step, read_len
+    # GTDB-220 k22/s12 is 113 GB (README.md:51); RefSeq-ABFV 9.9 GB (:52); Genbank-viral 373 MB (:50)
+    "gtdb": dict(root_bins=1024, child_bins=128, n_children=1020, total_bytes=113e9, root_frac=0.40,
+                 reads=131072, read_len=10000),
+    "refseq": dict(root_bins=512, child_bins=64, n_children=508, total_bytes=9.9e9, root_frac=0.40,
+                   reads=131072, read_len=10000),
+    "viral": dict(root_bins=256, child_bins=64, n_children=252, total_bytes=373e6, root_frac=0.40,
+                  reads=131072, read_len=5000),
+    "tiny": dict(root_bins=64, child_bins=32, n_children=8, total_bytes=8e6, root_frac=0.40,
+                 reads=2048, read_len=3000),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("TAXOR_BENCH_WORKLOAD", "gtdb"), choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=int, default=0, help="reads per step and GPU (0 = workload default)")
+    ap.add_argument("--read-len", type=int, default=0)
+    ap.add_argument("--genomes", type=int, default=32)
+    ap.add_argument("--genome-len", type=int, default=1000000)
+    ap.add_argument("--read-error", type=float, default=0.02)
+    ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--traffic-bytes", type=float, default=None,
+                    help="HBM bytes per k_query_level launch from a separate rocprofv3 --pmc pass")
+    args = ap.parse_args()
+
+    import torch                      # first: its bundled HIP runtime is the one the process uses
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from taxor_amd import GpuIndex, Searcher, synth
+
+    wl = dict(WORKLOADS[args.workload])
+    n_reads = args.reads or wl["reads"]
+    read_len = args.read_len or wl["read_len"]
+    k, s, t = 22, 12, 5
+    ncpu = os.cpu_count() or 8
+
+    # ---- planted genomes and their syncmer hashes (hashed on the GPU; same seed on every rank) -------------
+    t0 = time.time()
+    g, go = synth.random_genomes(args.genomes, args.genome_len, seed=synth.DEFAULT_SEED)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins, k, s, t,
+                     device=local_rank)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(args.genomes)]
+    hs.close()
+    dummy.close()
+    log(f"{args.genomes} genomes x {args.genome_len} bp hashed on GPU: {int(hoff[-1])} syncmers, {time.time()-t0:.1f}s")
+
+    # ---- footprint-faithful layout -----------------------------------------------------------------------------
+    t0 = time.time()
+    root_rows = wl["total_bytes"] * wl["root_frac"] / wl["root_bins"]
+    child_rows = wl["total_bytes"] * (1 - wl["root_frac"]) / ((wl["n_children"] + 1) * max(64, wl["child_bins"]))
+    root_max = max(int((root_rows - 32) / 1.23), 8)
+    child_max = max(int((child_rows - 32) / 1.23), 8)
+    need_root = max(sum(len(p) for p in planted[2:]) // max(1, min(wl["n_children"], len(planted) - 2)) * 2,
+                    max(len(p) for p in planted))
+    root_max = max(root_max, need_root)
+    child_max = max(child_max, max(len(p) for p in planted) * 2)
+    lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
+                            n_children=wl["n_children"], root_max_elems=root_max, child_max_elems=child_max,
+                            seed=synth.DEFAULT_SEED)
+    idx = synth.device_index(lay, k, s, t, device=local_rank)
+    log(f"index in HBM: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs, depth {idx.depth}, root {wl['root_bins']} bins, "
+        f"children {wl['child_bins']} bins, {time.time()-t0:.1f}s")
+
+    # ---- reads of this rank's shard (seed + rank), resident in HBM before the timed region -----------------------
+    t0 = time.time()
+    bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
+                                            seed=synth.DEFAULT_SEED + rank, threads=ncpu)
+    log(f"{n_reads} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
+    sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+    t0 = time.time()
+    sr.upload(bases, offs)
+    t_upload = time.time() - t0
+
+    gather_bufs = {}
+
+    def gather_results():
+        """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
+        if world == 1:
+            return
+        nr, nt = sr.result_sizes()
+        dev = torch.device("cuda", local_rank)
+        sizes = torch.tensor([nr, nt], dtype=torch.int64, device=dev)
+        all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(all_sizes, sizes)
+        mine = [torch.empty(nr + 1, dtype=torch.int64, device=dev), torch.empty(max(nt, 1), dtype=torch.int64, device=dev),
+                torch.empty(max(nt, 1), dtype=torch.int32, device=dev), torch.empty(max(nr, 1), dtype=torch.int32, device=dev)]
+        sr.export_device(mine[0].data_ptr(), mine[1].data_ptr(), mine[2].data_ptr(), mine[3].data_ptr())
+        ops = []
+        if rank == 0:
+            for p in range(1, world):
+                pr, pt = int(all_sizes[p][0]), int(all_sizes[p][1])
+                bufs = [torch.empty(pr + 1, dtype=torch.int64, device=dev), torch.empty(max(pt, 1), dtype=torch.int64, device=dev),
+                        torch.empty(max(pt, 1), dtype=torch.int32, device=dev), torch.empty(max(pr, 1), dtype=torch.int32, device=dev)]
+                gather_bufs[p] = bufs
+                ops += [dist.P2POp(dist.irecv, b, p) for b in bufs]
+        else:
+            ops += [dist.P2POp(dist.isend, b, 0) for b in mine]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def step():
+        sr.run()
+        sr.sync()
+        gather_results()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    q_ms = q_bytes = 0.0
+    q_launches = 0
+    for _ in range(args.steps):
+        step()
+        st = sr.stats()
+        q_ms += st["query_ms"]
+        q_bytes += st["query_bytes"]
+        q_launches += st["query_launches"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    st = sr.stats()
+    total_bases = float(n_reads) * read_len * world * args.steps
+    value = total_bases / elapsed / 1e6
+
+    out = None
+    if rank == 0:
+        achieved = q_bytes / (q_ms * 1e-3) / 1e9 if q_ms > 0 else 0.0
+        res = sr.fetch()
+        classified = int(((res.read_off[1:] - res.read_off[:-1]) > 0).sum())
+        out = {
+            "metric": "Mbp/s classified (taxor search) vs GTDB k22/s12", "value": round(value, 2), "unit": "Mbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-class synthetic HIXF k22/s12/t5, {idx.data_bytes/1e9:.1f} GB resident, "
+                                   f"root {wl['root_bins']} bins / children {wl['child_bins']} bins / depth {idx.depth}, "
+                                   f"{n_reads} reads x {read_len} bp per GPU per step",
+                       "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "root_bins": wl["root_bins"],
+                       "child_bins": wl["child_bins"], "reads_per_gpu": n_reads, "read_len": read_len,
+                       "read_error": args.read_error, "search_error_rate": args.error_rate,
+                       "planted_genomes": args.genomes, "sharding": "reads by rank, index replicated",
+                       "hashes_per_read": round(st["n_hashes"] / max(1, n_reads), 1),
+                       "tuples_per_read": round(st["n_tuples"] / max(1, n_reads), 3),
+                       "reads_with_hits": classified, "work_items_per_read": round(st["n_work_items"] / max(1, n_reads), 3)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": args.traffic_bytes, "kernel": "k_query_level",
+                         "launches": q_launches, "avg_launch_ms": round(q_ms / max(1, q_launches), 4),
+                         "algorithmic_bytes_per_launch": round(q_bytes / max(1, q_launches), 1),
+                         "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
+            "stage_ms_last_step": {"syncmers": round(st["syncmer_ms"], 3), "query": round(st["query_ms"], 3),
+                                   "finalize": round(st["finalize_ms"], 3), "total": round(st["total_ms"], 3)},
+            "pcie_inclusive": {"upload_s": round(t_upload, 3),
+                               "value": round(float(n_reads) * read_len / (t_upload + elapsed / args.steps) / 1e6, 2),
+                               "unit": "Mbp/s", "note": "ASCII bases from pageable host memory + on-device pack, 1 GPU"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu)
+        print(json.dumps(out), flush=True)
+    sr.close()
+    idx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
+    """The CPU oracle (a port of the reference path) on a bounded sample of the same reads + index, same box."""
+    from oracle import oracle as orc
+    threads = min(ncpu, 32)                      # the reference caps --threads at 32 (taxor_search.cpp:51-55)
+    # host copy of the IXFs the sample can visit: the root plus every IXF holding a planted path; the rest get
+    # untouched virtual memory (never read: the traversal enters a child only when its merged bin passes the
+    # threshold, which random fingerprints cannot)
+    needed = {0}
+    for i, f in enumerate(lay["ixfs"]):
+        if f["columns"] and i > 0:
+            needed.add(i)
+    try:
+        host = []
+        for i, f in enumerate(lay["ixfs"]):
+            nbytes = 3 * f["seg_len"] * f["stride"]
+            data = idx.download_ixf(i) if i in needed else np.empty(nbytes, dtype=np.uint8)
+            host.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], data=data))
+        h = orc.Hixf(host, [f["next_ixf"] for f in lay["ixfs"]], [f["fname_idx"] for f in lay["ixfs"]])
+    except MemoryError as e:
+        return {"value": None, "unit": "Mbp/s", "cores": threads, "kind": "port", "sample": f"skipped: {e}"}
+
+    def run(n):
+        t0 = time.perf_counter()
+        o = h.search_batch(bases[: n * read_len], offs[: n + 1], err=args.error_rate, threads=threads)
+        return time.perf_counter() - t0, o
+
+    n = min(256 * threads // 8 + 64, len(offs) - 1)
+    dt, o = run(n)
+    n2 = int(min(len(offs) - 1, max(n, n * args.cpu_seconds / max(dt, 1e-3))))
+    if n2 > n:
+        n = n2
+        dt, o = run(n)
+    nh, off, ub, cnt, _ = o
+    lo = int(res.read_off[n])
+    same = (np.array_equal(res.n_hashes[:n], nh) and np.array_equal(res.read_off[: n + 1], off)
+            and np.array_equal(res.user_bin[:lo], ub) and np.array_equal(res.count[:lo], cnt))
+    if not same:
+        raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
+    return {"value": round(n * read_len / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} of the step's reads ({n*read_len/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
+                      f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
+
+
+if __name__ == "__main__":
+    main()

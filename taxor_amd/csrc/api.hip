@@ -557,6 +557,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     f.ctr = s->d_ctr;
     f.n_reads = n_reads;
     f.tuple_cap = s->tuple_cap;
+    f.hit_cap = s->hit_cap;
     f.is_last = is_last;
     size_t slot;
     if (ev_begin(s, 2, &slot)) return TAXOR_E_HIP;

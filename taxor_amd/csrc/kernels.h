@@ -106,6 +106,7 @@ struct FinalizeArgs {
     Counters *ctr;
     uint32_t n_reads;          // reads in this sub-batch
     uint64_t tuple_cap;
+    uint32_t hit_cap;
     int is_last;
 };
 

@@ -614,7 +614,9 @@ __global__ __launch_bounds__(1024) void k_scan_offsets(const FinalizeArgs a)
 
 __global__ __launch_bounds__(BLK) void k_scatter_hits(const FinalizeArgs a)
 {
-    const uint32_t n = min(a.ctr->n_hits, 0xFFFFFFFFu);
+    // after a queue/hit overflow the host grows the buffers and reruns; nothing here may index past hit_cap
+    if (a.ctr->flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW)) return;
+    const uint32_t n = min(a.ctr->n_hits, a.hit_cap);
     const unsigned long long base = a.ctr->tuple_total - a.roff[a.n_reads]; // first tuple of this sub-batch
     for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
         const uint4 h = a.hits[i];
@@ -634,7 +636,7 @@ __global__ __launch_bounds__(BLK) void k_sort_small(const FinalizeArgs a)
     const uint32_t wave = (blockIdx.x * BLK + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * BLK) >> 6;
     const unsigned long long base0 = a.ctr->tuple_total - a.roff[a.n_reads];
-    if (a.ctr->tuple_total > a.tuple_cap) return;
+    if (a.ctr->tuple_total > a.tuple_cap || (a.ctr->flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW))) return;
     for (uint32_t r = wave; r < a.n_reads; r += nwaves) {
         const uint32_t n = a.read_hits[r];
         if (n < 2) continue;
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(BLK) void k_sort_big(const FinalizeArgs a)
 {
     const uint32_t nbig = a.ctr->n_big;
     const unsigned long long base0 = a.ctr->tuple_total - a.roff[a.n_reads];
-    if (a.ctr->tuple_total > a.tuple_cap) return;
+    if (a.ctr->tuple_total > a.tuple_cap || (a.ctr->flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW))) return;
     for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const uint32_t r = a.biglist[bi];
         const uint32_t n = a.read_hits[r];
