@@ -29,14 +29,16 @@ if ROOT not in sys.path:
 WORKLOADS = {
     # name: root_bins, child_bins, n_children, total index bytes, reads/step, read_len
     # GTDB-220 k22/s12 is 113 GB (README.md:51); RefSeq-ABFV 9.9 GB (:52); Genbank-viral 373 MB (:50)
+    # planted genomes are sized so that one step's reads cover them only ~2.5x (131072 x 10 kb over 512 Mbp):
+    # little row reuse between reads, like a diverse metagenomic sample
     "gtdb": dict(root_bins=1024, child_bins=128, n_children=1020, total_bytes=113e9, root_frac=0.40,
-                 reads=131072, read_len=10000),
+                 reads=131072, read_len=10000, genomes=128, genome_len=4000000),
     "refseq": dict(root_bins=512, child_bins=64, n_children=508, total_bytes=9.9e9, root_frac=0.40,
-                   reads=131072, read_len=10000),
+                   reads=131072, read_len=10000, genomes=64, genome_len=2000000),
     "viral": dict(root_bins=256, child_bins=64, n_children=252, total_bytes=373e6, root_frac=0.40,
-                  reads=131072, read_len=5000),
+                  reads=131072, read_len=5000, genomes=64, genome_len=100000),
     "tiny": dict(root_bins=64, child_bins=32, n_children=8, total_bytes=8e6, root_frac=0.40,
-                 reads=2048, read_len=3000),
+                 reads=2048, read_len=3000, genomes=8, genome_len=50000),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -54,8 +56,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("TAXOR_BENCH_WORKLOAD", "gtdb"), choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=int, default=0, help="reads per step and GPU (0 = workload default)")
     ap.add_argument("--read-len", type=int, default=0)
-    ap.add_argument("--genomes", type=int, default=32)
-    ap.add_argument("--genome-len", type=int, default=1000000)
+    ap.add_argument("--genomes", type=int, default=0, help="planted genomes (0 = workload default)")
+    ap.add_argument("--genome-len", type=int, default=0)
     ap.add_argument("--read-error", type=float, default=0.02)
     ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -85,6 +87,8 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     n_reads = args.reads or wl["reads"]
     read_len = args.read_len or wl["read_len"]
+    args.genomes = args.genomes or wl["genomes"]
+    args.genome_len = args.genome_len or wl["genome_len"]
     k, s, t = 22, 12, 5
     ncpu = os.cpu_count() or 8
 

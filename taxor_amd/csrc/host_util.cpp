@@ -77,26 +77,33 @@ void taxor_classify_filter(const uint32_t *count, uint64_t n, uint8_t *keep)
 uint64_t taxor_ixf_seg_len(uint64_t max_bin_elements) { return taxor::ixf_seg_len(max_bin_elements); }
 
 // XOR-filter construction for one bin: peel the 3-uniform hypergraph, assign fingerprints in reverse
-// (the algorithm family of src/main/xorfilter.hpp:142-334; queue formulation).
+// (the algorithm family of src/main/xorfilter.hpp:142-334; queue formulation).  The dense per-row scratch is
+// kept per thread and only the touched rows are cleared, so sparse bins of a very tall IXF cost O(n).
 int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint8_t *column)
 {
     const uint64_t rows = 3 * seg_len;
     std::memset(column, 0, rows);
     if (n == 0) return 0;
     if (seg_len == 0 || seg_len > 0x55555555ull) return 1;
-    std::vector<uint32_t> cnt(rows, 0);
-    std::vector<uint64_t> xr(rows, 0);
+    static thread_local std::vector<uint32_t> cnt;
+    static thread_local std::vector<uint64_t> xr;
+    if (cnt.size() < rows) {
+        cnt.assign(rows, 0);
+        xr.assign(rows, 0);
+    }
+    std::vector<uint32_t> touched;
+    touched.reserve(3 * n);
     for (uint64_t i = 0; i < n; ++i) {
         const taxor::ixf_probe p = taxor::ixf_probe_key(keys[i], seed, (uint32_t)seg_len);
         for (int j = 0; j < 3; ++j) {
-            cnt[p.row[j]]++;
+            if (cnt[p.row[j]]++ == 0) touched.push_back(p.row[j]);
             xr[p.row[j]] ^= keys[i];
         }
     }
     std::vector<uint32_t> queue;
-    queue.reserve(rows);
-    for (uint64_t r = 0; r < rows; ++r)
-        if (cnt[r] == 1) queue.push_back((uint32_t)r);
+    queue.reserve(touched.size());
+    for (uint32_t r : touched)
+        if (cnt[r] == 1) queue.push_back(r);
     std::vector<uint64_t> st_key;
     std::vector<uint32_t> st_row;
     st_key.reserve(n);
@@ -115,6 +122,10 @@ int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_
             xr[rr] ^= key;
             if (cnt[rr] == 1) queue.push_back(rr);
         }
+    }
+    for (uint32_t r : touched) { // leave the scratch clean for the next call
+        cnt[r] = 0;
+        xr[r] = 0;
     }
     if (st_key.size() != n) return 1; // not peelable under this seed (or duplicate keys)
     for (size_t i = st_key.size(); i-- > 0;) {
