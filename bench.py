@@ -29,10 +29,10 @@ if ROOT not in sys.path:
 WORKLOADS = {
     # name: root_bins, child_bins, n_children, total index bytes, reads/step, read_len
     # GTDB-220 k22/s12 is 113 GB (README.md:51); RefSeq-ABFV 9.9 GB (:52); Genbank-viral 373 MB (:50)
-    # planted genomes are sized so that one step's reads cover them only ~2.5x (131072 x 10 kb over 512 Mbp):
+    # planted genomes are sized so that one step's reads cover them only ~2.5x (131072 x 10 kb over 384 Mbp):
     # little row reuse between reads, like a diverse metagenomic sample
     "gtdb": dict(root_bins=1024, child_bins=128, n_children=1020, total_bytes=113e9, root_frac=0.40,
-                 reads=131072, read_len=10000, genomes=128, genome_len=4000000),
+                 reads=131072, read_len=10000, genomes=128, genome_len=3000000),
     "refseq": dict(root_bins=512, child_bins=64, n_children=508, total_bytes=9.9e9, root_frac=0.40,
                    reads=131072, read_len=10000, genomes=64, genome_len=2000000),
     "viral": dict(root_bins=256, child_bins=64, n_children=252, total_bytes=373e6, root_frac=0.40,
@@ -115,7 +115,7 @@ def main():
     need_root = max(sum(len(p) for p in planted[2:]) // max(1, min(wl["n_children"], len(planted) - 2)) * 2,
                     max(len(p) for p in planted))
     root_max = max(root_max, need_root)
-    child_max = max(child_max, max(len(p) for p in planted) * 2)
+    child_max = max(child_max, max(len(p) for p in planted) + 1024)
     lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
                             n_children=wl["n_children"], root_max_elems=root_max, child_max_elems=child_max,
                             seed=synth.DEFAULT_SEED)
@@ -133,7 +133,8 @@ def main():
     sr.upload(bases, offs)
     t_upload = time.time() - t0
 
-    gather_bufs = {}
+    from taxor_amd import distributed as td
+    gathered = {}
 
     def gather_results():
         """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
@@ -141,25 +142,13 @@ def main():
             return
         nr, nt = sr.result_sizes()
         dev = torch.device("cuda", local_rank)
-        sizes = torch.tensor([nr, nt], dtype=torch.int64, device=dev)
-        all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(all_sizes, sizes)
-        mine = [torch.empty(nr + 1, dtype=torch.int64, device=dev), torch.empty(max(nt, 1), dtype=torch.int64, device=dev),
-                torch.empty(max(nt, 1), dtype=torch.int32, device=dev), torch.empty(max(nr, 1), dtype=torch.int32, device=dev)]
-        sr.export_device(mine[0].data_ptr(), mine[1].data_ptr(), mine[2].data_ptr(), mine[3].data_ptr())
-        ops = []
-        if rank == 0:
-            for p in range(1, world):
-                pr, pt = int(all_sizes[p][0]), int(all_sizes[p][1])
-                bufs = [torch.empty(pr + 1, dtype=torch.int64, device=dev), torch.empty(max(pt, 1), dtype=torch.int64, device=dev),
-                        torch.empty(max(pt, 1), dtype=torch.int32, device=dev), torch.empty(max(pr, 1), dtype=torch.int32, device=dev)]
-                gather_bufs[p] = bufs
-                ops += [dist.P2POp(dist.irecv, b, p) for b in bufs]
-        else:
-            ops += [dist.P2POp(dist.isend, b, 0) for b in mine]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        ro = torch.empty(nr + 1, dtype=torch.int64, device=dev)
+        ub = torch.empty(nt, dtype=torch.int64, device=dev)
+        ct = torch.empty(nt, dtype=torch.int32, device=dev)
+        nh = torch.empty(nr, dtype=torch.int32, device=dev)
+        sr.export_device(ro.data_ptr(), ub.data_ptr() if nt else None, ct.data_ptr() if nt else None,
+                         nh.data_ptr() if nr else None)
+        gathered["last"] = td.gather_csr(ro, ub, ct, nh, dst=0)
 
     def step():
         sr.run()
@@ -214,7 +203,7 @@ def main():
                        "reads_with_hits": classified, "work_items_per_read": round(st["n_work_items"] / max(1, n_reads), 3)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": args.traffic_bytes, "kernel": "k_query_level",
+                         "traffic": traffic_from_profiles(args), "kernel": "k_query_level",
                          "launches": q_launches, "avg_launch_ms": round(q_ms / max(1, q_launches), 4),
                          "algorithmic_bytes_per_launch": round(q_bytes / max(1, q_launches), 1),
                          "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
@@ -232,6 +221,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def traffic_from_profiles(args):
+    """HBM bytes per k_query_level launch from the separate rocprofv3 --pmc passes (profiles/run_profiles.sh):
+    FETCH_SIZE (doubled, gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE.  None if never collected for
+    this workload at its default size."""
+    if args.traffic_bytes is not None:
+        return args.traffic_bytes
+    if args.reads or args.read_len:
+        return None
+    p = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+    if os.path.exists(p):
+        with open(p) as f:
+            return json.load(f).get("k_query_level_bytes_per_launch")
+    return None
 
 
 def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):

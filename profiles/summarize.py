@@ -15,6 +15,7 @@ def find(pattern):
     return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
 
 
+traffic = {}
 print(f"== rocprofv3 summary: {os.path.basename(out)} ({wl})")
 for f in find("stats/**/*kernel_stats.csv"):
     print(f"-- {os.path.relpath(f, out)}")
@@ -49,3 +50,13 @@ for kind, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             corr = 2.0 if counter == "FETCH_SIZE" else 1.0
             print(f"-- {counter} {key}: launches={launches} raw_sum_KB={kb:.0f} per_launch_bytes_raw={kb*1024/launches:.3e} "
                   f"per_launch_bytes_corrected(x{corr:g})={kb*1024*corr/launches:.3e}")
+            traffic.setdefault(key, 0.0)
+            traffic[key] += kb * 1024 * corr / launches
+if traffic.get("k_query_level"):
+    j = {"workload": wl, "k_query_level_bytes_per_launch": round(traffic["k_query_level"], 1),
+         "k_syncmers_bytes_per_launch": round(traffic.get("k_syncmers", 0.0), 1),
+         "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
+                   + os.path.basename(out)}
+    with open(os.path.join(out, f"traffic_{wl}.json"), "w") as f:
+        json.dump(j, f, indent=1)
+    print("-- traffic:", json.dumps(j))
