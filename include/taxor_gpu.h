@@ -171,6 +171,45 @@ int taxor_gpu_bulk_contains(taxor_gpu_searcher *s, const uint64_t *hashes, uint6
                             taxor_gpu_results *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * .hixf on-disk format (drop-in): cereal BinaryOutputArchive of taxor_index<hixf_t>, native little endian,
+ * no header (src/main/store_index.hpp:24-27).  Envelope order is pinned by src/main/index.hpp:208-244,
+ * src/taxonomy/Species.hpp:40-50 and hierarchical_interleaved_xor_filter.hpp:152-158,277-282; the record of
+ * one seqan3::interleaved_xor_filter is UN-VENDORED -- this library's schema for it is documented in
+ * taxor_amd/csrc/hixf_io.cpp (one place to change).  The loader fails loudly on truncated or inconsistent
+ * files (the reference swallows read errors, index.hpp:235-238 -- deliberate behavioural improvement).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const char *organism_name, *accession_id, *taxid, *taxnames_string, *taxid_string; /* Species.hpp:43-47 */
+    uint64_t user_bin, seq_len;                                                       /* :48-49           */
+} taxor_species;
+
+typedef struct {
+    uint64_t window_size;     /* index.hpp:217 */
+    uint8_t parts;            /* :222 */
+    uint8_t compressed;       /* :225 */
+    uint64_t n_species;
+    const taxor_species *species;            /* :227 */
+    uint64_t n_user_bin_filenames;
+    const char *const *user_bin_filenames;   /* hixf.hpp:280; bin_path (index.hpp:226) is written as one
+                                                single-element vector per filename, like taxor_build.cpp:519-523 */
+} taxor_hixf_meta;
+
+typedef struct taxor_hixf taxor_hixf;  /* a parsed .hixf held in host memory (mmap) */
+
+int taxor_hixf_load(const char *path, taxor_hixf **out);
+void taxor_hixf_free(taxor_hixf *h);
+const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h);
+const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h);
+int taxor_hixf_store(const char *path, const taxor_hixf_view *view, const taxor_hixf_meta *meta);
+
+/* Per-read output text (taxor_search.cpp:268-305): appends the line(s) of one read to buf (capacity cap) and
+ * returns the number of bytes the text needs (call again with a larger buffer if > cap).  Species lookup
+ * follows the reference: user_bin -> first species with that user_bin, species[0] if none (:172-178,289). */
+uint64_t taxor_format_read(const taxor_hixf *h, const char *id, uint64_t id_len, uint64_t read_len,
+                           uint32_t n_hashes, const int64_t *user_bin, const uint32_t *count, uint64_t n_tuples,
+                           char *buf, uint64_t cap);
+
+/* ------------------------------------------------------------------------------------------------
  * Host-side scalars of the path (no GPU needed).
  * ---------------------------------------------------------------------------------------------- */
 /* threshold::threshold + get(): ratio by which the hash count is multiplied.  percentage in (0,1] selects

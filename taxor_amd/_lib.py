@@ -45,6 +45,18 @@ class RunStats(C.Structure):
                 ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
 
 
+class Species(C.Structure):
+    _fields_ = [("organism_name", C.c_char_p), ("accession_id", C.c_char_p), ("taxid", C.c_char_p),
+                ("taxnames_string", C.c_char_p), ("taxid_string", C.c_char_p), ("user_bin", C.c_uint64),
+                ("seq_len", C.c_uint64)]
+
+
+class HixfMeta(C.Structure):
+    _fields_ = [("window_size", C.c_uint64), ("parts", C.c_uint8), ("compressed", C.c_uint8),
+                ("n_species", C.c_uint64), ("species", C.POINTER(Species)), ("n_user_bin_filenames", C.c_uint64),
+                ("user_bin_filenames", C.POINTER(C.c_char_p))]
+
+
 # every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -71,6 +83,13 @@ SIGNATURES = {
                                      C.POINTER(C.POINTER(C.c_uint64))]),
     "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),
     "taxor_gpu_bulk_contains": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(Results)]),
+    "taxor_hixf_load": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "taxor_hixf_free": (None, [_P]),
+    "taxor_hixf_get_view": (C.POINTER(HixfView), [_P]),
+    "taxor_hixf_get_meta": (C.POINTER(HixfMeta), [_P]),
+    "taxor_hixf_store": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta)]),
+    "taxor_format_read": (C.c_uint64, [_P, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64,
+                                       _P, C.c_uint64]),
     "taxor_threshold_ratio": (C.c_double, [C.c_uint32, C.c_double, C.c_double]),
     "taxor_threshold": (C.c_uint64, [C.c_uint64, C.c_double]),
     "taxor_classify_filter": (None, [_P, C.c_uint64, _P]),

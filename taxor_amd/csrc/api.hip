@@ -130,6 +130,7 @@ struct taxor_gpu_searcher {
 };
 
 extern "C" const char *taxor_gpu_last_error(void) { return g_err.c_str(); }
+extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 
 // =========================================================================================================
 // index

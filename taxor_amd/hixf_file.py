@@ -1,0 +1,81 @@
+"""`.hixf` files through the library's reader / writer (taxor_amd/csrc/hixf_io.cpp): the drop-in on-disk
+format of `taxor search` (cereal binary envelope of src/main/index.hpp:208-244)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None, window_size=None, scaling=1):
+    """ixfs: list of dicts {bins, stride, seg_len, seed, data, next_ixf, fname_idx} (host data required);
+    species: list of dicts {organism_name, accession_id, taxid, taxnames_string, taxid_string, user_bin, seq_len}"""
+    keep = []
+    arr = (_lib.IxfView * len(ixfs))()
+    for i, f in enumerate(ixfs):
+        d = np.ascontiguousarray(f["data"], dtype=np.uint8)
+        nx = np.ascontiguousarray(f["next_ixf"], dtype=np.int64)
+        fn = np.ascontiguousarray(f["fname_idx"], dtype=np.int64)
+        keep += [d, nx, fn]
+        arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data, nx.ctypes.data, fn.ctypes.data)
+    view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1, scaling)
+    sp = (_lib.Species * len(species))()
+    for i, x in enumerate(species):
+        sp[i] = _lib.Species(x["organism_name"].encode(), x["accession_id"].encode(), x["taxid"].encode(),
+                             x["taxnames_string"].encode(), x["taxid_string"].encode(), x["user_bin"], x["seq_len"])
+    if filenames is None:
+        filenames = [f"user_bin_{i}.fna" for i in range(n_user_bins)]
+    fns = (C.c_char_p * len(filenames))(*[f.encode() for f in filenames])
+    meta = _lib.HixfMeta(window_size if window_size is not None else k, 1, 0, len(species), sp, len(filenames), fns)
+    check(_lib.lib().taxor_hixf_store(str(path).encode(), C.byref(view), C.byref(meta)))
+
+
+class HixfFile:
+    """A parsed .hixf (mmap).  .ixfs are zero-copy numpy views valid while the object lives."""
+
+    def __init__(self, path):
+        h = C.c_void_p()
+        check(_lib.lib().taxor_hixf_load(str(path).encode(), C.byref(h)))
+        self._h = h
+        v = _lib.lib().taxor_hixf_get_view(h).contents
+        m = _lib.lib().taxor_hixf_get_meta(h).contents
+        self.k, self.s, self.t = v.kmer_size, v.syncmer_size, v.t_syncmer
+        self.use_syncmer, self.scaling = bool(v.use_syncmer), v.scaling
+        self.n_user_bins = int(v.n_user_bins)
+        self.window_size = int(m.window_size)
+        self.ixfs = []
+        for i in range(v.n_ixf):
+            f = v.ixf[i]
+            n = 3 * f.seg_len * f.stride
+            data = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_uint8)), shape=(n,))
+            nx = np.ctypeslib.as_array(C.cast(f.next_ixf, C.POINTER(C.c_int64)), shape=(f.bins,))
+            fn = np.ctypeslib.as_array(C.cast(f.fname_idx, C.POINTER(C.c_int64)), shape=(f.bins,))
+            self.ixfs.append(dict(bins=int(f.bins), stride=int(f.stride), seg_len=int(f.seg_len), seed=int(f.seed),
+                                  data=data, next_ixf=nx, fname_idx=fn))
+        self.species = [dict(organism_name=m.species[i].organism_name.decode(), accession_id=m.species[i].accession_id.decode(),
+                             taxid=m.species[i].taxid.decode(), taxnames_string=m.species[i].taxnames_string.decode(),
+                             taxid_string=m.species[i].taxid_string.decode(), user_bin=int(m.species[i].user_bin),
+                             seq_len=int(m.species[i].seq_len)) for i in range(m.n_species)]
+        self.filenames = [m.user_bin_filenames[i].decode() for i in range(m.n_user_bin_filenames)]
+
+    def format_read(self, read_id: str, read_len, n_hashes, user_bin, count):
+        ub = np.ascontiguousarray(user_bin, dtype=np.int64)
+        ct = np.ascontiguousarray(count, dtype=np.uint32)
+        rid = read_id.encode()
+        buf = C.create_string_buffer(4096)
+        n = _lib.lib().taxor_format_read(self._h, rid, len(rid), read_len, n_hashes, ub.ctypes.data, ct.ctypes.data,
+                                         ub.size, buf, len(buf))
+        if n > len(buf):
+            buf = C.create_string_buffer(int(n))
+            n = _lib.lib().taxor_format_read(self._h, rid, len(rid), read_len, n_hashes, ub.ctypes.data, ct.ctypes.data,
+                                             ub.size, buf, len(buf))
+        return buf.raw[:n].decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ixfs = []
+            _lib.lib().taxor_hixf_free(self._h)
+            self._h = None
+
+    __del__ = close

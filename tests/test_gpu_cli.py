@@ -1,0 +1,106 @@
+"""End to end through the drop-in surface: `taxor search --index-file x.hixf --query-file reads.fq ...`
+(the C++ host in taxor_amd/csrc) must write byte-identical TSV to what the reference's per-read driver
+(taxor_search.cpp:196-313,340-360) produces from the oracle's tuples."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from taxor_amd import GpuIndex, Searcher, synth
+from taxor_amd.hixf_file import store_hixf
+from tests.test_hixf_file_cpu import HEADER, expected_lines, make_species
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAXOR = os.path.join(ROOT, "taxor_amd", "taxor")
+
+
+def _setup(tmp_path, seed):
+    g, go = synth.random_genomes(7, 15000, seed=seed)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(7)]
+    lay = synth.make_layout(planted, root_bins=68, child_bins=40, n_children=3, seed=seed)
+    host = synth.materialize_host(lay)
+    sp = make_species(lay)
+    path = tmp_path / f"idx{seed}.hixf"
+    store_hixf(path, host, lay["n_user_bins"], sp)
+    return g, go, host, sp, path
+
+
+def _expected(host, sp, ids, reads, err=0.04, percentage=-1.0):
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    norm = [orc.dna4_normalise(r) for r in reads]
+    B = np.frombuffer(b"".join(norm), dtype=np.uint8)
+    O = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    nh, off, ub, cnt, _ = h.search_batch(B, O, err=err, percentage=percentage, threads=4)
+    out = ""
+    for i, rid in enumerate(ids):
+        tup = [(int(a), int(b)) for a, b in zip(ub[int(off[i]):int(off[i + 1])], cnt[int(off[i]):int(off[i + 1])])]
+        out += expected_lines(sp, rid, len(reads[i]), int(nh[i]), tup)
+    return out
+
+
+def test_cli_fastq_gz_fasta_multi(tmp_path):
+    g, go, host, sp, idx_path = _setup(tmp_path, 31)
+    bases, offs, origin = synth.synth_reads(g, go, 180, 1500, error_rate=0.02, frac_random=0.2, seed=5)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(180)]
+    reads += [b"ACGTNNNNRYKM" * 30, b"ACGTACGT", bytes(g[:22])]
+    ids = [f"read_{i} len={len(r)} some description" for i, r in enumerate(reads)]
+    # FASTQ, gzip
+    fq = tmp_path / "reads.fastq.gz"
+    with gzip.open(fq, "wb") as f:
+        for rid, r in zip(ids, reads):
+            f.write(b"@" + rid.encode() + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    # FASTA, multi-line, plain
+    fa = tmp_path / "reads2.fa"
+    ids2 = [f"fa_{i}" for i in range(40)]
+    reads2 = reads[100:140]
+    with open(fa, "wb") as f:
+        for rid, r in zip(ids2, reads2):
+            f.write(b">" + rid.encode() + b"\n")
+            for j in range(0, len(r), 70):
+                f.write(r[j:j + 70] + b"\n")
+    out = tmp_path / "out.tsv"
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--output-file",
+                         str(out), "--threads", "4", "--batch-reads", "50"], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr
+    assert "checking input ... done!" in cp.stdout and "use syncmer model" in cp.stdout
+    want = HEADER + _expected(host, sp, ids, reads) + _expected(host, sp, ids2, reads2)
+    assert open(out).read() == want
+
+    # --error-rate / --percentage change the threshold exactly like the reference's models
+    for extra, kw in ((["--error-rate", "0.1"], dict(err=0.1)), (["--percentage", "0.3"], dict(percentage=0.3))):
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out)]
+                            + extra, capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0, cp.stderr
+        assert open(out).read() == HEADER + _expected(host, sp, ids2, reads2, **kw)
+
+
+def test_cli_errors(tmp_path):
+    g, go, host, sp, idx_path = _setup(tmp_path, 32)
+    out = tmp_path / "o.tsv"
+    fa = tmp_path / "r.fa"
+    open(fa, "w").write(">a\nACGT\n")
+    cases = [(["--index-file", str(tmp_path / "nope.hixf"), "--query-file", str(fa)], "does not exist"),
+             (["--index-file", str(idx_path), "--query-file", str(tmp_path / "nope.fa")], "does not exist"),
+             (["--index-file", str(idx_path), "--query-file", str(fa), "--threads", "64"], "range"),
+             (["--index-file", str(idx_path), "--query-file", str(fa), "--error-rate", "0.5"], "threshold model"),
+             (["--query-file", str(fa)], "required")]
+    for args, needle in cases:
+        cp = subprocess.run([TAXOR, "search", "--output-file", str(out)] + args, capture_output=True, text=True, timeout=120)
+        assert cp.returncode != 0
+        assert "[TAXOR SEARCH ERROR]" in cp.stderr and needle in cp.stderr, (args, cp.stderr)
+    bad = tmp_path / "bad.fa"
+    open(bad, "w").write(">a\nACGTACGTACGTACGTACGTACGTACGT#ACGT\n")
+    cp = subprocess.run([TAXOR, "search", "--output-file", str(out), "--index-file", str(idx_path), "--query-file", str(bad)],
+                        capture_output=True, text=True, timeout=120)
+    assert cp.returncode != 0 and "dna15" in cp.stderr

@@ -1,0 +1,119 @@
+"""`.hixf` envelope writer/reader round trip, loud failure on damaged files, and the per-read output text
+(taxor_search.cpp:268-305) against a line-by-line Python restatement kept in this test."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from taxor_amd import synth
+from taxor_amd._lib import TaxorError
+from taxor_amd.hixf_file import HixfFile, store_hixf
+
+HEADER = "#QUERY_NAME\tACCESSION\tREFERENCE_NAME\tTAXID\tREF_LEN\tQUERY_LEN\tQHASH_COUNT\tQHASH_MATCH\tTAX_STR\tTAX_ID_STR\n"
+
+
+def make_species(lay):
+    sp = []
+    for ub in range(lay["n_user_bins"]):
+        sp.append(dict(organism_name=f"Organism {ub}", accession_id=f"GCF_{ub:09d}.1", taxid=str(1000 + ub),
+                       taxnames_string=f"k__Bacteria;p__P{ub % 7};s__Organism {ub}", taxid_string=f"2;{ub % 7};{1000 + ub}",
+                       user_bin=ub, seq_len=1000000 + ub))
+    return sp
+
+
+def expected_lines(species, read_id, read_len, n_hashes, tuples):
+    """taxor_search.cpp:268-305 restated: '-' line, or the 0.8*max filter and ten tab-separated columns"""
+    ubi = {}
+    for i, s in enumerate(species):
+        ubi.setdefault(s["user_bin"], i)
+    if not tuples:
+        return f"{read_id}\t-\t-\t-\t-\t{read_len}\n"
+    mx = max(c for _, c in tuples)
+    out = ""
+    for ub, c in tuples:
+        if float(c) < float(mx) * 0.8:
+            continue
+        s = species[ubi.get(ub, 0)]
+        out += "\t".join([read_id, s["accession_id"], s["organism_name"], s["taxid"], str(s["seq_len"]), str(read_len),
+                          str(n_hashes), str(c), s["taxnames_string"], s["taxid_string"]]) + "\n"
+    return out
+
+
+def small_layout(seed=4):
+    rng = np.random.default_rng(seed)
+    planted = [np.unique(rng.integers(0, 2**63, size=300, dtype=np.uint64)) for _ in range(6)]
+    lay = synth.make_layout(planted, root_bins=66, child_bins=24, n_children=2, seed=seed)
+    return lay, synth.materialize_host(lay), planted
+
+
+def test_store_load_roundtrip(tmp_path):
+    lay, host, planted = small_layout()
+    sp = make_species(lay)
+    p = tmp_path / "toy.hixf"
+    store_hixf(p, host, lay["n_user_bins"], sp)
+    h = HixfFile(p)
+    assert (h.k, h.s, h.t, h.use_syncmer, h.scaling, h.window_size) == (22, 12, 5, True, 1, 22)
+    assert h.n_user_bins == lay["n_user_bins"] and len(h.ixfs) == len(host)
+    for a, b in zip(h.ixfs, host):
+        for key in ("bins", "stride", "seg_len", "seed"):
+            assert a[key] == b[key]
+        assert np.array_equal(a["data"], b["data"])
+        assert np.array_equal(a["next_ixf"], b["next_ixf"]) and np.array_equal(a["fname_idx"], b["fname_idx"])
+    assert h.species == sp
+    assert h.filenames == [f"user_bin_{i}.fna" for i in range(lay["n_user_bins"])]
+    # the loaded arrays drive the oracle exactly like the originals
+    ho = orc.Hixf(h.ixfs, [f["next_ixf"] for f in h.ixfs], [f["fname_idx"] for f in h.ixfs])
+    ub, cnt, _ = ho.bulk_contains(planted[1], planted[1].size)
+    assert lay["planted_user_bin"][1] in ub.tolist()
+    del ho
+    h.close()
+
+
+def test_envelope_bytes_follow_index_hpp(tmp_path):
+    """first bytes of the file: u32 version=1, u64 window, shape(u64 size, u64 bits), k, s, t, parts, use_syncmer,
+    u16 scaling, compressed (src/main/index.hpp:211-225)"""
+    lay, host, _ = small_layout()
+    p = tmp_path / "toy.hixf"
+    store_hixf(p, host, lay["n_user_bins"], make_species(lay))
+    raw = open(p, "rb").read(64)
+    assert int.from_bytes(raw[0:4], "little") == 1
+    assert int.from_bytes(raw[4:12], "little") == 22
+    assert int.from_bytes(raw[12:20], "little") == 22 and int.from_bytes(raw[20:28], "little") == (1 << 22) - 1
+    assert list(raw[28:33]) == [22, 12, 5, 1, 1]
+    assert int.from_bytes(raw[33:35], "little") == 1 and raw[35] == 0
+    assert int.from_bytes(raw[36:44], "little") == lay["n_user_bins"]     # bin_path outer size
+
+
+def test_damaged_files_fail_loudly(tmp_path):
+    lay, host, _ = small_layout()
+    p = tmp_path / "toy.hixf"
+    store_hixf(p, host, lay["n_user_bins"], make_species(lay))
+    raw = open(p, "rb").read()
+    for name, blob in [("truncated", raw[: len(raw) // 2]), ("trailing", raw + b"\0" * 8),
+                       ("version", b"\x02\0\0\0" + raw[4:]), ("tiny", raw[:16])]:
+        q = tmp_path / f"{name}.hixf"
+        open(q, "wb").write(blob)
+        with pytest.raises(TaxorError) as e:
+            HixfFile(q)
+        assert e.value.code == -5, name
+    with pytest.raises(TaxorError):
+        HixfFile(tmp_path / "does_not_exist.hixf")
+
+
+def test_format_read_matches_reference_text(tmp_path):
+    lay, host, _ = small_layout()
+    sp = make_species(lay)
+    sp[3]["user_bin"] = 9999          # user bin 3 has no species entry -> the reference falls back to species[0]
+    p = tmp_path / "toy.hixf"
+    store_hixf(p, host, lay["n_user_bins"], sp)
+    h = HixfFile(p)
+    cases = [("read_0 runid=abc", 5000, 435, []),
+             ("r1", 1139, 98, [(2, 56)]),
+             ("r2", 2589, 224, [(1, 104), (5, 104), (4, 83), (0, 84)]),      # 83 < 0.8*104 = 83.2 dropped, 84 kept
+             ("r3", 30, 0, [(0, 0), (1, 0), (2, 0)]),                        # zero-hash quirk: everything, count 0
+             ("r4", 4000, 300, [(3, 200)])]
+    for rid, rl, nh, tup in cases:
+        got = h.format_read(rid, rl, nh, [u for u, _ in tup], [c for _, c in tup])
+        assert got == expected_lines(sp, rid, rl, nh, tup), rid
+    h.close()
