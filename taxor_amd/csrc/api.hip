@@ -86,10 +86,14 @@ struct SubBatch {
 struct taxor_gpu_searcher {
     taxor_gpu_index *idx = nullptr;
     taxor_gpu_search_params prm{};
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;       // query + CSR assembly; the stream callers synchronise on
+    hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
+    std::vector<hipEvent_t> ev_sync_done, ev_query_done;
+    hipEvent_t ev_reset = nullptr;
+    DBuf<uint32_t> d_sync_cursor;
     Counters *d_ctr = nullptr;
     Counters h_ctr{};
-    int grid_sync = 0, grid_query = 0;
+    int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
     size_t lds_query = 0;
 
     // batch-resident input
@@ -104,7 +108,7 @@ struct taxor_gpu_searcher {
     uint64_t packed_word_count = 0, packed_in_bytes = 0;
 
     // per-sub-batch scratch
-    DBuf<uint64_t> d_cand, d_hashes;
+    DBuf<uint64_t> d_cand[2], d_hashes[2];   // double-buffered across sub-batches
     DBuf<uint2> d_q[2];
     DBuf<uint4> d_hits;
     DBuf<uint32_t> d_read_hits, d_cursor, d_roff, d_biglist, d_gtab;
@@ -360,6 +364,8 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     if (s->prm.sub_batch_bases == 0) s->prm.sub_batch_bases = 1ull << 29;
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
     if (e != hipSuccess) {
         delete s;
@@ -371,6 +377,14 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         return fail(TAXOR_E_ARG, "searcher_create: an IXF with %u-byte rows does not fit the LDS tally", idx->max_stride);
     }
     s->grid_sync = syncmers_grid(idx->device);
+    {   // syncmer launches that run beside a query kernel keep to one block per CU: with more, the query kernel
+        // stalls for as long as the syncmer kernel runs (measured); with one it is not slowed at all
+        hipDeviceProp_t p;
+        int per = 1;
+        if (const char *e = getenv("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+        s->grid_sync_overlap = hipGetDeviceProperties(&p, idx->device) == hipSuccess ? p.multiProcessorCount * per : s->grid_sync;
+        if (s->grid_sync_overlap > s->grid_sync) s->grid_sync_overlap = s->grid_sync;
+    }
     s->grid_query = query_grid(idx->device, s->lds_query);
     *out = s;
     return TAXOR_OK;
@@ -380,10 +394,17 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->idx->device);
+    if (s->st_sync) (void)hipStreamSynchronize(s->st_sync);
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->d_ascii.release(); s->d_aoff.release(); s->d_poff.release(); s->d_hoff.release();
     s->d_packed.release(); s->d_rlen.release(); s->d_hcap.release(); s->d_nh.release(); s->d_thr.release();
-    s->d_cand.release(); s->d_hashes.release(); s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
+    for (int b = 0; b < 2; ++b) { s->d_cand[b].release(); s->d_hashes[b].release(); }
+    s->d_sync_cursor.release();
+    for (auto ev : s->ev_sync_done) (void)hipEventDestroy(ev);
+    for (auto ev : s->ev_query_done) (void)hipEventDestroy(ev);
+    if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
+    if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
+    s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
     s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release();
     s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
     for (auto ev : s->ev) (void)hipEventDestroy(ev);
@@ -407,7 +428,7 @@ int ev_reserve(taxor_gpu_searcher *s)
 }
 
 // bracket helpers: begin returns the index of the start event
-int ev_begin(taxor_gpu_searcher *s, int kind, size_t *slot)
+int ev_begin(taxor_gpu_searcher *s, int kind, size_t *slot, hipStream_t st = nullptr)
 {
     *slot = (size_t)-1;
     if (!s->prm.time_kernels) return 0;
@@ -415,14 +436,14 @@ int ev_begin(taxor_gpu_searcher *s, int kind, size_t *slot)
     *slot = s->ev_used;
     s->ev_used += 2;
     s->ev_spans.push_back({*slot, kind});
-    HIP_TRY(hipEventRecord(s->ev[*slot], s->st));
+    HIP_TRY(hipEventRecord(s->ev[*slot], st ? st : s->st));
     return 0;
 }
 
-int ev_end(taxor_gpu_searcher *s, size_t slot)
+int ev_end(taxor_gpu_searcher *s, size_t slot, hipStream_t st = nullptr)
 {
     if (slot == (size_t)-1) return 0;
-    HIP_TRY(hipEventRecord(s->ev[slot + 1], s->st));
+    HIP_TRY(hipEventRecord(s->ev[slot + 1], st ? st : s->st));
     return 0;
 }
 
@@ -482,8 +503,16 @@ int ensure_scratch(taxor_gpu_searcher *s)
 {
     const taxor_gpu_index *idx = s->idx;
     const uint32_t R = std::max<uint32_t>(s->max_sub_reads, 1);
-    if (s->d_cand.reserve(s->max_slots + 64)) return TAXOR_E_HIP;
-    if (s->d_hashes.reserve(s->max_slots + 64)) return TAXOR_E_HIP;
+    for (int b = 0; b < 2; ++b)
+        if (s->d_cand[b].reserve(s->max_slots + 64) || s->d_hashes[b].reserve(s->max_slots + 64)) return TAXOR_E_HIP;
+    if (s->d_sync_cursor.reserve(s->subs.size() + 1)) return TAXOR_E_HIP;
+    while (s->ev_sync_done.size() < s->subs.size() + 1) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        s->ev_sync_done.push_back(a);
+        s->ev_query_done.push_back(b);
+    }
     const uint64_t qmin = std::max<uint64_t>(4ull * R, idx->h_ixf.size() + 64);
     const uint64_t hmin = std::max<uint64_t>(4ull * R, idx->leaf_runs + 64);
     if (s->q_cap < qmin) s->q_cap = (uint32_t)std::min<uint64_t>(qmin, 0x7FFFFFFFu);
@@ -492,10 +521,10 @@ int ensure_scratch(taxor_gpu_searcher *s)
     if (s->d_hits.reserve(s->hit_cap)) return TAXOR_E_HIP;
     if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R))
         return TAXOR_E_HIP;
-    // dedup scratch for reads whose table does not fit LDS (8192 slots)
+    // dedup scratch for reads whose table does not fit LDS (4096 slots)
     uint64_t ts = 64;
     while (ts < 2 * s->max_read_slots) ts <<= 1;
-    if (ts > 8192) {
+    if (ts > 4096) {
         if (ts > (1ull << 31)) return fail(TAXOR_E_ARG, "read too long for the dedup table");
         if (s->gtab_stride < ts) s->gtab_stride = (uint32_t)ts;
         if (s->d_gtab.reserve((size_t)s->gtab_stride * (size_t)s->grid_sync)) return TAXOR_E_HIP;
@@ -578,7 +607,9 @@ int reset_sub_counters(taxor_gpu_searcher *s, bool whole)
     return 0;
 }
 
-int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb)
+// syncmer kernel of sub-batch `sub_i` into scratch buffer `buf`, on stream `st`
+int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i, int buf, hipStream_t st,
+                        bool overlapped = false)
 {
     const taxor_gpu_index *idx = s->idx;
     SyncmerArgs a{};
@@ -587,8 +618,9 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb)
     a.rlen = s->d_rlen.p + sb.first;
     a.hoff = s->d_hoff.p + sb.first;
     a.hcap = s->d_hcap.p + sb.first;
-    a.cand = s->d_cand.p;
-    a.hashes = s->d_hashes.p;
+    a.cand = s->d_cand[buf].p;
+    a.hashes = s->d_hashes[buf].p;
+    a.cursor = s->d_sync_cursor.p + sub_i;
     a.nh = s->d_nh.p + sb.first;
     a.thr = s->d_thr.p + sb.first;
     a.ratio = s->prm.ratio;
@@ -600,9 +632,9 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb)
     a.s = idx->s;
     a.t = idx->t;
     size_t slot;
-    if (ev_begin(s, 0, &slot)) return TAXOR_E_HIP;
-    launch_syncmers(a, s->grid_sync, s->st);
-    if (ev_end(s, slot)) return TAXOR_E_HIP;
+    if (ev_begin(s, 0, &slot, st)) return TAXOR_E_HIP;
+    launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
+    if (ev_end(s, slot, st)) return TAXOR_E_HIP;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -680,17 +712,27 @@ extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
     s->stats = taxor_gpu_run_stats{};
     size_t tot_slot;
     if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
+    HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, (s->subs.size() + 1) * sizeof(uint32_t), s->st));
+    HIP_TRY(hipEventRecord(s->ev_reset, s->st));
+    HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
     if (s->subs.empty()) { // zero reads: CSR = [0]
         HIP_TRY(hipMemsetAsync(s->d_read_off.p, 0, sizeof(uint64_t), s->st));
     }
+    // Two streams: the syncmer kernel (LDS/latency bound) of sub-batch i+1 runs beside the HBM-bound query of
+    // sub-batch i; candidate/hash scratch is double buffered, events carry the two dependencies.
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
+        const int buf = (int)(i & 1);
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_query_done[i - 2], 0));
+        if (int rc = launch_syncmers_sub(s, sb, i, buf, s->st_sync, i > 0)) return rc;
+        HIP_TRY(hipEventRecord(s->ev_sync_done[i], s->st_sync));
+        HIP_TRY(hipStreamWaitEvent(s->st, s->ev_sync_done[i], 0));
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
-        if (int rc = launch_syncmers_sub(s, sb)) return rc;
-        if (int rc = run_query(s, s->d_hashes.p, s->d_hoff.p + sb.first, s->d_nh.p + sb.first, s->d_thr.p + sb.first, sb.n,
-                               s->d_read_off.p + sb.first, i + 1 == s->subs.size(), nullptr, -1))
+        if (int rc = run_query(s, s->d_hashes[buf].p, s->d_hoff.p + sb.first, s->d_nh.p + sb.first, s->d_thr.p + sb.first,
+                               sb.n, s->d_read_off.p + sb.first, i + 1 == s->subs.size(), nullptr, -1))
             return rc;
+        HIP_TRY(hipEventRecord(s->ev_query_done[i], s->st));
     }
     if (ev_end(s, tot_slot)) return TAXOR_E_HIP;
     s->ran = true;
@@ -815,14 +857,15 @@ extern "C" int taxor_gpu_syncmers(taxor_gpu_searcher *s, const char *bases, cons
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
-        if (int rc = launch_syncmers_sub(s, sb)) return rc;
+        HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, sizeof(uint32_t), s->st));
+        if (int rc = launch_syncmers_sub(s, sb, 0, 0, s->st)) return rc;
         bool rerun;
         if (int rc = check_flags(s, &rerun)) return rc;
         tmp.resize(sb.slots);
         hoff_h.resize(sb.n);
         HIP_TRY(hipMemcpy(s->h_nh.data() + sb.first, s->d_nh.p + sb.first, sb.n * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(hoff_h.data(), s->d_hoff.p + sb.first, sb.n * 8, hipMemcpyDeviceToHost));
-        if (sb.slots) HIP_TRY(hipMemcpy(tmp.data(), s->d_hashes.p, sb.slots * 8, hipMemcpyDeviceToHost));
+        if (sb.slots) HIP_TRY(hipMemcpy(tmp.data(), s->d_hashes[0].p, sb.slots * 8, hipMemcpyDeviceToHost));
         for (uint32_t r = 0; r < sb.n; ++r) {
             const uint32_t nh = s->h_nh[sb.first + r];
             s->h_hash_off[sb.first + r + 1] = s->h_hash_off[sb.first + r] + nh;
@@ -852,7 +895,7 @@ int stage_hash_list(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, u
     if (int rc = ensure_scratch(s)) return rc;
     const uint64_t zero = 0;
     const uint32_t nh = (uint32_t)n;
-    if (n) HIP_TRY(hipMemcpy(s->d_hashes.p, hashes, n * 8, hipMemcpyHostToDevice));
+    if (n) HIP_TRY(hipMemcpy(s->d_hashes[0].p, hashes, n * 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_hoff.p, &zero, 8, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_nh.p, &nh, 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->d_thr.p, &threshold, 8, hipMemcpyHostToDevice));
@@ -879,7 +922,7 @@ extern "C" int taxor_gpu_ixf_bulk_count(taxor_gpu_searcher *s, uint64_t ixf, con
     if (e != hipSuccess) rc = fail(TAXOR_E_HIP, "ixf_bulk_count: %s", hipGetErrorString(e));
     s->ev_used = 0;
     s->ev_spans.clear();
-    if (!rc) rc = run_query(s, s->d_hashes.p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, nullptr, 1, d_counts, (int)ixf);
+    if (!rc) rc = run_query(s, s->d_hashes[0].p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, nullptr, 1, d_counts, (int)ixf);
     if (!rc) {
         e = hipStreamSynchronize(s->st);
         if (e == hipSuccess) e = hipMemcpy(counts, d_counts, (size_t)bins * 4, hipMemcpyDeviceToHost);
@@ -899,7 +942,7 @@ extern "C" int taxor_gpu_bulk_contains(taxor_gpu_searcher *s, const uint64_t *ha
         if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
         s->ev_used = 0;
         s->ev_spans.clear();
-        if (int rc = run_query(s, s->d_hashes.p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, s->d_read_off.p, 1, nullptr, -1))
+        if (int rc = run_query(s, s->d_hashes[0].p, s->d_hoff.p, s->d_nh.p, s->d_thr.p, 1, s->d_read_off.p, 1, nullptr, -1))
             return rc;
         bool rerun;
         if (int rc = check_flags(s, &rerun)) return rc;

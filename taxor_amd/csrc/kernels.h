@@ -69,6 +69,7 @@ struct SyncmerArgs {
     uint32_t *gtab;           // per-block dedup scratch for reads whose table does not fit LDS
     uint32_t gtab_stride;     // slots per block (power of two), 0 = none
     Counters *ctr;
+    uint32_t *cursor;         // dynamic work cursor of this launch (zeroed by the host)
     uint32_t n_reads;
     int k, s, t;
 };

@@ -14,6 +14,8 @@
 #include "kernels.h"
 #include "ixf_arith.h"
 
+#include <cstdlib>
+
 namespace taxor {
 
 static constexpr int BLK = 256;
@@ -167,7 +169,8 @@ void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t
 static constexpr int SY_C = 8;                 // consecutive windows per thread in the resolve pass
 static constexpr int SY_T = BLK * SY_C;        // windows per tile
 static constexpr int SY_WORDS = SY_T / 16 + 8; // packed words staged per tile
-static constexpr int SY_LDS_TAB = 8192;        // dedup slots held in LDS
+static constexpr int SY_LDS_TAB = 4096;        // dedup slots held in LDS
+static constexpr int SY_LDS_CAND = 2048;       // candidate hashes held in LDS (the rest spill to global)
 
 __device__ __forceinline__ uint32_t revcomp32(uint32_t x, int nb)
 {
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
     __shared__ uint8_t sLm[SY_T];
     __shared__ uint8_t sRm[SY_T];
     __shared__ uint32_t sTab[SY_LDS_TAB];
+    __shared__ uint64_t sCand[SY_LDS_CAND];
     __shared__ uint32_t sScr[8];
     __shared__ int sCarry;
     __shared__ uint32_t sRead;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) sRead = atomicAdd(&a.ctr->cursor_sync, 1u);
+        if (tid == 0) sRead = atomicAdd(a.cursor, 1u);
         __syncthreads();
         const uint32_t r = sRead;
         if (r >= a.n_reads) break;
@@ -308,7 +312,10 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
                 const uint64_t f = extract_bases(sW, (x >> 4) - wbase, x & 15u, k);
                 const uint64_t rc = revcomp64(f, k);
                 const uint64_t h = wyhash_u64(f < rc ? f : rc); // syncmer.cpp:144-145
-                if (pos < cap) cand[pos] = h;
+                if (pos < cap) {
+                    if (pos < (uint32_t)SY_LDS_CAND) sCand[pos] = h; // reads up to ~22 kb never touch global here
+                    else cand[pos] = h;
+                }
                 ++pos;
             }
             n_sel += tot;
@@ -337,13 +344,14 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
             const uint32_t mask = ts - 1u;
             for (uint32_t i = tid; i < ts; i += BLK) tab[i] = 0xFFFFFFFFu;
             __syncthreads();
+            auto cand_at = [&](uint32_t i) -> uint64_t { return i < (uint32_t)SY_LDS_CAND ? sCand[i] : cand[i]; };
             for (uint32_t i = tid; i < n_sel; i += BLK) {
-                const uint64_t h = cand[i];
+                const uint64_t h = cand_at(i);
                 uint32_t q = dedup_slot(h, mask);
                 for (;;) {
                     const uint32_t cur = atomicCAS(&tab[q], 0xFFFFFFFFu, i);
                     if (cur == 0xFFFFFFFFu) break;
-                    if (cand[cur] == h) { atomicMin(&tab[q], i); break; }
+                    if (cand_at(cur) == h) { atomicMin(&tab[q], i); break; }
                     q = (q + 1u) & mask;
                 }
             }
@@ -353,12 +361,12 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
                 uint64_t h = 0;
                 uint32_t first = 0;
                 if (i < n_sel) {
-                    h = cand[i];
+                    h = cand_at(i);
                     uint32_t q = dedup_slot(h, mask);
                     for (;;) {
                         const uint32_t cur = tab[q];
                         if (cur == 0xFFFFFFFFu) break; // cannot happen for an inserted key
-                        if (cand[cur] == h) { first = (cur == i); break; }
+                        if (cand_at(cur) == h) { first = (cur == i); break; }
                         q = (q + 1u) & mask;
                     }
                 }
@@ -382,6 +390,7 @@ int syncmers_grid(int device)
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers, BLK, 0) != hipSuccess || per < 1) per = 2;
+    if (const char *e = getenv("TAXOR_SYNC_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
 
@@ -410,7 +419,24 @@ __device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
     return t >> 7;
 }
 
-__device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+// The row pointer comes out of an IxfDesc in memory, so the compiler cannot infer its address space and would
+// emit flat_load (which also ties up lgkmcnt and so serialises against the LDS probe reads): cast to global.
+typedef const uint32_t __attribute__((address_space(1))) *gptr32;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const u32x4 __attribute__((address_space(1))) *gptr128;
+
+template <bool NT> __device__ __forceinline__ uint4 ld16(const uint8_t *p)
+{
+    if constexpr (NT) {
+        // rows are random in a table far larger than any cache: stream them (no reuse to protect)
+        gptr32 q = (gptr32)(uintptr_t)p;
+        return make_uint4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
+                          __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+    } else {
+        const u32x4 v = *(gptr128)(uintptr_t)p;
+        return make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
 
 __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, const uint4 &y, const uint4 &z,
                                                  uint32_t fp4)
@@ -421,7 +447,7 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
     acc8.w += zero_bytes01(x.w ^ y.w ^ z.w ^ fp4);
 }
 
-__global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
+template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // all LDS in the dynamic region (keeps its base 16-B aligned): probes | work item | per-bin counts
@@ -431,6 +457,9 @@ __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lvl = a.level;
+    // This kernel is HBM-bound and needs few issue slots, but it needs them promptly: when the (VALU/LDS heavy)
+    // syncmer kernel of the next sub-batch shares the CU, age-based arbitration would starve these waves.
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl], a.q_cap) : a.n_level0;
 
     for (;;) {
@@ -477,14 +506,14 @@ __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
                     for (; i + 3u * G < nt; i += 4u * G) {
                         const uint4 p0 = sProbe[i], p1 = sProbe[i + G], p2 = sProbe[i + 2u * G],
                                     p3 = sProbe[i + 3u * G];
-                        const uint4 a0 = ld16(base + (size_t)p0.x * stride), b0 = ld16(base + (size_t)p0.y * stride),
-                                    c0 = ld16(base + (size_t)p0.z * stride);
-                        const uint4 a1 = ld16(base + (size_t)p1.x * stride), b1 = ld16(base + (size_t)p1.y * stride),
-                                    c1 = ld16(base + (size_t)p1.z * stride);
-                        const uint4 a2 = ld16(base + (size_t)p2.x * stride), b2 = ld16(base + (size_t)p2.y * stride),
-                                    c2 = ld16(base + (size_t)p2.z * stride);
-                        const uint4 a3 = ld16(base + (size_t)p3.x * stride), b3 = ld16(base + (size_t)p3.y * stride),
-                                    c3 = ld16(base + (size_t)p3.z * stride);
+                        const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
+                                    c0 = ld16<NT>(base + (size_t)p0.z * stride);
+                        const uint4 a1 = ld16<NT>(base + (size_t)p1.x * stride), b1 = ld16<NT>(base + (size_t)p1.y * stride),
+                                    c1 = ld16<NT>(base + (size_t)p1.z * stride);
+                        const uint4 a2 = ld16<NT>(base + (size_t)p2.x * stride), b2 = ld16<NT>(base + (size_t)p2.y * stride),
+                                    c2 = ld16<NT>(base + (size_t)p2.z * stride);
+                        const uint4 a3 = ld16<NT>(base + (size_t)p3.x * stride), b3 = ld16<NT>(base + (size_t)p3.y * stride),
+                                    c3 = ld16<NT>(base + (size_t)p3.z * stride);
                         probe_accumulate(acc8, a0, b0, c0, p0.w);
                         probe_accumulate(acc8, a1, b1, c1, p1.w);
                         probe_accumulate(acc8, a2, b2, c2, p2.w);
@@ -492,8 +521,8 @@ __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
                     }
                     for (; i < nt; i += G) {
                         const uint4 p0 = sProbe[i];
-                        const uint4 a0 = ld16(base + (size_t)p0.x * stride), b0 = ld16(base + (size_t)p0.y * stride),
-                                    c0 = ld16(base + (size_t)p0.z * stride);
+                        const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
+                                    c0 = ld16<NT>(base + (size_t)p0.z * stride);
                         probe_accumulate(acc8, a0, b0, c0, p0.w);
                     }
                     // widen the packed byte counters (<= 240 per byte) into 32-bit counters
@@ -561,15 +590,20 @@ int query_grid(int device, size_t lds_bytes)
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level, BLK, lds_bytes) != hipSuccess || per < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<false>, BLK, lds_bytes) != hipSuccess || per < 1)
         per = 2;
-    if (per > 8) per = 8;
+    // two resident blocks per CU already saturate HBM (measured: 1 -> -4 %, 2 = 3 = 4); staying at two leaves
+    // registers and LDS for the syncmer kernel of the next sub-batch to run beside this one
+    if (per > 2) per = 2;
+    if (const char *e = getenv("TAXOR_QUERY_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
 
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_query_level, dim3(grid), dim3(BLK), lds_bytes, st, a);
+    static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
+    if (nt) hipLaunchKernelGGL(k_query_level<true>, dim3(grid), dim3(BLK), lds_bytes, st, a);
+    else hipLaunchKernelGGL(k_query_level<false>, dim3(grid), dim3(BLK), lds_bytes, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------------
