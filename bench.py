@@ -161,13 +161,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    q_ms = q_bytes = 0.0
+    q_ms = q_bytes = q_touched = 0.0
     q_launches = 0
     for _ in range(args.steps):
         step()
         st = sr.stats()
         q_ms += st["query_ms"]
         q_bytes += st["query_bytes"]
+        q_touched += st["query_touched_bytes"]
         q_launches += st["query_launches"]
     torch.cuda.synchronize()
     if world > 1:
@@ -206,6 +207,8 @@ def main():
                          "traffic": traffic_from_profiles(args), "kernel": "k_query_level",
                          "launches": q_launches, "avg_launch_ms": round(q_ms / max(1, q_launches), 4),
                          "algorithmic_bytes_per_launch": round(q_bytes / max(1, q_launches), 1),
+                         "requested_bytes_per_launch": round(q_touched / max(1, q_launches), 1),
+                         "requested_GBps": round(q_touched / (q_ms * 1e-3) / 1e9, 1) if q_ms > 0 else 0.0,
                          "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
             "stage_ms_last_step": {"syncmers": round(st["syncmer_ms"], 3), "query": round(st["query_ms"], 3),
                                    "finalize": round(st["finalize_ms"], 3), "total": round(st["total_ms"], 3)},

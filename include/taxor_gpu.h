@@ -147,6 +147,8 @@ typedef struct {
     uint64_t n_reads, n_bases, n_hashes, n_tuples, n_work_items;
     uint64_t algorithmic_bytes;
     uint64_t query_bytes;
+    uint64_t query_touched_bytes; /* bytes k_query_level actually requested: threshold-aware pruning skips row
+                                     segments of bin runs that provably cannot reach the threshold       */
     uint32_t query_launches;
     float query_ms;
     float syncmer_ms;

@@ -41,7 +41,7 @@ class Results(C.Structure):
 class RunStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_hashes", C.c_uint64),
                 ("n_tuples", C.c_uint64), ("n_work_items", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
-                ("query_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
+                ("query_bytes", C.c_uint64), ("query_touched_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
                 ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
 
 

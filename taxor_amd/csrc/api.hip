@@ -94,6 +94,7 @@ struct taxor_gpu_searcher {
     Counters *d_ctr = nullptr;
     Counters h_ctr{};
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
+    bool prune = true;   // TAXOR_QUERY_PRUNE=0 disables the threshold-aware pruning (A/B measurements)
     size_t lds_query = 0;
 
     // batch-resident input
@@ -371,12 +372,13 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         delete s;
         return fail(TAXOR_E_HIP, "searcher_create: %s", hipGetErrorString(e));
     }
-    s->lds_query = 240 * 16 + 16 + (size_t)idx->max_stride * 4;
+    s->lds_query = query_lds_bytes(idx->max_stride);
     if (s->lds_query > 160 * 1024) {
         taxor_gpu_searcher_destroy(s);
         return fail(TAXOR_E_ARG, "searcher_create: an IXF with %u-byte rows does not fit the LDS tally", idx->max_stride);
     }
     s->grid_sync = syncmers_grid(idx->device);
+    if (const char *e = getenv("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
     {   // syncmer launches that run beside a query kernel keep to one block per CU: with more, the query kernel
         // stalls for as long as the syncmer kernel runs (measured); with one it is not slowed at all
         hipDeviceProp_t p;
@@ -558,6 +560,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.ctr = s->d_ctr;
     q.q_cap = s->q_cap;
     q.hit_cap = s->hit_cap;
+    q.map_words = query_map_words(idx->max_stride);
+    q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
         q.level = lvl;
@@ -758,6 +762,7 @@ extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
             st.n_tuples = s->h_ctr.tuple_total;
             st.n_work_items = s->h_ctr.n_work;
             st.query_bytes = s->h_ctr.query_bytes;
+            st.query_touched_bytes = s->h_ctr.touched_bytes;
             st.algorithmic_bytes = s->packed_in_bytes + st.query_bytes + 8 * st.n_reads + 12 * st.n_tuples;
             st.query_ms = st.syncmer_ms = st.finalize_ms = st.total_ms = 0.f;
             for (auto &sp : s->ev_spans) {

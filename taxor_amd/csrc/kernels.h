@@ -52,6 +52,7 @@ struct Counters {
     unsigned long long n_hashes;      // distinct hashes so far
     unsigned long long query_bytes;   // sum n_h*3*bins over work items
     unsigned long long n_work;        // work items processed
+    unsigned long long touched_bytes; // bytes the query kernel actually requested (after pruning)
 };
 static constexpr int MAX_LEVELS = 16;
 
@@ -90,6 +91,8 @@ struct QueryArgs {
     uint32_t level;
     uint32_t n_level0;        // number of items when q_in == nullptr
     uint32_t q_cap, hit_cap;
+    uint32_t map_words;       // words of the alive-unit bitmap in LDS (query_lds_map_words(max_stride))
+    uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)
 };
 
 struct FinalizeArgs {
@@ -118,6 +121,8 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st);
 int syncmers_grid(int device);
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
 int query_grid(int device, size_t lds_bytes);
+size_t query_lds_bytes(uint32_t max_stride);
+uint32_t query_map_words(uint32_t max_stride);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
 void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,

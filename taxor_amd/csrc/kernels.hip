@@ -447,13 +447,102 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
     acc8.w += zero_bytes01(x.w ^ y.w ^ z.w ^ fp4);
 }
 
+// LDS layout of k_query_level (all dynamic, base 16-B aligned):
+//   [0, Q_HT*16)                      probes of the current hash tile
+//   [.., +64)                          scalars: work item, alive-unit count
+//   [.., +Q_MAXU*4)                    list of alive 16-bin units
+//   [.., +map_words*4)                 bitmap of alive units (map_words = max_units/32 rounded up to 4 words)
+//   [.., +max_stride*4)                per-bin counts
+static constexpr int Q_MAXU = 32;   // more alive units than this -> finish the item densely
+
+__host__ __device__ inline size_t query_lds_map_words(uint32_t max_stride) { return (((size_t)max_stride / 16 + 31) / 32 + 3) & ~(size_t)3; }
+
+uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_words(max_stride); }
+
+size_t query_lds_bytes(uint32_t max_stride)
+{
+    return (size_t)Q_HT * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
+}
+
+// dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
+// its subset and counts byte matches; counters are flushed into the LDS counts at the end.
+template <bool NT>
+__device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64_t *__restrict__ hp, uint32_t h0,
+                                                  uint32_t h1, uint4 *sProbe, uint32_t *sC)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t units = D.units, stride = D.stride;
+    // column passes: 256 units (4096 bins) per pass; almost always exactly one
+    for (uint32_t u0 = 0; u0 < units; u0 += BLK) {
+        const uint32_t upass = min(units - u0, (uint32_t)BLK);
+        const uint32_t G = BLK / upass;           // hashes processed concurrently by the block
+        const uint32_t g = tid / upass;
+        const uint32_t u = u0 + (tid - g * upass);
+        const bool active = g < G;
+        const uint8_t *__restrict__ base = D.data + (size_t)u * 16u;
+        uint32_t acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0;
+
+        for (uint32_t t0 = h0; t0 < h1; t0 += Q_HT) {
+            const uint32_t nt = min((uint32_t)Q_HT, h1 - t0);
+            __syncthreads();
+            if (tid < nt) {
+                const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
+                sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+            }
+            __syncthreads();
+            if (active) {
+                uint4 acc8 = make_uint4(0, 0, 0, 0);
+                uint32_t i = g;
+                for (; i + 3u * G < nt; i += 4u * G) {
+                    const uint4 p0 = sProbe[i], p1 = sProbe[i + G], p2 = sProbe[i + 2u * G], p3 = sProbe[i + 3u * G];
+                    const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
+                                c0 = ld16<NT>(base + (size_t)p0.z * stride);
+                    const uint4 a1 = ld16<NT>(base + (size_t)p1.x * stride), b1 = ld16<NT>(base + (size_t)p1.y * stride),
+                                c1 = ld16<NT>(base + (size_t)p1.z * stride);
+                    const uint4 a2 = ld16<NT>(base + (size_t)p2.x * stride), b2 = ld16<NT>(base + (size_t)p2.y * stride),
+                                c2 = ld16<NT>(base + (size_t)p2.z * stride);
+                    const uint4 a3 = ld16<NT>(base + (size_t)p3.x * stride), b3 = ld16<NT>(base + (size_t)p3.y * stride),
+                                c3 = ld16<NT>(base + (size_t)p3.z * stride);
+                    probe_accumulate(acc8, a0, b0, c0, p0.w);
+                    probe_accumulate(acc8, a1, b1, c1, p1.w);
+                    probe_accumulate(acc8, a2, b2, c2, p2.w);
+                    probe_accumulate(acc8, a3, b3, c3, p3.w);
+                }
+                for (; i < nt; i += G) {
+                    const uint4 p0 = sProbe[i];
+                    const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
+                                c0 = ld16<NT>(base + (size_t)p0.z * stride);
+                    probe_accumulate(acc8, a0, b0, c0, p0.w);
+                }
+                // widen the packed byte counters (<= 240 per byte) into 32-bit counters
+                const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[4 * q + 0] += wv[q] & 0xFFu;
+                    acc[4 * q + 1] += (wv[q] >> 8) & 0xFFu;
+                    acc[4 * q + 2] += (wv[q] >> 16) & 0xFFu;
+                    acc[4 * q + 3] += wv[q] >> 24;
+                }
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (acc[j]) atomicAdd(&sC[u * 16u + (uint32_t)j], acc[j]);
+        }
+    }
+}
+
 template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // all LDS in the dynamic region (keeps its base 16-B aligned): probes | work item | per-bin counts
-    uint4 *sProbe = reinterpret_cast<uint4 *>(smem);                                // Q_HT probes
-    uint32_t *sItemP = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4));   // 16 B
-    uint32_t *sC = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4) + 16);  // stride words
+    uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
+    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4));       // [0] item, [1] n alive units
+    uint32_t *sUnits = sScal + 16;
+    uint32_t *sMap = sUnits + Q_MAXU;
+    uint32_t *sC = sMap + a.map_words;
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lvl = a.level;
@@ -464,9 +553,9 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) *sItemP = atomicAdd(&a.ctr->q_cursor[lvl], 1u);
+        if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl], 1u);
         __syncthreads();
-        const uint32_t item = *sItemP;
+        const uint32_t item = sScal[0];
         if (item >= n_items) break;
         uint32_t r, v;
         if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
@@ -476,70 +565,87 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
         const uint32_t n = a.nh[r];
         const uint64_t thr = a.thr[r];
         const uint64_t *__restrict__ hp = a.hashes + a.hoff[r];
-        const uint32_t units = D.units, stride = D.stride;
+        const uint32_t stride = D.stride;
+        const uint32_t *__restrict__ bi = a.binfo + D.bin_base;
+        const uint32_t nb_round = (D.bins + 63u) & ~63u;
 
         for (uint32_t i = tid; i < stride; i += BLK) sC[i] = 0;
+        for (uint32_t i = tid; i < a.map_words; i += BLK) sMap[i] = 0;
+        if (tid == 0) sScal[1] = 0;
 
-        // column passes: 256 units (4096 bins) per pass; almost always exactly one
-        for (uint32_t u0 = 0; u0 < units; u0 += BLK) {
-            const uint32_t upass = min(units - u0, (uint32_t)BLK);
-            const uint32_t G = BLK / upass;           // hashes processed concurrently by the block
-            const uint32_t g = tid / upass;
-            const uint32_t u = u0 + (tid - g * upass);
-            const bool active = g < G;
-            const uint8_t *__restrict__ base = D.data + (size_t)u * 16u;
-            uint32_t acc[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) acc[j] = 0;
+        // ---- threshold-aware pruning ---------------------------------------------------------------------------
+        // After `dense_end` hashes a run of `len` technical bins whose partial sum satisfies
+        // sum + (n - dense_end) * len < thr can never reach the threshold: the reference would neither report
+        // nor descend it, so its remaining counts are irrelevant.  dense_end = n - thr + 16 leaves random bins
+        // (expected count dense_end/256) far below the bound, so normally only true matches stay alive and the
+        // remaining hashes probe just their 16-bin units.  Runs that stay alive are counted exactly.
+        uint32_t dense_end = n;
+        if (a.prune && thr > 0) dense_end = (thr >= (uint64_t)n + 16u) ? 0u : min(n, (uint32_t)((uint64_t)n + 16u - thr));
+        uint64_t touched = 0;
 
-            for (uint32_t t0 = 0; t0 < n; t0 += Q_HT) {
-                const uint32_t nt = min((uint32_t)Q_HT, n - t0);
-                __syncthreads();
-                if (tid < nt) {
-                    const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
-                    sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
-                }
-                __syncthreads();
-                if (active) {
-                    uint4 acc8 = make_uint4(0, 0, 0, 0);
-                    uint32_t i = g;
-                    for (; i + 3u * G < nt; i += 4u * G) {
-                        const uint4 p0 = sProbe[i], p1 = sProbe[i + G], p2 = sProbe[i + 2u * G],
-                                    p3 = sProbe[i + 3u * G];
-                        const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
-                                    c0 = ld16<NT>(base + (size_t)p0.z * stride);
-                        const uint4 a1 = ld16<NT>(base + (size_t)p1.x * stride), b1 = ld16<NT>(base + (size_t)p1.y * stride),
-                                    c1 = ld16<NT>(base + (size_t)p1.z * stride);
-                        const uint4 a2 = ld16<NT>(base + (size_t)p2.x * stride), b2 = ld16<NT>(base + (size_t)p2.y * stride),
-                                    c2 = ld16<NT>(base + (size_t)p2.z * stride);
-                        const uint4 a3 = ld16<NT>(base + (size_t)p3.x * stride), b3 = ld16<NT>(base + (size_t)p3.y * stride),
-                                    c3 = ld16<NT>(base + (size_t)p3.z * stride);
-                        probe_accumulate(acc8, a0, b0, c0, p0.w);
-                        probe_accumulate(acc8, a1, b1, c1, p1.w);
-                        probe_accumulate(acc8, a2, b2, c2, p2.w);
-                        probe_accumulate(acc8, a3, b3, c3, p3.w);
-                    }
-                    for (; i < nt; i += G) {
-                        const uint4 p0 = sProbe[i];
-                        const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
-                                    c0 = ld16<NT>(base + (size_t)p0.z * stride);
-                        probe_accumulate(acc8, a0, b0, c0, p0.w);
-                    }
-                    // widen the packed byte counters (<= 240 per byte) into 32-bit counters
-                    const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[4 * q + 0] += wv[q] & 0xFFu;
-                        acc[4 * q + 1] += (wv[q] >> 8) & 0xFFu;
-                        acc[4 * q + 2] += (wv[q] >> 16) & 0xFFu;
-                        acc[4 * q + 3] += wv[q] >> 24;
+        query_dense_range<NT>(D, hp, 0, dense_end, sProbe, sC);
+        touched += (uint64_t)dense_end * 3ull * stride;
+        __syncthreads();
+
+        if (dense_end < n) {
+            const uint64_t rem = n - dense_end;
+            for (uint32_t b = tid; b < nb_round; b += BLK) {
+                if (b < D.bins) {
+                    const uint32_t info = bi[b];
+                    if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
+                        int bb = (int)b;
+                        uint64_t sum = sC[bb];
+                        if (!(info & BINFO_MERGED))
+                            while (bb > 0 && (bi[bb - 1] >> 30) == 0u) sum += sC[--bb];
+                        const uint64_t len = (uint64_t)b - (uint64_t)bb + 1u;
+                        if (sum + rem * len >= thr) {
+                            for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
+                                const uint32_t bit = 1u << (x & 31u);
+                                if (!(atomicOr(&sMap[x >> 5], bit) & bit)) {
+                                    const uint32_t k = atomicAdd(&sScal[1], 1u);
+                                    if (k < (uint32_t)Q_MAXU) sUnits[k] = x;
+                                }
+                            }
+                        }
                     }
                 }
             }
-            if (active) {
+            __syncthreads();
+            const uint32_t n_alive = sScal[1];
+            if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
+                query_dense_range<NT>(D, hp, dense_end, n, sProbe, sC);
+                touched += rem * 3ull * stride;
+            } else if (n_alive > 0) {
+                for (uint32_t t0 = dense_end; t0 < n; t0 += Q_HT) {
+                    const uint32_t nt = min((uint32_t)Q_HT, n - t0);
+                    __syncthreads();
+                    if (tid < nt) {
+                        const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
+                        sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                    }
+                    __syncthreads();
+                    const uint32_t tasks = nt * n_alive;
+                    for (uint32_t task = tid; task < tasks; task += BLK) {
+                        const uint32_t i = task / n_alive, j = task - i * n_alive;
+                        const uint32_t x = sUnits[j];
+                        const uint4 p = sProbe[i];
+                        const uint8_t *base = D.data + (size_t)x * 16u;
+                        const uint4 r0 = ld16<NT>(base + (size_t)p.x * stride), r1 = ld16<NT>(base + (size_t)p.y * stride),
+                                    r2 = ld16<NT>(base + (size_t)p.z * stride);
+                        const uint32_t z[4] = {zero_bytes01(r0.x ^ r1.x ^ r2.x ^ p.w), zero_bytes01(r0.y ^ r1.y ^ r2.y ^ p.w),
+                                               zero_bytes01(r0.z ^ r1.z ^ r2.z ^ p.w), zero_bytes01(r0.w ^ r1.w ^ r2.w ^ p.w)};
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if (acc[j]) atomicAdd(&sC[u * 16u + (uint32_t)j], acc[j]);
+                        for (int q = 0; q < 4; ++q) {
+                            uint32_t m = z[q];
+                            while (m) {
+                                const int bit = __ffs((int)m) - 1; // 0, 8, 16 or 24
+                                m &= m - 1u;
+                                atomicAdd(&sC[x * 16u + 4u * (uint32_t)q + ((uint32_t)bit >> 3)], 1u);
+                            }
+                        }
+                    }
+                }
+                touched += rem * (uint64_t)n_alive * 3ull * 64ull; // one 64-B sector per 16-B unit load
             }
         }
         __syncthreads();
@@ -548,8 +654,6 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
             for (uint32_t b = tid; b < D.bins; b += BLK) a.counts_out[b] = sC[b];
 
         // ---- tally: hierarchical_interleaved_xor_filter.hpp:313-338 --------------------------------------
-        const uint32_t *__restrict__ bi = a.binfo + D.bin_base;
-        const uint32_t nb_round = (D.bins + 63u) & ~63u;
         for (uint32_t b = tid; b < nb_round; b += BLK) {
             bool push_child = false, push_hit = false;
             uint32_t sum = 0, info = 0;
@@ -580,6 +684,7 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
         }
         if (tid == 0) {
             atomicAdd(&a.ctr->query_bytes, (unsigned long long)n * 3ull * D.bins);
+            atomicAdd(&a.ctr->touched_bytes, (unsigned long long)touched);
             atomicAdd(&a.ctr->n_work, 1ull);
         }
     }

@@ -310,3 +310,44 @@ def test_device_built_index_matches_host_copy():
     assert st["query_ms"] > 0 and st["query_launches"] == idx.depth
     sr.close()
     idx.close()
+
+
+def test_pruning_long_split_runs_and_thresholds():
+    """threshold-aware pruning: dead runs are skipped, alive runs counted exactly.  A user bin split over 640
+    technical bins keeps > 32 units alive (dense fallback); short runs exercise the sparse phase; results must
+    equal the oracle for thresholds on both sides of every boundary."""
+    rng = np.random.default_rng(12)
+    bins, stride = 700, 704
+    seg = synth.seg_len_for(3000)
+    keys_a = np.unique(rng.integers(0, 2**63, size=2500, dtype=np.uint64))     # planted in the long split run
+    keys_b = np.unique(rng.integers(0, 2**63, size=2000, dtype=np.uint64))     # planted in a 3-bin run
+    keys_c = np.unique(rng.integers(0, 2**63, size=1500, dtype=np.uint64))     # planted in a single bin
+    planted = {b: keys_a[b::640] for b in range(0, 640, 7)}
+    planted.update({650 + j: keys_b[j::3] for j in range(3)})
+    planted[690] = keys_c
+    seed, cols = synth.build_columns(planted, seg, 5)
+    data = rng.integers(0, 256, size=(3 * seg, stride), dtype=np.uint8)
+    for b, c in cols.items():
+        data[:, b] = c
+    fname = np.arange(bins, dtype=np.int64)
+    fname[:640] = 0
+    fname[650:653] = 650
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=seed, next_ixf=np.zeros(bins, np.int64), fname_idx=fname,
+               data=data.reshape(-1))
+    idx = GpuIndex([ixf], bins)
+    h = orc.Hixf([ixf], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    sr = Searcher(idx, ratio=0.5)
+    noise = rng.integers(0, 2**63, size=600, dtype=np.uint64)
+    for name, q in (("split640", np.concatenate([keys_a[:700], noise[:300]])),
+                    ("split3", np.concatenate([keys_b[:500], noise[:500]])),
+                    ("single", np.concatenate([keys_c[:400], noise])),
+                    ("mixed", np.concatenate([keys_a[:300], keys_b[:300], keys_c[:300], noise[:100]])),
+                    ("noise", noise)):
+        for thr in (1, 5, 17, 100, 299, 300, 301, 400, 401, 500, 501, 699, 700, 701, q.size - 1, q.size, q.size + 1, q.size + 40):
+            ub, cnt = sr.bulk_contains(q, thr)
+            wub, wcnt, _ = h.bulk_contains(q, thr)
+            assert np.array_equal(ub, wub) and np.array_equal(cnt, wcnt), (name, thr, ub.tolist(), wub.tolist())
+    # raw bulk_count is never pruned
+    assert np.array_equal(sr.ixf_bulk_count(0, noise), h.ixf_bulk_count(0, noise))
+    sr.close()
+    idx.close()
