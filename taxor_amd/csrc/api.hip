@@ -94,6 +94,7 @@ struct taxor_gpu_searcher {
     Counters *d_ctr = nullptr;
     Counters h_ctr{};
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
+    uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
     bool prune = true;   // TAXOR_QUERY_PRUNE=0 disables the threshold-aware pruning (A/B measurements)
     size_t lds_query = 0;
 
@@ -379,10 +380,12 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     }
     s->grid_sync = syncmers_grid(idx->device);
     if (const char *e = getenv("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
-    {   // syncmer launches that run beside a query kernel keep to one block per CU: with more, the query kernel
-        // stalls for as long as the syncmer kernel runs (measured); with one it is not slowed at all
+    if (const char *e = getenv("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
+    if (const char *e = getenv("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) s->prm.sub_batch_reads = (uint32_t)v; }
+    {   // syncmer launches that run beside a query kernel keep to two blocks per CU: at full occupancy (three) the
+        // query kernel stalls for as long as the syncmer kernel runs (measured); with one or two it is not slowed
         hipDeviceProp_t p;
-        int per = 1;
+        int per = 2;
         if (const char *e = getenv("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
         s->grid_sync_overlap = hipGetDeviceProperties(&p, idx->device) == hipSuccess ? p.multiProcessorCount * per : s->grid_sync;
         if (s->grid_sync_overlap > s->grid_sync) s->grid_sync_overlap = s->grid_sync;
@@ -473,7 +476,10 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         if (len >= (1ull << 31)) return fail(TAXOR_E_ARG, "read %llu longer than 2^31 bases", (unsigned long long)r);
         const uint64_t nwin = len >= (uint64_t)idx->k ? len - idx->k + 1 : 0;
         const uint64_t cap = round_up(nwin / gap + 2, 16); // 128-B aligned regions: no line shared between reads
-        if (r > sub_first && (r - sub_first >= s->prm.sub_batch_reads || sub_bases + len > s->prm.sub_batch_bases)) {
+        // the first sub-batch's syncmer kernel has nothing to hide behind: keep it a quarter the size
+        const uint64_t lim_reads = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_reads / s->first_div, 1) : s->prm.sub_batch_reads;
+        const uint64_t lim_bases = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_bases / s->first_div, 1) : s->prm.sub_batch_bases;
+        if (r > sub_first && (r - sub_first >= lim_reads || sub_bases + len > lim_bases)) {
             s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots});
             s->max_slots = std::max(s->max_slots, sub_slots);
             s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(r - sub_first));
@@ -654,12 +660,12 @@ int check_flags(taxor_gpu_searcher *s, bool *rerun)
     if (f & FLAG_DEDUP_OVERFLOW) return fail(TAXOR_E_INTERNAL, "dedup scratch too small");
     if (f & FLAG_QUEUE_OVERFLOW) {
         uint32_t need = 0;
-        for (int i = 0; i < MAX_LEVELS; ++i) need = std::max(need, s->h_ctr.q_n[i]);
+        for (int i = 0; i < MAX_LEVELS; ++i) need = std::max(need, s->h_ctr.q_n[i].v);
         s->q_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * s->q_cap, (uint64_t)need + 1024), 0x7FFFFFFFu);
         *rerun = true;
     }
     if (f & FLAG_HITS_OVERFLOW) {
-        s->hit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * s->hit_cap, (uint64_t)s->h_ctr.n_hits + 1024), 0x7FFFFFFFu);
+        s->hit_cap = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2ull * s->hit_cap, (uint64_t)s->h_ctr.n_hits.v + 1024), 0x7FFFFFFFu);
         *rerun = true;
     }
     if (f & FLAG_TUPLE_OVERFLOW) {
@@ -922,7 +928,7 @@ extern "C" int taxor_gpu_ixf_bulk_count(taxor_gpu_searcher *s, uint64_t ixf, con
     const uint2 item = make_uint2(0u, (uint32_t)ixf);
     const uint32_t one = 1;
     hipError_t e = hipMemcpyAsync(s->d_q[0].p, &item, sizeof item, hipMemcpyHostToDevice, s->st);
-    if (e == hipSuccess) e = hipMemcpyAsync(&s->d_ctr->q_n[0], &one, 4, hipMemcpyHostToDevice, s->st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&s->d_ctr->q_n[0].v, &one, 4, hipMemcpyHostToDevice, s->st);
     if (e == hipSuccess) e = hipStreamSynchronize(s->st);
     if (e != hipSuccess) rc = fail(TAXOR_E_HIP, "ixf_bulk_count: %s", hipGetErrorString(e));
     s->ev_used = 0;

@@ -39,20 +39,27 @@ enum : uint32_t {
     FLAG_DEDUP_OVERFLOW = 32u // dedup scratch too small (internal invariant)
 };
 
-// counters block (one per searcher, u32 words unless noted)
+// counters block (one per searcher).  Hot words sit on their own 128-B lines: returning atomics on one line are
+// serialised by a single L2 channel (~90 per microsecond), and a level with tens of thousands of short work items
+// would otherwise queue its cursor, queue-append, hit-append and statistics atomics behind each other.
+struct alignas(128) PaddedU32 {
+    uint32_t v;
+    uint32_t pad[31];
+};
 struct Counters {
     uint32_t flags;
-    uint32_t cursor_sync;      // dynamic work cursor of k_syncmers
-    uint32_t n_hits;
+    uint32_t reserved0;
     uint32_t n_big;
-    uint32_t q_n[16];          // work items per level
-    uint32_t q_cursor[16];     // dynamic work cursor per level
-    uint32_t pad[2];
-    unsigned long long tuple_total;   // tuples emitted so far in this batch run
-    unsigned long long n_hashes;      // distinct hashes so far
-    unsigned long long query_bytes;   // sum n_h*3*bins over work items
-    unsigned long long n_work;        // work items processed
-    unsigned long long touched_bytes; // bytes the query kernel actually requested (after pruning)
+    uint32_t pad0[29];
+    PaddedU32 n_hits;
+    PaddedU32 q_n[16];                // work items per level
+    PaddedU32 q_cursor[16];           // dynamic work cursor per level
+    alignas(128) unsigned long long tuple_total;   // tuples emitted so far in this batch run
+    unsigned long long n_hashes;                   // distinct hashes so far
+    alignas(128) unsigned long long query_bytes;   // sum n_h*3*bins over work items
+    unsigned long long n_work;                     // work items processed
+    unsigned long long touched_bytes;              // bytes the query kernel actually requested (after pruning)
+    unsigned long long pad1[13];
 };
 static constexpr int MAX_LEVELS = 16;
 

@@ -410,7 +410,8 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 // Tiles are <= 255 hashes so the byte counters cannot overflow before they are widened.  Counters are
 // merged through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
 // ------------------------------------------------------------------------------------------------------
-static constexpr int Q_HT = 240; // hashes per probe tile
+static constexpr int Q_HT = 240;   // hashes per probe tile when one thread sees every hash (byte counters stay < 256)
+static constexpr int Q_HT2 = 480;  // probe tile (and LDS probe capacity) when hashes are split over G >= 2 thread groups
 
 __device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
 {
@@ -448,7 +449,7 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
 }
 
 // LDS layout of k_query_level (all dynamic, base 16-B aligned):
-//   [0, Q_HT*16)                      probes of the current hash tile
+//   [0, Q_HT2*16)                     probes of the current hash tile
 //   [.., +64)                          scalars: work item, alive-unit count
 //   [.., +Q_MAXU*4)                    list of alive 16-bin units
 //   [.., +map_words*4)                 bitmap of alive units (map_words = max_units/32 rounded up to 4 words)
@@ -461,7 +462,7 @@ uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_w
 
 size_t query_lds_bytes(uint32_t max_stride)
 {
-    return (size_t)Q_HT * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
+    return (size_t)Q_HT2 * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
 }
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
@@ -484,12 +485,13 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0;
 
-        for (uint32_t t0 = h0; t0 < h1; t0 += Q_HT) {
-            const uint32_t nt = min((uint32_t)Q_HT, h1 - t0);
+        const uint32_t HT = (G == 1u) ? (uint32_t)Q_HT : (uint32_t)Q_HT2; // per-thread hashes per tile <= 240 either way
+        for (uint32_t t0 = h0; t0 < h1; t0 += HT) {
+            const uint32_t nt = min(HT, h1 - t0);
             __syncthreads();
-            if (tid < nt) {
-                const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
-                sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+            for (uint32_t i = tid; i < nt; i += BLK) {
+                const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
             __syncthreads();
             if (active) {
@@ -510,11 +512,25 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
                     probe_accumulate(acc8, a2, b2, c2, p2.w);
                     probe_accumulate(acc8, a3, b3, c3, p3.w);
                 }
-                for (; i < nt; i += G) {
-                    const uint4 p0 = sProbe[i];
+                if (i < nt) { // up to three left: issue their loads together (one memory round trip, not three)
+                    const bool v1 = i + G < nt, v2 = i + 2u * G < nt;
+                    const uint4 p0 = sProbe[i], p1 = sProbe[v1 ? i + G : i], p2 = sProbe[v2 ? i + 2u * G : i];
                     const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
                                 c0 = ld16<NT>(base + (size_t)p0.z * stride);
+                    uint4 a1 = a0, b1 = b0, c1 = c0, a2 = a0, b2 = b0, c2 = c0;
+                    if (v1) {
+                        a1 = ld16<NT>(base + (size_t)p1.x * stride);
+                        b1 = ld16<NT>(base + (size_t)p1.y * stride);
+                        c1 = ld16<NT>(base + (size_t)p1.z * stride);
+                    }
+                    if (v2) {
+                        a2 = ld16<NT>(base + (size_t)p2.x * stride);
+                        b2 = ld16<NT>(base + (size_t)p2.y * stride);
+                        c2 = ld16<NT>(base + (size_t)p2.z * stride);
+                    }
                     probe_accumulate(acc8, a0, b0, c0, p0.w);
+                    if (v1) probe_accumulate(acc8, a1, b1, c1, p1.w);
+                    if (v2) probe_accumulate(acc8, a2, b2, c2, p2.w);
                 }
                 // widen the packed byte counters (<= 240 per byte) into 32-bit counters
                 const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
@@ -539,7 +555,7 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
-    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_HT * sizeof(uint4));       // [0] item, [1] n alive units
+    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_HT2 * sizeof(uint4));       // [0] item, [1] n alive units
     uint32_t *sUnits = sScal + 16;
     uint32_t *sMap = sUnits + Q_MAXU;
     uint32_t *sC = sMap + a.map_words;
@@ -549,11 +565,12 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
     // This kernel is HBM-bound and needs few issue slots, but it needs them promptly: when the (VALU/LDS heavy)
     // syncmer kernel of the next sub-batch shares the CU, age-based arbitration would starve these waves.
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl], a.q_cap) : a.n_level0;
+    const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0;
+    unsigned long long st_bytes = 0, st_touched = 0, st_work = 0;
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl], 1u);
+        if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, 1u);
         __syncthreads();
         const uint32_t item = sScal[0];
         if (item >= n_items) break;
@@ -616,12 +633,12 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
                 query_dense_range<NT>(D, hp, dense_end, n, sProbe, sC);
                 touched += rem * 3ull * stride;
             } else if (n_alive > 0) {
-                for (uint32_t t0 = dense_end; t0 < n; t0 += Q_HT) {
-                    const uint32_t nt = min((uint32_t)Q_HT, n - t0);
+                for (uint32_t t0 = dense_end; t0 < n; t0 += Q_HT2) {
+                    const uint32_t nt = min((uint32_t)Q_HT2, n - t0);
                     __syncthreads();
-                    if (tid < nt) {
-                        const ixf_probe p = ixf_probe_key(hp[t0 + tid], D.seed, D.seg_len);
-                        sProbe[tid] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                    for (uint32_t i = tid; i < nt; i += BLK) {
+                        const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                        sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                     }
                     __syncthreads();
                     const uint32_t tasks = nt * n_alive;
@@ -669,12 +686,12 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
                     push_hit = (uint64_t)sum >= thr;               // :328
                 }
             }
-            const uint32_t qs = wave_append(push_child, &a.ctr->q_n[lvl + 1]);
+            const uint32_t qs = wave_append(push_child, &a.ctr->q_n[lvl + 1].v);
             if (push_child) {
                 if (qs < a.q_cap) a.q_out[qs] = make_uint2(r, info & 0x3FFFFFFFu);
                 else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
             }
-            const uint32_t hs = wave_append(push_hit, &a.ctr->n_hits);
+            const uint32_t hs = wave_append(push_hit, &a.ctr->n_hits.v);
             if (push_hit) {
                 if (hs < a.hit_cap) {
                     a.hits[hs] = make_uint4(r, D.bin_base + b, sum, 0u);
@@ -682,11 +699,14 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
                 } else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
             }
         }
-        if (tid == 0) {
-            atomicAdd(&a.ctr->query_bytes, (unsigned long long)n * 3ull * D.bins);
-            atomicAdd(&a.ctr->touched_bytes, (unsigned long long)touched);
-            atomicAdd(&a.ctr->n_work, 1ull);
-        }
+        st_bytes += (unsigned long long)n * 3ull * D.bins;
+        st_touched += touched;
+        st_work += 1ull;
+    }
+    if (tid == 0 && st_work) { // one set of statistics atomics per block, not per work item
+        atomicAdd(&a.ctr->query_bytes, st_bytes);
+        atomicAdd(&a.ctr->touched_bytes, st_touched);
+        atomicAdd(&a.ctr->n_work, st_work);
     }
 }
 
@@ -755,7 +775,7 @@ __global__ __launch_bounds__(BLK) void k_scatter_hits(const FinalizeArgs a)
 {
     // after a queue/hit overflow the host grows the buffers and reruns; nothing here may index past hit_cap
     if (a.ctr->flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW)) return;
-    const uint32_t n = min(a.ctr->n_hits, a.hit_cap);
+    const uint32_t n = min(a.ctr->n_hits.v, a.hit_cap);
     const unsigned long long base = a.ctr->tuple_total - a.roff[a.n_reads]; // first tuple of this sub-batch
     for (uint32_t i = blockIdx.x * BLK + threadIdx.x; i < n; i += gridDim.x * BLK) {
         const uint4 h = a.hits[i];
