@@ -204,12 +204,18 @@ __device__ __forceinline__ uint32_t dedup_slot(uint64_t h, uint32_t mask)
     return (uint32_t)(h >> 32) & mask;
 }
 
-__global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
+// FW > 0: fast path for a window of exactly FW s-mers (FW = 11 is taxor's k22/s12) with 2s+5 <= 32: each thread
+// owns SY_C consecutive windows, pulls their FW+SY_C-1 s-mer values out of a transposed (bank-conflict-free) LDS
+// tile once, and gets leftmost/rightmost argmin from two sparse-table min trees over keys (value<<5 | offset) and
+// (value<<5 | 31-offset).  FW == 0: generic window length, per-window scan in LDS.
+static constexpr int SY_RS = SY_T / SY_C + 5; // row stride (words) of the transposed s-mer tile; odd -> no bank conflicts
+
+template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
 {
     __shared__ uint32_t sW[SY_WORDS];
-    __shared__ uint32_t sV[SY_T + 32];
-    __shared__ uint8_t sLm[SY_T];
-    __shared__ uint8_t sRm[SY_T];
+    __shared__ uint32_t sV[SY_C * SY_RS];
+    __shared__ __attribute__((aligned(16))) uint8_t sLm[SY_T];
+    __shared__ __attribute__((aligned(16))) uint8_t sRm[SY_T];
     __shared__ uint32_t sTab[SY_LDS_TAB];
     __shared__ uint64_t sCand[SY_LDS_CAND];
     __shared__ uint32_t sScr[8];
@@ -249,41 +255,92 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
             __syncthreads();
             // ---- canonical s-mer values (syncmer.cpp:103-110; the s-mer "hash" is the raw 2-bit value)
             const int nv = min(SY_T + w - 1, (int)L - s + 1 - x0); // valid s-mer starts in this tile
-            for (int i = (int)tid; i < SY_T + w - 1; i += BLK) {
-                uint32_t v = 0xFFFFFFFFu;
-                if (i < nv) {
-                    const uint32_t pos = (uint32_t)(x0 + i);
-                    const uint32_t f = (uint32_t)extract_bases(sW, (pos >> 4) - wbase, pos & 15u, s) & smask;
-                    const uint32_t rc = revcomp32(f, s);
-                    v = min(f, rc);
-                }
-                sV[i] = v;
-            }
-            __syncthreads();
-            // ---- per window: leftmost / rightmost argmin (interleaved assignment: conflict-free LDS)
             const int nw_tile = min(SY_T, nwin - x0);
-#pragma unroll 2
-            for (int c = 0; c < SY_C; ++c) {
-                const int xl = c * BLK + (int)tid;
-                if (xl < nw_tile) {
-                    uint32_t m = sV[xl];
-                    int lm = 0, rm = 0;
-                    for (int j = 1; j < w; ++j) {
-                        const uint32_t v = sV[xl + j];
-                        if (v < m) { m = v; lm = j; rm = j; }
-                        else if (v == m) rm = j;
-                    }
-                    sLm[xl] = (uint8_t)lm;
-                    sRm[xl] = (uint8_t)rm;
-                }
-            }
-            __syncthreads();
-            // ---- resolve the tracked position per window (chunked assignment: SY_C consecutive windows)
             const int xs = (int)tid * SY_C;
             int last_anchor = -1;
-            for (int c = 0; c < SY_C; ++c) {
-                const int xl = xs + c;
-                if (xl < nw_tile && (sLm[xl] == sRm[xl] || x0 + xl == 0)) last_anchor = xl;
+            int lmr[SY_C], rmr[SY_C]; // fast path: argmin offsets of this thread's windows
+            if constexpr (FW > 0) {
+                for (int i = (int)tid; i < SY_T + FW - 1; i += BLK) {
+                    uint32_t v = 0x07FFFFFFu; // above every canonical value of <= 13 bases, and (v << 5) still fits
+                    if (i < nv) {
+                        const uint32_t pos = (uint32_t)(x0 + i);
+                        const uint32_t f = (uint32_t)extract_bases(sW, (pos >> 4) - wbase, pos & 15u, s) & smask;
+                        const uint32_t rc = revcomp32(f, s);
+                        v = min(f, rc);
+                    }
+                    sV[(i & (SY_C - 1)) * SY_RS + (i >> 3)] = v;
+                }
+                __syncthreads();
+                constexpr int NV = FW + SY_C - 1;
+                uint32_t kl[NV], kr[NV];
+#pragma unroll
+                for (int c = 0; c < NV; ++c) {
+                    const uint32_t v = sV[(c & (SY_C - 1)) * SY_RS + (int)tid + (c >> 3)];
+                    kl[c] = (v << 5) | (uint32_t)c;
+                    kr[c] = (v << 5) | (uint32_t)(31 - c);
+                }
+                // sparse-table minima: m2 over 2, m4 over 4, m8 over 8 consecutive keys; FW = 8 + (FW - 8)
+                static_assert(FW >= 8 && FW <= 16, "fast path covers window lengths 8..16");
+                uint32_t l2[NV - 1], r2[NV - 1], l4[NV - 3], r4[NV - 3], l8[SY_C + FW - 8], r8[SY_C + FW - 8];
+#pragma unroll
+                for (int c = 0; c < NV - 1; ++c) { l2[c] = min(kl[c], kl[c + 1]); r2[c] = min(kr[c], kr[c + 1]); }
+#pragma unroll
+                for (int c = 0; c < NV - 3; ++c) { l4[c] = min(l2[c], l2[c + 2]); r4[c] = min(r2[c], r2[c + 2]); }
+#pragma unroll
+                for (int c = 0; c < SY_C + FW - 8; ++c) { l8[c] = min(l4[c], l4[c + 4]); r8[c] = min(r4[c], r4[c + 4]); }
+                uint64_t packL = 0, packR = 0;
+#pragma unroll
+                for (int c = 0; c < SY_C; ++c) {
+                    // window c covers keys c .. c+FW-1 = [c, c+8) U [c+FW-8, c+FW)
+                    const uint32_t ml = min(l8[c], l8[c + FW - 8]);
+                    const uint32_t mr = min(r8[c], r8[c + FW - 8]);
+                    lmr[c] = (int)(ml & 31u) - c;
+                    rmr[c] = 31 - (int)(mr & 31u) - c;
+                    packL |= (uint64_t)(uint32_t)lmr[c] << (8 * c);
+                    packR |= (uint64_t)(uint32_t)rmr[c] << (8 * c);
+                    const int xl = xs + c;
+                    if (xl < nw_tile && (lmr[c] == rmr[c] || x0 + xl == 0)) last_anchor = xl;
+                }
+                *reinterpret_cast<uint64_t *>(&sLm[xs]) = packL;
+                *reinterpret_cast<uint64_t *>(&sRm[xs]) = packR;
+            } else {
+                for (int i = (int)tid; i < SY_T + w - 1; i += BLK) {
+                    uint32_t v = 0xFFFFFFFFu;
+                    if (i < nv) {
+                        const uint32_t pos = (uint32_t)(x0 + i);
+                        const uint32_t f = (uint32_t)extract_bases(sW, (pos >> 4) - wbase, pos & 15u, s) & smask;
+                        const uint32_t rc = revcomp32(f, s);
+                        v = min(f, rc);
+                    }
+                    sV[i] = v;
+                }
+                __syncthreads();
+                // ---- per window: leftmost / rightmost argmin (interleaved assignment: conflict-free LDS)
+#pragma unroll 2
+                for (int c = 0; c < SY_C; ++c) {
+                    const int xl = c * BLK + (int)tid;
+                    if (xl < nw_tile) {
+                        uint32_t m = sV[xl];
+                        int lm = 0, rm = 0;
+                        for (int j = 1; j < w; ++j) {
+                            const uint32_t v = sV[xl + j];
+                            if (v < m) { m = v; lm = j; rm = j; }
+                            else if (v == m) rm = j;
+                        }
+                        sLm[xl] = (uint8_t)lm;
+                        sRm[xl] = (uint8_t)rm;
+                    }
+                }
+                __syncthreads();
+                // ---- resolve the tracked position per window (chunked assignment: SY_C consecutive windows)
+                for (int c = 0; c < SY_C; ++c) {
+                    const int xl = xs + c;
+                    if (xl < nw_tile) {
+                        lmr[c] = sLm[xl];
+                        rmr[c] = sRm[xl];
+                        if (lmr[c] == rmr[c] || x0 + xl == 0) last_anchor = xl;
+                    }
+                }
             }
             const int anchor = block_excl_max(last_anchor, (int *)sScr);
             uint32_t selmask = 0;
@@ -291,13 +348,15 @@ __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
             if (xs < nw_tile) {
                 p = anchor >= 0 ? anchor + (int)sLm[anchor] : sCarry - x0;
                 while (p < xs) p = (p + 1) + (int)sRm[p + 1];
+#pragma unroll
                 for (int c = 0; c < SY_C; ++c) {
                     const int xl = xs + c;
-                    if (xl >= nw_tile) break;
-                    const int lm = sLm[xl], rm = sRm[xl];
-                    if (lm == rm || x0 + xl == 0) p = xl + lm;
-                    else if (p < xl) p = xl + rm;
-                    if (p == xl + t - 1) selmask |= 1u << c;
+                    if (xl < nw_tile) {
+                        const int lm = lmr[c], rm = rmr[c];
+                        if (lm == rm || x0 + xl == 0) p = xl + lm;
+                        else if (p < xl) p = xl + rm;
+                        if (p == xl + t - 1) selmask |= 1u << c;
+                    }
                 }
             }
             __syncthreads();
@@ -389,7 +448,7 @@ int syncmers_grid(int device)
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers, BLK, 0) != hipSuccess || per < 1) per = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers<11>, BLK, 0) != hipSuccess || per < 1) per = 2;
     if (const char *e = getenv("TAXOR_SYNC_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
@@ -397,7 +456,9 @@ int syncmers_grid(int device)
 void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 {
     if (!a.n_reads) return;
-    hipLaunchKernelGGL(k_syncmers, dim3(grid), dim3(BLK), 0, st, a);
+    static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
+    if (!generic_only && a.k - a.s + 1 == 11 && a.s <= 13) hipLaunchKernelGGL(k_syncmers<11>, dim3(grid), dim3(BLK), 0, st, a);
+    else hipLaunchKernelGGL(k_syncmers<0>, dim3(grid), dim3(BLK), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------------
