@@ -351,3 +351,66 @@ def test_pruning_long_split_runs_and_thresholds():
     assert np.array_equal(sr.ixf_bulk_count(0, noise), h.ixf_bulk_count(0, noise))
     sr.close()
     idx.close()
+
+
+def test_empty_and_degenerate_batches():
+    g, go, lay, host = _planted_setup(13, n_genomes=5, glen=6000, root_bins=66, child_bins=24, n_children=2)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    sr = Searcher(idx)
+    # zero reads
+    res = sr.search_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert res.read_off.tolist() == [0] and res.user_bin.size == 0 and res.n_hashes.size == 0
+    # only empty reads: threshold 0 -> every leaf run, count 0 (reference quirk), per read
+    res = sr.search_batch(np.zeros(0, np.uint8), np.zeros(4, np.uint64))
+    assert res.n_hashes.tolist() == [0, 0, 0] and int(res.read_off[-1]) == 3 * idx.leaf_runs
+    assert not res.count.any()
+    want = h.search_batch(np.zeros(0, np.uint8), np.zeros(4, np.uint64))
+    assert np.array_equal(res.user_bin, want[2])
+    # one read longer than a tile, offsets not starting at 0 (a slice of a larger buffer)
+    big = np.concatenate([np.frombuffer(b"TTTT", dtype=np.uint8), g[:5000]])
+    offs = np.array([4, 5004], dtype=np.uint64)
+    res = sr.search_batch(big, offs)
+    want = h.search_batch(g[:5000], np.array([0, 5000], dtype=np.uint64))
+    assert np.array_equal(res.n_hashes, want[0]) and np.array_equal(res.user_bin, want[2]) and np.array_equal(res.count, want[3])
+    # API misuse is an error, not a crash
+    s2 = Searcher(idx)
+    with pytest.raises(TaxorError):
+        s2.fetch()
+    with pytest.raises(TaxorError):
+        Searcher(idx, ratio=1.5)
+    s2.close()
+    sr.close()
+    idx.close()
+
+
+def test_index_validation_errors():
+    bins, stride, seg = 64, 64, 16
+    base = dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64),
+                fname_idx=np.arange(bins), data=np.zeros(3 * seg * stride, np.uint8))
+    for mutate, needle in [(lambda d: d.update(stride=96), "malformed"),
+                           (lambda d: d["fname_idx"].__setitem__(3, 10**6), "out of range"),
+                           (lambda d: (d["fname_idx"].__setitem__(3, -1), d["next_ixf"].__setitem__(3, 7)), "bad child")]:
+        d = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+        mutate(d)
+        if d["stride"] != stride:
+            d["data"] = np.zeros(3 * seg * d["stride"], np.uint8)
+        with pytest.raises(TaxorError) as e:
+            GpuIndex([d], bins)
+        assert needle in str(e.value)
+    # unsupported modes are rejected loudly (out of scope: k-mer/minimiser indexes, FracMinHash scaling)
+    with pytest.raises(TaxorError):
+        GpuIndex([base], bins, use_syncmer=False)
+    with pytest.raises(TaxorError):
+        GpuIndex([base], bins, scaling=10)
+    # a merged bin whose child is referenced twice is not a tree
+    a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+    a["fname_idx"][0] = -1
+    a["next_ixf"][0] = 1
+    a["fname_idx"][1] = -1
+    a["next_ixf"][1] = 1
+    b = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
+    b["next_ixf"] = np.full(bins, 1, np.int64)
+    with pytest.raises(TaxorError) as e:
+        GpuIndex([a, b], bins)
+    assert "not a tree" in str(e.value)
