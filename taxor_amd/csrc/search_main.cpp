@@ -9,13 +9,64 @@
 #include <sys/stat.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
+
+// one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
+struct Batch {
+    std::vector<std::string> ids;
+    std::string bases;
+    std::vector<uint64_t> offsets;
+    // results copied out of the searcher (its buffers are reused by the next batch)
+    std::vector<uint64_t> read_off;
+    std::vector<int64_t> user_bin;
+    std::vector<uint32_t> count, n_hashes;
+};
+
+template <typename T> class BoundedQueue {
+public:
+    explicit BoundedQueue(size_t cap) : cap_(cap) {}
+    void push(T v)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(v));
+        not_empty_.notify_one();
+    }
+    bool pop(T &out) // false once closed and drained
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
+    void close()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        closed_ = true;
+        not_empty_.notify_all();
+    }
+
+private:
+    std::mutex m_;
+    std::condition_variable not_full_, not_empty_;
+    std::deque<T> q_;
+    size_t cap_;
+    bool closed_ = false;
+};
 
 struct Config {                              // taxor_search_configuration.hpp:8-20
     std::string index_file, query_file, report_file;
@@ -64,7 +115,9 @@ void usage()
             "  --batch-reads <n>        reads per GPU batch (default 65536)\n");
 }
 
-// ---- minimal FASTA / FASTQ reader over zlib (plain or .gz); ids are the full header line --------------------
+// ---- FASTA / FASTQ reader over zlib (plain or .gz); ids are the full header line (seqan3 default).  Lines are
+//      located with memchr inside a large refill buffer; sequence lines are appended straight into the batch and
+//      quality lines are skipped without being copied.
 struct FastxReader {
     gzFile f = nullptr;
     std::vector<char> buf;
@@ -75,35 +128,49 @@ struct FastxReader {
     bool open(const std::string &path)
     {
         f = gzopen(path.c_str(), "rb");
-        buf.resize(1 << 20);
+        if (f) gzbuffer(f, 1 << 20);
+        buf.resize(8u << 20);
         return f != nullptr;
     }
     ~FastxReader() { if (f) gzclose(f); }
-    bool getline(std::string &line)
+    bool refill()
     {
-        line.clear();
+        if (eof) return false;
+        const int n = gzread(f, buf.data(), (unsigned)buf.size());
+        if (n <= 0) { eof = true; return false; }
+        pos = 0;
+        len = (size_t)n;
+        return true;
+    }
+    // next line -> appended to `out` (if non-null); returns false at end of input with nothing read
+    bool line_to(std::string *out, bool *nonempty_first_char = nullptr, char *first = nullptr)
+    {
+        bool any = false;
         for (;;) {
-            if (pos == len) {
-                if (eof) return !line.empty();
-                const int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n <= 0) { eof = true; return !line.empty(); }
-                pos = 0;
-                len = (size_t)n;
+            if (pos == len && !refill()) {
+                if (any && out && !out->empty() && out->back() == '\r') out->pop_back();
+                return any;
             }
             const char *s = buf.data() + pos;
             const char *e = (const char *)memchr(s, '\n', len - pos);
+            const size_t n = e ? (size_t)(e - s) : len - pos;
+            if (!any && n && first) { *first = s[0]; if (nonempty_first_char) *nonempty_first_char = true; }
+            if (out) out->append(s, n);
+            any = any || n || e;
+            pos += n + (e ? 1 : 0);
             if (e) {
-                line.append(s, e - s);
-                pos += (size_t)(e - s) + 1;
-                if (!line.empty() && line.back() == '\r') line.pop_back();
+                if (out && !out->empty() && out->back() == '\r') out->pop_back();
                 return true;
             }
-            line.append(s, len - pos);
-            pos = len;
         }
     }
-    // returns false at end of file
-    bool next(std::string &id, std::string &seq)
+    bool getline(std::string &line)
+    {
+        line.clear();
+        return line_to(&line);
+    }
+    // appends the record's sequence to `bases`; returns false at end of file
+    bool next(std::string &id, std::string &bases)
     {
         std::string line;
         if (pending.empty()) {
@@ -114,20 +181,21 @@ struct FastxReader {
             line.swap(pending);
             pending.clear();
         }
-        seq.clear();
         if (line[0] == '>') {
-            id = line.substr(1);
-            while (getline(line)) {
-                if (!line.empty() && line[0] == '>') { pending = line; break; }
-                seq += line;
+            id.assign(line, 1, std::string::npos);
+            for (;;) {
+                // peek the first character of the next line
+                if (pos == len && !refill()) break;
+                if (buf[pos] == '>') { getline(pending); break; }
+                line_to(&bases);
             }
             return true;
         }
         if (line[0] == '@') {
-            id = line.substr(1);
-            if (!getline(seq)) die("truncated FASTQ record: " + id);
-            std::string plus, qual;
-            if (!getline(plus) || plus.empty() || plus[0] != '+' || !getline(qual)) die("malformed FASTQ record: " + id);
+            id.assign(line, 1, std::string::npos);
+            if (!line_to(&bases)) die("truncated FASTQ record: " + id);
+            if (!getline(line) || line.empty() || line[0] != '+') die("malformed FASTQ record: " + id);
+            if (!line_to(nullptr)) die("truncated FASTQ record: " + id);   // quality: skipped, never copied
             return true;
         }
         die("query file is neither FASTA nor FASTQ");
@@ -226,46 +294,72 @@ int main(int argc, char **argv)
             taxor_gpu_searcher *sr = nullptr;
             if (taxor_gpu_searcher_create(gidx, &prm, &sr) != TAXOR_OK) die(taxor_gpu_last_error());
 
-            FastxReader rd;
-            if (!rd.open(query)) die("cannot open query file " + query);
-            std::vector<std::string> ids;
-            std::string bases, id, seq, text;
-            std::vector<uint64_t> offsets;
-            std::vector<char> line;
-            bool more = true;
-            while (more) {
-                t0 = now();
-                ids.clear();
-                bases.clear();
-                offsets.assign(1, 0);
-                while (ids.size() < cfg.batch_reads && bases.size() < cfg.batch_bases && (more = rd.next(id, seq))) {
-                    ids.push_back(id);
-                    bases += seq;
-                    offsets.push_back(bases.size());
+            // Three overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
+            //   reader thread  : FASTA/FASTQ(.gz) -> chunks of records          (taxor_search.cpp:315-321)
+            //   this thread    : chunk -> GPU (upload, kernels, fetch)           (:325)
+            //   writer thread  : tuples -> 0.8*max filter -> TSV lines -> file   (:266-311)
+            // Output stays in input order (the reference's order at --threads 1).
+            BoundedQueue<std::unique_ptr<Batch>> q_in(2), q_out(2);
+            double t_reads_local = 0;
+            std::thread reader([&] {
+                FastxReader rd;
+                if (!rd.open(query)) die("cannot open query file " + query);
+                std::string id;
+                bool more = true;
+                while (more) {
+                    const double t1 = now();
+                    auto b = std::make_unique<Batch>();
+                    b->offsets.assign(1, 0);
+                    b->bases.reserve(std::min<uint64_t>(cfg.batch_bases, 1ull << 30));
+                    while (b->ids.size() < cfg.batch_reads && b->bases.size() < cfg.batch_bases && (more = rd.next(id, b->bases))) {
+                        b->ids.push_back(id);
+                        b->offsets.push_back(b->bases.size());
+                    }
+                    t_reads_local += now() - t1;
+                    if (b->ids.empty()) break;
+                    q_in.push(std::move(b));
                 }
-                t_reads += now() - t0;
-                if (ids.empty()) break;
+                q_in.close();
+            });
+            std::thread writer([&] {
+                std::unique_ptr<Batch> b;
+                std::string text;
+                std::vector<char> line(4096);
+                while (q_out.pop(b)) {
+                    text.clear();
+                    for (size_t r = 0; r < b->ids.size(); ++r) {
+                        const uint64_t lo = b->read_off[r], n = b->read_off[r + 1] - lo;
+                        const uint64_t rl = b->offsets[r + 1] - b->offsets[r];
+                        uint64_t need = taxor_format_read(h, b->ids[r].data(), b->ids[r].size(), rl, b->n_hashes[r],
+                                                          b->user_bin.data() + lo, b->count.data() + lo, n, line.data(), line.size());
+                        if (need > line.size()) {
+                            line.resize(need + 1024);
+                            need = taxor_format_read(h, b->ids[r].data(), b->ids[r].size(), rl, b->n_hashes[r],
+                                                     b->user_bin.data() + lo, b->count.data() + lo, n, line.data(), line.size());
+                        }
+                        text.append(line.data(), need);
+                    }
+                    fwrite(text.data(), 1, text.size(), out);
+                }
+            });
+            std::unique_ptr<Batch> b;
+            while (q_in.pop(b)) {
                 t0 = now();
                 taxor_gpu_results res{};
-                if (taxor_gpu_search_batch(sr, bases.data(), offsets.data(), ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                if (taxor_gpu_search_batch(sr, b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
+                b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
+                b->count.assign(res.count, res.count + res.n_tuples);
+                b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
                 t_compute += now() - t0;
-                text.clear();
-                for (size_t r = 0; r < ids.size(); ++r) {
-                    const uint64_t lo = res.read_off[r], n = res.read_off[r + 1] - lo;
-                    const uint64_t rl = offsets[r + 1] - offsets[r];
-                    uint64_t need = taxor_format_read(h, ids[r].data(), ids[r].size(), rl, res.n_hashes[r], res.user_bin + lo,
-                                                      res.count + lo, n, line.data(), line.size());
-                    if (need > line.size()) {
-                        line.resize(need + 1024);
-                        need = taxor_format_read(h, ids[r].data(), ids[r].size(), rl, res.n_hashes[r], res.user_bin + lo,
-                                                 res.count + lo, n, line.data(), line.size());
-                    }
-                    text.append(line.data(), need);
-                }
-                fwrite(text.data(), 1, text.size(), out);
-                total_reads += ids.size();
-                total_bases += bases.size();
+                total_reads += b->ids.size();
+                total_bases += b->bases.size();
+                q_out.push(std::move(b));
             }
+            q_out.close();
+            reader.join();
+            writer.join();
+            t_reads += t_reads_local;
             taxor_gpu_searcher_destroy(sr);
             taxor_gpu_index_destroy(gidx);
             taxor_hixf_free(h);
