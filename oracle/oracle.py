@@ -13,10 +13,29 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libtaxor_oracle.so")
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def build(force=False):
+    """The oracle is compiled -march=native, so a library built on another machine (the build container) is
+    rebuilt on the machine that runs it (the GPU box has the same image and gcc)."""
     src = [os.path.join(_HERE, f) for f in ("taxor_oracle.c", "taxor_oracle.h", "Makefile")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+    stamp = os.path.join(_HERE, ".build_host")
+    host = _cpu_model()
+    built_for = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if (force or not os.path.exists(_SO) or built_for != host
+            or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libtaxor_oracle.so"])
+        with open(stamp, "w") as f:
+            f.write(host + "\n")
     return _SO
 
 
