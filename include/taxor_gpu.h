@@ -61,7 +61,8 @@ typedef struct {
     uint64_t n_user_bins;
     uint8_t kmer_size, syncmer_size, t_syncmer; /* src/main/index.hpp:219-221 */
     uint8_t use_syncmer;                        /* :223; must be 1 (k-mer/minimiser mode is out of scope) */
-    uint16_t scaling;                           /* :224; must be 1 (FracMinHash down-scaling out of scope) */
+    uint16_t scaling;                           /* :224; >1 = FracMinHash down-sampling of the syncmer hashes
+                                                   (taxor_search.cpp:223-233), applied on the device */
 } taxor_hixf_view;
 
 typedef struct taxor_gpu_index taxor_gpu_index;
@@ -161,7 +162,8 @@ int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out);
  * Stage entry points (used by the parity tests; each stage is checked on its own against the oracle).
  * ---------------------------------------------------------------------------------------------- */
 /* hashing::seq_to_syncmers (src/hashing/syncmer.hpp:23) for a batch: distinct hashes of read r, in first-
- * insertion order, at hashes[hash_off[r] .. hash_off[r+1]).  Pointers valid until the next call. */
+ * insertion order, at hashes[hash_off[r] .. hash_off[r+1]) -- after the FracMinHash filter of
+ * taxor_search.cpp:223-233 when the index has scaling > 1.  Pointers valid until the next call. */
 int taxor_gpu_syncmers(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                        const uint64_t **hash_off, const uint64_t **hashes);
 /* ixf.counting_agent<uint32_t>().bulk_count(values) for one IXF of the index

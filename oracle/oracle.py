@@ -51,7 +51,7 @@ class _Hixf(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("k", C.c_int), ("s", C.c_int), ("t", C.c_int),
-                ("error_rate", C.c_double), ("percentage", C.c_double)]
+                ("error_rate", C.c_double), ("percentage", C.c_double), ("scaling", C.c_int)]
 
 
 _lib = None
@@ -172,13 +172,13 @@ class Hixf:
         return ub[:n].copy(), cnt[:n].copy(), int(vb[0])
 
     def search_batch(self, bases: np.ndarray, offsets: np.ndarray, k=22, s=12, t=5, err=0.04,
-                     percentage=-1.0, threads=1):
+                     percentage=-1.0, threads=1, scaling=1):
         """bases: np.uint8 ASCII (already dna4-normalised), offsets: uint64[n+1].
         Returns (n_hashes u32[n], out_off u64[n+1], user_bin i64[], count u32[], visited_bytes)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
-        prm = _Params(k, s, t, err, percentage)
+        prm = _Params(k, s, t, err, percentage, scaling)
         nh = np.zeros(n, dtype=np.uint32)
         off = np.zeros(n + 1, dtype=np.uint64)
         cap = max(4 * n, 1024)

@@ -359,6 +359,14 @@ size_t orc_search_read(const orc_hixf *h, const orc_search_params *p, const char
     oset set;
     oset_init(&set);
     syncmers_into(seq, len, (uint64_t)p->k, (uint64_t)p->s, (uint64_t)p->t, &set);     /* :222 */
+    if (p->scaling > 1) {                                                              /* :223-233 */
+        size_t m = 0;
+        for (size_t i = 0; i < set.n; ++i) {
+            uint64_t v = orc_wyhash_u64(set.dense[i]);
+            if ((double)v <= (double)UINT64_MAX / (double)p->scaling) set.dense[m++] = set.dense[i];
+        }
+        set.n = m;
+    }
     size_t hash_count = set.n;                                                         /* :261 */
     size_t thr = orc_threshold(hash_count, (size_t)p->k, p->error_rate, p->percentage); /* :263 */
     size_t n = orc_bulk_contains(h, set.dense, hash_count, thr, user_bin, count, cap, visited_bytes); /* :265 */

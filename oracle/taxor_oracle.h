@@ -99,6 +99,7 @@ typedef struct {
     int k, s, t;
     double error_rate;   /* --error-rate, default 0.04 (taxor_search_configuration.hpp:16) */
     double percentage;   /* --percentage, default -1.0                                    */
+    int scaling;         /* index scaling (FracMinHash down-sampling), 1 = off            */
 } orc_search_params;
 
 /* One read: dna4-normalised ASCII in, tuples (before the 0.8*max filter) out. Returns #tuples. */

@@ -76,6 +76,7 @@ struct taxor_gpu_index {
     uint64_t n_user_bins = 0, total_bins = 0, leaf_runs = 0;
     uint32_t depth = 0, max_stride = 0;
     int k = 0, s = 0, t = 0;
+    uint32_t scaling = 1;
 };
 
 struct SubBatch {
@@ -146,7 +147,6 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
     if (!v || !out || v->n_ixf == 0 || !v->ixf) return fail(TAXOR_E_ARG, "index_create: empty view");
     if (!v->use_syncmer)
         return fail(TAXOR_E_ARG, "index_create: use_syncmer=false (k-mer/minimiser indexes) is out of scope");
-    if (v->scaling > 1) return fail(TAXOR_E_ARG, "index_create: scaling>1 (FracMinHash) is out of scope");
     const int k = v->kmer_size, s = v->syncmer_size, t = v->t_syncmer;
     if (k < 2 || k > 32 || s < 1 || s > 16 || s >= k || k - s + 1 > 32 || t < 1)
         return fail(TAXOR_E_ARG, "index_create: unsupported k=%d s=%d t=%d (need k<=32, s<=16, s<k, t>=1)", k, s, t);
@@ -158,6 +158,7 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
     idx->k = k;
     idx->s = s;
     idx->t = t;
+    idx->scaling = v->scaling ? v->scaling : 1;
     idx->n_user_bins = v->n_user_bins;
     const uint64_t n = v->n_ixf;
     idx->h_ixf.resize(n);
@@ -634,6 +635,8 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.nh = s->d_nh.p + sb.first;
     a.thr = s->d_thr.p + sb.first;
     a.ratio = s->prm.ratio;
+    // same expression as the reference: double(UINT64_MAX) / double(scaling)  (taxor_search.cpp:228)
+    a.scaling_limit = idx->scaling > 1 ? (double)UINT64_MAX / (double)idx->scaling : 0.0;
     a.gtab = s->d_gtab.p;
     a.gtab_stride = s->gtab_stride;
     a.ctr = s->d_ctr;

@@ -74,6 +74,7 @@ struct SyncmerArgs {
     uint32_t *nh;             // distinct count per read
     uint64_t *thr;            // (size_t)(nh * ratio)
     double ratio;
+    double scaling_limit;     // > 0: keep a hash only if (double)wyhash(hash) <= limit (FracMinHash, taxor_search.cpp:223-233)
     uint32_t *gtab;           // per-block dedup scratch for reads whose table does not fit LDS
     uint32_t gtab_stride;     // slots per block (power of two), 0 = none
     Counters *ctr;

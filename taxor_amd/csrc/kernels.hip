@@ -428,6 +428,9 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                         if (cand_at(cur) == h) { first = (cur == i); break; }
                         q = (q + 1u) & mask;
                     }
+                    // FracMinHash down-sampling of a scaled index: a pure function of the hash, so filtering the
+                    // first occurrences equals filtering the reference's set (taxor_search.cpp:223-233)
+                    if (first && a.scaling_limit > 0.0 && !((double)wyhash_u64(h) <= a.scaling_limit)) first = 0;
                 }
                 uint32_t tot;
                 const uint32_t rank = block_excl_add(first, sScr, &tot);

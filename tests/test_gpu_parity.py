@@ -398,11 +398,9 @@ def test_index_validation_errors():
         with pytest.raises(TaxorError) as e:
             GpuIndex([d], bins)
         assert needle in str(e.value)
-    # unsupported modes are rejected loudly (out of scope: k-mer/minimiser indexes, FracMinHash scaling)
+    # unsupported modes are rejected loudly (out of scope: k-mer/minimiser indexes)
     with pytest.raises(TaxorError):
         GpuIndex([base], bins, use_syncmer=False)
-    with pytest.raises(TaxorError):
-        GpuIndex([base], bins, scaling=10)
     # a merged bin whose child is referenced twice is not a tree
     a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
     a["fname_idx"][0] = -1
@@ -414,3 +412,25 @@ def test_index_validation_errors():
     with pytest.raises(TaxorError) as e:
         GpuIndex([a, b], bins)
     assert "not a tree" in str(e.value)
+
+
+def test_fracminhash_scaling():
+    """scaled syncmer index (taxor_search.cpp:223-233): hashes are kept iff double(wyhash(h)) <= 2^64/scaling;
+    QHASH_COUNT and the threshold use the filtered count"""
+    g, go, lay, host = _planted_setup(17, n_genomes=6, glen=20000)
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, origin = synth.synth_reads(g, go, 300, 3000, error_rate=0.01, frac_random=0.1, seed=8)
+    for scaling in (2, 10):
+        idx = GpuIndex(host, lay["n_user_bins"], scaling=scaling)
+        sr = Searcher(idx)
+        res = sr.search_batch(bases, offs)
+        want = h.search_batch(bases, offs, scaling=scaling, threads=4)
+        _compare(res, want, 300)
+        full = h.search_batch(bases, offs, threads=4)
+        assert 0.5 / scaling < res.n_hashes.sum() / full[0].sum() < 2.0 / scaling
+        hoff, hashes = sr.seq_to_syncmers(bases[:3000], offs[:2])
+        ref = orc.seq_to_syncmers(bases[:3000].tobytes())
+        keep = [int(x) for x in ref if float(orc.wyhash(int(x))) <= float(2**64 - 1) / scaling]
+        assert hashes.tolist() == keep
+        sr.close()
+        idx.close()
