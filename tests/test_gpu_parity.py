@@ -434,3 +434,51 @@ def test_fracminhash_scaling():
         assert hashes.tolist() == keep
         sr.close()
         idx.close()
+
+
+def test_deep_hierarchy_chain():
+    """a depth-7 merged chain with side leaves at every level: the level loop, queue ping-pong and DFS ordering
+    beyond three levels.  Tuples must come out in the reference's recursion order."""
+    rng = np.random.default_rng(33)
+    depth, bins = 7, 70
+    keys = np.unique(rng.integers(0, 2**63, size=900, dtype=np.uint64))
+    side = [np.unique(rng.integers(0, 2**63, size=200, dtype=np.uint64)) for _ in range(depth)]
+    seg = synth.seg_len_for(2600)
+    ixfs = []
+    ub = 0
+    for lvl in range(depth):
+        fname = np.zeros(bins, dtype=np.int64)
+        nxt = np.full(bins, lvl, dtype=np.int64)
+        planted = {}
+        merged_bin = 5 + lvl            # the chain moves to a different bin at every level
+        for b in range(bins):
+            if lvl + 1 < depth and b == merged_bin:
+                fname[b] = -1
+                nxt[b] = lvl + 1
+                planted[b] = np.unique(np.concatenate([keys] + side[lvl + 1:]))   # union of everything below
+            else:
+                fname[b] = ub
+                ub += 1
+        planted[2] = side[lvl]                                          # a side leaf before the merged bin
+        if lvl == depth - 1:
+            planted[60] = keys                                           # the deepest leaf holds the planted keys
+        else:
+            planted[65] = keys[: 300 + 40 * lvl]                         # partial copies after the merged bin
+        seed, cols = synth.build_columns(planted, seg, 100 + lvl)
+        data = rng.integers(0, 256, size=(3 * seg, 128), dtype=np.uint8)
+        for b, c in cols.items():
+            data[:, b] = c
+        ixfs.append(dict(bins=bins, stride=128, seg_len=seg, seed=seed, next_ixf=nxt, fname_idx=fname, data=data.reshape(-1)))
+    idx = GpuIndex(ixfs, ub)
+    assert idx.depth == depth
+    h = orc.Hixf(ixfs, [f["next_ixf"] for f in ixfs], [f["fname_idx"] for f in ixfs])
+    sr = Searcher(idx, ratio=0.5)
+    q = np.concatenate([keys[:700], side[0][:100], side[3][:150], rng.integers(0, 2**63, size=50, dtype=np.uint64)])
+    for thr in (0, 1, 90, 140, 160, 290, 350, 420, 460, 500, 699, 700, 701):
+        ubg, cntg = sr.bulk_contains(q, thr)
+        ubo, cnto, _ = h.bulk_contains(q, thr)
+        assert np.array_equal(ubg, ubo) and np.array_equal(cntg, cnto), (thr, ubg.tolist(), ubo.tolist())
+    ubg, cntg = sr.bulk_contains(q, 300)
+    assert ubg.size >= 3      # side leaf, deep leaf and partial copies all reported, in DFS order
+    sr.close()
+    idx.close()
