@@ -136,9 +136,13 @@ def main():
                                             seed=synth.DEFAULT_SEED + rank, threads=ncpu)
     log(f"{n_reads} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
     sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+    # the drop-in call with host buffers (bases cross PCIe inside the call, streamed per sub-batch); reported as
+    # pcie_inclusive, never as `value`
+    sr.search_batch(bases, offs)
     t0 = time.time()
+    sr.search_batch(bases, offs)
+    t_dropin = time.time() - t0
     sr.upload(bases, offs)
-    t_upload = time.time() - t0
 
     from taxor_amd import distributed as td
     gathered = {}
@@ -229,9 +233,10 @@ def main():
                          "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
             "stage_ms_last_step": {"syncmers": round(st["syncmer_ms"], 3), "query": round(st["query_ms"], 3),
                                    "finalize": round(st["finalize_ms"], 3), "total": round(st["total_ms"], 3)},
-            "pcie_inclusive": {"upload_s": round(t_upload, 3),
-                               "value": round(float(n_reads) * read_len / (t_upload + elapsed / args.steps) / 1e6, 2),
-                               "unit": "Mbp/s", "note": "ASCII bases from pageable host memory + on-device pack, 1 GPU"},
+            "pcie_inclusive": {"seconds": round(t_dropin, 4), "value": round(float(n_reads) * read_len / t_dropin / 1e6, 2),
+                               "unit": "Mbp/s",
+                               "note": "taxor_gpu_search_batch on host buffers: ASCII bases from pageable memory, streamed "
+                                       "H2D + on-device pack overlapped with compute, results fetched to host; per GPU"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu)

@@ -81,7 +81,8 @@ struct taxor_gpu_index {
 
 struct SubBatch {
     uint32_t first, n;
-    uint64_t slots; // candidate/hash slots of this sub-batch
+    uint64_t slots;          // candidate/hash slots of this sub-batch
+    uint64_t a_begin, a_end; // ASCII byte range of its reads within the batch
 };
 
 struct taxor_gpu_searcher {
@@ -89,7 +90,8 @@ struct taxor_gpu_searcher {
     taxor_gpu_search_params prm{};
     hipStream_t st = nullptr;       // query + CSR assembly; the stream callers synchronise on
     hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
-    std::vector<hipEvent_t> ev_sync_done, ev_query_done;
+    hipStream_t st_copy = nullptr;  // H2D of the next sub-batch's bases + packing (streamed search_batch)
+    std::vector<hipEvent_t> ev_sync_done, ev_query_done, ev_pack_done;
     hipEvent_t ev_reset = nullptr;
     DBuf<uint32_t> d_sync_cursor;
     Counters *d_ctr = nullptr;
@@ -368,6 +370,7 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
     if (e != hipSuccess) {
@@ -400,6 +403,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->idx->device);
+    if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
     if (s->st_sync) (void)hipStreamSynchronize(s->st_sync);
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->d_ascii.release(); s->d_aoff.release(); s->d_poff.release(); s->d_hoff.release();
@@ -408,6 +412,8 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     s->d_sync_cursor.release();
     for (auto ev : s->ev_sync_done) (void)hipEventDestroy(ev);
     for (auto ev : s->ev_query_done) (void)hipEventDestroy(ev);
+    for (auto ev : s->ev_pack_done) (void)hipEventDestroy(ev);
+    if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
     s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
@@ -481,7 +487,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         const uint64_t lim_reads = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_reads / s->first_div, 1) : s->prm.sub_batch_reads;
         const uint64_t lim_bases = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_bases / s->first_div, 1) : s->prm.sub_batch_bases;
         if (r > sub_first && (r - sub_first >= lim_reads || sub_bases + len > lim_bases)) {
-            s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots});
+            s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[r] - offsets[0]});
             s->max_slots = std::max(s->max_slots, sub_slots);
             s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(r - sub_first));
             sub_first = (uint32_t)r;
@@ -498,7 +504,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         s->max_read_slots = std::max(s->max_read_slots, cap);
     }
     if (n_reads > sub_first) {
-        s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), sub_slots});
+        s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[n_reads] - offsets[0]});
         s->max_slots = std::max(s->max_slots, sub_slots);
         s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(n_reads - sub_first));
     }
@@ -516,11 +522,13 @@ int ensure_scratch(taxor_gpu_searcher *s)
         if (s->d_cand[b].reserve(s->max_slots + 64) || s->d_hashes[b].reserve(s->max_slots + 64)) return TAXOR_E_HIP;
     if (s->d_sync_cursor.reserve(s->subs.size() + 1)) return TAXOR_E_HIP;
     while (s->ev_sync_done.size() < s->subs.size() + 1) {
-        hipEvent_t a, b;
+        hipEvent_t a, b, c;
         HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c, hipEventDisableTiming));
         s->ev_sync_done.push_back(a);
         s->ev_query_done.push_back(b);
+        s->ev_pack_done.push_back(c);
     }
     const uint64_t qmin = std::max<uint64_t>(4ull * R, idx->h_ixf.size() + 64);
     const uint64_t hmin = std::max<uint64_t>(4ull * R, idx->leaf_runs + 64);
@@ -680,7 +688,10 @@ int check_flags(taxor_gpu_searcher *s, bool *rerun)
 
 } // namespace
 
-extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+namespace {
+
+// host-side layout + device copies of the per-read arrays (everything except the bases themselves)
+int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
     if (!s || !offsets || (!bases && n_reads && offsets[n_reads] != offsets[0]))
         return fail(TAXOR_E_ARG, "batch_upload: null argument");
@@ -700,7 +711,6 @@ extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, 
     std::vector<uint64_t> aoff(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) aoff[r] = offsets[r] - a0;
     HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(Counters), s->st));
-    if (nb) HIP_TRY(hipMemcpyAsync(s->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, s->st));
     HIP_TRY(hipMemcpyAsync(s->d_aoff.p, aoff.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
     if (n_reads) {
         HIP_TRY(hipMemcpyAsync(s->d_poff.p, poff.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
@@ -708,17 +718,14 @@ extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, 
         HIP_TRY(hipMemcpyAsync(s->d_rlen.p, rlen.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
         HIP_TRY(hipMemcpyAsync(s->d_hcap.p, hcap.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
     }
-    launch_pack_dna4(s->d_ascii.p, s->d_aoff.p, s->d_poff.p, s->d_packed.p, (uint32_t)n_reads, s->d_ctr, s->st);
-    HIP_TRY(hipGetLastError());
-    bool rerun;
-    if (int rc = check_flags(s, &rerun)) return rc; // synchronises; the pageable host vectors above may now die
+    HIP_TRY(hipStreamSynchronize(s->st)); // the pageable host vectors above may now die
     return ensure_scratch(s);
 }
 
-extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
+// The whole pipeline for the uploaded (host_ascii == nullptr) or streaming (host_ascii = first base of the batch)
+// case.  Streams: st_copy (H2D + pack of sub-batch i+1), st_sync (syncmers of i+1), st (query + CSR of i).
+int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
 {
-    if (!s) return fail(TAXOR_E_ARG, "batch_run: null searcher");
-    HIP_TRY(hipSetDevice(s->idx->device));
     if (int rc = ensure_scratch(s)) return rc;
     s->ev_used = 0;
     s->ev_spans.clear();
@@ -728,15 +735,28 @@ extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
     HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, (s->subs.size() + 1) * sizeof(uint32_t), s->st));
     HIP_TRY(hipEventRecord(s->ev_reset, s->st));
     HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_reset, 0));
+    HIP_TRY(hipStreamWaitEvent(s->st_copy, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
     if (s->subs.empty()) { // zero reads: CSR = [0]
         HIP_TRY(hipMemsetAsync(s->d_read_off.p, 0, sizeof(uint64_t), s->st));
     }
-    // Two streams: the syncmer kernel (LDS/latency bound) of sub-batch i+1 runs beside the HBM-bound query of
-    // sub-batch i; candidate/hash scratch is double buffered, events carry the two dependencies.
+    // The syncmer kernel (VALU/LDS bound) of sub-batch i+1 runs beside the HBM-bound query of sub-batch i;
+    // candidate/hash scratch is double buffered, events carry the dependencies.  When streaming, the bases of
+    // sub-batch i+1 cross PCIe (pageable copy: the host blocks in it, the GPU keeps working) and are packed on
+    // a third stream meanwhile.
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
         const int buf = (int)(i & 1);
+        if (host_ascii) {
+            if (sb.a_end > sb.a_begin)
+                HIP_TRY(hipMemcpyAsync(s->d_ascii.p + sb.a_begin, host_ascii + sb.a_begin, sb.a_end - sb.a_begin,
+                                       hipMemcpyHostToDevice, s->st_copy));
+            launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr,
+                             s->st_copy);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(s->ev_pack_done[i], s->st_copy));
+            HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_pack_done[i], 0));
+        }
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_query_done[i - 2], 0));
         if (int rc = launch_syncmers_sub(s, sb, i, buf, s->st_sync, i > 0)) return rc;
         HIP_TRY(hipEventRecord(s->ev_sync_done[i], s->st_sync));
@@ -751,6 +771,26 @@ extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
     s->ran = true;
     s->synced = false;
     return TAXOR_OK;
+}
+
+} // namespace
+
+extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    if (int rc = prepare_batch(s, bases, offsets, n_reads)) return rc;
+    const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
+    if (nb) HIP_TRY(hipMemcpyAsync(s->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, s->st));
+    launch_pack_dna4(s->d_ascii.p, s->d_aoff.p, s->d_poff.p, s->d_packed.p, (uint32_t)n_reads, s->d_ctr, s->st);
+    HIP_TRY(hipGetLastError());
+    bool rerun;
+    return check_flags(s, &rerun); // synchronises; reports a non-dna15 character
+}
+
+extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
+{
+    if (!s) return fail(TAXOR_E_ARG, "batch_run: null searcher");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    return run_pipeline(s, nullptr);
 }
 
 extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
@@ -850,8 +890,9 @@ extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *o
 extern "C" int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                                       taxor_gpu_results *out)
 {
-    if (int rc = taxor_gpu_batch_upload(s, bases, offsets, n_reads)) return rc;
-    if (int rc = taxor_gpu_batch_run(s)) return rc;
+    // streamed: the bases of sub-batch i+1 are copied and packed while sub-batch i is being classified
+    if (int rc = prepare_batch(s, bases, offsets, n_reads)) return rc;
+    if (int rc = run_pipeline(s, n_reads ? bases + offsets[0] : nullptr)) return rc;
     return taxor_gpu_batch_fetch(s, out);
 }
 
