@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=0)
     ap.add_argument("--read-error", type=float, default=0.02)
     ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
+    ap.add_argument("--len-mix", default="", help="'ont': skewed read lengths 1-100 kb (same total bases) instead of a fixed length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -132,8 +133,24 @@ def main():
 
     # ---- reads of this rank's shard (seed + rank), resident in HBM before the timed region -----------------------
     t0 = time.time()
-    bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
-                                            seed=synth.DEFAULT_SEED + rank, threads=ncpu)
+    if args.len_mix == "ont":
+        # ONT-like skew with the same total bases: 1, 3, 10, 30, 100 kb carrying 10/20/40/20/10 % of the bases, shuffled
+        total = n_reads * read_len
+        parts = []
+        for L, frac in ((1000, 0.1), (3000, 0.2), (10000, 0.4), (30000, 0.2), (100000, 0.1)):
+            cnt = max(1, int(total * frac / L))
+            b, o, _ = synth.synth_reads(g, go, cnt, L, error_rate=args.read_error, frac_random=0.1,
+                                        seed=synth.DEFAULT_SEED + rank + L, threads=ncpu)
+            parts += [(b, int(o[i]), int(o[i + 1])) for i in range(cnt)]
+        perm = np.random.default_rng(synth.DEFAULT_SEED + rank).permutation(len(parts))
+        bases = np.concatenate([parts[i][0][parts[i][1]:parts[i][2]] for i in perm])
+        offs = np.concatenate([[0], np.cumsum([parts[i][2] - parts[i][1] for i in perm])]).astype(np.uint64)
+        origin = None
+        n_reads = len(parts)
+        read_len = int(offs[-1]) / n_reads
+    else:
+        bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
+                                                seed=synth.DEFAULT_SEED + rank, threads=ncpu)
     log(f"{n_reads} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
     sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
     # the drop-in call with host buffers (bases cross PCIe inside the call, streamed per sub-batch); reported as
@@ -254,7 +271,7 @@ def traffic_from_profiles(args):
     this workload at its default size."""
     if args.traffic_bytes is not None:
         return args.traffic_bytes
-    if args.reads or args.read_len:
+    if args.reads or args.read_len or args.len_mix:
         return None
     p = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
     if os.path.exists(p):
@@ -286,7 +303,7 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
 
     def run(n):
         t0 = time.perf_counter()
-        o = h.search_batch(bases[: n * read_len], offs[: n + 1], err=args.error_rate, threads=threads)
+        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=threads)
         return time.perf_counter() - t0, o
 
     n = min(256 * threads // 8 + 64, len(offs) - 1)
@@ -301,8 +318,8 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
             and np.array_equal(res.user_bin[:lo], ub) and np.array_equal(res.count[:lo], cnt))
     if not same:
         raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
-    return {"value": round(n * read_len / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
-            "sample": f"first {n} of the step's reads ({n*read_len/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
+    return {"value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} of the step's reads ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
                       f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
 
 

@@ -105,7 +105,7 @@ struct taxor_gpu_searcher {
     uint64_t n_reads = 0, n_bases = 0;
     DBuf<uint8_t> d_ascii;
     DBuf<uint64_t> d_aoff, d_poff, d_hoff;
-    DBuf<uint32_t> d_packed, d_rlen, d_hcap, d_nh;
+    DBuf<uint32_t> d_packed, d_rlen, d_hcap, d_nh, d_order;
     DBuf<uint64_t> d_thr;
     std::vector<SubBatch> subs;
     uint64_t max_slots = 0, max_read_slots = 0;
@@ -408,6 +408,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->d_ascii.release(); s->d_aoff.release(); s->d_poff.release(); s->d_hoff.release();
     s->d_packed.release(); s->d_rlen.release(); s->d_hcap.release(); s->d_nh.release(); s->d_thr.release();
+    s->d_order.release();
     for (int b = 0; b < 2; ++b) { s->d_cand[b].release(); s->d_hashes[b].release(); }
     s->d_sync_cursor.release();
     for (auto ev : s->ev_sync_done) (void)hipEventDestroy(ev);
@@ -461,7 +462,8 @@ int ev_end(taxor_gpu_searcher *s, size_t slot, hipStream_t st = nullptr)
 
 // host-side layout of a batch: packed offsets, candidate slots, sub-batch partition
 int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_reads, std::vector<uint64_t> &poff,
-                 std::vector<uint32_t> &rlen, std::vector<uint64_t> &hoff, std::vector<uint32_t> &hcap)
+                 std::vector<uint32_t> &rlen, std::vector<uint64_t> &hoff, std::vector<uint32_t> &hcap,
+                 std::vector<uint32_t> &order)
 {
     const taxor_gpu_index *idx = s->idx;
     const int w = idx->k - idx->s + 1;
@@ -507,6 +509,15 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[n_reads] - offsets[0]});
         s->max_slots = std::max(s->max_slots, sub_slots);
         s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(n_reads - sub_first));
+    }
+    // processing order inside each sub-batch: longest reads first (stable), so the dynamic work cursors hand out
+    // the expensive items early and no long read is left alone at the tail of a launch
+    order.resize(n_reads);
+    for (const SubBatch &sb : s->subs) {
+        uint32_t *o = order.data() + sb.first;
+        for (uint32_t i = 0; i < sb.n; ++i) o[i] = i;
+        if (!getenv("TAXOR_NO_ORDER")) // A/B knob for measurements
+            std::stable_sort(o, o + sb.n, [&](uint32_t a, uint32_t b) { return rlen[sb.first + a] > rlen[sb.first + b]; });
     }
     s->packed_word_count = words + 16;
     s->packed_in_bytes = 0;
@@ -557,7 +568,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
 // level loop + CSR assembly for one group of reads whose hashes / thresholds are already on the device
 int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d_hoff, const uint32_t *d_nh,
               const uint64_t *d_thr, uint32_t n_reads, uint64_t *d_read_off, int is_last, uint32_t *d_counts_out,
-              int only_ixf)
+              int only_ixf, const uint32_t *d_order = nullptr)
 {
     const taxor_gpu_index *idx = s->idx;
     HIP_TRY(hipMemsetAsync(s->d_read_hits.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
@@ -583,6 +594,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.q_in = (lvl == 0 && only_ixf < 0) ? nullptr : s->d_q[lvl & 1].p;
         q.q_out = s->d_q[(lvl + 1) & 1].p;
         q.n_level0 = n_reads;
+        q.order0 = d_order;
         size_t slot;
         if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
         launch_query_level(q, s->grid_query, s->lds_query, s->st);
@@ -640,6 +652,7 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.cand = s->d_cand[buf].p;
     a.hashes = s->d_hashes[buf].p;
     a.cursor = s->d_sync_cursor.p + sub_i;
+    a.order = s->d_order.p ? s->d_order.p + sb.first : nullptr;
     a.nh = s->d_nh.p + sb.first;
     a.thr = s->d_thr.p + sb.first;
     a.ratio = s->prm.ratio;
@@ -699,14 +712,15 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     HIP_TRY(hipSetDevice(s->idx->device));
     s->ran = s->synced = false;
     std::vector<uint64_t> poff, hoff;
-    std::vector<uint32_t> rlen, hcap;
-    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap)) return rc;
+    std::vector<uint32_t> rlen, hcap, order;
+    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order)) return rc;
     s->n_reads = n_reads;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     s->n_bases = nb;
     if (s->d_ascii.reserve(nb + 64) || s->d_aoff.reserve(n_reads + 1) || s->d_poff.reserve(n_reads + 1) ||
         s->d_hoff.reserve(n_reads + 1) || s->d_rlen.reserve(n_reads + 1) || s->d_hcap.reserve(n_reads + 1) ||
-        s->d_nh.reserve(n_reads + 1) || s->d_thr.reserve(n_reads + 1) || s->d_packed.reserve(s->packed_word_count))
+        s->d_nh.reserve(n_reads + 1) || s->d_thr.reserve(n_reads + 1) || s->d_order.reserve(n_reads + 1) ||
+        s->d_packed.reserve(s->packed_word_count))
         return TAXOR_E_HIP;
     std::vector<uint64_t> aoff(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) aoff[r] = offsets[r] - a0;
@@ -717,6 +731,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         HIP_TRY(hipMemcpyAsync(s->d_hoff.p, hoff.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
         HIP_TRY(hipMemcpyAsync(s->d_rlen.p, rlen.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
         HIP_TRY(hipMemcpyAsync(s->d_hcap.p, hcap.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+        HIP_TRY(hipMemcpyAsync(s->d_order.p, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
     }
     HIP_TRY(hipStreamSynchronize(s->st)); // the pageable host vectors above may now die
     return ensure_scratch(s);
@@ -763,7 +778,7 @@ int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
         HIP_TRY(hipStreamWaitEvent(s->st, s->ev_sync_done[i], 0));
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
         if (int rc = run_query(s, s->d_hashes[buf].p, s->d_hoff.p + sb.first, s->d_nh.p + sb.first, s->d_thr.p + sb.first,
-                               sb.n, s->d_read_off.p + sb.first, i + 1 == s->subs.size(), nullptr, -1))
+                               sb.n, s->d_read_off.p + sb.first, i + 1 == s->subs.size(), nullptr, -1, s->d_order.p + sb.first))
             return rc;
         HIP_TRY(hipEventRecord(s->ev_query_done[i], s->st));
     }

@@ -79,6 +79,7 @@ struct SyncmerArgs {
     uint32_t gtab_stride;     // slots per block (power of two), 0 = none
     Counters *ctr;
     uint32_t *cursor;         // dynamic work cursor of this launch (zeroed by the host)
+    const uint32_t *order;    // processing order: longest reads first, so that no long read is left for the tail
     uint32_t n_reads;
     int k, s, t;
 };
@@ -98,6 +99,7 @@ struct QueryArgs {
     Counters *ctr;
     uint32_t level;
     uint32_t n_level0;        // number of items when q_in == nullptr
+    const uint32_t *order0;   // level 0: item i is read order0[i] (longest first); nullptr = identity
     uint32_t q_cap, hit_cap;
     uint32_t map_words;       // words of the alive-unit bitmap in LDS (query_lds_map_words(max_stride))
     uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)

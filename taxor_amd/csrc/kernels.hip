@@ -231,8 +231,8 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
         __syncthreads();
         if (tid == 0) sRead = atomicAdd(a.cursor, 1u);
         __syncthreads();
-        const uint32_t r = sRead;
-        if (r >= a.n_reads) break;
+        if (sRead >= a.n_reads) break;
+        const uint32_t r = a.order ? a.order[sRead] : sRead;
 
         const uint32_t L = a.rlen[r];
         const uint32_t *__restrict__ pk = a.packed + a.poff[r];
@@ -640,7 +640,7 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
         if (item >= n_items) break;
         uint32_t r, v;
         if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
-        else { r = item; v = 0; }
+        else { r = a.order0 ? a.order0[item] : item; v = 0; }
 
         const IxfDesc D = a.ixf[v];
         const uint32_t n = a.nh[r];

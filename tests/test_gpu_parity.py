@@ -482,3 +482,25 @@ def test_deep_hierarchy_chain():
     assert ubg.size >= 3      # side leaf, deep leaf and partial copies all reported, in DFS order
     sr.close()
     idx.close()
+
+
+def test_mixed_read_lengths_longest_first_order():
+    """ONT-like length skew (200 bp .. 150 kb) in one batch: reads are processed longest-first inside a
+    sub-batch but results stay in input order and bit-identical"""
+    g, go, lay, host = _planted_setup(41, n_genomes=6, glen=160000, root_bins=70, child_bins=48, n_children=3)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    rng = np.random.default_rng(3)
+    reads = []
+    for L, n in ((200, 60), (1500, 60), (9000, 30), (40000, 6), (150000, 2), (21, 5), (22, 5)):
+        b, o, _ = synth.synth_reads(g, go, n, L, error_rate=0.02, frac_random=0.2, seed=int(rng.integers(1, 10**6)))
+        reads += [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(n)]
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    B, O = _cat(reads)
+    for sub in (0, 50):
+        sr = Searcher(idx, sub_batch_reads=sub)
+        res = sr.search_batch(B, O)
+        _compare(res, h.search_batch(B, O, threads=8), len(reads))
+        sr.close()
+    idx.close()
