@@ -48,7 +48,8 @@ def test_viral_class_one_million_reads():
     assert st["n_hashes"] == int(res.n_hashes.astype(np.int64).sum())
     assert st["n_tuples"] == res.user_bin.size == int(res.read_off[-1])
     assert np.all(np.diff(res.read_off.astype(np.int64)) >= 0)
-    assert st["query_touched_bytes"] < st["query_bytes"]          # pruning removed traffic
+    if os.environ.get("TAXOR_QUERY_PRUNE") != "0":
+        assert st["query_touched_bytes"] < st["query_bytes"]      # pruning removed traffic
     # idempotence on the resident batch
     sr.run()
     assert _csr_equal(res, sr.fetch())
