@@ -531,7 +531,7 @@ size_t query_lds_bytes(uint32_t max_stride)
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
 // its subset and counts byte matches; counters are flushed into the LDS counts at the end.
-template <bool NT>
+template <bool NT, int U>
 __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64_t *__restrict__ hp, uint32_t h0,
                                                   uint32_t h1, uint4 *sProbe, uint32_t *sC)
 {
@@ -561,40 +561,39 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
             if (active) {
                 uint4 acc8 = make_uint4(0, 0, 0, 0);
                 uint32_t i = g;
-                for (; i + 3u * G < nt; i += 4u * G) {
-                    const uint4 p0 = sProbe[i], p1 = sProbe[i + G], p2 = sProbe[i + 2u * G], p3 = sProbe[i + 3u * G];
-                    const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
-                                c0 = ld16<NT>(base + (size_t)p0.z * stride);
-                    const uint4 a1 = ld16<NT>(base + (size_t)p1.x * stride), b1 = ld16<NT>(base + (size_t)p1.y * stride),
-                                c1 = ld16<NT>(base + (size_t)p1.z * stride);
-                    const uint4 a2 = ld16<NT>(base + (size_t)p2.x * stride), b2 = ld16<NT>(base + (size_t)p2.y * stride),
-                                c2 = ld16<NT>(base + (size_t)p2.z * stride);
-                    const uint4 a3 = ld16<NT>(base + (size_t)p3.x * stride), b3 = ld16<NT>(base + (size_t)p3.y * stride),
-                                c3 = ld16<NT>(base + (size_t)p3.z * stride);
-                    probe_accumulate(acc8, a0, b0, c0, p0.w);
-                    probe_accumulate(acc8, a1, b1, c1, p1.w);
-                    probe_accumulate(acc8, a2, b2, c2, p2.w);
-                    probe_accumulate(acc8, a3, b3, c3, p3.w);
+                for (; i + (uint32_t)(U - 1) * G < nt; i += (uint32_t)U * G) { // U hashes = 3U row loads in flight per lane
+                    uint4 p[U], ra[U], rb[U], rc[U];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) p[j] = sProbe[i + (uint32_t)j * G];
+#pragma unroll
+                    for (int j = 0; j < U; ++j) {
+                        ra[j] = ld16<NT>(base + (size_t)p[j].x * stride);
+                        rb[j] = ld16<NT>(base + (size_t)p[j].y * stride);
+                        rc[j] = ld16<NT>(base + (size_t)p[j].z * stride);
+                    }
+#pragma unroll
+                    for (int j = 0; j < U; ++j) probe_accumulate(acc8, ra[j], rb[j], rc[j], p[j].w);
                 }
-                if (i < nt) { // up to three left: issue their loads together (one memory round trip, not three)
-                    const bool v1 = i + G < nt, v2 = i + 2u * G < nt;
-                    const uint4 p0 = sProbe[i], p1 = sProbe[v1 ? i + G : i], p2 = sProbe[v2 ? i + 2u * G : i];
-                    const uint4 a0 = ld16<NT>(base + (size_t)p0.x * stride), b0 = ld16<NT>(base + (size_t)p0.y * stride),
-                                c0 = ld16<NT>(base + (size_t)p0.z * stride);
-                    uint4 a1 = a0, b1 = b0, c1 = c0, a2 = a0, b2 = b0, c2 = c0;
-                    if (v1) {
-                        a1 = ld16<NT>(base + (size_t)p1.x * stride);
-                        b1 = ld16<NT>(base + (size_t)p1.y * stride);
-                        c1 = ld16<NT>(base + (size_t)p1.z * stride);
+                if (i < nt) { // up to U-1 left: issue their loads together (one memory round trip)
+                    uint4 p[U - 1], ra[U - 1], rb[U - 1], rc[U - 1];
+                    bool ok[U - 1];
+#pragma unroll
+                    for (int j = 0; j < U - 1; ++j) {
+                        ok[j] = i + (uint32_t)j * G < nt;
+                        p[j] = sProbe[ok[j] ? i + (uint32_t)j * G : i];
                     }
-                    if (v2) {
-                        a2 = ld16<NT>(base + (size_t)p2.x * stride);
-                        b2 = ld16<NT>(base + (size_t)p2.y * stride);
-                        c2 = ld16<NT>(base + (size_t)p2.z * stride);
+#pragma unroll
+                    for (int j = 0; j < U - 1; ++j) {
+                        ra[j] = rb[j] = rc[j] = make_uint4(0, 0, 0, 0);
+                        if (ok[j]) {
+                            ra[j] = ld16<NT>(base + (size_t)p[j].x * stride);
+                            rb[j] = ld16<NT>(base + (size_t)p[j].y * stride);
+                            rc[j] = ld16<NT>(base + (size_t)p[j].z * stride);
+                        }
                     }
-                    probe_accumulate(acc8, a0, b0, c0, p0.w);
-                    if (v1) probe_accumulate(acc8, a1, b1, c1, p1.w);
-                    if (v2) probe_accumulate(acc8, a2, b2, c2, p2.w);
+#pragma unroll
+                    for (int j = 0; j < U - 1; ++j)
+                        if (ok[j]) probe_accumulate(acc8, ra[j], rb[j], rc[j], p[j].w);
                 }
                 // widen the packed byte counters (<= 240 per byte) into 32-bit counters
                 const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
@@ -615,7 +614,7 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
     }
 }
 
-template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
+template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
@@ -664,7 +663,7 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
         if (a.prune && thr > 0) dense_end = (thr >= (uint64_t)n + 16u) ? 0u : min(n, (uint32_t)((uint64_t)n + 16u - thr));
         uint64_t touched = 0;
 
-        query_dense_range<NT>(D, hp, 0, dense_end, sProbe, sC);
+        query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC);
         touched += (uint64_t)dense_end * 3ull * stride;
         __syncthreads();
 
@@ -694,7 +693,7 @@ template <bool NT> __global__ __launch_bounds__(BLK) void k_query_level(const Qu
             __syncthreads();
             const uint32_t n_alive = sScal[1];
             if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
-                query_dense_range<NT>(D, hp, dense_end, n, sProbe, sC);
+                query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC);
                 touched += rem * 3ull * stride;
             } else if (n_alive > 0) {
                 for (uint32_t t0 = dense_end; t0 < n; t0 += Q_HT2) {
@@ -779,11 +778,13 @@ int query_grid(int device, size_t lds_bytes)
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<false>, BLK, lds_bytes) != hipSuccess || per < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<false, 4>, BLK, lds_bytes) != hipSuccess || per < 1)
         per = 2;
-    // two resident blocks per CU already saturate HBM (measured: 1 -> -4 %, 2 = 3 = 4); staying at two leaves
-    // registers and LDS for the syncmer kernel of the next sub-batch to run beside this one
-    if (per > 2) per = 2;
+    // Measured: HBM streaming saturates from two resident blocks per CU (1 -> -4 %, 2 = 3 = 4), but the per-item
+    // latency-bound phases (metadata fetch, probe staging, pruning check, tally) hide better with three, which
+    // matters for short reads and small child IXFs (+14 % viral-class, +23 % at 1 kb reads).  Three blocks of the
+    // 2x-unrolled kernel (88 VGPRs) still leave registers and LDS for two syncmer blocks of the next sub-batch.
+    if (per > 3) per = 3;
     if (const char *e = getenv("TAXOR_QUERY_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
@@ -791,8 +792,14 @@ int query_grid(int device, size_t lds_bytes)
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
 {
     static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
-    if (nt) hipLaunchKernelGGL(k_query_level<true>, dim3(grid), dim3(BLK), lds_bytes, st, a);
-    else hipLaunchKernelGGL(k_query_level<false>, dim3(grid), dim3(BLK), lds_bytes, st, a);
+    static const int unroll = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
+    if (unroll == 2) {
+        if (nt) hipLaunchKernelGGL((k_query_level<true, 2>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+        else hipLaunchKernelGGL((k_query_level<false, 2>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_query_level<true, 4>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+        else hipLaunchKernelGGL((k_query_level<false, 4>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------
