@@ -475,7 +475,8 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 // merged through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
 // ------------------------------------------------------------------------------------------------------
 static constexpr int Q_HT = 240;   // hashes per probe tile when one thread sees every hash (byte counters stay < 256)
-static constexpr int Q_HT2 = 480;  // probe tile (and LDS probe capacity) when hashes are split over G >= 2 thread groups
+static constexpr int Q_HT2 = 480;  // probe tile when hashes are split over G >= 2 thread groups
+static constexpr int Q_CAP = 1024; // LDS probe capacity: reads with n_h <= Q_CAP stage all their probes once per work item
 
 __device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
 {
@@ -513,7 +514,7 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
 }
 
 // LDS layout of k_query_level (all dynamic, base 16-B aligned):
-//   [0, Q_HT2*16)                     probes of the current hash tile
+//   [0, Q_CAP*16)                     probes (all of the read's if n_h <= Q_CAP, else the current hash tile)
 //   [.., +64)                          scalars: work item, alive-unit count
 //   [.., +Q_MAXU*4)                    list of alive 16-bin units
 //   [.., +map_words*4)                 bitmap of alive units (map_words = max_units/32 rounded up to 4 words)
@@ -526,14 +527,14 @@ uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_w
 
 size_t query_lds_bytes(uint32_t max_stride)
 {
-    return (size_t)Q_HT2 * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
+    return (size_t)Q_CAP * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
 }
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
 // its subset and counts byte matches; counters are flushed into the LDS counts at the end.
 template <bool NT, int U>
 __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64_t *__restrict__ hp, uint32_t h0,
-                                                  uint32_t h1, uint4 *sProbe, uint32_t *sC)
+                                                  uint32_t h1, uint4 *sProbe, uint32_t *sC, bool staged)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t units = D.units, stride = D.stride;
@@ -549,22 +550,27 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[j] = 0;
 
-        const uint32_t HT = (G == 1u) ? (uint32_t)Q_HT : (uint32_t)Q_HT2; // per-thread hashes per tile <= 240 either way
+        // a tile bounds the per-thread increments of the packed byte counters (<= 240); when the probes are not
+        // pre-staged it is also what fits the staging loop
+        const uint32_t HT = staged ? 240u * G : ((G == 1u) ? (uint32_t)Q_HT : (uint32_t)Q_HT2);
         for (uint32_t t0 = h0; t0 < h1; t0 += HT) {
             const uint32_t nt = min(HT, h1 - t0);
-            __syncthreads();
-            for (uint32_t i = tid; i < nt; i += BLK) {
-                const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
-                sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+            const uint4 *pr = sProbe + (staged ? t0 : 0u);
+            if (!staged) {
+                __syncthreads();
+                for (uint32_t i = tid; i < nt; i += BLK) {
+                    const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                    sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if (active) {
                 uint4 acc8 = make_uint4(0, 0, 0, 0);
                 uint32_t i = g;
                 for (; i + (uint32_t)(U - 1) * G < nt; i += (uint32_t)U * G) { // U hashes = 3U row loads in flight per lane
                     uint4 p[U], ra[U], rb[U], rc[U];
 #pragma unroll
-                    for (int j = 0; j < U; ++j) p[j] = sProbe[i + (uint32_t)j * G];
+                    for (int j = 0; j < U; ++j) p[j] = pr[i + (uint32_t)j * G];
 #pragma unroll
                     for (int j = 0; j < U; ++j) {
                         ra[j] = ld16<NT>(base + (size_t)p[j].x * stride);
@@ -580,7 +586,7 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 #pragma unroll
                     for (int j = 0; j < U - 1; ++j) {
                         ok[j] = i + (uint32_t)j * G < nt;
-                        p[j] = sProbe[ok[j] ? i + (uint32_t)j * G : i];
+                        p[j] = pr[ok[j] ? i + (uint32_t)j * G : i];
                     }
 #pragma unroll
                     for (int j = 0; j < U - 1; ++j) {
@@ -618,7 +624,7 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
-    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_HT2 * sizeof(uint4));       // [0] item, [1] n alive units
+    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_CAP * sizeof(uint4));       // [0] item, [1] n alive units
     uint32_t *sUnits = sScal + 16;
     uint32_t *sMap = sUnits + Q_MAXU;
     uint32_t *sC = sMap + a.map_words;
@@ -663,7 +669,14 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
         if (a.prune && thr > 0) dense_end = (thr >= (uint64_t)n + 16u) ? 0u : min(n, (uint32_t)((uint64_t)n + 16u - thr));
         uint64_t touched = 0;
 
-        query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC);
+        const bool staged = n <= (uint32_t)Q_CAP; // all probes of this read fit: stage them once for both phases
+        if (staged)
+            for (uint32_t i = tid; i < n; i += BLK) {
+                const ixf_probe p = ixf_probe_key(hp[i], D.seed, D.seg_len);
+                sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+            }
+        __syncthreads();
+        query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC, staged);
         touched += (uint64_t)dense_end * 3ull * stride;
         __syncthreads();
 
@@ -693,22 +706,26 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
             __syncthreads();
             const uint32_t n_alive = sScal[1];
             if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
-                query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC);
+                query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC, staged);
                 touched += rem * 3ull * stride;
             } else if (n_alive > 0) {
-                for (uint32_t t0 = dense_end; t0 < n; t0 += Q_HT2) {
-                    const uint32_t nt = min((uint32_t)Q_HT2, n - t0);
-                    __syncthreads();
-                    for (uint32_t i = tid; i < nt; i += BLK) {
-                        const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
-                        sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                const uint32_t ST = staged ? (uint32_t)rem : (uint32_t)Q_HT2;
+                for (uint32_t t0 = dense_end; t0 < n; t0 += ST) {
+                    const uint32_t nt = min(ST, n - t0);
+                    const uint4 *pr = sProbe + (staged ? t0 : 0u);
+                    if (!staged) {
+                        __syncthreads();
+                        for (uint32_t i = tid; i < nt; i += BLK) {
+                            const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                            sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
+                        }
+                        __syncthreads();
                     }
-                    __syncthreads();
                     const uint32_t tasks = nt * n_alive;
                     for (uint32_t task = tid; task < tasks; task += BLK) {
                         const uint32_t i = task / n_alive, j = task - i * n_alive;
                         const uint32_t x = sUnits[j];
-                        const uint4 p = sProbe[i];
+                        const uint4 p = pr[i];
                         const uint8_t *base = D.data + (size_t)x * 16u;
                         const uint4 r0 = ld16<NT>(base + (size_t)p.x * stride), r1 = ld16<NT>(base + (size_t)p.y * stride),
                                     r2 = ld16<NT>(base + (size_t)p.z * stride);
