@@ -200,6 +200,27 @@ typedef struct {
 
 typedef struct taxor_hixf taxor_hixf;  /* a parsed .hixf held in host memory (mmap) */
 
+/* Layout of one seqan3::interleaved_xor_filter record inside the file (UN-VENDORED in the reference): n_before
+ * u64 scalars, the fingerprint vector (u64 length + bytes), n_after u64 scalars.  idx_* select the scalar (counted
+ * over before-then-after) that holds a field, -1 = not stored: bins then come from next_ixf_id's inner sizes,
+ * stride = ceil(bins/64)*64, seg_len = rows/3 with rows = length/stride, seed = default_seed. */
+typedef struct {
+    uint32_t n_before, n_after;
+    int32_t idx_bins, idx_stride, idx_seg_len, idx_seed;
+    uint32_t seg_len_is_rows;   /* 1: the idx_seg_len scalar holds rows = 3*seg_len */
+    uint64_t default_seed;      /* 13572355802537770549 = the fixed start seed of src/main/xorfilter.hpp:153 */
+} taxor_ixf_schema;
+
+/* this library's own schema: bins | technical_bins | seg_len | bin_words | seed | ftype | data */
+void taxor_ixf_schema_default(taxor_ixf_schema *out);
+/* `hixf-probe`: walk a real file with every (n_before, n_after) until the records re-parse n times and the
+ * pinned tail (next_ixf_id, user_bins) lands exactly on end-of-file, then infer which scalar is which.  Writes a
+ * human-readable report (NUL-terminated, truncated to cap).  SURVEY.md 8(f) #2. */
+int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *report, uint64_t cap);
+int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *schema, taxor_hixf **out);
+int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *view, const taxor_hixf_meta *meta,
+                            const taxor_ixf_schema *schema);
+/* load with the default schema; if the records do not fit it, probe the file and load with what was found */
 int taxor_hixf_load(const char *path, taxor_hixf **out);
 void taxor_hixf_free(taxor_hixf *h);
 const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h);

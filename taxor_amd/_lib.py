@@ -57,6 +57,12 @@ class HixfMeta(C.Structure):
                 ("user_bin_filenames", C.POINTER(C.c_char_p))]
 
 
+class IxfSchema(C.Structure):
+    _fields_ = [("n_before", C.c_uint32), ("n_after", C.c_uint32), ("idx_bins", C.c_int32), ("idx_stride", C.c_int32),
+                ("idx_seg_len", C.c_int32), ("idx_seed", C.c_int32), ("seg_len_is_rows", C.c_uint32),
+                ("default_seed", C.c_uint64)]
+
+
 # every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
@@ -84,6 +90,10 @@ SIGNATURES = {
     "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),
     "taxor_gpu_bulk_contains": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(Results)]),
     "taxor_hixf_load": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
+    "taxor_ixf_schema_default": (None, [C.POINTER(IxfSchema)]),
+    "taxor_hixf_probe": (C.c_int, [C.c_char_p, C.POINTER(IxfSchema), C.c_char_p, C.c_uint64]),
+    "taxor_hixf_load_schema": (C.c_int, [C.c_char_p, C.POINTER(IxfSchema), C.POINTER(_P)]),
+    "taxor_hixf_store_schema": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta), C.POINTER(IxfSchema)]),
     "taxor_hixf_free": (None, [_P]),
     "taxor_hixf_get_view": (C.POINTER(HixfView), [_P]),
     "taxor_hixf_get_meta": (C.POINTER(HixfMeta), [_P]),

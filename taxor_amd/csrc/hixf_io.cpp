@@ -24,6 +24,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -98,9 +99,15 @@ static int io_fail(int code, const std::string &msg)
     return code;
 }
 
-extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
+namespace {
+
+struct Mapped {
+    void *map = nullptr;
+    size_t len = 0;
+};
+
+int map_file(const char *path, Mapped &m)
 {
-    if (!path || !out) return io_fail(TAXOR_E_ARG, "hixf_load: null argument");
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return io_fail(TAXOR_E_IO, std::string("cannot open index file ") + path);
     struct stat sb;
@@ -108,24 +115,25 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
         close(fd);
         return io_fail(TAXOR_E_IO, std::string("index file too small: ") + path);
     }
-    void *m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    void *p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     close(fd);
-    if (m == MAP_FAILED) return io_fail(TAXOR_E_IO, std::string("mmap failed for ") + path);
-    auto h = new taxor_hixf();
-    h->map = m;
-    h->map_len = (size_t)sb.st_size;
-    Cursor c{(const uint8_t *)m, (const uint8_t *)m + sb.st_size};
-    auto bail = [&](const std::string &why) {
-        taxor_hixf_free(h);
-        return io_fail(TAXOR_E_IO, std::string(path) + ": " + why);
-    };
+    if (p == MAP_FAILED) return io_fail(TAXOR_E_IO, std::string("mmap failed for ") + path);
+    m.map = p;
+    m.len = (size_t)sb.st_size;
+    return 0;
+}
 
+// envelope up to (and including) the IXF count; fills header fields, species and leaves the cursor at the first IXF
+// record.  Returns an error string (empty = ok).
+std::string parse_envelope(Cursor &c, taxor_hixf *h, std::vector<uint64_t> &sp_ub, std::vector<uint64_t> &sp_len,
+                           uint64_t &n_ixf)
+{
+    const uint64_t fsz = (uint64_t)(c.end - c.p);
     const uint32_t version = c.get<uint32_t>();                          // index.hpp:211-212
-    if (version != 1) return bail("unsupported index version " + std::to_string(version));
+    if (version != 1) return "unsupported index version " + std::to_string(version);
     h->meta.window_size = c.get<uint64_t>();                             // :217
     const uint64_t shape_size = c.get<uint64_t>();                       // :218 shape (dynamic_bitset)
-    const uint64_t shape_bits = c.get<uint64_t>();
-    (void)shape_bits;
+    (void)c.get<uint64_t>();
     h->view.kmer_size = c.get<uint8_t>();                                // :219
     h->view.syncmer_size = c.get<uint8_t>();                             // :220
     h->view.t_syncmer = c.get<uint8_t>();                                // :221
@@ -134,74 +142,124 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
     h->view.scaling = c.get<uint16_t>();                                 // :224
     h->meta.compressed = c.get<uint8_t>();                               // :225
     if (!c.ok || shape_size > 58 || shape_size != h->view.kmer_size)
-        return bail("header inconsistent (shape size " + std::to_string(shape_size) + " vs k " +
-                    std::to_string(h->view.kmer_size) + ")");
+        return "header inconsistent (shape size " + std::to_string(shape_size) + " vs k " + std::to_string(h->view.kmer_size) + ")";
     const uint64_t n_paths = c.get<uint64_t>();                          // :226 bin_path
-    if (!c.ok || n_paths > (uint64_t)sb.st_size) return bail("bin_path count implausible");
+    if (!c.ok || n_paths > fsz) return "bin_path count implausible";
     for (uint64_t i = 0; i < n_paths && c.ok; ++i) {
         const uint64_t m2 = c.get<uint64_t>();
-        if (m2 > (uint64_t)sb.st_size) return bail("bin_path entry implausible");
+        if (m2 > fsz) return "bin_path entry implausible";
         for (uint64_t j = 0; j < m2 && c.ok; ++j) (void)c.str();
     }
     const uint64_t n_species = c.get<uint64_t>();                        // :227
-    if (!c.ok || n_species > (uint64_t)sb.st_size) return bail("species count implausible");
-    std::vector<uint64_t> sp_ub(n_species), sp_len(n_species);
+    if (!c.ok || n_species > fsz) return "species count implausible";
+    sp_ub.resize(n_species);
+    sp_len.resize(n_species);
     h->strings.reserve(5 * n_species + 16);
     for (uint64_t i = 0; i < n_species && c.ok; ++i) {                   // Species.hpp:43-49
         for (int j = 0; j < 5; ++j) h->strings.push_back(c.str());
         sp_ub[i] = c.get<uint64_t>();
         sp_len[i] = c.get<uint64_t>();
     }
-    if (!c.ok) return bail("truncated in species");
-    const uint64_t n_ixf = c.get<uint64_t>();                            // hixf.hpp:155 ixf_vector
-    if (!c.ok || n_ixf == 0 || n_ixf > (uint64_t)sb.st_size / 56) return bail("IXF count implausible");
-    h->ixf.resize(n_ixf);
-    h->data_copy.resize(n_ixf);
-    for (uint64_t i = 0; i < n_ixf; ++i) {                               // IXF record, schema in the header comment
-        taxor_ixf_view &f = h->ixf[i];
-        f.bins = c.get<uint64_t>();
-        f.stride = c.get<uint64_t>();
-        f.seg_len = c.get<uint64_t>();
-        const uint64_t bin_words = c.get<uint64_t>();
-        f.seed = c.get<uint64_t>();
-        const uint64_t ftype = c.get<uint64_t>();
-        const uint64_t len = c.get<uint64_t>();
-        if (!c.ok) return bail("truncated in IXF " + std::to_string(i));
-        if (ftype != 8 || bin_words * 64 != f.stride || f.stride < f.bins || f.seg_len == 0 ||
-            f.seg_len > (1ull << 31) || len / 3 / f.seg_len != f.stride || len != 3 * f.seg_len * f.stride)
-            return bail("IXF " + std::to_string(i) + " record inconsistent (bins " + std::to_string(f.bins) + ", stride " +
-                        std::to_string(f.stride) + ", seg_len " + std::to_string(f.seg_len) + ", data " + std::to_string(len) +
-                        " bytes) -- the IXF schema of this library may differ from the file's (see hixf_io.cpp)");
-        f.data = c.bytes(len);
-        if (!c.ok) return bail("truncated in IXF " + std::to_string(i) + " data");
-    }
-    auto read_vv = [&](std::vector<std::vector<int64_t>> &vv, const char *what) -> bool {
+    if (!c.ok) return "truncated in species";
+    n_ixf = c.get<uint64_t>();                                           // hixf.hpp:155 ixf_vector
+    if (!c.ok || n_ixf == 0 || n_ixf > fsz / 16) return "IXF count implausible";
+    return "";
+}
+
+// pinned tail after the IXF records: next_ixf_id | user_bin_filenames | ixf_bin_to_filename_position, to end of file
+std::string parse_tail(Cursor &c, taxor_hixf *h, uint64_t n_ixf, size_t &first_fn, uint64_t &n_files, bool keep)
+{
+    const uint64_t fsz = (uint64_t)(c.end - c.p) + 16;
+    auto read_vv = [&](std::vector<std::vector<int64_t>> &vv, const char *what, bool first) -> std::string {
         const uint64_t n = c.get<uint64_t>();
-        if (!c.ok || n != n_ixf) { g_io_err = std::string(what) + " outer size != IXF count"; return false; }
+        if (!c.ok || n != n_ixf) return std::string(what) + " outer size != IXF count";
         vv.resize(n);
         for (uint64_t i = 0; i < n; ++i) {
             const uint64_t m2 = c.get<uint64_t>();
-            if (!c.ok || m2 != h->ixf[i].bins) { g_io_err = std::string(what) + " inner size != bins of IXF " + std::to_string(i); return false; }
+            if (!c.ok || m2 == 0 || m2 > fsz / 8) return std::string(what) + " inner size implausible";
+            if (!first && m2 != h->next_ixf[i].size()) return std::string(what) + " inner size != next_ixf_id's for IXF " + std::to_string(i);
             const uint8_t *b = c.bytes(m2 * 8);
-            if (!b) { g_io_err = std::string("truncated in ") + what; return false; }
+            if (!b) return std::string("truncated in ") + what;
             vv[i].resize(m2);
-            std::memcpy(vv[i].data(), b, m2 * 8);
+            if (keep || first) std::memcpy(vv[i].data(), b, m2 * 8);
         }
-        return true;
+        return "";
     };
-    if (!read_vv(h->next_ixf, "next_ixf_id")) return bail(g_io_err);           // hixf.hpp:156
-    const uint64_t n_files = c.get<uint64_t>();                                 // :280 user_bin_filenames
-    if (!c.ok || n_files > (uint64_t)sb.st_size) return bail("user_bin_filenames count implausible");
-    const size_t first_fn = h->strings.size();
-    for (uint64_t i = 0; i < n_files && c.ok; ++i) h->strings.push_back(c.str());
-    if (!c.ok) return bail("truncated in user_bin_filenames");
-    if (!read_vv(h->fname_idx, "ixf_bin_to_filename_position")) return bail(g_io_err); // :281
-    if (c.p != c.end) return bail(std::to_string((size_t)(c.end - c.p)) + " trailing bytes after the index");
-
-    for (uint64_t i = 0; i < n_ixf; ++i) {
-        h->ixf[i].next_ixf = h->next_ixf[i].data();
-        h->ixf[i].fname_idx = h->fname_idx[i].data();
+    std::string e = read_vv(h->next_ixf, "next_ixf_id", true);                  // hixf.hpp:156
+    if (!e.empty()) return e;
+    n_files = c.get<uint64_t>();                                                // :280 user_bin_filenames
+    if (!c.ok || n_files > fsz) return "user_bin_filenames count implausible";
+    first_fn = h->strings.size();
+    for (uint64_t i = 0; i < n_files && c.ok; ++i) {
+        std::string t = c.str();
+        if (keep) h->strings.push_back(std::move(t));
     }
+    if (!c.ok) return "truncated in user_bin_filenames";
+    e = read_vv(h->fname_idx, "ixf_bin_to_filename_position", false);           // :281
+    if (!e.empty()) return e;
+    if (c.p != c.end) return std::to_string((size_t)(c.end - c.p)) + " trailing bytes after the index";
+    return "";
+}
+
+inline uint64_t ceil64(uint64_t x) { return (x + 63) / 64 * 64; }
+
+// IXF records under `sc`; bins are cross-checked against next_ixf_id's inner sizes by the caller
+std::string parse_ixfs(Cursor &c, const taxor_ixf_schema &sc, taxor_hixf *h, uint64_t n_ixf,
+                       std::vector<std::vector<uint64_t>> *scalars_out = nullptr, std::vector<uint64_t> *lens_out = nullptr)
+{
+    h->ixf.assign(n_ixf, taxor_ixf_view{});
+    const uint32_t ns = sc.n_before + sc.n_after;
+    std::vector<uint64_t> sv(ns);
+    for (uint64_t i = 0; i < n_ixf; ++i) {
+        for (uint32_t j = 0; j < sc.n_before; ++j) sv[j] = c.get<uint64_t>();
+        const uint64_t len = c.get<uint64_t>();
+        if (!c.ok) return "truncated in IXF " + std::to_string(i);
+        const uint8_t *data = c.bytes(len);
+        if (!data) return "IXF " + std::to_string(i) + ": fingerprint vector of " + std::to_string(len) + " bytes runs past the end of the file";
+        for (uint32_t j = 0; j < sc.n_after; ++j) sv[sc.n_before + j] = c.get<uint64_t>();
+        if (!c.ok) return "truncated after IXF " + std::to_string(i);
+        taxor_ixf_view &f = h->ixf[i];
+        f.data = data;
+        f.bins = sc.idx_bins >= 0 ? sv[sc.idx_bins] : 0;                 // 0: filled from next_ixf_id later
+        f.stride = sc.idx_stride >= 0 ? sv[sc.idx_stride] : 0;
+        f.seg_len = sc.idx_seg_len >= 0 ? sv[sc.idx_seg_len] : 0;
+        f.seed = sc.idx_seed >= 0 ? sv[sc.idx_seed] : sc.default_seed;
+        if (scalars_out) scalars_out->push_back(sv);
+        if (lens_out) lens_out->push_back(len);
+        // stash the length in next_ixf (pointer slot is unused until the tail is parsed): validated in finish_ixfs
+        f.next_ixf = reinterpret_cast<const int64_t *>(static_cast<uintptr_t>(len));
+    }
+    return "";
+}
+
+std::string finish_ixfs(const taxor_ixf_schema &sc, taxor_hixf *h)
+{
+    for (size_t i = 0; i < h->ixf.size(); ++i) {
+        taxor_ixf_view &f = h->ixf[i];
+        const uint64_t len = static_cast<uint64_t>(reinterpret_cast<uintptr_t>(f.next_ixf));
+        const uint64_t bins = h->next_ixf[i].size();
+        if (sc.idx_bins >= 0 && f.bins != bins)
+            return "IXF " + std::to_string(i) + ": stored bin count " + std::to_string(f.bins) + " != next_ixf_id's " + std::to_string(bins);
+        f.bins = bins;
+        if (sc.idx_stride < 0) f.stride = ceil64(bins);
+        if (f.stride < bins || f.stride % 64 != 0 || f.stride == 0 || len % f.stride != 0)
+            return "IXF " + std::to_string(i) + ": row stride " + std::to_string(f.stride) + " inconsistent with " + std::to_string(bins) +
+                   " bins / " + std::to_string(len) + " fingerprint bytes";
+        const uint64_t rows = len / f.stride;
+        if (sc.idx_seg_len < 0) f.seg_len = rows / 3;
+        else if (sc.seg_len_is_rows) f.seg_len = f.seg_len / 3;
+        if (f.seg_len == 0 || f.seg_len > (1ull << 31) || 3 * f.seg_len != rows)
+            return "IXF " + std::to_string(i) + ": " + std::to_string(rows) + " rows are not 3 x segment length " + std::to_string(f.seg_len);
+        f.next_ixf = h->next_ixf[i].data();
+        f.fname_idx = h->fname_idx[i].data();
+    }
+    return "";
+}
+
+void finish_meta(taxor_hixf *h, const std::vector<uint64_t> &sp_ub, const std::vector<uint64_t> &sp_len, size_t first_fn,
+                 uint64_t n_files)
+{
+    const uint64_t n_species = sp_ub.size();
     h->species.resize(n_species);
     for (uint64_t i = 0; i < n_species; ++i) {
         taxor_species &s = h->species[i];
@@ -220,11 +278,176 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
     h->meta.species = h->species.data();
     h->meta.n_user_bin_filenames = n_files;
     h->meta.user_bin_filenames = h->filenames.data();
-    h->view.n_ixf = n_ixf;
+    h->view.n_ixf = h->ixf.size();
     h->view.ixf = h->ixf.data();
     h->view.n_user_bins = n_files;
+}
+
+// 0 ok; TAXOR_E_IO with *schema_problem=true when only the IXF records did not fit the schema
+int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bool *schema_problem)
+{
+    if (schema_problem) *schema_problem = false;
+    Mapped m;
+    if (int rc = map_file(path, m)) return rc;
+    auto h = new taxor_hixf();
+    h->map = m.map;
+    h->map_len = m.len;
+    Cursor c{(const uint8_t *)m.map, (const uint8_t *)m.map + m.len};
+    auto bail = [&](const std::string &why) {
+        taxor_hixf_free(h);
+        return io_fail(TAXOR_E_IO, std::string(path) + ": " + why);
+    };
+    std::vector<uint64_t> sp_ub, sp_len;
+    uint64_t n_ixf = 0, n_files = 0;
+    size_t first_fn = 0;
+    std::string e = parse_envelope(c, h, sp_ub, sp_len, n_ixf);
+    if (!e.empty()) return bail(e);
+    e = parse_ixfs(c, sc, h, n_ixf);
+    if (e.empty()) e = parse_tail(c, h, n_ixf, first_fn, n_files, true);
+    if (e.empty()) e = finish_ixfs(sc, h);
+    if (!e.empty()) {
+        if (schema_problem) *schema_problem = true;
+        return bail(e + " -- the IXF record layout of this file may differ from the schema used (taxor_hixf_probe)");
+    }
+    finish_meta(h, sp_ub, sp_len, first_fn, n_files);
     *out = h;
     return TAXOR_OK;
+}
+
+} // namespace
+
+extern "C" void taxor_ixf_schema_default(taxor_ixf_schema *out)
+{
+    if (!out) return;
+    *out = taxor_ixf_schema{6, 0, 0, 1, 2, 4, 0, 13572355802537770549ull};
+}
+
+extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *schema, taxor_hixf **out)
+{
+    if (!path || !schema || !out) return io_fail(TAXOR_E_ARG, "hixf_load_schema: null argument");
+    const int ns = (int)(schema->n_before + schema->n_after);
+    if (schema->n_before > 32 || schema->n_after > 32 || schema->idx_bins >= ns || schema->idx_stride >= ns ||
+        schema->idx_seg_len >= ns || schema->idx_seed >= ns)
+        return io_fail(TAXOR_E_ARG, "hixf_load_schema: schema indices out of range");
+    return load_with(path, *schema, out, nullptr);
+}
+
+extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *report, uint64_t cap)
+{
+    if (!path || !out) return io_fail(TAXOR_E_ARG, "hixf_probe: null argument");
+    std::string rep;
+    auto emit = [&](int rc) {
+        if (report && cap) {
+            const size_t n = std::min<size_t>(rep.size(), (size_t)cap - 1);
+            std::memcpy(report, rep.data(), n);
+            report[n] = 0;
+        }
+        return rc;
+    };
+    Mapped m;
+    if (int rc = map_file(path, m)) return rc;
+    taxor_hixf scratch;
+    scratch.map = nullptr;
+    Cursor c0{(const uint8_t *)m.map, (const uint8_t *)m.map + m.len};
+    std::vector<uint64_t> sp_ub, sp_len;
+    uint64_t n_ixf = 0;
+    std::string e = parse_envelope(c0, &scratch, sp_ub, sp_len, n_ixf);
+    if (!e.empty()) {
+        munmap(m.map, m.len);
+        return io_fail(TAXOR_E_IO, std::string(path) + ": " + e);
+    }
+    rep += "envelope ok: k=" + std::to_string(scratch.view.kmer_size) + " s=" + std::to_string(scratch.view.syncmer_size) +
+           " t=" + std::to_string(scratch.view.t_syncmer) + " scaling=" + std::to_string(scratch.view.scaling) + " species=" +
+           std::to_string(sp_ub.size()) + " ixf_count=" + std::to_string(n_ixf) + "\n";
+    // 1. record framing: fewest scalars first
+    bool found = false;
+    taxor_ixf_schema sc{};
+    std::vector<std::vector<uint64_t>> scal;
+    std::vector<uint64_t> lens;
+    taxor_hixf tail;
+    for (uint32_t total = 0; total <= 16 && !found; ++total)
+        for (uint32_t na = 0; na <= std::min<uint32_t>(total, 4) && !found; ++na) {
+            taxor_ixf_schema t{total - na, na, -1, -1, -1, -1, 0, 13572355802537770549ull};
+            Cursor c = c0;
+            taxor_hixf trial;
+            scal.clear();
+            lens.clear();
+            size_t first_fn = 0;
+            uint64_t n_files = 0;
+            if (!parse_ixfs(c, t, &trial, n_ixf, &scal, &lens).empty()) continue;
+            if (!parse_tail(c, &trial, n_ixf, first_fn, n_files, false).empty()) continue;
+            found = true;
+            sc = t;
+            tail.next_ixf = trial.next_ixf;
+        }
+    if (!found) {
+        munmap(m.map, m.len);
+        rep += "no (n_before, n_after) framing re-parses to the end of the file\n";
+        emit(0);
+        return io_fail(TAXOR_E_IO, std::string(path) + ": IXF record framing not recognised");
+    }
+    rep += "framing: " + std::to_string(sc.n_before) + " u64 scalars | fingerprint vector | " + std::to_string(sc.n_after) + " u64 scalars\n";
+    // 2. which scalar is which
+    const uint32_t ns = sc.n_before + sc.n_after;
+    auto all = [&](auto pred) {
+        std::vector<int> r;
+        for (uint32_t j = 0; j < ns; ++j) {
+            bool ok = true;
+            for (uint64_t i = 0; i < n_ixf && ok; ++i) ok = pred(i, scal[i][j]);
+            if (ok) r.push_back((int)j);
+        }
+        return r;
+    };
+    auto bins_of = [&](uint64_t i) { return (uint64_t)tail.next_ixf[i].size(); };
+    const std::vector<int> cb = all([&](uint64_t i, uint64_t v) { return v == bins_of(i); });
+    if (!cb.empty()) sc.idx_bins = cb[0];
+    std::vector<int> cs = all([&](uint64_t i, uint64_t v) { return v >= bins_of(i) && v % 64 == 0 && v != 0 && lens[i] % v == 0 && v < bins_of(i) + 64; });
+    for (int j : cs)
+        if (j != sc.idx_bins) { sc.idx_stride = j; break; }
+    if (sc.idx_stride < 0 && !cs.empty()) sc.idx_stride = cs[0];
+    auto stride_of = [&](uint64_t i) { return sc.idx_stride >= 0 ? scal[i][sc.idx_stride] : ceil64(bins_of(i)); };
+    bool rows_ok = true;
+    for (uint64_t i = 0; i < n_ixf; ++i) rows_ok = rows_ok && lens[i] % stride_of(i) == 0 && (lens[i] / stride_of(i)) % 3 == 0;
+    const std::vector<int> cseg = all([&](uint64_t i, uint64_t v) { return 3 * v == lens[i] / stride_of(i); });
+    const std::vector<int> crow = all([&](uint64_t i, uint64_t v) { return v == lens[i] / stride_of(i) && v != bins_of(i); });
+    if (!cseg.empty()) sc.idx_seg_len = cseg[0];
+    else if (!crow.empty()) { sc.idx_seg_len = crow[0]; sc.seg_len_is_rows = 1; }
+    // seed: an unused scalar that looks like a 64-bit random value (or the reference's fixed start seed) everywhere
+    uint64_t best_min = 0;
+    for (uint32_t j = 0; j < ns; ++j) {
+        if ((int)j == sc.idx_bins || (int)j == sc.idx_stride || (int)j == sc.idx_seg_len) continue;
+        uint64_t mn = ~0ull;
+        for (uint64_t i = 0; i < n_ixf; ++i) mn = std::min(mn, scal[i][j]);
+        if (mn >= (1ull << 32) && mn > best_min) { best_min = mn; sc.idx_seed = (int)j; }
+    }
+    rep += "bins: " + (sc.idx_bins >= 0 ? "scalar " + std::to_string(sc.idx_bins) : std::string("not stored (taken from next_ixf_id)")) + "\n";
+    rep += "row stride: " + (sc.idx_stride >= 0 ? "scalar " + std::to_string(sc.idx_stride) : std::string("not stored (ceil(bins/64)*64)")) + "\n";
+    rep += "segment length: " + (sc.idx_seg_len >= 0 ? "scalar " + std::to_string(sc.idx_seg_len) + (sc.seg_len_is_rows ? " (holds 3*seg_len)" : "")
+                                                     : std::string("not stored (rows/3)")) + "\n";
+    rep += "seed: " + (sc.idx_seed >= 0 ? "scalar " + std::to_string(sc.idx_seed) : std::string("not stored -> default 13572355802537770549 (xorfilter.hpp:153) -- VERIFY with a positive control")) + "\n";
+    if (!rows_ok) rep += "WARNING: fingerprint bytes are not 3 x seg_len x stride under this reading; the fork's layout differs\n";
+    for (uint32_t j = 0; j < ns; ++j) {
+        rep += "  scalar " + std::to_string(j) + " of IXF 0: " + std::to_string(scal[0][j]) + "\n";
+    }
+    munmap(m.map, m.len);
+    *out = sc;
+    emit(0);
+    if (!rows_ok) return io_fail(TAXOR_E_IO, std::string(path) + ": framing found but the fingerprint array does not factor as 3*seg_len*stride");
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
+{
+    if (!path || !out) return io_fail(TAXOR_E_ARG, "hixf_load: null argument");
+    taxor_ixf_schema sc;
+    taxor_ixf_schema_default(&sc);
+    bool schema_problem = false;
+    const int rc = load_with(path, sc, out, &schema_problem);
+    if (rc == TAXOR_OK || !schema_problem) return rc;
+    // the records did not fit this library's schema: probe the file and retry with what it found
+    taxor_ixf_schema probed;
+    if (taxor_hixf_probe(path, &probed, nullptr, 0) != TAXOR_OK) return TAXOR_E_IO;
+    return load_with(path, probed, out, nullptr);
 }
 
 extern "C" void taxor_hixf_free(taxor_hixf *h)
@@ -237,9 +460,10 @@ extern "C" void taxor_hixf_free(taxor_hixf *h)
 extern "C" const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h) { return h ? &h->view : nullptr; }
 extern "C" const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h) { return h ? &h->meta : nullptr; }
 
-extern "C" int taxor_hixf_store(const char *path, const taxor_hixf_view *v, const taxor_hixf_meta *m)
+extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *v, const taxor_hixf_meta *m,
+                                       const taxor_ixf_schema *sc)
 {
-    if (!path || !v || !m) return io_fail(TAXOR_E_ARG, "hixf_store: null argument");
+    if (!path || !v || !m || !sc) return io_fail(TAXOR_E_ARG, "hixf_store: null argument");
     FILE *f = fopen(path, "wb");
     if (!f) return io_fail(TAXOR_E_IO, std::string("cannot create ") + path);
     Writer w{f};
@@ -271,21 +495,29 @@ extern "C" int taxor_hixf_store(const char *path, const taxor_hixf_view *v, cons
         w.put<uint64_t>(s.seq_len);
     }
     w.put<uint64_t>(v->n_ixf);
+    const uint32_t ns = sc->n_before + sc->n_after;
+    std::vector<uint64_t> sv(ns);
     for (uint64_t i = 0; i < v->n_ixf; ++i) {
         const taxor_ixf_view &x = v->ixf[i];
         if (!x.data) {
             fclose(f);
             return io_fail(TAXOR_E_ARG, "hixf_store: IXF without host data");
         }
-        w.put<uint64_t>(x.bins);
-        w.put<uint64_t>(x.stride);
-        w.put<uint64_t>(x.seg_len);
-        w.put<uint64_t>(x.stride / 64);
-        w.put<uint64_t>(x.seed);
-        w.put<uint64_t>(8);
+        // scalars the schema does not name carry the other members such a class would hold
+        const uint64_t filler[4] = {x.stride / 64, 8, x.bins ? (x.bins + 63) / 64 : 0, 3};
+        uint32_t fi = 0;
+        for (uint32_t j = 0; j < ns; ++j) {
+            if ((int)j == sc->idx_bins) sv[j] = x.bins;
+            else if ((int)j == sc->idx_stride) sv[j] = x.stride;
+            else if ((int)j == sc->idx_seg_len) sv[j] = sc->seg_len_is_rows ? 3 * x.seg_len : x.seg_len;
+            else if ((int)j == sc->idx_seed) sv[j] = x.seed;
+            else sv[j] = filler[fi++ % 4];
+        }
+        for (uint32_t j = 0; j < sc->n_before; ++j) w.put<uint64_t>(sv[j]);
         const uint64_t len = 3 * x.seg_len * x.stride;
         w.put<uint64_t>(len);
         w.bytes(x.data, len);
+        for (uint32_t j = 0; j < sc->n_after; ++j) w.put<uint64_t>(sv[sc->n_before + j]);
     }
     w.put<uint64_t>(v->n_ixf);
     for (uint64_t i = 0; i < v->n_ixf; ++i) {
@@ -302,6 +534,13 @@ extern "C" int taxor_hixf_store(const char *path, const taxor_hixf_view *v, cons
     const bool ok = w.ok && fclose(f) == 0;
     if (!ok) return io_fail(TAXOR_E_IO, std::string("write failed: ") + path);
     return TAXOR_OK;
+}
+
+extern "C" int taxor_hixf_store(const char *path, const taxor_hixf_view *v, const taxor_hixf_meta *m)
+{
+    taxor_ixf_schema sc;
+    taxor_ixf_schema_default(&sc);
+    return taxor_hixf_store_schema(path, v, m, &sc);
 }
 
 // taxor_search.cpp:268-305

@@ -212,6 +212,22 @@ double now()
 int main(int argc, char **argv)
 {
     int a = 1;
+    if (argc > 1 && strcmp(argv[1], "probe") == 0) {                       // hixf-probe: report a file's IXF record layout
+        const char *path = nullptr;
+        for (int i = 2; i < argc; ++i) {
+            if (strcmp(argv[i], "--index-file") == 0 && i + 1 < argc) path = argv[++i];
+            else if (argv[i][0] != '-') path = argv[i];
+        }
+        if (!path) die("usage: taxor probe --index-file <file.hixf>");
+        taxor_ixf_schema sc;
+        std::vector<char> rep(16384);
+        const int rc = taxor_hixf_probe(path, &sc, rep.data(), rep.size());
+        fputs(rep.data(), stdout);
+        if (rc != TAXOR_OK) die(taxor_gpu_last_error());
+        printf("schema: n_before=%u n_after=%u idx_bins=%d idx_stride=%d idx_seg_len=%d%s idx_seed=%d\n", sc.n_before, sc.n_after,
+               sc.idx_bins, sc.idx_stride, sc.idx_seg_len, sc.seg_len_is_rows ? "(rows)" : "", sc.idx_seed);
+        return 0;
+    }
     if (argc > 1 && strcmp(argv[1], "search") == 0) a = 2;                 // `taxor search ...` like the reference
     else if (argc > 1 && (strcmp(argv[1], "build") == 0 || strcmp(argv[1], "profile") == 0)) {
         fprintf(stderr, "[TAXOR ERROR] only the `search` subcommand is provided by this build\n");

@@ -8,7 +8,8 @@ from . import _lib
 from ._lib import check
 
 
-def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None, window_size=None, scaling=1):
+def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None, window_size=None, scaling=1,
+               schema=None):
     """ixfs: list of dicts {bins, stride, seg_len, seed, data, next_ixf, fname_idx} (host data required);
     species: list of dicts {organism_name, accession_id, taxid, taxnames_string, taxid_string, user_bin, seq_len}"""
     keep = []
@@ -28,15 +29,40 @@ def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None
         filenames = [f"user_bin_{i}.fna" for i in range(n_user_bins)]
     fns = (C.c_char_p * len(filenames))(*[f.encode() for f in filenames])
     meta = _lib.HixfMeta(window_size if window_size is not None else k, 1, 0, len(species), sp, len(filenames), fns)
-    check(_lib.lib().taxor_hixf_store(str(path).encode(), C.byref(view), C.byref(meta)))
+    if schema is None:
+        check(_lib.lib().taxor_hixf_store(str(path).encode(), C.byref(view), C.byref(meta)))
+    else:
+        check(_lib.lib().taxor_hixf_store_schema(str(path).encode(), C.byref(view), C.byref(meta), C.byref(schema)))
+
+
+def default_schema():
+    sc = _lib.IxfSchema()
+    _lib.lib().taxor_ixf_schema_default(C.byref(sc))
+    return sc
+
+
+def make_schema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows=0):
+    return _lib.IxfSchema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows,
+                          13572355802537770549)
+
+
+def probe_hixf(path):
+    """hixf-probe: infer the IXF record layout of a file -> (schema, report text)"""
+    sc = _lib.IxfSchema()
+    buf = C.create_string_buffer(8192)
+    check(_lib.lib().taxor_hixf_probe(str(path).encode(), C.byref(sc), buf, len(buf)))
+    return sc, buf.value.decode()
 
 
 class HixfFile:
     """A parsed .hixf (mmap).  .ixfs are zero-copy numpy views valid while the object lives."""
 
-    def __init__(self, path):
+    def __init__(self, path, schema=None):
         h = C.c_void_p()
-        check(_lib.lib().taxor_hixf_load(str(path).encode(), C.byref(h)))
+        if schema is None:
+            check(_lib.lib().taxor_hixf_load(str(path).encode(), C.byref(h)))
+        else:
+            check(_lib.lib().taxor_hixf_load_schema(str(path).encode(), C.byref(schema), C.byref(h)))
         self._h = h
         v = _lib.lib().taxor_hixf_get_view(h).contents
         m = _lib.lib().taxor_hixf_get_meta(h).contents

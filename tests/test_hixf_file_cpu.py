@@ -117,3 +117,52 @@ def test_format_read_matches_reference_text(tmp_path):
         got = h.format_read(rid, rl, nh, [u for u, _ in tup], [c for _, c in tup])
         assert got == expected_lines(sp, rid, rl, nh, tup), rid
     h.close()
+
+
+def test_probe_recovers_foreign_ixf_schemas(tmp_path):
+    """The IXF record layout of the seqan3 fork is un-vendored; `taxor_hixf_probe` must find framing and fields of
+    files written with other member orders (scalars before/after the vector, fields not stored at all), and
+    `taxor_hixf_load` must fall back to it on its own."""
+    from taxor_amd.hixf_file import default_schema, make_schema, probe_hixf
+    lay, host, planted = small_layout(9)
+    sp = make_species(lay)
+    cases = {
+        "default": None,
+        # seqan3-IBF-like member order: bins, technical_bins, bin_size(=rows), hash_shift-ish filler, bin_words, seed
+        "ibf_like_rows": make_schema(7, 0, 0, 1, 2, 6, seg_len_is_rows=1),
+        # seed first, data in the middle, stride after the vector
+        "seed_first_stride_after": make_schema(3, 2, 1, 3, 2, 0),
+        # nothing but the seed and the vector: bins / stride / seg_len derived
+        "minimal": make_schema(1, 0, -1, -1, -1, 0),
+        # no seed stored at all -> default start seed, flagged in the report
+        "no_seed": make_schema(2, 0, 0, 1, -1, -1),
+    }
+    dflt = default_schema()
+    assert (dflt.n_before, dflt.n_after, dflt.idx_bins, dflt.idx_stride, dflt.idx_seg_len, dflt.idx_seed) == (6, 0, 0, 1, 2, 4)
+    for name, sc in cases.items():
+        p = tmp_path / f"{name}.hixf"
+        store_hixf(p, host, lay["n_user_bins"], sp, schema=sc)
+        got, report = probe_hixf(p)
+        want = sc if sc is not None else dflt
+        assert (got.n_before, got.n_after) == (want.n_before, want.n_after), (name, report)
+        assert "framing:" in report and "seed:" in report
+        if name == "no_seed":
+            assert got.idx_seed == -1 and "VERIFY" in report
+        h = HixfFile(p)                      # default schema first, probe fallback when the records do not fit
+        for a, b in zip(h.ixfs, host):
+            for key in ("bins", "stride", "seg_len"):
+                assert a[key] == b[key], (name, key)
+            if name != "no_seed":
+                assert a["seed"] == b["seed"], name
+            assert np.array_equal(a["data"], b["data"]), name
+            assert np.array_equal(a["next_ixf"], b["next_ixf"]) and np.array_equal(a["fname_idx"], b["fname_idx"])
+        assert h.species == sp
+        h.close()
+        h2 = HixfFile(p, schema=got)
+        assert len(h2.ixfs) == len(host)
+        h2.close()
+    # a file that is not a .hixf at all is still an error, not a guess
+    junk = tmp_path / "junk.hixf"
+    open(junk, "wb").write(b"\x01\0\0\0" + bytes(range(256)) * 8)
+    with pytest.raises(TaxorError):
+        probe_hixf(junk)
