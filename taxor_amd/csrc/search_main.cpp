@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -24,6 +25,7 @@ namespace {
 
 // one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
 struct Batch {
+    uint64_t seq = 0;   // position of this chunk in the input
     std::vector<std::string> ids;
     std::string bases;
     std::vector<uint64_t> offsets;
@@ -72,7 +74,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     std::string index_file, query_file, report_file;
     double threshold = -1.0, error_rate = 0.04;
     unsigned threads = 1;
-    int gpu = 0;
+    std::vector<int> gpus{0};   // devices that classify batches in parallel, each with its own index replica
     uint64_t batch_reads = 65536, batch_bases = 1ull << 30;
 };
 
@@ -112,6 +114,8 @@ void usage()
             "  --percentage <0..1>      if set, this threshold is used instead of the syncmer model\n"
             "  --error-rate <0..1>      expected error rate of the reads (default 0.04)\n"
             "  --gpu <id>               device ordinal (default 0)\n"
+            "  --gpus <n>               use devices 0..n-1: the index is replicated, batches of reads are sharded\n"
+            "  --gpu-list <a,b,..>      explicit device list (a device may be listed twice)\n"
             "  --batch-reads <n>        reads per GPU batch (default 65536)\n");
 }
 
@@ -253,7 +257,17 @@ int main(int argc, char **argv)
         } else if (k == "--error-rate") {
             cfg.error_rate = atof(val().c_str());
             if (cfg.error_rate < 0.0 || cfg.error_rate > 1.0) die("Validation failed for option --error-rate: Value not in range [0,1]."); // :63-67
-        } else if (k == "--gpu") cfg.gpu = atoi(val().c_str());
+        } else if (k == "--gpu") cfg.gpus.assign(1, atoi(val().c_str()));
+        else if (k == "--gpus") {
+            const int n = atoi(val().c_str());
+            if (n < 1 || n > 64) die("Validation failed for option --gpus: Value not in range [1,64].");
+            cfg.gpus.clear();
+            for (int i = 0; i < n; ++i) cfg.gpus.push_back(i);
+        } else if (k == "--gpu-list") {
+            cfg.gpus.clear();
+            for (const auto &t : str_split(val(), ',')) cfg.gpus.push_back(atoi(t.c_str()));
+            if (cfg.gpus.empty()) die("--gpu-list is empty");
+        }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "-h" || k == "--help") { usage(); return 0; }
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
@@ -292,14 +306,28 @@ int main(int argc, char **argv)
 
     double t_index = 0, t_reads = 0, t_compute = 0;
     uint64_t total_reads = 0, total_bases = 0;
+    std::mutex stat_mu;
     for (const auto &query : query_files) {
         for (const auto &hixf_file : index_files) {                        // :344-358
             double t0 = now();
             taxor_hixf *h = nullptr;
             if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
             const taxor_hixf_view *view = taxor_hixf_get_view(h);
-            taxor_gpu_index *gidx = nullptr;
-            if (taxor_gpu_index_create(view, cfg.gpu, &gidx) != TAXOR_OK) die(taxor_gpu_last_error());
+            // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
+            // replicated, batches are sharded); replicas are uploaded concurrently
+            const size_t ng = cfg.gpus.size();
+            std::vector<taxor_gpu_index *> gidx(ng, nullptr);
+            {
+                std::vector<std::thread> up;
+                std::vector<std::string> errs(ng);
+                for (size_t g = 0; g < ng; ++g)
+                    up.emplace_back([&, g] {
+                        if (taxor_gpu_index_create(view, cfg.gpus[g], &gidx[g]) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                    });
+                for (auto &t : up) t.join();
+                for (const auto &e : errs)
+                    if (!e.empty()) die(e);
+            }
             t_index += now() - t0;
             // threshold model (threshold.hpp:22-47)
             const double ratio = taxor_threshold_ratio(view->kmer_size, cfg.error_rate, cfg.threshold);
@@ -307,24 +335,27 @@ int main(int argc, char **argv)
             else printf("use syncmer model\n");
             if (ratio < 0) die("no syncmer threshold model for k=" + std::to_string(view->kmer_size) + " and error rate " + std::to_string(cfg.error_rate));
             taxor_gpu_search_params prm{ratio, 0, 0, 0};
-            taxor_gpu_searcher *sr = nullptr;
-            if (taxor_gpu_searcher_create(gidx, &prm, &sr) != TAXOR_OK) die(taxor_gpu_last_error());
+            std::vector<taxor_gpu_searcher *> sr(ng, nullptr);
+            for (size_t g = 0; g < ng; ++g)
+                if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());
 
-            // Three overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
-            //   reader thread  : FASTA/FASTQ(.gz) -> chunks of records          (taxor_search.cpp:315-321)
-            //   this thread    : chunk -> GPU (upload, kernels, fetch)           (:325)
-            //   writer thread  : tuples -> 0.8*max filter -> TSV lines -> file   (:266-311)
+            // Overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
+            //   reader thread     : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321)
+            //   one thread per GPU: chunk -> GPU (streamed upload, kernels, fetch)   (:325)
+            //   writer thread     : tuples -> 0.8*max filter -> TSV lines -> file, in chunk order (:266-311)
             // Output stays in input order (the reference's order at --threads 1).
-            BoundedQueue<std::unique_ptr<Batch>> q_in(2), q_out(2);
+            BoundedQueue<std::unique_ptr<Batch>> q_in(ng + 1), q_out(2 * ng + 2);
             double t_reads_local = 0;
             std::thread reader([&] {
                 FastxReader rd;
                 if (!rd.open(query)) die("cannot open query file " + query);
                 std::string id;
                 bool more = true;
+                uint64_t seq = 0;
                 while (more) {
                     const double t1 = now();
                     auto b = std::make_unique<Batch>();
+                    b->seq = seq++;
                     b->offsets.assign(1, 0);
                     b->bases.reserve(std::min<uint64_t>(cfg.batch_bases, 1ull << 30));
                     while (b->ids.size() < cfg.batch_reads && b->bases.size() < cfg.batch_bases && (more = rd.next(id, b->bases))) {
@@ -339,45 +370,63 @@ int main(int argc, char **argv)
             });
             std::thread writer([&] {
                 std::unique_ptr<Batch> b;
+                std::map<uint64_t, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
+                uint64_t next_seq = 0;
                 std::string text;
                 std::vector<char> line(4096);
                 while (q_out.pop(b)) {
-                    text.clear();
-                    for (size_t r = 0; r < b->ids.size(); ++r) {
-                        const uint64_t lo = b->read_off[r], n = b->read_off[r + 1] - lo;
-                        const uint64_t rl = b->offsets[r + 1] - b->offsets[r];
-                        uint64_t need = taxor_format_read(h, b->ids[r].data(), b->ids[r].size(), rl, b->n_hashes[r],
-                                                          b->user_bin.data() + lo, b->count.data() + lo, n, line.data(), line.size());
-                        if (need > line.size()) {
-                            line.resize(need + 1024);
-                            need = taxor_format_read(h, b->ids[r].data(), b->ids[r].size(), rl, b->n_hashes[r],
-                                                     b->user_bin.data() + lo, b->count.data() + lo, n, line.data(), line.size());
+                    pending.emplace(b->seq, std::move(b));
+                    while (!pending.empty() && pending.begin()->first == next_seq) {
+                        std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
+                        pending.erase(pending.begin());
+                        ++next_seq;
+                        text.clear();
+                        for (size_t r = 0; r < cur->ids.size(); ++r) {
+                            const uint64_t lo = cur->read_off[r], n = cur->read_off[r + 1] - lo;
+                            const uint64_t rl = cur->offsets[r + 1] - cur->offsets[r];
+                            uint64_t need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
+                                                              cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
+                            if (need > line.size()) {
+                                line.resize(need + 1024);
+                                need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
+                                                         cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
+                            }
+                            text.append(line.data(), need);
                         }
-                        text.append(line.data(), need);
+                        fwrite(text.data(), 1, text.size(), out);
                     }
-                    fwrite(text.data(), 1, text.size(), out);
                 }
             });
-            std::unique_ptr<Batch> b;
-            while (q_in.pop(b)) {
-                t0 = now();
-                taxor_gpu_results res{};
-                if (taxor_gpu_search_batch(sr, b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
-                b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
-                b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
-                b->count.assign(res.count, res.count + res.n_tuples);
-                b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
-                t_compute += now() - t0;
-                total_reads += b->ids.size();
-                total_bases += b->bases.size();
-                q_out.push(std::move(b));
-            }
+            std::vector<std::thread> workers;
+            for (size_t g = 0; g < ng; ++g)
+                workers.emplace_back([&, g] {
+                    std::unique_ptr<Batch> b;
+                    while (q_in.pop(b)) {
+                        const double t1 = now();
+                        taxor_gpu_results res{};
+                        if (taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                        b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
+                        b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
+                        b->count.assign(res.count, res.count + res.n_tuples);
+                        b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
+                        {
+                            std::lock_guard<std::mutex> lk(stat_mu);
+                            t_compute += now() - t1;
+                            total_reads += b->ids.size();
+                            total_bases += b->bases.size();
+                        }
+                        q_out.push(std::move(b));
+                    }
+                });
+            for (auto &t : workers) t.join();
             q_out.close();
             reader.join();
             writer.join();
             t_reads += t_reads_local;
-            taxor_gpu_searcher_destroy(sr);
-            taxor_gpu_index_destroy(gidx);
+            for (size_t g = 0; g < ng; ++g) {
+                taxor_gpu_searcher_destroy(sr[g]);
+                taxor_gpu_index_destroy(gidx[g]);
+            }
             taxor_hixf_free(h);
         }
     }

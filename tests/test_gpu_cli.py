@@ -77,6 +77,14 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
     want = HEADER + _expected(host, sp, ids, reads) + _expected(host, sp, ids2, reads2)
     assert open(out).read() == want
 
+    # two (three) workers sharding the chunks -- here on the same device -- must give the identical file in input order
+    for devs in ("0,0", "0,0,0"):
+        out2 = tmp_path / "out_multi.tsv"
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--output-file",
+                             str(out2), "--gpu-list", devs, "--batch-reads", "17"], capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0, cp.stderr
+        assert open(out2).read() == want
+
     # --error-rate / --percentage change the threshold exactly like the reference's models
     for extra, kw in ((["--error-rate", "0.1"], dict(err=0.1)), (["--percentage", "0.3"], dict(percentage=0.3))):
         cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out)]
