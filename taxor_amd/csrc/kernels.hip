@@ -468,11 +468,13 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 // k_query_level
 //
 // One work item = (read, IXF).  The block stages the read's probes (rows + fingerprint, per this IXF's seed
-// and segment length) in LDS a tile at a time; thread (u, g) owns the 16-B unit u of every row and the hash
-// subset g, g+G, ...; each hash costs the thread three 16-B loads (whole block: three contiguous row
-// segments), an XOR3, and an exact zero-byte test whose 0/1 bytes accumulate in packed byte counters.
-// Tiles are <= 255 hashes so the byte counters cannot overflow before they are widened.  Counters are
-// merged through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
+// and segment length) in LDS -- all of them at once when n_h <= Q_CAP, otherwise a tile at a time; thread (u, g)
+// owns the 16-B unit u of every row and the hash subset g, g+G, ...; each hash costs the thread three 16-B
+// global loads (whole block: three contiguous row segments), an XOR, and an exact zero-byte test whose 0/1
+// bytes accumulate in packed byte counters (a thread adds at most 240 per tile before they are widened).
+// After n_h - thr + 16 hashes, bin runs that can no longer reach the threshold are dropped and the remaining
+// hashes probe only the surviving 16-bin units (threshold-aware pruning, see the kernel).  Counters are merged
+// through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
 // ------------------------------------------------------------------------------------------------------
 static constexpr int Q_HT = 240;   // hashes per probe tile when one thread sees every hash (byte counters stay < 256)
 static constexpr int Q_HT2 = 480;  // probe tile when hashes are split over G >= 2 thread groups
