@@ -126,7 +126,7 @@ struct FinalizeArgs {
 
 // launch wrappers (all asynchronous on `st`)
 void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,
-                      uint32_t n_reads, Counters *ctr, hipStream_t st);
+                      uint32_t n_reads, Counters *ctr, hipStream_t st, int max_grid = 0);
 void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st);
 int syncmers_grid(int device);
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);

@@ -115,6 +115,9 @@ __global__ __launch_bounds__(BLK) void k_pack_dna4(const uint8_t *__restrict__ a
                                                    uint32_t *__restrict__ packed, uint32_t n_reads,
                                                    Counters *ctr)
 {
+    __shared__ uint8_t sLut[256]; // char -> 2-bit code, 0xFF = not a dna15 letter
+    sLut[threadIdx.x] = (uint8_t)(((uint8_t)((threadIdx.x | 0x20u) - 'a') < 26u) ? dna4_code((uint8_t)threadIdx.x) : 0xFFu);
+    __syncthreads();
     for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
         const uint64_t a0 = aoff[r];
         const uint32_t len = (uint32_t)(aoff[r + 1] - a0);
@@ -125,18 +128,27 @@ __global__ __launch_bounds__(BLK) void k_pack_dna4(const uint8_t *__restrict__ a
         for (uint32_t w = threadIdx.x; w < nw_pad; w += BLK) {
             uint32_t word = 0;
             if (w < nw) {
+                // 16 characters = five aligned dwords funnel-shifted by the read's byte misalignment (the ASCII
+                // buffer has slack past its end, so the fifth dword is always readable)
+                const uint64_t A = a0 + ((uint64_t)w << 4);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(ascii + (A & ~3ull));
+                const uint32_t sh = (uint32_t)(A & 3ull) * 8u;
+                uint32_t q[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) q[j] = src[j];
                 const uint32_t b0 = w << 4;
 #pragma unroll
-                for (uint32_t j = 0; j < 16; ++j) {
-                    uint32_t code = 0;
-                    if (b0 + j < len) {
-                        const uint8_t ch = ascii[a0 + b0 + j];
-                        code = dna4_code(ch);
-                        // reject anything that is not a letter of dna15 (digits etc. share no case bit trick)
-                        const bool letter = (uint8_t)((ch | 0x20) - 'a') < 26;
-                        if (code == 0xFFu || !letter) { bad = true; code = 0; }
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t x = sh ? ((q[j] >> sh) | (q[j + 1] << (32u - sh))) : q[j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const uint32_t pos = b0 + 4u * (uint32_t)j + (uint32_t)c;
+                        if (pos < len) {
+                            uint32_t code = sLut[(x >> (8 * c)) & 0xFFu];
+                            if (code == 0xFFu) { bad = true; code = 0; }
+                            word |= code << (30u - 2u * (4u * (uint32_t)j + (uint32_t)c));
+                        }
                     }
-                    word |= code << (30u - 2u * j);
                 }
             }
             dst[w] = word;
@@ -146,10 +158,11 @@ __global__ __launch_bounds__(BLK) void k_pack_dna4(const uint8_t *__restrict__ a
 }
 
 void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,
-                      uint32_t n_reads, Counters *ctr, hipStream_t st)
+                      uint32_t n_reads, Counters *ctr, hipStream_t st, int max_grid)
 {
     if (!n_reads) return;
-    const int grid = (int)(n_reads < 8192u ? n_reads : 8192u);
+    int grid = (int)(n_reads < 8192u ? n_reads : 8192u);
+    if (max_grid > 0 && grid > max_grid) grid = max_grid;
     hipLaunchKernelGGL(k_pack_dna4, dim3(grid), dim3(BLK), 0, st, ascii, aoff, poff, packed, n_reads, ctr);
 }
 
