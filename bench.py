@@ -126,8 +126,8 @@ def main():
     child_max = max(child_max, max(len(p) for p in planted) + 1024)
     lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
                             n_children=wl["n_children"], root_max_elems=root_max, child_max_elems=child_max,
-                            seed=synth.DEFAULT_SEED)
-    idx = synth.device_index(lay, k, s, t, device=local_rank)
+                            seed=synth.DEFAULT_SEED, build="gpu")
+    idx = synth.device_index(lay, k, s, t, device=local_rank)   # planted columns constructed on the GPU
     log(f"index in HBM: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs, depth {idx.depth}, root {wl['root_bins']} bins, "
         f"children {wl['child_bins']} bins, {time.time()-t0:.1f}s")
 
@@ -289,7 +289,7 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
     # threshold, which random fingerprints cannot)
     needed = {0}
     for i, f in enumerate(lay["ixfs"]):
-        if f["columns"] and i > 0:
+        if (f["columns"] or f.get("key_sets")) and i > 0:
             needed.add(i)
     try:
         host = []

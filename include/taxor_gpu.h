@@ -82,6 +82,13 @@ int taxor_gpu_index_fill_random(taxor_gpu_index *idx, uint64_t ixf, uint64_t see
 int taxor_gpu_index_upload_bin(taxor_gpu_index *idx, uint64_t ixf, uint64_t bin, const uint8_t *column,
                                uint64_t rows);
 int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8_t *data, uint64_t len);
+/* GPU construction of the fingerprint columns of one IXF, in place (the reference builds on
+ * the CPU: src/hixf/build/construct_ixf.cpp:50-165, add_bin_elements + reseed loop).  keys = the bins' key lists
+ * concatenated (distinct within a bin), key_off[bins+1]; bins without keys keep their content.  All bins are peeled
+ * in parallel rounds; if a bin does not peel the IXF is re-seeded and rebuilt, like the reference.  On success the
+ * IXF carries *seed_out (also written into the resident index); *rounds_out = peeling rounds of the slowest chunk. */
+int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
+                              uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Searcher = one GPU-side "membership agent" + the per-read driver state.

@@ -309,6 +309,27 @@ extern "C" void taxor_gpu_index_destroy(taxor_gpu_index *idx)
     delete idx;
 }
 
+// library-internal accessors for builder.hip
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_gpu_index *idx, uint64_t ixf, uint8_t **data,
+                                                                          uint64_t *stride, uint64_t *seg_len, uint64_t *bins,
+                                                                          int *device)
+{
+    if (!idx || ixf >= idx->h_ixf.size()) return -1;
+    *data = const_cast<uint8_t *>(idx->h_ixf[ixf].data);
+    *stride = idx->h_ixf[ixf].stride;
+    *seg_len = idx->h_ixf[ixf].seg_len;
+    *bins = idx->h_ixf[ixf].bins;
+    *device = idx->device;
+    return 0;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed)
+{
+    if (!idx || ixf >= idx->h_ixf.size()) return -1;
+    idx->h_ixf[ixf].seed = seed;
+    return hipMemcpy(&idx->d_ixf[ixf], &idx->h_ixf[ixf], sizeof(IxfDesc), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
 extern "C" uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx) { return idx ? idx->data_bytes : 0; }
 extern "C" uint64_t taxor_gpu_index_leaf_runs(const taxor_gpu_index *idx) { return idx ? idx->leaf_runs : 0; }
 extern "C" uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx) { return idx ? idx->depth : 0; }

@@ -114,6 +114,21 @@ class GpuIndex:
         col = np.ascontiguousarray(column, dtype=np.uint8)
         check(_lib.lib().taxor_gpu_index_upload_bin(self._h, ixf, bin_, _p(col), col.size))
 
+    def build_ixf(self, ixf, bin_keys, seed0=1):
+        """GPU construction of IXF `ixf` in place from {bin: uint64 keys}; returns (seed, peeling rounds)."""
+        bins = self.shapes[ixf][0]
+        off = np.zeros(bins + 1, dtype=np.uint64)
+        parts = []
+        for b in range(bins):
+            k = np.ascontiguousarray(bin_keys.get(b, np.zeros(0, np.uint64)), dtype=np.uint64)
+            parts.append(k)
+            off[b + 1] = off[b] + np.uint64(k.size)
+        keys = np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+        seed, rounds = C.c_uint64(), C.c_uint32()
+        check(_lib.lib().taxor_gpu_index_build_ixf(self._h, ixf, _p(keys) if keys.size else None, _p(off), int(seed0),
+                                                   C.byref(seed), C.byref(rounds)))
+        return int(seed.value), int(rounds.value)
+
     def download_ixf(self, ixf):
         bins, stride, seg = self.shapes[ixf]
         out = np.empty(3 * seg * stride, dtype=np.uint8)

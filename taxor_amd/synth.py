@@ -74,7 +74,7 @@ def _stride(bins):
 
 
 def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_elems=None,
-                child_max_elems=None, seed=DEFAULT_SEED, with_split=True, with_deep=True):
+                child_max_elems=None, seed=DEFAULT_SEED, with_split=True, with_deep=True, build="host"):
     """Build a 2-3 level HIXF layout with the planted hash sets on full root->leaf paths.
 
     planted: list of uint64 arrays (distinct syncmer hashes of genome i).  Returns a dict:
@@ -83,7 +83,9 @@ def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_ele
     Root: planted[0] split over bins 0..2 (one user bin), planted[1] a single leaf at bin 3, bins
     4..4+n_children-1 merged (children), the rest decoy leaves.  The other planted sets go round-robin into
     the children; in child 0 one of them is split over two bins and, with_deep, another sits in a grandchild
-    reached through a merged bin of child 0 (depth-3 chain)."""
+    reached through a merged bin of child 0 (depth-3 chain).
+    build="host": XOR-filter columns are constructed here (CPU); build="gpu": only the key sets are returned
+    (`key_sets`) and device_index() constructs the columns with taxor_gpu_index_build_ixf."""
     planted = [np.unique(np.ascontiguousarray(p, dtype=np.uint64)) for p in planted]
     P = len(planted)
     assert P >= 2 and root_bins >= 4 + n_children and child_bins >= 8
@@ -180,12 +182,14 @@ def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_ele
         assert cap >= mx, f"IXF {i}: max_elems {cap} < largest bin {mx}"
         seg = seg_len_for(cap)
         nonempty = {bb: k for bb, k in f["keys"].items() if len(k)}   # empty bins stay random fill
-        sd, cols = build_columns(nonempty, seg, int(rng.integers(1, 2**63)))
+        seed0 = int(rng.integers(1, 2**63))
+        sd, cols = build_columns(nonempty, seg, seed0) if build == "host" else (seed0, {})
         nx = np.full(f["bins"], i, dtype=np.int64)       # next_ixf_id[i][b] == i  <=>  not merged
         for bb, ch in f["child_of"].items():
             nx[bb] = ch
         out.append(dict(bins=f["bins"], stride=f["stride"], seg_len=seg, seed=sd, next_ixf=nx,
-                        fname_idx=f["fname_idx"], columns=cols, fill_seed=int(rng.integers(1, 2**63))))
+                        fname_idx=f["fname_idx"], columns=cols, fill_seed=int(rng.integers(1, 2**63)),
+                        key_sets=nonempty if build != "host" else {}))
     depth = 3 if deep_member is not None else 2
     return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth)
 
@@ -215,4 +219,6 @@ def device_index(layout, k=22, s=12, t=5, device=0):
         idx.fill_random(i, f["fill_seed"])
         for b, col in f["columns"].items():
             idx.upload_bin(i, b, col)
+        if f.get("key_sets"):                      # columns constructed on the GPU; it may re-seed the IXF
+            f["seed"], _ = idx.build_ixf(i, f["key_sets"], seed0=f["seed"])
     return idx

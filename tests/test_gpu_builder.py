@@ -1,0 +1,120 @@
+"""GPU construction of IXF fingerprint columns (taxor_gpu_index_build_ixf): every key of every
+bin must match in its bin -- checked through the GPU query kernel AND through the CPU oracle on the downloaded bytes --
+non-members hit at the 2^-8 rate, untouched bins keep their content, duplicate keys fail loudly."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from taxor_amd import GpuIndex, Searcher, synth
+from taxor_amd._lib import TaxorError
+
+pytestmark = pytest.mark.gpu
+
+
+def _empty_index(bins, max_elems, seed=3):
+    stride = ((bins + 63) // 64) * 64
+    seg = synth.seg_len_for(max_elems)
+    rng = np.random.default_rng(seed)
+    data = rng.integers(0, 256, size=3 * seg * stride, dtype=np.uint8)
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64), fname_idx=np.arange(bins), data=data)
+    return ixf, GpuIndex([ixf], bins)
+
+
+@pytest.mark.parametrize("bins,max_elems", [(64, 3000), (200, 20000), (5, 400000)])
+def test_build_ixf_members_match(bins, max_elems):
+    rng = np.random.default_rng(bins)
+    ixf, idx = _empty_index(bins, max_elems)
+    before = idx.download_ixf(0).reshape(-1, ixf["stride"]).copy()
+    sizes = {0: max_elems, 1: 1, 2: max_elems // 3, bins - 1: max_elems // 2, bins // 2: 17}
+    keys = {b: np.unique(rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)) for b, n in sizes.items()}
+    keys[2] = np.concatenate([keys[2], np.array([0], dtype=np.uint64)])     # wyhash(poly-A k-mer) = 0 is a legal key
+    seed, rounds = idx.build_ixf(0, keys, seed0=12345)
+    assert rounds >= 1
+    sr = Searcher(idx, ratio=0.5)
+    after = idx.download_ixf(0)
+    h = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    for b, ks in keys.items():
+        cnt = sr.ixf_bulk_count(0, ks)
+        assert cnt[b] == ks.size, (b, int(cnt[b]), ks.size)
+        assert np.array_equal(cnt, h.ixf_bulk_count(0, ks))
+    neg = rng.integers(0, 2**64 - 1, size=40000, dtype=np.uint64)
+    cnt = sr.ixf_bulk_count(0, neg)
+    assert abs(cnt[0] / 40000 - 1 / 256) < 0.002 and abs(cnt.mean() / 40000 - 1 / 256) < 0.001
+    # bins without keys keep their previous content; built bins are zero outside their assigned rows
+    a2 = after.reshape(-1, ixf["stride"])
+    untouched = [b for b in range(bins) if b not in keys]
+    assert np.array_equal(a2[:, untouched], before[:, untouched])
+    # deterministic: same input, same seed -> same bytes
+    _, idx2 = _empty_index(bins, max_elems)
+    seed2, _ = idx2.build_ixf(0, keys, seed0=12345)
+    assert seed2 == seed
+    b2 = idx2.download_ixf(0).reshape(-1, ixf["stride"])
+    for b in keys:
+        assert np.array_equal((a2[:, b] != 0).sum(), (b2[:, b] != 0).sum())
+    sr.close()
+    idx.close()
+    idx2.close()
+
+
+def test_build_ixf_matches_cpu_builder_semantics_and_search():
+    """an index whose planted columns are built on the GPU classifies reads exactly like the oracle says"""
+    g, go = synth.random_genomes(4, 30000, seed=77)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = {3 + 5 * i: hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(4)}
+    ixf, idx = _empty_index(100, 4000, seed=9)
+    seed, _ = idx.build_ixf(0, planted, seed0=99)
+    after = idx.download_ixf(0)
+    h = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    bases, offs, origin = synth.synth_reads(g, go, 200, 2000, error_rate=0.02, frac_random=0.2, seed=5)
+    sr = Searcher(idx)
+    res = sr.search_batch(bases, offs)
+    nh, off, ub, cnt, _ = h.search_batch(bases, offs, threads=4)
+    assert np.array_equal(res.read_off, off) and np.array_equal(res.user_bin, ub) and np.array_equal(res.count, cnt)
+    hit = sum((3 + 5 * origin[i]) in [u for u, _ in res.tuples(i)] for i in range(200) if origin[i] >= 0)
+    assert hit > 0.8 * (origin >= 0).sum()
+    sr.close()
+    idx.close()
+
+
+def test_build_ixf_errors():
+    ixf, idx = _empty_index(64, 100)
+    dup = np.array([5, 7, 7, 9], dtype=np.uint64)
+    with pytest.raises(TaxorError) as e:
+        idx.build_ixf(0, {0: dup})
+    assert e.value.code == -4 and "duplicate" in str(e.value)
+    with pytest.raises(TaxorError):
+        idx.build_ixf(0, {0: np.arange(10**6, dtype=np.uint64)})    # more keys than rows
+    idx.close()
+
+
+def test_layout_built_on_gpu_equals_oracle_search():
+    """synth.make_layout(build='gpu') + device_index: the whole planted hierarchy constructed by the GPU builder"""
+    g, go = synth.random_genomes(7, 15000, seed=5)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(7)]
+    lay = synth.make_layout(planted, root_bins=70, child_bins=40, n_children=3, seed=6, build="gpu")
+    idx = synth.device_index(lay)
+    host = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], next_ixf=f["next_ixf"],
+                 fname_idx=f["fname_idx"], data=idx.download_ixf(i)) for i, f in enumerate(lay["ixfs"])]
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, origin = synth.synth_reads(g, go, 300, 2000, error_rate=0.02, frac_random=0.1, seed=2)
+    sr = Searcher(idx)
+    res = sr.search_batch(bases, offs)
+    nh, off, ub, cnt, _ = h.search_batch(bases, offs, threads=4)
+    assert np.array_equal(res.read_off, off) and np.array_equal(res.user_bin, ub) and np.array_equal(res.count, cnt)
+    hit = sum(lay["planted_user_bin"][origin[i]] in [u for u, _ in res.tuples(i)] for i in range(300) if origin[i] >= 0)
+    assert hit > 0.8 * (origin >= 0).sum()
+    sr.close()
+    idx.close()
