@@ -677,11 +677,19 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
         // ---- threshold-aware pruning ---------------------------------------------------------------------------
         // After `dense_end` hashes a run of `len` technical bins whose partial sum satisfies
         // sum + (n - dense_end) * len < thr can never reach the threshold: the reference would neither report
-        // nor descend it, so its remaining counts are irrelevant.  dense_end = n - thr + 16 leaves random bins
-        // (expected count dense_end/256) far below the bound, so normally only true matches stay alive and the
+        // nor descend it, so its remaining counts are irrelevant.  dense_end = n - thr + margin leaves random bins
+        // (expected count dense_end/256) below the bound, so normally only true matches stay alive and the
         // remaining hashes probe just their 16-bin units.  Runs that stay alive are counted exactly.
         uint32_t dense_end = n;
-        if (a.prune && thr > 0) dense_end = (thr >= (uint64_t)n + 16u) ? 0u : min(n, (uint32_t)((uint64_t)n + 16u - thr));
+        if (a.prune && thr > 0) {
+            // margin above the minimum n - thr + 1: a random bin collects ~Poisson((n-thr)/256) matches in the dense
+            // phase; mean + 4 sigma + 4 keeps the expected number of falsely surviving units per item below ~0.1
+            // for reads of any length (a fixed margin either wastes dense traffic on short reads or lets every bin
+            // of a 100-kb read survive).  The margin only trades dense against sparse work, never exactness.
+            const float mu = thr < (uint64_t)n ? (float)((uint64_t)n - thr) * (1.0f / 256.0f) : 0.0f;
+            const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + 4.5f);
+            dense_end = (thr >= (uint64_t)n + margin) ? 0u : min(n, (uint32_t)((uint64_t)n + margin - thr));
+        }
         uint64_t touched = 0;
 
         const bool staged = n <= (uint32_t)Q_CAP; // all probes of this read fit: stage them once for both phases
