@@ -485,7 +485,7 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 // owns the 16-B unit u of every row and the hash subset g, g+G, ...; each hash costs the thread three 16-B
 // global loads (whole block: three contiguous row segments), an XOR, and an exact zero-byte test whose 0/1
 // bytes accumulate in packed byte counters (a thread adds at most 240 per tile before they are widened).
-// After n_h - thr + 16 hashes, bin runs that can no longer reach the threshold are dropped and the remaining
+// After n_h - thr + margin hashes, bin runs that can no longer reach the threshold are dropped and the remaining
 // hashes probe only the surviving 16-bin units (threshold-aware pruning, see the kernel).  Counters are merged
 // through LDS, then the bins are walked exactly like bulk_contains_impl (hixf.hpp:313-338).
 // ------------------------------------------------------------------------------------------------------
