@@ -504,3 +504,34 @@ def test_mixed_read_lengths_longest_first_order():
         _compare(res, h.search_batch(B, O, threads=8), len(reads))
         sr.close()
     idx.close()
+
+
+def test_pruning_with_rows_wider_than_one_block_pass():
+    """5000 bins = 313 units: the dense loop needs two column passes and the alive-unit bitmap spans ten words;
+    pruning, sparse probing and the tally must still equal the oracle"""
+    rng = np.random.default_rng(44)
+    bins, stride = 5000, 5056
+    seg = synth.seg_len_for(1200)
+    planted = {b: np.unique(rng.integers(0, 2**63, size=900, dtype=np.uint64)) for b in (7, 2500, 4099, 4999)}
+    seed, cols = synth.build_columns(planted, seg, 3)
+    data = rng.integers(0, 256, size=(3 * seg, stride), dtype=np.uint8)
+    for b, c in cols.items():
+        data[:, b] = c
+    fname = np.arange(bins, dtype=np.int64)
+    fname[4096:4100] = 4096                      # a split run straddling the first column pass boundary
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=seed, next_ixf=np.zeros(bins, np.int64), fname_idx=fname,
+               data=data.reshape(-1))
+    idx = GpuIndex([ixf], bins)
+    h = orc.Hixf([ixf], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    sr = Searcher(idx, ratio=0.5)
+    noise = rng.integers(0, 2**63, size=500, dtype=np.uint64)
+    for name, q in (("b7", np.concatenate([planted[7][:600], noise[:300]])),
+                    ("b4099", np.concatenate([planted[4099][:700], noise[:200]])),
+                    ("two", np.concatenate([planted[2500][:450], planted[4999][:450], noise[:100]])),
+                    ("noise", noise)):
+        for thr in (1, 3, 200, 440, 450, 451, 600, 700, 701, q.size):
+            ub, cnt = sr.bulk_contains(q, thr)
+            wub, wcnt, _ = h.bulk_contains(q, thr)
+            assert np.array_equal(ub, wub) and np.array_equal(cnt, wcnt), (name, thr)
+    sr.close()
+    idx.close()
