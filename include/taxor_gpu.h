@@ -129,6 +129,13 @@ typedef struct {
 int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets,
                            uint64_t n_reads, taxor_gpu_results *out);
 
+/* Optional: pin a host buffer that the caller passes to taxor_gpu_search_batch / taxor_gpu_batch_upload again and
+ * again (a recycled staging buffer, like the reference's per-chunk `records` vector, taxor_search.cpp:319).  Copies
+ * from registered memory are direct DMA; for pageable memory the runtime locks and unlocks the pages on every call
+ * (~2.4 ms per 64 MB on MI355X).  The registration covers all devices; unregister before freeing or resizing. */
+int taxor_gpu_host_register(void *ptr, uint64_t bytes);
+int taxor_gpu_host_unregister(void *ptr);
+
 /* The same call split into its three phases so that a caller can keep a batch resident in HBM
  * (upload once, run many times) and overlap transfers with compute:
  *   upload : H2D of the ASCII bases + on-device dna4 mapping and 2-bit packing

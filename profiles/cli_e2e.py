@@ -50,14 +50,15 @@ with open(fq, "wb") as f:
         f.write(b"\n")
 print(f"index {os.path.getsize(idx_path)/1e6:.0f} MB, fastq {os.path.getsize(fq)/1e9:.2f} GB written in {time.time()-t0:.1f}s", flush=True)
 out = os.path.join(tmp, "out.tsv")
-for extra in ([], ["--batch-reads", "262144"]):
+configs = ([], [], ["--threads", "16"], ["--gpu-list", "0,0"], ["--threads", "1"])
+for extra in configs:
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq,
-                         "--output-file", out, "--threads", "32"] + extra, capture_output=True, text=True)
+                         "--output-file", out] + (["--threads", "32"] if "--threads" not in extra else []) + extra, capture_output=True, text=True, env=dict(os.environ, TAXOR_CLI_TRACE="1"))
     dt = time.time() - t0
     print(" ".join(extra) or "(default batch)", "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end")
     print(cp.stdout.strip().replace("\n", " | "))
-    print(cp.stderr.strip()[:300])
+    print(cp.stderr.strip()[:1500])
 lines = sum(1 for _ in open(out))
 print("tsv lines", lines)
 subprocess.run(["rm", "-rf", tmp])

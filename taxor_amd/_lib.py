@@ -78,6 +78,8 @@ SIGNATURES = {
     "taxor_gpu_index_build_ixf": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "taxor_gpu_searcher_create": (C.c_int, [_P, C.POINTER(SearchParams), C.POINTER(_P)]),
     "taxor_gpu_searcher_destroy": (None, [_P]),
+    "taxor_gpu_host_register": (C.c_int, [_P, C.c_uint64]),
+    "taxor_gpu_host_unregister": (C.c_int, [_P]),
     "taxor_gpu_search_batch": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(Results)]),
     "taxor_gpu_batch_upload": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "taxor_gpu_batch_run": (C.c_int, [_P]),

@@ -138,6 +138,19 @@ struct taxor_gpu_searcher {
     taxor_gpu_run_stats stats{};
 };
 
+extern "C" int taxor_gpu_host_register(void *ptr, uint64_t bytes)
+{
+    if (!ptr || !bytes) return fail(TAXOR_E_ARG, "taxor_gpu_host_register: null buffer");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    return TAXOR_OK;
+}
+extern "C" int taxor_gpu_host_unregister(void *ptr)
+{
+    if (!ptr) return fail(TAXOR_E_ARG, "taxor_gpu_host_unregister: null buffer");
+    HIP_TRY(hipHostUnregister(ptr));
+    return TAXOR_OK;
+}
+
 extern "C" const char *taxor_gpu_last_error(void) { return g_err.c_str(); }
 extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const char *msg) { g_err = msg ? msg : ""; }
 

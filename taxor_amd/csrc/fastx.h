@@ -1,0 +1,252 @@
+// fastx.h -- FASTA / FASTQ record readers feeding `taxor search` (the reference reads its queries with
+// seqan3::sequence_file_input, src/main/taxor_search.cpp:181-184,315-321: ids are the full header line, sequences
+// are dna4).  Two sources produce the same numbered batches of records:
+//   * FastxReader       : sequential, over zlib (plain or .gz, any stream);
+//   * RangedFastx       : a plain file cut into byte ranges that start at record boundaries; each range is read
+//                         (pread into a small per-thread buffer: no page-table traffic) and parsed by its own
+//                         FastxReader, as many at a time as --threads allows.
+// Errors are thrown as std::runtime_error.
+#pragma once
+
+#include <zlib.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace fastx {
+
+// one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
+struct Batch {
+    uint64_t seq = 0;   // position of this chunk in the input
+    std::vector<std::string> ids;
+    std::string bases;
+    std::vector<uint64_t> offsets;
+    // results copied out of the searcher (its buffers are reused by the next batch)
+    std::vector<uint64_t> read_off;
+    std::vector<int64_t> user_bin;
+    std::vector<uint32_t> count, n_hashes;
+    // bases.data() as pinned for DMA by the consumer (search_main.cpp); the producer keeps bases from reallocating
+    void *pinned = nullptr;
+    bool may_pin = false;
+};
+
+// ---- sequential reader over zlib.  Lines are located with memchr inside a large refill buffer; sequence lines are
+//      appended straight into the batch and quality lines are skipped without being copied.
+struct FastxReader {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, len = 0;
+    bool eof = false;
+    std::string pending; // header line read ahead (FASTA)
+    int fd = -1;         // range mode: bytes [rpos, rend) of a plain file, read with pread
+    uint64_t rpos = 0, rend = 0;
+
+    void open_range(int fd_, uint64_t b, uint64_t e)
+    {
+        fd = fd_;
+        rpos = b;
+        rend = e;
+        pos = len = 0;
+        eof = false;
+        pending.clear();
+        if (buf.size() < (4u << 20)) buf.resize(4u << 20);
+    }
+    bool open(const std::string &path)
+    {
+        f = gzopen(path.c_str(), "rb");
+        if (f) gzbuffer(f, 1 << 20);
+        buf.resize(8u << 20);
+        return f != nullptr;
+    }
+    ~FastxReader() { if (f) gzclose(f); }
+    bool refill()
+    {
+        if (eof) return false;
+        long n;
+        if (fd >= 0) {
+            const uint64_t want = std::min<uint64_t>(buf.size(), rend - rpos);
+            n = want ? (long)pread(fd, buf.data(), want, (off_t)rpos) : 0;
+            if (n > 0) rpos += (uint64_t)n;
+        } else {
+            n = gzread(f, buf.data(), (unsigned)buf.size());
+        }
+        if (n <= 0) { eof = true; return false; }
+        pos = 0;
+        len = (size_t)n;
+        return true;
+    }
+    // next line -> appended to `out` (if non-null); returns false at end of input with nothing read
+    bool line_to(std::string *out)
+    {
+        bool any = false;
+        for (;;) {
+            if (pos == len && !refill()) {
+                if (any && out && !out->empty() && out->back() == '\r') out->pop_back();
+                return any;
+            }
+            const char *s = buf.data() + pos;
+            const char *e = (const char *)memchr(s, '\n', len - pos);
+            const size_t n = e ? (size_t)(e - s) : len - pos;
+            if (out) out->append(s, n);
+            any = any || n || e;
+            pos += n + (e ? 1 : 0);
+            if (e) {
+                if (out && !out->empty() && out->back() == '\r') out->pop_back();
+                return true;
+            }
+        }
+    }
+    bool getline(std::string &line)
+    {
+        line.clear();
+        return line_to(&line);
+    }
+    // appends the record's sequence to `bases`; returns false at end of file
+    bool next(std::string &id, std::string &bases)
+    {
+        std::string line;
+        if (pending.empty()) {
+            do {
+                if (!getline(line)) return false;
+            } while (line.empty());
+        } else {
+            line.swap(pending);
+            pending.clear();
+        }
+        if (line[0] == '>') {
+            id.assign(line, 1, std::string::npos);
+            for (;;) {
+                // peek the first character of the next line
+                if (pos == len && !refill()) break;
+                if (buf[pos] == '>') { getline(pending); break; }
+                line_to(&bases);
+            }
+            return true;
+        }
+        if (line[0] == '@') {
+            id.assign(line, 1, std::string::npos);
+            if (!line_to(&bases)) throw std::runtime_error("truncated FASTQ record: " + id);
+            if (!getline(line) || line.empty() || line[0] != '+') throw std::runtime_error("malformed FASTQ record: " + id);
+            if (!line_to(nullptr)) throw std::runtime_error("truncated FASTQ record: " + id);   // quality: skipped, never copied
+            return true;
+        }
+        throw std::runtime_error("query file is neither FASTA nor FASTQ");
+    }
+};
+
+// ---- plain file in byte ranges ---------------------------------------------------------------------------------------
+inline const char *next_line(const char *p, const char *e)
+{
+    const char *q = (const char *)memchr(p, '\n', (size_t)(e - p));
+    return q ? q + 1 : e;
+}
+
+// first record start at or after line start `p`, or `e` if the window [p, e) shows none.  FASTA: a line beginning
+// with '>'.  Four-line FASTQ: a line beginning with '@' whose second successor begins with '+' -- a quality line may
+// begin with '@' too, but then its second successor is a sequence line, which cannot begin with '+'.
+inline const char *resync(const char *p, const char *e, char kind)
+{
+    while (p < e) {
+        if (kind == '>') {
+            if (*p == '>') return p;
+        } else if (*p == '@') {
+            const char *l2 = next_line(next_line(p, e), e);
+            if (l2 < e && *l2 == '+') return p;
+        }
+        p = next_line(p, e);
+    }
+    return e;
+}
+
+// upper bound of the sequence bytes in `len` bytes of file
+inline size_t bases_bound(uint64_t len, char kind) { return kind == '@' ? (size_t)len / 2 + 64 : (size_t)len; }
+
+struct RangedFastx {
+    int fd = -1;
+    uint64_t size = 0, cur = 0;
+    char kind = 0;              // '>' FASTA, '@' FASTQ
+    uint64_t range_bytes = 0;   // target size of one range
+    uint64_t seq = 0;
+    std::mutex mu;
+    std::vector<char> win;
+
+    ~RangedFastx() { if (fd >= 0) ::close(fd); }
+
+    bool read_at(uint64_t off, size_t n)
+    {
+        win.resize(n);
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t r = pread(fd, win.data() + got, n - got, (off_t)(off + got));
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        return true;
+    }
+    // false: not a regular plain-text file (gzip, pipe, empty) -- use the sequential FastxReader
+    bool open(const std::string &path)
+    {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size < 2) return false;
+        size = (uint64_t)sb.st_size;
+        const size_t n = (size_t)std::min<uint64_t>(size, 1u << 16);
+        if (!read_at(0, n)) return false;
+        if ((unsigned char)win[0] == 0x1f && (unsigned char)win[1] == 0x8b) return false;      // gzip
+        size_t i = 0;
+        while (i < n && (win[i] == '\n' || win[i] == '\r')) ++i;
+        if (i == n) return false;
+        cur = i;
+        kind = win[i];
+        if (kind != '>' && kind != '@') throw std::runtime_error("query file is neither FASTA nor FASTQ");
+        return true;
+    }
+    // file offset of the first record that starts after the line containing offset `from`
+    uint64_t record_start_after(uint64_t from)
+    {
+        for (size_t w = 1u << 20;; w *= 4) {
+            const size_t n = (size_t)std::min<uint64_t>(w, size - from);
+            if (!read_at(from, n)) throw std::runtime_error("query file: read error");
+            const char *b = win.data(), *e = b + n;
+            const char *r = resync(next_line(b, e), e, kind);
+            if (r < e) return from + (uint64_t)(r - b);
+            if (from + n == size) return size;          // no further record: the rest belongs to the current range
+        }
+    }
+    // size ranges to hold about `batch_reads` records (calibrated on the first records) and at most `max_bytes`
+    void plan(uint64_t batch_reads, uint64_t max_bytes)
+    {
+        uint64_t p = cur;
+        unsigned n = 0;
+        while (n < 64 && p < size) {
+            p = record_start_after(p);
+            ++n;
+        }
+        const double per_rec = n ? (double)(p - cur) / n : 1.0;
+        double want = per_rec * (double)batch_reads;
+        if (want > (double)max_bytes) want = (double)max_bytes;
+        range_bytes = want < 1.0 ? 1 : (uint64_t)want;
+    }
+    // next byte range [b, e) of whole records; thread-safe; false when the file is exhausted
+    bool next_range(uint64_t &b, uint64_t &e, uint64_t &s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (cur >= size) return false;
+        b = cur;
+        e = cur = (size - cur > range_bytes) ? record_start_after(cur + range_bytes) : size;
+        s = seq++;
+        return true;
+    }
+};
+
+} // namespace fastx

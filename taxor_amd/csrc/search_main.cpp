@@ -3,8 +3,7 @@
 // (include/taxor_gpu.h).  Host work here: argument parsing (:32-80), sanity checks (:97-151), FASTA/FASTQ(.gz)
 // reading (:181-184), batching (:315-326) and output (:268-311, :343).
 #include "../../include/taxor_gpu.h"
-
-#include <zlib.h>
+#include "fastx.h"
 
 #include <sys/stat.h>
 
@@ -14,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -23,17 +23,7 @@
 
 namespace {
 
-// one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
-struct Batch {
-    uint64_t seq = 0;   // position of this chunk in the input
-    std::vector<std::string> ids;
-    std::string bases;
-    std::vector<uint64_t> offsets;
-    // results copied out of the searcher (its buffers are reused by the next batch)
-    std::vector<uint64_t> read_off;
-    std::vector<int64_t> user_bin;
-    std::vector<uint32_t> count, n_hashes;
-};
+using fastx::Batch;
 
 template <typename T> class BoundedQueue {
 public:
@@ -70,12 +60,38 @@ private:
     bool closed_ = false;
 };
 
+// Finished batches go back to the producers: their buffers stay mapped and warm, and at most `cap` batches exist at
+// a time (get() blocks), which bounds the host memory the pipeline touches -- faulting in and releasing fresh pages
+// costs more than parsing into them.
+struct BatchPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<std::unique_ptr<Batch>> free_;
+    size_t cap = 8, made = 0;
+    std::unique_ptr<Batch> get()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !free_.empty() || made < cap; });
+        if (free_.empty()) { ++made; return std::make_unique<Batch>(); }
+        auto b = std::move(free_.back());
+        free_.pop_back();
+        return b;
+    }
+    void put(std::unique_ptr<Batch> b)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        free_.push_back(std::move(b));
+        cv.notify_one();
+    }
+};
+
 struct Config {                              // taxor_search_configuration.hpp:8-20
     std::string index_file, query_file, report_file;
     double threshold = -1.0, error_rate = 0.04;
     unsigned threads = 1;
     std::vector<int> gpus{0};   // devices that classify batches in parallel, each with its own index replica
-    uint64_t batch_reads = 65536, batch_bases = 1ull << 30;
+    uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
+                                                           // file per batch (plain file, parsed in parallel)
 };
 
 std::vector<std::string> str_split(const std::string &s, char delim)         // taxor_search.cpp:82-95
@@ -119,96 +135,101 @@ void usage()
             "  --batch-reads <n>        reads per GPU batch (default 65536)\n");
 }
 
-// ---- FASTA / FASTQ reader over zlib (plain or .gz); ids are the full header line (seqan3 default).  Lines are
-//      located with memchr inside a large refill buffer; sequence lines are appended straight into the batch and
-//      quality lines are skipped without being copied.
-struct FastxReader {
-    gzFile f = nullptr;
-    std::vector<char> buf;
-    size_t pos = 0, len = 0;
-    bool eof = false;
-    std::string pending; // header line read ahead (FASTA)
-
-    bool open(const std::string &path)
-    {
-        f = gzopen(path.c_str(), "rb");
-        if (f) gzbuffer(f, 1 << 20);
-        buf.resize(8u << 20);
-        return f != nullptr;
-    }
-    ~FastxReader() { if (f) gzclose(f); }
-    bool refill()
-    {
-        if (eof) return false;
-        const int n = gzread(f, buf.data(), (unsigned)buf.size());
-        if (n <= 0) { eof = true; return false; }
-        pos = 0;
-        len = (size_t)n;
-        return true;
-    }
-    // next line -> appended to `out` (if non-null); returns false at end of input with nothing read
-    bool line_to(std::string *out, bool *nonempty_first_char = nullptr, char *first = nullptr)
-    {
-        bool any = false;
-        for (;;) {
-            if (pos == len && !refill()) {
-                if (any && out && !out->empty() && out->back() == '\r') out->pop_back();
-                return any;
-            }
-            const char *s = buf.data() + pos;
-            const char *e = (const char *)memchr(s, '\n', len - pos);
-            const size_t n = e ? (size_t)(e - s) : len - pos;
-            if (!any && n && first) { *first = s[0]; if (nonempty_first_char) *nonempty_first_char = true; }
-            if (out) out->append(s, n);
-            any = any || n || e;
-            pos += n + (e ? 1 : 0);
-            if (e) {
-                if (out && !out->empty() && out->back() == '\r') out->pop_back();
-                return true;
-            }
-        }
-    }
-    bool getline(std::string &line)
-    {
-        line.clear();
-        return line_to(&line);
-    }
-    // appends the record's sequence to `bases`; returns false at end of file
-    bool next(std::string &id, std::string &bases)
-    {
-        std::string line;
-        if (pending.empty()) {
-            do {
-                if (!getline(line)) return false;
-            } while (line.empty());
-        } else {
-            line.swap(pending);
-            pending.clear();
-        }
-        if (line[0] == '>') {
-            id.assign(line, 1, std::string::npos);
-            for (;;) {
-                // peek the first character of the next line
-                if (pos == len && !refill()) break;
-                if (buf[pos] == '>') { getline(pending); break; }
-                line_to(&bases);
-            }
-            return true;
-        }
-        if (line[0] == '@') {
-            id.assign(line, 1, std::string::npos);
-            if (!line_to(&bases)) die("truncated FASTQ record: " + id);
-            if (!getline(line) || line.empty() || line[0] != '+') die("malformed FASTQ record: " + id);
-            if (!line_to(nullptr)) die("truncated FASTQ record: " + id);   // quality: skipped, never copied
-            return true;
-        }
-        die("query file is neither FASTA nor FASTQ");
-    }
-};
-
 double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// TAXOR_CLI_TRACE=1: wall-clock marks of the pipeline stages on stderr
+const double g_t0 = now();
+void trace(const char *what)
+{
+    static const bool on = getenv("TAXOR_CLI_TRACE") != nullptr;
+    if (on) fprintf(stderr, "[trace] %8.3f s  %s\n", now() - g_t0, what);
+}
+
+// Numbered batches of records from one query file -> push() (called from several threads, batches may arrive out
+// of order; `seq` gives the input order).  A plain file is read and parsed by up to `threads` threads, each taking
+// the next byte range of about cfg.batch_reads records; anything else (gzip, pipes) goes through the sequential
+// zlib reader, which cuts batches at exactly cfg.batch_reads records.  Returns the wall time spent producing.
+double produce_batches(const std::string &query, const Config &cfg, bool allow_ranges, BatchPool &pool,
+                       const std::function<void(std::unique_ptr<Batch>)> &push)
+{
+    const double t_begin = now();
+    double blocked = 0;   // time the sequential reader spent waiting for the consumers
+    fastx::RangedFastx rf;
+    bool ranged = false;
+    try {
+        ranged = allow_ranges && rf.open(query);
+    } catch (const std::exception &e) { die(e.what()); }
+    if (ranged) {
+        if (cfg.batch_reads) rf.plan(cfg.batch_reads, std::min<uint64_t>(cfg.batch_bases, 1ull << 30));
+        else rf.range_bytes = rf.kind == '@' ? (128u << 20) : (64u << 20);
+        const unsigned nt = std::max(1u, std::min(cfg.threads, 16u));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&] {
+                fastx::FastxReader rd;
+                std::string id;
+                uint64_t b, e, seq;
+                for (;;) {
+                    auto bt = pool.get();                   // buffer first: ranges are then taken in the order they can be filled
+                    try {
+                        if (!rf.next_range(b, e, seq)) { pool.put(std::move(bt)); break; }
+                        bt->seq = seq;
+                        bt->may_pin = true;
+                        const size_t need = fastx::bases_bound(e - b, rf.kind);
+                        if (need > bt->bases.capacity()) {  // grow before parsing, and only with the old block unpinned
+                            if (bt->pinned) { taxor_gpu_host_unregister(bt->pinned); bt->pinned = nullptr; }
+                            bt->bases.clear();
+                            bt->bases.reserve((need + need / 16 + (2u << 20)) & ~size_t((2u << 20) - 1));
+                        }
+                        bt->ids.clear();
+                        bt->bases.clear();
+                        bt->offsets.assign(1, 0);
+                        rd.open_range(rf.fd, b, e);
+                        while (rd.next(id, bt->bases)) {
+                            bt->ids.push_back(id);
+                            bt->offsets.push_back(bt->bases.size());
+                        }
+                    } catch (const std::exception &ex) { die(ex.what()); }
+                    push(std::move(bt));
+                }
+            });
+        for (auto &t : th) t.join();
+        return now() - t_begin;
+    }
+    fastx::FastxReader rd;
+    if (!rd.open(query)) die("cannot open query file " + query);
+    std::string id;
+    bool more = true;
+    uint64_t seq = 0;
+    const uint64_t batch_reads = cfg.batch_reads ? cfg.batch_reads : 65536;
+    try {
+        while (more) {
+            auto b = pool.get();
+            b->seq = seq++;
+            b->ids.clear();
+            b->bases.clear();
+            b->offsets.assign(1, 0);
+            while (b->ids.size() < batch_reads && b->bases.size() < cfg.batch_bases && (more = rd.next(id, b->bases))) {
+                b->ids.push_back(id);
+                b->offsets.push_back(b->bases.size());
+            }
+            if (b->ids.empty()) { pool.put(std::move(b)); break; }
+            const double t1 = now();
+            push(std::move(b));
+            blocked += now() - t1;
+        }
+    } catch (const std::exception &ex) { die(ex.what()); }
+    return now() - t_begin - blocked;
+}
+
+uint64_t fnv1a(const char *p, size_t n)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+    return h;
 }
 
 } // namespace
@@ -230,6 +251,38 @@ int main(int argc, char **argv)
         if (rc != TAXOR_OK) die(taxor_gpu_last_error());
         printf("schema: n_before=%u n_after=%u idx_bins=%d idx_stride=%d idx_seg_len=%d%s idx_seed=%d\n", sc.n_before, sc.n_after,
                sc.idx_bins, sc.idx_stride, sc.idx_seg_len, sc.seg_len_is_rows ? "(rows)" : "", sc.idx_seed);
+        return 0;
+    }
+    if (argc > 1 && strcmp(argv[1], "reads") == 0) {                       // reader check: id, length, FNV-1a of every record
+        Config cfg;
+        bool allow_ranges = true;
+        for (int i = 2; i < argc; ++i) {
+            if (strcmp(argv[i], "--query-file") == 0 && i + 1 < argc) cfg.query_file = argv[++i];
+            else if (strcmp(argv[i], "--threads") == 0 && i + 1 < argc) cfg.threads = (unsigned)atoi(argv[++i]);
+            else if (strcmp(argv[i], "--batch-reads") == 0 && i + 1 < argc) cfg.batch_reads = strtoull(argv[++i], nullptr, 10);
+            else if (strcmp(argv[i], "--sequential") == 0) allow_ranges = false;
+        }
+        if (cfg.query_file.empty() || !file_exists(cfg.query_file)) die("usage: taxor reads --query-file <fasta|fastq[.gz]> [--threads n] [--batch-reads n] [--sequential]");
+        std::mutex mu;
+        std::map<uint64_t, std::unique_ptr<Batch>> got;
+        BatchPool pool;
+        pool.cap = ~size_t(0);                                        // this check keeps every batch
+        const double dt = produce_batches(cfg.query_file, cfg, allow_ranges, pool, [&](std::unique_ptr<Batch> b) {
+            std::lock_guard<std::mutex> lk(mu);
+            got.emplace(b->seq, std::move(b));
+        });
+        uint64_t n = 0, nb = 0, expect = 0;
+        for (const auto &kv : got) {
+            if (kv.first != expect++) die("batch numbering has a gap");
+            const Batch &b = *kv.second;
+            for (size_t r = 0; r < b.ids.size(); ++r) {
+                const uint64_t lo = b.offsets[r], len = b.offsets[r + 1] - lo;
+                printf("%s\t%llu\t%016llx\n", b.ids[r].c_str(), (unsigned long long)len, (unsigned long long)fnv1a(b.bases.data() + lo, len));
+                ++n;
+                nb += len;
+            }
+        }
+        fprintf(stderr, "%llu reads, %llu bases, %zu batches, %.3f s\n", (unsigned long long)n, (unsigned long long)nb, got.size(), dt);
         return 0;
     }
     if (argc > 1 && strcmp(argv[1], "search") == 0) a = 2;                 // `taxor search ...` like the reference
@@ -299,12 +352,14 @@ int main(int argc, char **argv)
     for (const auto &f : query_files)
         if (!file_exists(f)) die("Please check the given input query files. \nThe following query file does not exist: " + f);
     printf("done!\n");
+    trace("input checked");
 
     FILE *out = fopen(cfg.report_file.c_str(), "wb");                       // search_hixf, :340-343
     if (!out) die("cannot open output file " + cfg.report_file);
     fputs("#QUERY_NAME\tACCESSION\tREFERENCE_NAME\tTAXID\tREF_LEN\tQUERY_LEN\tQHASH_COUNT\tQHASH_MATCH\tTAX_STR\tTAX_ID_STR\n", out);
 
-    double t_index = 0, t_reads = 0, t_compute = 0;
+    double t_index = 0, t_reads = 0, t_compute = 0, t_pin = 0, t_search = 0;
+    uint64_t n_batches = 0;
     uint64_t total_reads = 0, total_bases = 0;
     std::mutex stat_mu;
     for (const auto &query : query_files) {
@@ -312,6 +367,7 @@ int main(int argc, char **argv)
             double t0 = now();
             taxor_hixf *h = nullptr;
             if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
+            trace("index file loaded");
             const taxor_hixf_view *view = taxor_hixf_get_view(h);
             // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
             // replicated, batches are sharded); replicas are uploaded concurrently
@@ -329,6 +385,7 @@ int main(int argc, char **argv)
                     if (!e.empty()) die(e);
             }
             t_index += now() - t0;
+            trace("index resident in HBM");
             // threshold model (threshold.hpp:22-47)
             const double ratio = taxor_threshold_ratio(view->kmer_size, cfg.error_rate, cfg.threshold);
             if (cfg.threshold > 0.0 && cfg.threshold <= 1.0) printf("use percentage-model\t%g\n", cfg.threshold);
@@ -340,33 +397,19 @@ int main(int argc, char **argv)
                 if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());
 
             // Overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
-            //   reader thread     : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321)
+            //   reader thread(s)  : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321);
+            //                       plain files are parsed by up to --threads threads (fastx.h)
             //   one thread per GPU: chunk -> GPU (streamed upload, kernels, fetch)   (:325)
             //   writer thread     : tuples -> 0.8*max filter -> TSV lines -> file, in chunk order (:266-311)
             // Output stays in input order (the reference's order at --threads 1).
             BoundedQueue<std::unique_ptr<Batch>> q_in(ng + 1), q_out(2 * ng + 2);
             double t_reads_local = 0;
+            BatchPool pool;
+            pool.cap = std::min(cfg.threads, 16u) + 3 * ng + 3;      // being parsed + q_in + on a GPU + q_out / writer
             std::thread reader([&] {
-                FastxReader rd;
-                if (!rd.open(query)) die("cannot open query file " + query);
-                std::string id;
-                bool more = true;
-                uint64_t seq = 0;
-                while (more) {
-                    const double t1 = now();
-                    auto b = std::make_unique<Batch>();
-                    b->seq = seq++;
-                    b->offsets.assign(1, 0);
-                    b->bases.reserve(std::min<uint64_t>(cfg.batch_bases, 1ull << 30));
-                    while (b->ids.size() < cfg.batch_reads && b->bases.size() < cfg.batch_bases && (more = rd.next(id, b->bases))) {
-                        b->ids.push_back(id);
-                        b->offsets.push_back(b->bases.size());
-                    }
-                    t_reads_local += now() - t1;
-                    if (b->ids.empty()) break;
-                    q_in.push(std::move(b));
-                }
+                t_reads_local = produce_batches(query, cfg, true, pool, [&](std::unique_ptr<Batch> b) { q_in.push(std::move(b)); });
                 q_in.close();
+                trace("reader done");
             });
             std::thread writer([&] {
                 std::unique_ptr<Batch> b;
@@ -394,6 +437,7 @@ int main(int argc, char **argv)
                             text.append(line.data(), need);
                         }
                         fwrite(text.data(), 1, text.size(), out);
+                        pool.put(std::move(cur));
                     }
                 }
             });
@@ -403,14 +447,22 @@ int main(int argc, char **argv)
                     std::unique_ptr<Batch> b;
                     while (q_in.pop(b)) {
                         const double t1 = now();
+                        if (b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
+                            taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
+                            b->pinned = &b->bases[0];       // recycled with the batch: pinned once, DMA source from then on
+                        const double t2 = now();
                         taxor_gpu_results res{};
                         if (taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                        const double t3 = now();
                         b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
                         b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
                         b->count.assign(res.count, res.count + res.n_tuples);
                         b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
                         {
                             std::lock_guard<std::mutex> lk(stat_mu);
+                            t_pin += t2 - t1;
+                            t_search += t3 - t2;
+                            ++n_batches;
                             t_compute += now() - t1;
                             total_reads += b->ids.size();
                             total_bases += b->bases.size();
@@ -419,19 +471,40 @@ int main(int argc, char **argv)
                     }
                 });
             for (auto &t : workers) t.join();
+            trace("GPU workers done");
             q_out.close();
             reader.join();
             writer.join();
+            trace("writer done");
             t_reads += t_reads_local;
             for (size_t g = 0; g < ng; ++g) {
                 taxor_gpu_searcher_destroy(sr[g]);
                 taxor_gpu_index_destroy(gidx[g]);
             }
+            trace("GPU memory released");
             taxor_hixf_free(h);
+            trace("host index released");
+            const bool last = &query == &query_files.back() && &hixf_file == &index_files.back();
+            if (last) {
+                // the process is about to end: unpinning and unmapping gigabytes of staging buffers page by page
+                // would only delay the exit (~0.1 s per GB)
+                for (auto &b : pool.free_) (void)b.release();
+            } else {
+                for (auto &b : pool.free_)
+                    if (b->pinned) taxor_gpu_host_unregister(b->pinned);
+            }
+            pool.free_.clear();
+            trace("batch buffers released");
         }
     }
     fclose(out);
+    trace("output closed");
+    if (getenv("TAXOR_CLI_TRACE"))
+        fprintf(stderr, "[trace] %llu batches: pin %.3f s, search_batch %.3f s, copy-out %.3f s\n", (unsigned long long)n_batches, t_pin,
+                t_search, t_compute - t_pin - t_search);
     printf("Index I/O\tReads I/O\tCompute\n%.2f\t%.2f\t%.2f\n", t_index, t_reads, t_compute);   // :328-336
     printf("%llu reads, %llu bases classified\n", (unsigned long long)total_reads, (unsigned long long)total_bases);
-    return 0;
+    fflush(stdout);
+    fflush(stderr);
+    _exit(0);   // everything is written and closed; skip the runtime's and the allocator's teardown
 }

@@ -79,11 +79,11 @@ class HixfFile:
             fn = np.ctypeslib.as_array(C.cast(f.fname_idx, C.POINTER(C.c_int64)), shape=(f.bins,))
             self.ixfs.append(dict(bins=int(f.bins), stride=int(f.stride), seg_len=int(f.seg_len), seed=int(f.seed),
                                   data=data, next_ixf=nx, fname_idx=fn))
-        self.species = [dict(organism_name=m.species[i].organism_name.decode(), accession_id=m.species[i].accession_id.decode(),
-                             taxid=m.species[i].taxid.decode(), taxnames_string=m.species[i].taxnames_string.decode(),
-                             taxid_string=m.species[i].taxid_string.decode(), user_bin=int(m.species[i].user_bin),
+        self.species = [dict(organism_name=m.species[i].organism_name.decode("utf-8", "replace"), accession_id=m.species[i].accession_id.decode("utf-8", "replace"),
+                             taxid=m.species[i].taxid.decode("utf-8", "replace"), taxnames_string=m.species[i].taxnames_string.decode("utf-8", "replace"),
+                             taxid_string=m.species[i].taxid_string.decode("utf-8", "replace"), user_bin=int(m.species[i].user_bin),
                              seq_len=int(m.species[i].seq_len)) for i in range(m.n_species)]
-        self.filenames = [m.user_bin_filenames[i].decode() for i in range(m.n_user_bin_filenames)]
+        self.filenames = [m.user_bin_filenames[i].decode("utf-8", "replace") for i in range(m.n_user_bin_filenames)]
 
     def format_read(self, read_id: str, read_len, n_hashes, user_bin, count):
         ub = np.ascontiguousarray(user_bin, dtype=np.int64)
@@ -96,7 +96,7 @@ class HixfFile:
             buf = C.create_string_buffer(int(n))
             n = _lib.lib().taxor_format_read(self._h, rid, len(rid), read_len, n_hashes, ub.ctypes.data, ct.ctypes.data,
                                              ub.size, buf, len(buf))
-        return buf.raw[:n].decode()
+        return buf.raw[:n].decode("utf-8", "replace")
 
     def close(self):
         if getattr(self, "_h", None):

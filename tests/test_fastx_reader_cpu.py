@@ -1,0 +1,134 @@
+"""The CLI's FASTA/FASTQ readers (taxor_amd/csrc/fastx.h): the sequential zlib reader and the memory-mapped parallel
+parser must produce the same records -- id = full header line, sequence = concatenated lines -- as a plain Python
+restatement of what seqan3::sequence_file_input hands the reference (src/main/taxor_search.cpp:181-184,315-321).
+`taxor reads` prints id, length and FNV-1a of every record; no GPU involved."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "taxor_amd", "taxor")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(EXE), reason="taxor CLI not built")
+
+
+def fnv1a(b: bytes) -> int:
+    h = 1469598103934665603
+    for c in b:
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def run_reads(path, *extra):
+    cp = subprocess.run([EXE, "reads", "--query-file", str(path), *extra], capture_output=True, text=True)
+    assert cp.returncode == 0, cp.stderr
+    rows = [l.split("\t") for l in cp.stdout.split("\n") if l]
+    n_batches = int(cp.stderr.split(" batches")[0].split(", ")[-1])
+    return [(r[0], int(r[1]), int(r[2], 16)) for r in rows], n_batches
+
+
+def expected(records):
+    return [(i, len(s), fnv1a(s)) for i, s in records]
+
+
+def make_records(rng, n, lo=0, hi=400):
+    recs = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=L))
+        recs.append((f"read_{i} some description/{i % 7}", s))
+    return recs
+
+
+def write_fastq(path, recs, rng, eol=b"\n", final_eol=True, opener=open):
+    qchars = np.frombuffer(b"@+!I5>#", np.uint8)     # quality lines that start with '@', '+' and '>' are legal
+    with opener(path, "wb") as f:
+        for j, (i, s) in enumerate(recs):
+            q = bytes(rng.choice(qchars, size=len(s)))
+            last = j == len(recs) - 1
+            f.write(b"@" + i.encode() + eol + s + eol + b"+" + (i.encode() if j % 3 == 0 else b"") + eol + q +
+                    (eol if (final_eol or not last) else b""))
+
+
+def write_fasta(path, recs, rng, eol=b"\n", width=60, blank_every=0, opener=open):
+    with opener(path, "wb") as f:
+        for j, (i, s) in enumerate(recs):
+            f.write(b">" + i.encode() + eol)
+            w = width if width else max(1, len(s))
+            for a in range(0, len(s), w):
+                f.write(s[a:a + w] + eol)
+            if blank_every and j % blank_every == 0:
+                f.write(eol)
+
+
+MODES = [("--sequential",), ("--threads", "1"), ("--threads", "4"), ("--threads", "4", "--batch-reads", "7"),
+         ("--threads", "3", "--batch-reads", "1"), ("--sequential", "--batch-reads", "5")]
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n"])
+def test_fastq_all_paths_agree(tmp_path, eol):
+    rng = np.random.default_rng(1)
+    recs = make_records(rng, 300)
+    p = tmp_path / "r.fastq"
+    write_fastq(p, recs, rng, eol=eol)
+    want = expected(recs)
+    for m in MODES:
+        got, nb = run_reads(p, *m)
+        assert got == want, m
+        if "--batch-reads" in m and "--sequential" not in m:
+            assert nb > 10          # ranges really were cut inside the file, at record starts
+
+
+def test_fastq_without_final_newline_and_gz(tmp_path):
+    rng = np.random.default_rng(2)
+    recs = make_records(rng, 50, lo=1)
+    p = tmp_path / "r.fastq"
+    write_fastq(p, recs, rng, final_eol=False)
+    for m in MODES:
+        assert run_reads(p, *m)[0] == expected(recs)
+    pz = tmp_path / "r.fastq.gz"
+    write_fastq(pz, recs, np.random.default_rng(2), opener=gzip.open)
+    assert run_reads(pz, "--threads", "4")[0] == expected(recs)      # gzip: falls back to the sequential reader
+
+
+@pytest.mark.parametrize("eol,width,blank", [(b"\n", 60, 0), (b"\r\n", 13, 0), (b"\n", 0, 0), (b"\n", 50, 4)])
+def test_fasta_all_paths_agree(tmp_path, eol, width, blank):
+    rng = np.random.default_rng(3)
+    recs = make_records(rng, 200, lo=0, hi=500)
+    p = tmp_path / "r.fa"
+    write_fasta(p, recs, rng, eol=eol, width=width, blank_every=blank)
+    want = expected(recs)
+    for m in MODES:
+        assert run_reads(p, *m)[0] == want, m
+
+
+def test_long_records_span_many_ranges(tmp_path):
+    """records much longer than a byte range: a range then holds exactly one record"""
+    rng = np.random.default_rng(4)
+    recs = [(f"long_{i}", bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(L))))
+            for i, L in enumerate([300000, 5, 170000, 1, 0, 250000])]
+    p = tmp_path / "l.fastq"
+    write_fastq(p, recs, rng)
+    for m in MODES:
+        assert run_reads(p, *m)[0] == expected(recs), m
+    p2 = tmp_path / "l.fa"
+    write_fasta(p2, recs, rng)
+    for m in MODES:
+        assert run_reads(p2, *m)[0] == expected(recs), m
+
+
+@pytest.mark.parametrize("text,msg", [
+    (b"@r1\nACGT\n+\nIIII\n@r2\nACGT\n", "FASTQ record: r2"),
+    (b"@r1\nACGT\n+\nIIII\n@r2\nACGT\n+\n", "truncated FASTQ record: r2"),
+    (b"@r1\nACGT\nIIII\n@r2\nAC\n+\nII\n", "malformed"),
+    (b"hello\nworld\n", "neither FASTA nor FASTQ"),
+])
+def test_damaged_input_fails_loudly(tmp_path, text, msg):
+    p = tmp_path / "bad.fq"
+    p.write_bytes(text)
+    for m in (("--sequential",), ("--threads", "2")):
+        cp = subprocess.run([EXE, "reads", "--query-file", str(p), *m], capture_output=True, text=True)
+        assert cp.returncode != 0 and msg in cp.stderr, (m, cp.stderr)

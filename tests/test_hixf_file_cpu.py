@@ -166,3 +166,47 @@ def test_probe_recovers_foreign_ixf_schemas(tmp_path):
     open(junk, "wb").write(b"\x01\0\0\0" + bytes(range(256)) * 8)
     with pytest.raises(TaxorError):
         probe_hixf(junk)
+
+
+def test_loader_survives_random_corruption(tmp_path):
+    """fuzz: flipped bytes, truncations and spliced garbage must produce a clean error or a consistent index --
+    never a crash or an out-of-bounds view (the reference swallows read errors, index.hpp:235-238)"""
+    lay, host, _ = small_layout(11)
+    sp = make_species(lay)[:20]
+    p = tmp_path / "base.hixf"
+    store_hixf(p, host, lay["n_user_bins"], sp)
+    raw = bytearray(open(p, "rb").read())
+    data_start = raw.find(bytes(host[0]["data"][:64]))          # fingerprints may be corrupted freely: not validated
+    assert data_start > 0
+    rng = np.random.default_rng(5)
+    meta_positions = list(range(0, data_start)) + list(range(len(raw) - 4000, len(raw)))
+    outcomes = {"ok": 0, "err": 0}
+    for trial in range(250):
+        blob = bytearray(raw)
+        kind = trial % 4
+        if kind == 0:      # flip a few metadata bytes
+            for _ in range(int(rng.integers(1, 4))):
+                blob[int(rng.choice(meta_positions))] ^= int(rng.integers(1, 256))
+        elif kind == 1:    # overwrite an aligned u64 in the metadata with a huge / tiny value
+            pos = int(rng.choice(meta_positions)) & ~7
+            blob[pos:pos + 8] = [0, 1, 2**63, 2**64 - 1, 2**40][int(rng.integers(0, 5))].to_bytes(8, "little")
+        elif kind == 2:    # truncate
+            blob = blob[: int(rng.integers(1, len(blob)))]
+        else:              # splice garbage
+            pos = int(rng.integers(0, len(blob)))
+            blob[pos:pos] = bytes(rng.integers(0, 256, size=int(rng.integers(1, 64)), dtype=np.uint8))
+        q = tmp_path / "fuzz.hixf"
+        open(q, "wb").write(bytes(blob))
+        try:
+            h = HixfFile(q)
+        except TaxorError as e:
+            assert e.code in (-5, -1)
+            outcomes["err"] += 1
+            continue
+        # accepted: every view must be internally consistent
+        for f in h.ixfs:
+            assert f["data"].size == 3 * f["seg_len"] * f["stride"] and f["stride"] % 64 == 0 and f["stride"] >= f["bins"]
+            assert f["next_ixf"].size == f["bins"] and f["fname_idx"].size == f["bins"]
+        h.close()
+        outcomes["ok"] += 1
+    assert outcomes["err"] > 100          # most corruptions of the metadata are detected
