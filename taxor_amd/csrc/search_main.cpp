@@ -126,13 +126,13 @@ void usage()
             "  --index-file <f[,f..]>   taxor index file(s) containing HIXF index and reference information (required)\n"
             "  --query-file <f[,f..]>   file(s) containing sequences to query against the index\n"
             "  --output-file <f>        file name for the resulting output\n"
-            "  --threads <1..32>        host worker threads (accepted for compatibility)\n"
+            "  --threads <1..32>        host threads parsing the query file (plain FASTA/FASTQ; gzip is one stream)\n"
             "  --percentage <0..1>      if set, this threshold is used instead of the syncmer model\n"
             "  --error-rate <0..1>      expected error rate of the reads (default 0.04)\n"
             "  --gpu <id>               device ordinal (default 0)\n"
             "  --gpus <n>               use devices 0..n-1: the index is replicated, batches of reads are sharded\n"
             "  --gpu-list <a,b,..>      explicit device list (a device may be listed twice)\n"
-            "  --batch-reads <n>        reads per GPU batch (default 65536)\n");
+            "  --batch-reads <n>        reads per GPU batch (default: about 128 MB of query file, 65536 reads for gzip)\n");
 }
 
 double now()
