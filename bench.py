@@ -223,6 +223,12 @@ def main():
 
     out = None
     if rank == 0:
+        # measured gather ceiling: random whole-row reads of the same IXFs by a kernel that does nothing
+        # else; outside the timed region
+        ceiling = {}
+        for name, ixf in (("root", 0), ("child", 1 if idx.n_ixf > 1 else 0)):
+            gbps, row_bytes = idx.gather_ceiling(ixf, want_bytes=16 << 30, reps=3)
+            ceiling[name] = {"ixf": ixf, "row_bytes": row_bytes, "GBps": round(gbps, 1)}
         achieved = q_bytes / (q_ms * 1e-3) / 1e9 if q_ms > 0 else 0.0
         res = sr.fetch()
         classified = int(((res.read_off[1:] - res.read_off[:-1]) > 0).sum())
@@ -251,6 +257,7 @@ def main():
                          "algorithmic_bytes_per_launch": round(q_bytes / max(1, q_launches), 1),
                          "requested_bytes_per_launch": round(q_touched / max(1, q_launches), 1),
                          "requested_GBps": round(q_touched / (q_ms * 1e-3) / 1e9, 1) if q_ms > 0 else 0.0,
+                         "gather_ceiling": ceiling,
                          "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
             "stage_ms_last_step": {"syncmers": round(st["syncmer_ms"], 3), "query": round(st["query_ms"], 3),
                                    "finalize": round(st["finalize_ms"], 3), "total": round(st["total_ms"], 3)},

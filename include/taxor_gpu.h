@@ -74,6 +74,11 @@ uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx);
 /* number of leaf runs (= tuples a threshold-0 read produces) and IXF tree depth */
 uint64_t taxor_gpu_index_leaf_runs(const taxor_gpu_index *idx);
 uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx);
+/* Measurement aid (SURVEY.md 8(d) "measured gather ceiling"): read about want_bytes of IXF `ixf` as whole rows at
+ * random row indices with the access shape of the query kernel's dense phase (16 B per lane, neighbouring lanes on
+ * one row) and nothing else, `reps` times; reports the requested-bytes rate and the bytes read per row. */
+int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint64_t want_bytes, int reps, double *gb_per_s,
+                             uint64_t *row_bytes);
 /* Index construction helpers for synthetic / planted indexes (what a GPU builder would use):
  * fill one IXF with seeded pseudo-random fingerprints (behaves like non-matching bins, FPR 2^-8),
  * overwrite one bin column (rows = 3*seg_len bytes), read an IXF back (to hand the same bytes to a

@@ -358,6 +358,39 @@ extern "C" int taxor_gpu_index_fill_random(taxor_gpu_index *idx, uint64_t ixf, u
     return TAXOR_OK;
 }
 
+extern "C" int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint64_t want_bytes, int reps, double *gb_per_s,
+                                        uint64_t *row_bytes)
+{
+    if (!idx || ixf >= idx->h_ixf.size() || !gb_per_s) return fail(TAXOR_E_ARG, "gather_ceiling: bad argument");
+    const IxfDesc &f = idx->h_ixf[ixf];
+    const uint32_t units = (f.bins + 15) / 16;
+    if (units > 256) return fail(TAXOR_E_ARG, "gather_ceiling: rows wider than 4096 bins");
+    if (reps < 1) reps = 1;
+    HIP_TRY(hipSetDevice(idx->device));
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 4));
+    HIP_TRY(hipMemset(sink, 0, 4));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
+    uint64_t bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 1, sink, nt, nullptr);   // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps; ++r)
+        bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 2 + r, sink, nt, nullptr);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    *gb_per_s = ms > 0.f ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    if (row_bytes) *row_bytes = (uint64_t)units * 16;
+    return TAXOR_OK;
+}
+
 extern "C" int taxor_gpu_index_upload_bin(taxor_gpu_index *idx, uint64_t ixf, uint64_t bin, const uint8_t *column,
                                           uint64_t rows)
 {

@@ -135,6 +135,9 @@ size_t query_lds_bytes(uint32_t max_stride);
 uint32_t query_map_words(uint32_t max_stride);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
+// random whole-row reads of one IXF, nothing else; returns the bytes the launch requests
+uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,
+                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st);
 void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,
                            hipStream_t st);
 

@@ -14,6 +14,7 @@
 #include "kernels.h"
 #include "ixf_arith.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace taxor {
@@ -979,6 +980,51 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t st)
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(k_sort_small, dim3(grid), dim3(BLK), 0, st, a);
     hipLaunchKernelGGL(k_sort_big, dim3(256), dim3(BLK), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// gather ceiling: the same access pattern as the dense phase of k_query_level -- whole rows of one
+// IXF at random row indices, 16 B per lane, neighbouring lanes on neighbouring units of one row -- with nothing else:
+// no probes, no counting, no queues.  What this reaches is what the memory system gives a random-row reader of that
+// row size; the query kernel's requested-bytes rate is judged against it.
+// ------------------------------------------------------------------------------------------------------
+template <bool NT>
+__global__ __launch_bounds__(BLK) void k_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t units,
+                                                        uint32_t passes, uint64_t seed, uint32_t *sink)
+{
+    const uint32_t per_pass = BLK / units;                  // rows one block reads per pass
+    const uint32_t slot = threadIdx.x / units, u = threadIdx.x - slot * units;
+    if (slot >= per_pass) return;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint64_t d = ((uint64_t)blockIdx.x * passes) * per_pass + slot;
+    constexpr int U = 8;
+    for (uint32_t p = 0; p < passes; p += U) {
+        uint4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint64_t h = murmur64(seed + d + (uint64_t)j * per_pass);
+            const uint64_t row = (uint64_t)(((unsigned __int128)h * rows) >> 64);
+            v[j] = ld16<NT>(data + row * stride + (uint64_t)u * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        d += (uint64_t)U * per_pass;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) atomicAdd(sink, 1u);   // keeps the loads alive
+}
+
+uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,
+                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st)
+{
+    const uint32_t units = (bins + 15) / 16;                // like the query kernel: only units that hold bins are read
+    const uint32_t per_pass = BLK / units;
+    const uint32_t passes = 256;
+    const uint64_t per_block = (uint64_t)passes * per_pass * units * 16;
+    uint64_t grid = std::max<uint64_t>(1, want_bytes / per_block);
+    if (grid > (1u << 30)) grid = 1u << 30;
+    if (nt) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
+    else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
+    return grid * per_block;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -107,6 +107,12 @@ class GpuIndex:
     def depth(self):
         return int(_lib.lib().taxor_gpu_index_depth(self._h))
 
+    def gather_ceiling(self, ixf=0, want_bytes=32 << 30, reps=3):
+        """random whole-row reads of IXF `ixf`, nothing else -> (GB/s requested, bytes read per row)"""
+        g, rb = C.c_double(), C.c_uint64()
+        check(_lib.lib().taxor_gpu_gather_ceiling(self._h, ixf, int(want_bytes), int(reps), C.byref(g), C.byref(rb)))
+        return g.value, int(rb.value)
+
     def fill_random(self, ixf, seed):
         check(_lib.lib().taxor_gpu_index_fill_random(self._h, ixf, seed))
 

@@ -535,3 +535,17 @@ def test_pruning_with_rows_wider_than_one_block_pass():
             assert np.array_equal(ub, wub) and np.array_equal(cnt, wcnt), (name, thr)
     sr.close()
     idx.close()
+
+
+@pytest.mark.gpu
+def test_gather_ceiling_runs_on_every_row_width():
+    """measurement aid: the random-row reader must run (and report a sane rate) for narrow, odd and widest rows"""
+    rng = np.random.default_rng(0)
+    for bins in (1, 64, 80, 1000, 4096):
+        stride = (bins + 63) // 64 * 64
+        seg = 4096
+        idx = GpuIndex([dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64),
+                             fname_idx=np.arange(bins), data=rng.integers(0, 256, 3 * seg * stride, dtype=np.uint8))], bins)
+        gbps, row_bytes = idx.gather_ceiling(0, want_bytes=1 << 28, reps=2)
+        assert row_bytes == (bins + 15) // 16 * 16 and gbps > 1.0
+        idx.close()
