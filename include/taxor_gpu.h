@@ -60,9 +60,13 @@ typedef struct {
     const taxor_ixf_view *ixf;
     uint64_t n_user_bins;
     uint8_t kmer_size, syncmer_size, t_syncmer; /* src/main/index.hpp:219-221 */
-    uint8_t use_syncmer;                        /* :223; must be 1 (k-mer/minimiser mode is out of scope) */
-    uint16_t scaling;                           /* :224; >1 = FracMinHash down-sampling of the syncmer hashes
-                                                   (taxor_search.cpp:223-233), applied on the device */
+    uint8_t use_syncmer;                        /* :223; 1 = open canonical syncmers (syncmer.cpp:80-165); 0 = index built
+                                                   without --use-syncmer: seqan3 minimiser_hash over window_size
+                                                   (taxor_search.cpp:210-212,239-260), every emitted value counts */
+    uint16_t scaling;                           /* :224; >1 = FracMinHash down-sampling of the hashes
+                                                   (taxor_search.cpp:223-233,243-249), applied on the device */
+    uint64_t window_size;                       /* :212; used when use_syncmer == 0: window_size == kmer_size selects
+                                                   every canonical k-mer, larger windows select minimisers */
 } taxor_hixf_view;
 
 typedef struct taxor_gpu_index taxor_gpu_index;
@@ -98,14 +102,22 @@ int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t
 /* ------------------------------------------------------------------------------------------------
  * Searcher = one GPU-side "membership agent" + the per-read driver state.
  * Replaces: the worker lambda's locals (taxor_search.cpp:198-203) and hixf::threshold::threshold
- * (src/hixf/search/threshold.hpp:22-81): `ratio` is what threshold::get multiplies the hash count by --
- * get_min_syncmer_match_ratio(k, error_rate) or --percentage; use taxor_threshold_ratio() to derive it.
+ * (src/hixf/search/threshold.hpp:22-81).  For the syncmer and percentage kinds `ratio` is what threshold::get
+ * multiplies the hash count by -- get_min_syncmer_match_ratio(k, error_rate) or --percentage
+ * (taxor_threshold_ratio()).  For indexes built without --use-syncmer the kind is the k-mer model (window == k) or
+ * the FracMinHash containment model (window > k): those thresholds are evaluated per read on the HOST, in the same
+ * double expressions as the reference (taxor_threshold_model()), between the hashing and the query kernels.
+ * taxor_threshold_select() fills `ratio`, `model` and `error_rate` the way threshold::threshold's constructor picks.
  * ---------------------------------------------------------------------------------------------- */
+enum { TAXOR_THR_PERCENTAGE = 0, TAXOR_THR_SYNCMER = 1, TAXOR_THR_KMER = 2, TAXOR_THR_FRACMINHASH = 3 };
+
 typedef struct {
     double ratio;             /* threshold = (size_t)(n_hashes * ratio), threshold.hpp:60,76-79 */
     uint32_t sub_batch_reads; /* reads per internal launch group (0 = default 32768)           */
     uint64_t sub_batch_bases; /* bases per internal launch group (0 = default 2^29)            */
     uint32_t time_kernels;    /* 1 = bracket the dominant kernel with HIP events               */
+    uint32_t model;           /* TAXOR_THR_*; PERCENTAGE and SYNCMER use `ratio`               */
+    double error_rate;        /* --error-rate, used by the KMER and FRACMINHASH models         */
 } taxor_gpu_search_params;
 
 typedef struct taxor_gpu_searcher taxor_gpu_searcher;
@@ -260,6 +272,16 @@ uint64_t taxor_format_read(const taxor_hixf *h, const char *id, uint64_t id_len,
  * the percentage model (threshold.hpp:27-32), otherwise get_min_syncmer_match_ratio(k, error_rate)
  * (syncmer_model.hpp:38-50).  Returns a negative value where the reference would read out of bounds. */
 double taxor_threshold_ratio(uint32_t kmer_size, double error_rate, double percentage);
+/* threshold::threshold's choice of model (threshold.hpp:22-47) -> TAXOR_THR_* */
+int taxor_threshold_kind(int use_syncmer, uint32_t kmer_size, uint64_t window_size, double percentage);
+/* threshold::get for every kind (threshold.hpp:51-81; kmer_model.cpp:10-23, fracminhash_model.cpp:8-33,
+ * gaussian_inverse.cpp:13-50); scaling_factor = count / (read_len - k + 1) as at taxor_search.cpp:263.  size_t
+ * arithmetic wraps exactly like the reference's (a short read's threshold can be unreachable). */
+uint64_t taxor_threshold_model(int kind, uint64_t count, uint32_t kmer_size, double error_rate, double percentage,
+                               double scaling_factor);
+/* fills prm->ratio / model / error_rate for an index and the command-line values; leaves the other fields alone.
+ * TAXOR_E_ARG where the syncmer model has no entry (k odd or outside 12..30, error rate outside [0, 0.2]). */
+int taxor_threshold_select(const taxor_hixf_view *view, double error_rate, double percentage, taxor_gpu_search_params *prm);
 /* (size_t)(hash_count * ratio) */
 uint64_t taxor_threshold(uint64_t hash_count, double ratio);
 /* keep[i] = !(double(count[i]) < double(max)*0.8), taxor_search.cpp:275-286 */

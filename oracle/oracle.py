@@ -51,7 +51,8 @@ class _Hixf(C.Structure):
 
 class _Params(C.Structure):
     _fields_ = [("k", C.c_int), ("s", C.c_int), ("t", C.c_int),
-                ("error_rate", C.c_double), ("percentage", C.c_double), ("scaling", C.c_int)]
+                ("error_rate", C.c_double), ("percentage", C.c_double), ("scaling", C.c_int),
+                ("window", C.c_int)]
 
 
 _lib = None
@@ -71,6 +72,16 @@ def lib():
         L.orc_syncmer_match_ratio.argtypes = [C.c_size_t, C.c_double]
         L.orc_threshold.restype = C.c_size_t
         L.orc_threshold.argtypes = [C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+        L.orc_threshold_kind.restype = C.c_int
+        L.orc_threshold_kind.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double]
+        L.orc_threshold_model.restype = C.c_size_t
+        L.orc_threshold_model.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double]
+        L.orc_normal_cdf_inverse.restype = C.c_double
+        L.orc_normal_cdf_inverse.argtypes = [C.c_double]
+        L.orc_adjust_seed.restype = C.c_uint64
+        L.orc_adjust_seed.argtypes = [C.c_int]
+        L.orc_minimiser_hash.restype = C.c_size_t
+        L.orc_minimiser_hash.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_ixf_seg_len.restype = C.c_uint64
         L.orc_ixf_seg_len.argtypes = [C.c_uint64]
         L.orc_ixf_probe.restype = None
@@ -119,6 +130,29 @@ def syncmer_match_ratio(k, err):
 
 def threshold(hash_count, k=22, err=0.04, percentage=-1.0):
     return int(lib().orc_threshold(hash_count, k, err, percentage))
+
+
+THR_PERCENTAGE, THR_SYNCMER, THR_KMER, THR_FRACMINHASH = 0, 1, 2, 3
+
+
+def threshold_kind(use_syncmer, k, window, percentage=-1.0):
+    return int(lib().orc_threshold_kind(1 if use_syncmer else 0, k, window, percentage))
+
+
+def threshold_model(kind, count, k=22, err=0.04, percentage=-1.0, scaling_factor=1.0):
+    return int(lib().orc_threshold_model(kind, count, k, err, percentage, scaling_factor))
+
+
+def adjust_seed(k):
+    return int(lib().orc_adjust_seed(k))
+
+
+def minimiser_hash(seq: bytes, k=20, w=20) -> np.ndarray:
+    cap = max(len(seq), 1)
+    out = np.empty(cap, dtype=np.uint64)
+    n = lib().orc_minimiser_hash(seq, len(seq), k, w, _p(out), cap)
+    assert n <= cap
+    return out[:n].copy()
 
 
 def ixf_seg_len(max_bin_elements):
@@ -172,13 +206,13 @@ class Hixf:
         return ub[:n].copy(), cnt[:n].copy(), int(vb[0])
 
     def search_batch(self, bases: np.ndarray, offsets: np.ndarray, k=22, s=12, t=5, err=0.04,
-                     percentage=-1.0, threads=1, scaling=1):
+                     percentage=-1.0, threads=1, scaling=1, window=0):
         """bases: np.uint8 ASCII (already dna4-normalised), offsets: uint64[n+1].
         Returns (n_hashes u32[n], out_off u64[n+1], user_bin i64[], count u32[], visited_bytes)."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
-        prm = _Params(k, s, t, err, percentage, scaling)
+        prm = _Params(k, s, t, err, percentage, scaling, window)   # window > 0: index built without --use-syncmer
         nh = np.zeros(n, dtype=np.uint32)
         off = np.zeros(n + 1, dtype=np.uint64)
         cap = max(4 * n, 1024)

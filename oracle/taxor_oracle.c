@@ -242,6 +242,113 @@ size_t orc_threshold(size_t hash_count, size_t kmer_size, double error_rate, dou
     return (size_t)((double)hash_count * ratio);                                       /* :60 */
 }
 
+
+/* ---- k-mer and FracMinHash threshold models (used for indexes built without --use-syncmer) ------------- */
+
+/* static_cast<size_t>(double) as the reference's stock build executes it.  Converting a negative or NaN double to
+ * size_t is undefined in C++; the reference does it for very short reads (variance < 0 -> sqrt = NaN, or a negative
+ * containment bound).  Its build uses no -march flag (src/CMakeLists.txt:17-29), so GCC emits the baseline x86-64
+ * sequence around cvttsd2si; this function states that sequence's result explicitly so that the oracle does not
+ * depend on the machine it is compiled for (AVX-512's vcvttsd2usi would return all-ones instead). */
+static size_t orc_f64_to_size(double x)
+{
+    const double two63 = 9223372036854775808.0;
+    if (x != x) return (size_t)UINT64_C(0x8000000000000000);                           /* NaN: "integer indefinite" */
+    if (x >= two63) {
+        double y = x - two63;
+        if (y >= two63) return 0;                                                      /* indefinite ^ sign bit */
+        return (size_t)((uint64_t)(int64_t)y ^ UINT64_C(0x8000000000000000));
+    }
+    if (x <= -two63) return (size_t)UINT64_C(0x8000000000000000);
+    return (size_t)(uint64_t)(int64_t)x;                                               /* truncates toward zero; negatives wrap */
+}
+
+/* RationalApproximation / NormalCDFInverse, gaussian_inverse.cpp:13-50 (Abramowitz-Stegun 26.2.23).
+ * The reference throws for p outside (0,1); the callers below only pass 0.975. */
+static double orc_rational_approximation(double t)
+{
+    const double c[] = {2.515517, 0.802853, 0.010328};
+    const double d[] = {1.432788, 0.189269, 0.001308};
+    return t - ((c[2] * t + c[1]) * t + c[0]) / (((d[2] * t + d[1]) * t + d[0]) * t + 1.0);
+}
+
+double orc_normal_cdf_inverse(double p)
+{
+    if (p < 0.5) return -orc_rational_approximation(sqrt(-2.0 * log(p)));              /* :41-44 */
+    return orc_rational_approximation(sqrt(-2.0 * log(1.0 - p)));                      /* :45-49 */
+}
+
+/* variance_nmut_kmer / expected_nmut_kmer / expected_nmut_kmer_squared, kmer_model.cpp:26-46; the
+ * expression order is the reference's (double arithmetic is not associative). */
+static double orc_expected_nmut_kmer(double r, size_t kmer_size, size_t kmer_count)
+{
+    double q = 1.0 - pow(1.0 - r, kmer_size);
+    return kmer_count * q;
+}
+
+static double orc_variance_nmut_kmer(double r, size_t kmer_size, size_t kmer_count)
+{
+    double q = 1.0 - pow(1.0 - r, kmer_size);
+    double varN = (double)kmer_count * (1.0 - q) * (q * (2.0 * (double)kmer_size + (2.0 / r) - 1.0) - 2.0 * (double)kmer_size)
+                  + (double)kmer_size * ((double)kmer_size - 1.0) * pow((1.0 - q), 2.0)
+                  + (2.0 * (1.0 - q) / (pow(r, 2.0))) * ((1.0 + ((double)kmer_size - 1.0) * (1.0 - q)) * r - q);
+    return varN;
+}
+
+static double orc_expected_nmut_kmer_squared(double r, size_t kmer_size, size_t kmer_count)
+{
+    return pow(orc_expected_nmut_kmer(r, kmer_size, kmer_count), 2) + orc_variance_nmut_kmer(r, kmer_size, kmer_count);
+}
+
+/* calculate_nmut_kmer_CI(...).second, kmer_model.cpp:10-23 (only the upper bound is used, threshold.hpp:65) */
+static size_t orc_nmut_kmer_ci_high(double r, size_t kmer_size, size_t kmer_count, double confidence)
+{
+    double q = 1.0 - pow(1.0 - r, kmer_size);
+    double varN = orc_variance_nmut_kmer(r, kmer_size, kmer_count);                    /* same expression, :13-15 */
+    double alpha = 1 - confidence;
+    double z = orc_normal_cdf_inverse(1.0 - alpha / 2.0);
+    return orc_f64_to_size(ceil(kmer_count * q + z * sqrt(varN)));                     /* :19 */
+}
+
+/* calculate_containment_index_CI(...).first, fracminhash_model.cpp:8-33 */
+static double orc_containment_index_ci_low(double r, size_t kmer_size, size_t kmer_count, double scaling_factor, double confidence)
+{
+    double z_alpha = orc_normal_cdf_inverse(1.0 - (1.0 - confidence) / 2.0);
+    double term3 = orc_variance_nmut_kmer(r, kmer_size, kmer_count) / pow(kmer_count, 2);
+    double term2 = kmer_count * orc_expected_nmut_kmer(r, kmer_size, kmer_count) - orc_expected_nmut_kmer_squared(r, kmer_size, kmer_count);
+    double denominator = scaling_factor * pow(kmer_count, 3) * pow(1.0 - pow(1.0 - scaling_factor, kmer_count), 2);
+    double term1 = (1.0 - scaling_factor) / denominator;
+    double var = term1 * term2 + term3;
+    return pow((1.0 - r), kmer_size) - z_alpha * sqrt(var);
+}
+
+int orc_threshold_kind(int use_syncmer, size_t kmer_size, size_t window_size, double percentage)
+{
+    size_t kmers_per_window = window_size - kmer_size + 1;                             /* threshold.hpp:26 */
+    if (percentage > 0.0 && percentage <= 1.0) return ORC_THR_PERCENTAGE;              /* :28 */
+    if (use_syncmer) return ORC_THR_SYNCMER;                                           /* :34 */
+    if (kmers_per_window == 1) return ORC_THR_KMER;    /* :39; `fracminhash` is always false, search_arguments.hpp:72 */
+    return ORC_THR_FRACMINHASH;                                                        /* :44 */
+}
+
+size_t orc_threshold_model(int kind, size_t minimiser_count, size_t kmer_size, double error_rate, double percentage,
+                           double scaling_factor)
+{
+    size_t fp_correction = (size_t)((double)minimiser_count * 0.0039);                 /* :53 */
+    switch (kind) {
+    case ORC_THR_SYNCMER:
+        return (size_t)((double)minimiser_count * orc_syncmer_match_ratio(kmer_size, error_rate)); /* :57-61 */
+    case ORC_THR_KMER:
+        /* size_t arithmetic: wraps (to a threshold no bin can reach) when the bound exceeds the count, :64-66 */
+        return minimiser_count - orc_nmut_kmer_ci_high(error_rate, kmer_size, minimiser_count, 0.95) - fp_correction;
+    case ORC_THR_FRACMINHASH:
+        return orc_f64_to_size(orc_containment_index_ci_low(error_rate, kmer_size, minimiser_count, scaling_factor, 0.95) *
+                               (double)minimiser_count) - fp_correction;               /* :68-75 */
+    default:
+        return (size_t)((double)minimiser_count * percentage);                         /* :76-79 */
+    }
+}
+
 /* =============================================================================================== */
 /* interleaved XOR filter  [un-vendored; restated from xorfilter.hpp + hashutil.hpp evidence]      */
 /* =============================================================================================== */
@@ -352,10 +459,92 @@ size_t orc_bulk_contains(const orc_hixf *h, const uint64_t *hashes, size_t n, si
 /* per-read driver -- taxor_search.cpp:196-313                                                     */
 /* =============================================================================================== */
 
+
+/* ---- minimiser / k-mer hashing (indexes built without --use-syncmer) -------------------------------------
+ * seqan3::views::minimiser_hash(ungapped{k}, window_size{w}, seed{adjust_seed(k)}), call sites
+ * taxor_search.cpp:210-212,241-256 and taxor_build.cpp:316-318.  The view lives in the un-vendored seqan3 fork:
+ * restated from the published seqan3 3.x algorithm -- parity unpinned for w > k (which of several equal minima
+ * is kept); for w == k every canonical k-mer value is emitted and no tie rule is involved.
+ *   value of k-mer i   = min(fwd_i ^ seed, rc_i ^ seed), fwd/rc = 2-bit rank encoding (A0 C1 G2 T3) of the k-mer
+ *                        and of its reverse complement (kmer_hash of the complemented, reversed text)
+ *   window             = w-k+1 consecutive k-mer values (all of them if the read has fewer)
+ *   first window       : the RIGHTMOST minimum is the minimiser (min_element with less_equal) -> emitted
+ *   each shift         : minimiser left the window -> rightmost minimum of the new window, emitted;
+ *                        else new value < minimiser -> it becomes the minimiser, emitted; else nothing. */
+uint64_t orc_adjust_seed(int k) { return UINT64_C(0x8F3F73B5CF1C9ADE) >> (64u - 2u * (unsigned)k); } /* adjust_seed.hpp:40-44 */
+
+size_t orc_minimiser_hash(const char *seq, size_t len, int k, int w, uint64_t *out, size_t cap)
+{
+    if (k < 1 || k > 32 || w < k || len < (size_t)k) return 0;
+    const uint64_t seed = orc_adjust_seed(k);
+    const uint64_t mask = k == 32 ? ~UINT64_C(0) : ((UINT64_C(1) << (2 * k)) - 1);
+    const unsigned shift = 2u * (unsigned)(k - 1);
+    const size_t nk = len - (size_t)k + 1;
+    uint64_t *val = (uint64_t *)malloc(nk * sizeof(uint64_t));
+    uint64_t f = 0, r = 0;
+    for (size_t i = 0; i < len; ++i) {
+        uint64_t c = nt4((unsigned char)seq[i]) & 3u;           /* reads are dna4 here (dna4_traits.hpp:15-18) */
+        f = ((f << 2) | c) & mask;
+        r = (r >> 2) | ((3u - c) << shift);
+        if (i + 1 >= (size_t)k) {
+            uint64_t a = f ^ seed, b = r ^ seed;
+            val[i + 1 - (size_t)k] = a < b ? a : b;
+        }
+    }
+    size_t W = (size_t)(w - k + 1);
+    if (W > nk) W = nk;
+    size_t n = 0;
+    /* first window: rightmost minimum */
+    size_t pos = 0;
+    for (size_t j = 1; j < W; ++j)
+        if (val[j] <= val[pos]) pos = j;
+    if (n < cap) out[n] = val[pos];
+    ++n;
+    for (size_t j = 1; j + W <= nk; ++j) {                      /* window j = val[j .. j+W-1] */
+        const size_t newest = j + W - 1;
+        int emit = 0;
+        if (pos < j) {                                          /* minimiser_position_offset == 0 before the shift */
+            pos = j;
+            for (size_t x = j + 1; x <= newest; ++x)
+                if (val[x] <= val[pos]) pos = x;
+            emit = 1;
+        } else if (val[newest] < val[pos]) {
+            pos = newest;
+            emit = 1;
+        }
+        if (emit) {
+            if (n < cap) out[n] = val[pos];
+            ++n;
+        }
+    }
+    free(val);
+    return n;
+}
+
 size_t orc_search_read(const orc_hixf *h, const orc_search_params *p, const char *seq, size_t len,
                        uint32_t *n_hashes, int64_t *user_bin, uint32_t *count, size_t cap,
                        uint64_t *visited_bytes)
 {
+    if (p->window > 0) {                                                               /* !compute_syncmer, :239-260 */
+        size_t capn = len + 1, m = 0;
+        uint64_t *hs = (uint64_t *)malloc(capn * sizeof(uint64_t));
+        size_t cnt = orc_minimiser_hash(seq, len, p->k, p->window, hs, capn);
+        for (size_t i = 0; i < cnt; ++i) {                                             /* no dedup: every emitted value counts */
+            if (p->scaling > 1) {
+                uint64_t v = orc_wyhash_u64(hs[i]);
+                if (!((double)v <= (double)UINT64_MAX / (double)p->scaling)) continue; /* :243-249 */
+            }
+            hs[m++] = hs[i];
+        }
+        size_t hash_count = m;                                                         /* :261 */
+        int kind = orc_threshold_kind(0, (size_t)p->k, (size_t)p->window, p->percentage);
+        double sf = (double)hash_count / ((double)len - (double)p->k + 1.0);           /* :263 */
+        size_t thr = orc_threshold_model(kind, hash_count, (size_t)p->k, p->error_rate, p->percentage, sf);
+        size_t nt = orc_bulk_contains(h, hs, hash_count, thr, user_bin, count, cap, visited_bytes);
+        if (n_hashes) *n_hashes = (uint32_t)hash_count;
+        free(hs);
+        return nt;
+    }
     oset set;
     oset_init(&set);
     syncmers_into(seq, len, (uint64_t)p->k, (uint64_t)p->s, (uint64_t)p->t, &set);     /* :222 */

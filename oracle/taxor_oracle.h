@@ -6,7 +6,7 @@
  * the checker for the HIP path -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may load it.  The product library (libtaxor_gpu.so) never links, loads or calls anything in oracle/.
  *
- * PINNING STATUS -- "parity unpinned" at two boundaries:
+ * PINNING STATUS -- "parity unpinned" at three boundaries:
  *   The reference has no tests, golden vectors or fixtures, and it cannot be built
  *   in this image: every translation unit on the path includes seqan3 / cereal / ankerl headers that are
  *   fetched by git at configure time and are absent here (src/seqan/CMakeLists.txt.in:7-62,
@@ -18,6 +18,9 @@
  *     (2) orc_ixf_*        -- restates the interleaved XOR filter of the author's seqan3 fork
  *         (JensUweUlrich/seqan3@master, un-vendored, un-pinned) from the in-repo evidence
  *         src/main/xorfilter.hpp:22-68,338-350 + src/main/hashutil.hpp:50-61.        parity unpinned
+ *     (3) orc_minimiser_hash -- restates seqan3::views::minimiser_hash (same un-vendored fork), used for
+ *         indexes built without --use-syncmer; call sites src/main/taxor_search.cpp:210-212,241-256.
+ *         Window > k: which of several equal minima is kept is recalled, not read.   parity unpinned
  *   Everything else (syncmer selector, HIXF traversal/tally, thresholds, classification call, TSV) is
  *   restated from code that IS in /root/reference and is cross-checked against a second, independent
  *   pure-Python restatement (tests/golden/make_golden.py) whose outputs are committed under tests/golden/.
@@ -57,6 +60,20 @@ double orc_syncmer_match_ratio(size_t kmer_size, double error_rate);
 /* threshold::get, syncmer and percentage branches (threshold.hpp:22-47,51-81).
  * percentage in (0,1] selects the percentage model exactly as the constructor does. */
 size_t orc_threshold(size_t hash_count, size_t kmer_size, double error_rate, double percentage);
+
+/* threshold::threshold kind selection (threshold.hpp:22-47) and threshold::get for every kind (:51-81), including
+ * the k-mer model (kmer_model.cpp:10-23, gaussian_inverse.cpp:13-50) and the FracMinHash containment model
+ * (fracminhash_model.cpp:8-33).  scaling_factor = hash_count / (read_len - k + 1) as at taxor_search.cpp:263. */
+enum { ORC_THR_PERCENTAGE = 0, ORC_THR_SYNCMER = 1, ORC_THR_KMER = 2, ORC_THR_FRACMINHASH = 3 };
+int orc_threshold_kind(int use_syncmer, size_t kmer_size, size_t window_size, double percentage);
+size_t orc_threshold_model(int kind, size_t minimiser_count, size_t kmer_size, double error_rate, double percentage,
+                           double scaling_factor);
+double orc_normal_cdf_inverse(double p);
+
+/* hixf::adjust_seed (adjust_seed.hpp:40-44) and seqan3::views::minimiser_hash as the reference calls it
+ * (taxor_search.cpp:210-212): values in emission order, duplicates kept.  See the .c for the pinning status. */
+uint64_t orc_adjust_seed(int k);
+size_t orc_minimiser_hash(const char *seq, size_t len, int k, int w, uint64_t *out, size_t cap);
 
 /* ---- interleaved XOR filter (un-vendored; see header comment) ---------------------------------- */
 
@@ -100,6 +117,7 @@ typedef struct {
     double error_rate;   /* --error-rate, default 0.04 (taxor_search_configuration.hpp:16) */
     double percentage;   /* --percentage, default -1.0                                    */
     int scaling;         /* index scaling (FracMinHash down-sampling), 1 = off            */
+    int window;          /* 0: syncmer index (use_syncmer); >= k: index built without --use-syncmer, this window size */
 } orc_search_params;
 
 /* One read: dna4-normalised ASCII in, tuples (before the 0.8*max filter) out. Returns #tuples. */

@@ -24,12 +24,15 @@ class IxfView(C.Structure):
 class HixfView(C.Structure):
     _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
                 ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),
-                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16)]
+                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64)]
 
 
 class SearchParams(C.Structure):
     _fields_ = [("ratio", C.c_double), ("sub_batch_reads", C.c_uint32), ("sub_batch_bases", C.c_uint64),
-                ("time_kernels", C.c_uint32)]
+                ("time_kernels", C.c_uint32), ("model", C.c_uint32), ("error_rate", C.c_double)]
+
+
+THR_PERCENTAGE, THR_SYNCMER, THR_KMER, THR_FRACMINHASH = 0, 1, 2, 3
 
 
 class Results(C.Structure):
@@ -79,6 +82,9 @@ SIGNATURES = {
     "taxor_gpu_index_build_ixf": (C.c_int, [_P, C.c_uint64, _P, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     "taxor_gpu_searcher_create": (C.c_int, [_P, C.POINTER(SearchParams), C.POINTER(_P)]),
     "taxor_gpu_searcher_destroy": (None, [_P]),
+    "taxor_threshold_kind": (C.c_int, [C.c_int, C.c_uint32, C.c_uint64, C.c_double]),
+    "taxor_threshold_model": (C.c_uint64, [C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_double, C.c_double]),
+    "taxor_threshold_select": (C.c_int, [C.POINTER(HixfView), C.c_double, C.c_double, C.POINTER(SearchParams)]),
     "taxor_gpu_host_register": (C.c_int, [_P, C.c_uint64]),
     "taxor_gpu_host_unregister": (C.c_int, [_P]),
     "taxor_gpu_search_batch": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(Results)]),

@@ -77,6 +77,7 @@ struct taxor_gpu_index {
     uint32_t depth = 0, max_stride = 0;
     int k = 0, s = 0, t = 0;
     uint32_t scaling = 1;
+    int w_min = 0;           // > 0: index built without --use-syncmer, minimiser window size (== k: every k-mer)
 };
 
 struct SubBatch {
@@ -88,6 +89,8 @@ struct SubBatch {
 struct taxor_gpu_searcher {
     taxor_gpu_index *idx = nullptr;
     taxor_gpu_search_params prm{};
+    std::vector<uint32_t> h_rlen, h_nh_sub;   // k-mer / FracMinHash threshold models are evaluated on the host
+    std::vector<uint64_t> h_thr_sub;
     hipStream_t st = nullptr;       // query + CSR assembly; the stream callers synchronise on
     hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
     hipStream_t st_copy = nullptr;  // H2D of the next sub-batch's bases + packing (streamed search_batch)
@@ -160,10 +163,14 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
 {
     if (!v || !out || v->n_ixf == 0 || !v->ixf) return fail(TAXOR_E_ARG, "index_create: empty view");
-    if (!v->use_syncmer)
-        return fail(TAXOR_E_ARG, "index_create: use_syncmer=false (k-mer/minimiser indexes) is out of scope");
+    if (!v->use_syncmer) { // seqan3 minimiser_hash over window_size (taxor_search.cpp:210-212)
+        if (v->kmer_size < 1 || v->kmer_size > 32)
+            return fail(TAXOR_E_ARG, "index_create: k-mer size %u outside [1,32]", (unsigned)v->kmer_size);
+        if (v->window_size < v->kmer_size || v->window_size - v->kmer_size + 1 > 512)
+            return fail(TAXOR_E_ARG, "index_create: window size %llu must be in [k, k+511]", (unsigned long long)v->window_size);
+    }
     const int k = v->kmer_size, s = v->syncmer_size, t = v->t_syncmer;
-    if (k < 2 || k > 32 || s < 1 || s > 16 || s >= k || k - s + 1 > 32 || t < 1)
+    if (v->use_syncmer && (k < 2 || k > 32 || s < 1 || s > 16 || s >= k || k - s + 1 > 32 || t < 1))
         return fail(TAXOR_E_ARG, "index_create: unsupported k=%d s=%d t=%d (need k<=32, s<=16, s<k, t>=1)", k, s, t);
     if (v->n_ixf >= (1u << 30)) return fail(TAXOR_E_ARG, "index_create: too many IXFs");
     HIP_TRY(hipSetDevice(device));
@@ -174,6 +181,7 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
     idx->s = s;
     idx->t = t;
     idx->scaling = v->scaling ? v->scaling : 1;
+    idx->w_min = v->use_syncmer ? 0 : (int)v->window_size;
     idx->n_user_bins = v->n_user_bins;
     const uint64_t n = v->n_ixf;
     idx->h_ixf.resize(n);
@@ -426,8 +434,14 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
                                          taxor_gpu_searcher **out)
 {
     if (!idx || !prm || !out) return fail(TAXOR_E_ARG, "searcher_create: null argument");
-    if (!(prm->ratio >= 0.0) || !(prm->ratio <= 1.0))
+    const bool by_ratio = prm->model == TAXOR_THR_PERCENTAGE || prm->model == TAXOR_THR_SYNCMER;
+    if (by_ratio && (!(prm->ratio >= 0.0) || !(prm->ratio <= 1.0)))
         return fail(TAXOR_E_ARG, "searcher_create: threshold ratio %g outside [0,1] (error rate / k outside the model?)", prm->ratio);
+    if (prm->model > TAXOR_THR_FRACMINHASH) return fail(TAXOR_E_ARG, "searcher_create: unknown threshold model %u", prm->model);
+    if (!by_ratio && (!(prm->error_rate > 0.0) || !(prm->error_rate < 1.0)))
+        return fail(TAXOR_E_ARG, "searcher_create: the k-mer / FracMinHash threshold models need an error rate in (0,1), got %g", prm->error_rate);
+    if (prm->model == TAXOR_THR_SYNCMER && idx->w_min > 0)
+        return fail(TAXOR_E_ARG, "searcher_create: syncmer threshold model on an index built without syncmers");
     HIP_TRY(hipSetDevice(idx->device));
     auto s = new taxor_gpu_searcher();
     s->idx = idx;
@@ -551,7 +565,8 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         const uint64_t len = offsets[r + 1] - offsets[r];
         if (len >= (1ull << 31)) return fail(TAXOR_E_ARG, "read %llu longer than 2^31 bases", (unsigned long long)r);
         const uint64_t nwin = len >= (uint64_t)idx->k ? len - idx->k + 1 : 0;
-        const uint64_t cap = round_up(nwin / gap + 2, 16); // 128-B aligned regions: no line shared between reads
+        // 128-B aligned regions: no line shared between reads.  Minimiser mode emits at most one value per window.
+        const uint64_t cap = round_up((idx->w_min > 0 ? nwin : nwin / gap) + 2, 16);
         // the first sub-batch's syncmer kernel has nothing to hide behind: keep it a quarter the size
         const uint64_t lim_reads = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_reads / first_div, 1) : s->prm.sub_batch_reads;
         const uint64_t lim_bases = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_bases / first_div, 1) : s->prm.sub_batch_bases;
@@ -596,8 +611,9 @@ int ensure_scratch(taxor_gpu_searcher *s)
 {
     const taxor_gpu_index *idx = s->idx;
     const uint32_t R = std::max<uint32_t>(s->max_sub_reads, 1);
+    const bool syncmer_mode = idx->w_min == 0;  // minimiser mode writes its hashes directly: no candidates, no dedup
     for (int b = 0; b < 2; ++b)
-        if (s->d_cand[b].reserve(s->max_slots + 64) || s->d_hashes[b].reserve(s->max_slots + 64)) return TAXOR_E_HIP;
+        if ((syncmer_mode && s->d_cand[b].reserve(s->max_slots + 64)) || s->d_hashes[b].reserve(s->max_slots + 64)) return TAXOR_E_HIP;
     if (s->d_sync_cursor.reserve(s->subs.size() + 1)) return TAXOR_E_HIP;
     while (s->ev_sync_done.size() < s->subs.size() + 1) {
         hipEvent_t a, b, c;
@@ -619,7 +635,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
     // dedup scratch for reads whose table does not fit LDS (4096 slots)
     uint64_t ts = 64;
     while (ts < 2 * s->max_read_slots) ts <<= 1;
-    if (ts > 4096) {
+    if (syncmer_mode && ts > 4096) {
         if (ts > (1ull << 31)) return fail(TAXOR_E_ARG, "read too long for the dedup table");
         if (s->gtab_stride < ts) s->gtab_stride = (uint32_t)ts;
         if (s->d_gtab.reserve((size_t)s->gtab_stride * (size_t)s->grid_sync)) return TAXOR_E_HIP;
@@ -732,11 +748,29 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.k = idx->k;
     a.s = idx->s;
     a.t = idx->t;
+    a.w_min = idx->w_min;
+    a.thr_on_device = s->prm.model == TAXOR_THR_PERCENTAGE ? 1 : 0;
     size_t slot;
     if (ev_begin(s, 0, &slot, st)) return TAXOR_E_HIP;
     launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
     if (ev_end(s, slot, st)) return TAXOR_E_HIP;
     HIP_TRY(hipGetLastError());
+    if (s->prm.model == TAXOR_THR_KMER || s->prm.model == TAXOR_THR_FRACMINHASH) {
+        // threshold::get of the k-mer / FracMinHash models (threshold.hpp:62-75) is a page of double arithmetic with
+        // pow / log / sqrt whose result is truncated to an integer: evaluated on the host, with the host's libm, so
+        // that it is the reference's value bit for bit.  The GPU keeps classifying the previous sub-batch meanwhile.
+        s->h_nh_sub.resize(sb.n);
+        s->h_thr_sub.resize(sb.n);
+        HIP_TRY(hipMemcpyAsync(s->h_nh_sub.data(), s->d_nh.p + sb.first, sb.n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t i = 0; i < sb.n; ++i) {
+            const uint64_t n = s->h_nh_sub[i];
+            const double sf = (double)n / ((double)s->h_rlen[sb.first + i] - (double)idx->k + 1.0);   // taxor_search.cpp:263
+            s->h_thr_sub[i] = taxor_threshold_model((int)s->prm.model, n, (uint32_t)idx->k, s->prm.error_rate, -1.0, sf);
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_thr.p + sb.first, s->h_thr_sub.data(), sb.n * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st)); // h_thr_sub is reused by the next sub-batch
+    }
     return 0;
 }
 
@@ -784,6 +818,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? std::max(s->first_div, 4u) : s->first_div))
         return rc;
     s->n_reads = n_reads;
+    s->h_rlen = rlen;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     s->n_bases = nb;
     if (s->d_ascii.reserve(nb + 64) || s->d_aoff.reserve(n_reads + 1) || s->d_poff.reserve(n_reads + 1) ||

@@ -132,6 +132,7 @@ std::string parse_envelope(Cursor &c, taxor_hixf *h, std::vector<uint64_t> &sp_u
     const uint32_t version = c.get<uint32_t>();                          // index.hpp:211-212
     if (version != 1) return "unsupported index version " + std::to_string(version);
     h->meta.window_size = c.get<uint64_t>();                             // :217
+    h->view.window_size = h->meta.window_size;
     const uint64_t shape_size = c.get<uint64_t>();                       // :218 shape (dynamic_bitset)
     (void)c.get<uint64_t>();
     h->view.kmer_size = c.get<uint8_t>();                                // :219

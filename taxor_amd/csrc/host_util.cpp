@@ -60,6 +60,96 @@ double taxor_threshold_ratio(uint32_t kmer_size, double error_rate, double perce
     return kMatchingRatios[row][col];
 }
 
+int taxor_threshold_kind(int use_syncmer, uint32_t kmer_size, uint64_t window_size, double percentage)
+{
+    const uint64_t kmers_per_window = window_size - kmer_size + 1;          // threshold.hpp:26
+    if (percentage > 0.0 && percentage <= 1.0) return TAXOR_THR_PERCENTAGE; // :28
+    if (use_syncmer) return TAXOR_THR_SYNCMER;                              // :34
+    // the `fracminhash` member is always false here (search_arguments.hpp:61-75), so the window decides
+    return kmers_per_window == 1 ? TAXOR_THR_KMER : TAXOR_THR_FRACMINHASH;  // :39-47
+}
+
+namespace {
+
+// static_cast<size_t>(double) as the reference's stock build performs it.  For very short reads the reference casts
+// NaN (sqrt of a negative variance) or a negative bound to size_t, which is undefined in C++; its build sets no
+// -march (src/CMakeLists.txt:17-29), so GCC emits the baseline x86-64 cvttsd2si sequence, whose results are spelled
+// out here instead of being left to whatever this compiler and this CPU would do.
+uint64_t to_size_like_reference(double x)
+{
+    constexpr double two63 = 9223372036854775808.0;
+    constexpr uint64_t indefinite = 0x8000000000000000ull;
+    if (std::isnan(x) || x <= -two63) return indefinite;
+    if (x < two63) return (uint64_t)(int64_t)x;
+    const double y = x - two63;
+    return y >= two63 ? 0 : ((uint64_t)(int64_t)y ^ indefinite);
+}
+
+double normal_cdf_inverse(double p)                                         // gaussian_inverse.cpp:13-50
+{
+    auto approx = [](double t) {
+        constexpr double c0 = 2.515517, c1 = 0.802853, c2 = 0.010328, d0 = 1.432788, d1 = 0.189269, d2 = 0.001308;
+        return t - ((c2 * t + c1) * t + c0) / (((d2 * t + d1) * t + d0) * t + 1.0);
+    };
+    return p < 0.5 ? -approx(std::sqrt(-2.0 * std::log(p))) : approx(std::sqrt(-2.0 * std::log(1.0 - p)));
+}
+
+// moments of the number of mutated k-mers (Blanca et al.), kmer_model.cpp:26-46; the operand order is the
+// reference's, because double arithmetic is not associative and the result is truncated to an integer threshold
+struct NmutMoments {
+    double q, expected, variance;
+    NmutMoments(double r, double k, double n)
+    {
+        q = 1.0 - std::pow(1.0 - r, k);
+        expected = n * q;
+        variance = n * (1.0 - q) * (q * (2.0 * k + (2.0 / r) - 1.0) - 2.0 * k) + k * (k - 1.0) * std::pow((1.0 - q), 2.0) +
+                   (2.0 * (1.0 - q) / (std::pow(r, 2.0))) * ((1.0 + (k - 1.0) * (1.0 - q)) * r - q);
+    }
+};
+
+} // namespace
+
+uint64_t taxor_threshold_model(int kind, uint64_t count, uint32_t kmer_size, double error_rate, double percentage,
+                               double scaling_factor)
+{
+    const uint64_t fp_correction = (uint64_t)((double)count * 0.0039);      // threshold.hpp:53
+    const double n = (double)count, k = (double)kmer_size;
+    switch (kind) {
+    case TAXOR_THR_SYNCMER: return (uint64_t)(n * taxor_threshold_ratio(kmer_size, error_rate, -1.0)); // :57-61
+    case TAXOR_THR_KMER: {                                                  // :62-67, kmer_model.cpp:10-23
+        const NmutMoments m(error_rate, k, n);
+        const double z = normal_cdf_inverse(1.0 - (1 - 0.95) / 2.0);
+        const uint64_t high = to_size_like_reference(std::ceil(n * m.q + z * std::sqrt(m.variance)));
+        return count - high - fp_correction;                               // size_t arithmetic: may wrap
+    }
+    case TAXOR_THR_FRACMINHASH: {                                           // :68-75, fracminhash_model.cpp:8-33
+        const NmutMoments m(error_rate, k, n);
+        const double z = normal_cdf_inverse(1.0 - (1.0 - 0.95) / 2.0);
+        const double term3 = m.variance / std::pow(n, 2);
+        const double term2 = n * m.expected - (std::pow(m.expected, 2) + m.variance);
+        const double denominator = scaling_factor * std::pow(n, 3) * std::pow(1.0 - std::pow(1.0 - scaling_factor, n), 2);
+        const double term1 = (1.0 - scaling_factor) / denominator;
+        const double c_low = std::pow((1.0 - error_rate), k) - z * std::sqrt(term1 * term2 + term3);
+        return to_size_like_reference(c_low * n) - fp_correction;
+    }
+    default: return (uint64_t)(n * percentage);                             // :76-79
+    }
+}
+
+int taxor_threshold_select(const taxor_hixf_view *view, double error_rate, double percentage, taxor_gpu_search_params *prm)
+{
+    if (!view || !prm) return TAXOR_E_ARG;
+    prm->model = (uint32_t)taxor_threshold_kind(view->use_syncmer, view->kmer_size, view->window_size, percentage);
+    prm->error_rate = error_rate;
+    prm->ratio = 0.0;
+    if (prm->model == TAXOR_THR_PERCENTAGE) prm->ratio = percentage;
+    else if (prm->model == TAXOR_THR_SYNCMER) {
+        prm->ratio = taxor_threshold_ratio(view->kmer_size, error_rate, -1.0);
+        if (prm->ratio < 0.0) return TAXOR_E_ARG;
+    } else if (!(error_rate > 0.0) || !(error_rate < 1.0)) return TAXOR_E_ARG; // the models divide by r and take log-free powers of 1-r
+    return TAXOR_OK;
+}
+
 uint64_t taxor_threshold(uint64_t hash_count, double ratio)
 {
     return (uint64_t)((double)hash_count * ratio); // threshold.hpp:60

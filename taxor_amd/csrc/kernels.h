@@ -82,6 +82,8 @@ struct SyncmerArgs {
     const uint32_t *order;    // processing order: longest reads first, so that no long read is left for the tail
     uint32_t n_reads;
     int k, s, t;
+    int w_min;                // > 0: minimiser / k-mer mode with this window size (index built without --use-syncmer)
+    int thr_on_device;        // minimiser mode: 1 = thr = (size_t)(nh * ratio) here; 0 = the host applies a model
 };
 
 struct QueryArgs {

@@ -460,6 +460,140 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// k_minimisers -- hashing for indexes built WITHOUT --use-syncmer (taxor_search.cpp:210-212,239-260):
+// seqan3::views::minimiser_hash(ungapped{k}, window_size{w}, seed{adjust_seed(k)}).  Value of the k-mer at
+// position i = min(fwd ^ seed, revcomp ^ seed); a window is W = w-k+1 consecutive values (all of them when the read
+// has fewer); the view emits the minimiser of the first window and then one value whenever the minimiser changes.
+// Which of several equal minima is the minimiser is stateful (first window and every re-scan after the minimiser
+// left the window: the RIGHTMOST minimum; a newcomer replaces it only when strictly smaller).  Per tile of MN_T
+// windows every thread finds the rightmost / leftmost minimum of its windows; a tile in which every window has a
+// unique minimum (any tile of ordinary sequence; every tile when w == k) needs no state at all, otherwise one
+// thread replays the reference's rule over the tile (low-complexity sequence only).  No dedup: every emitted
+// value counts (the reference pushes them into a vector), FracMinHash down-sampling as in the syncmer path.
+// ------------------------------------------------------------------------------------------------------
+static constexpr int MN_C = 4;                    // windows per thread
+static constexpr int MN_T = BLK * MN_C;           // windows per tile
+static constexpr int MN_WMAX = 512;               // k-mers per window supported (w - k + 1)
+static constexpr int MN_WORDS = (MN_T + MN_WMAX + 32) / 16 + 4;
+
+__global__ __launch_bounds__(BLK) void k_minimisers(const SyncmerArgs a)
+{
+    __shared__ uint32_t sW[MN_WORDS];
+    __shared__ uint64_t sV[MN_T + MN_WMAX];
+    __shared__ uint16_t sP[MN_T];                 // minimiser position of window xl, relative to the tile's first value
+    __shared__ uint32_t sScr[8];
+    __shared__ uint32_t sRead, sTie;
+    __shared__ int sCarry;                        // minimiser position (absolute) of the last window of the previous tile
+
+    const int k = a.k;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t seed = 0x8F3F73B5CF1C9ADEull >> (64 - 2 * k);        // hixf::adjust_seed, adjust_seed.hpp:40-44
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) sRead = atomicAdd(a.cursor, 1u);
+        __syncthreads();
+        if (sRead >= a.n_reads) break;
+        const uint32_t r = a.order ? a.order[sRead] : sRead;
+        const uint32_t L = a.rlen[r];
+        const uint32_t *__restrict__ pk = a.packed + a.poff[r];
+        const uint32_t nwords = (((L + 15u) >> 4) + 3u) & ~3u;
+        uint64_t *__restrict__ outh = a.hashes + a.hoff[r];
+        const uint32_t cap = a.hcap[r];
+        const int nk = (int)L - k + 1;                                   // k-mer values of the read
+        const int W = nk > 0 ? min(a.w_min - k + 1, nk) : 0;             // the view shrinks the window to the text
+        const int nwin = nk > 0 ? nk - W + 1 : 0;
+        uint32_t n_out = 0;
+
+        for (int j0 = 0; j0 < nwin; j0 += MN_T) {
+            __syncthreads();
+            const uint32_t wbase = (uint32_t)j0 >> 4;
+            for (uint32_t i = tid; i < (uint32_t)MN_WORDS; i += BLK) {
+                const uint32_t wi = wbase + i;
+                sW[i] = wi < nwords ? pk[wi] : 0u;
+            }
+            if (tid == 0) sTie = 0;
+            __syncthreads();
+            const int nw_tile = min(MN_T, nwin - j0);
+            const int nval = nw_tile + W - 1;
+            for (int i = (int)tid; i < nval; i += BLK) {
+                const uint32_t pos = (uint32_t)(j0 + i);
+                const uint64_t f = extract_bases(sW, (pos >> 4) - wbase, pos & 15u, k);
+                const uint64_t rc = revcomp64(f, k);
+                sV[i] = min(f ^ seed, rc ^ seed);
+            }
+            __syncthreads();
+            int rm[MN_C];
+            bool tie = false;
+#pragma unroll
+            for (int c = 0; c < MN_C; ++c) {
+                const int xl = (int)tid * MN_C + c;
+                rm[c] = 0;
+                if (xl < nw_tile) {
+                    uint64_t m = sV[xl];
+                    int lm = 0;
+                    for (int x = 1; x < W; ++x) {
+                        const uint64_t v = sV[xl + x];
+                        if (v < m) { m = v; lm = x; rm[c] = x; }
+                        else if (v == m) rm[c] = x;
+                    }
+                    tie |= lm != rm[c];
+                    sP[xl] = (uint16_t)(xl + rm[c]);                      // unique minimum: the minimiser, whatever the history
+                }
+            }
+            if (tie) sTie = 1;
+            __syncthreads();
+            if (sTie && tid == 0) {
+                // replay of minimiser_view::next_minimiser over the tile; sP holds xl + Rm(xl) on entry
+                int p = sCarry;
+                for (int xl = 0; xl < nw_tile; ++xl) {
+                    const int j = j0 + xl, newest = xl + W - 1;
+                    if (j == 0 || p < j) p = j0 + (int)sP[xl];
+                    else if (sV[newest] < sV[p - j0]) p = j0 + newest;
+                    sP[xl] = (uint16_t)(p - j0);
+                }
+            }
+            __syncthreads();
+            const int carry_in = sCarry;
+            uint32_t cnt = 0;
+            uint64_t val[MN_C];
+            bool em[MN_C];
+#pragma unroll
+            for (int c = 0; c < MN_C; ++c) {
+                const int xl = (int)tid * MN_C + c;
+                em[c] = false;
+                if (xl < nw_tile) {
+                    const int p = j0 + (int)sP[xl];
+                    const int prev = xl ? j0 + (int)sP[xl - 1] : (j0 ? carry_in : -1);
+                    em[c] = p != prev;
+                    val[c] = sV[p - j0];
+                    if (em[c] && a.scaling_limit > 0.0 && !((double)wyhash_u64(val[c]) <= a.scaling_limit)) em[c] = false; // :243-249
+                    cnt += em[c] ? 1u : 0u;
+                }
+            }
+            uint32_t tot;
+            uint32_t off = n_out + block_excl_add(cnt, sScr, &tot);
+#pragma unroll
+            for (int c = 0; c < MN_C; ++c)
+                if (em[c]) {
+                    if (off < cap) outh[off] = val[c];
+                    else atomicOr(&a.ctr->flags, FLAG_CAND_OVERFLOW);
+                    ++off;
+                }
+            n_out += tot;
+            __syncthreads();
+            if (tid == 0) sCarry = j0 + (int)sP[nw_tile - 1];
+        }
+        if (tid == 0) {
+            a.nh[r] = n_out;                                                    // taxor_search.cpp:261
+            if (a.thr_on_device) a.thr[r] = (uint64_t)((double)n_out * a.ratio); // percentage model, threshold.hpp:76-79
+            atomicAdd(&a.ctr->n_hashes, (unsigned long long)n_out);
+        }
+    }
+}
+
 int syncmers_grid(int device)
 {
     hipDeviceProp_t p;
@@ -473,6 +607,10 @@ int syncmers_grid(int device)
 void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 {
     if (!a.n_reads) return;
+    if (a.w_min > 0) { // index built without --use-syncmer
+        hipLaunchKernelGGL(k_minimisers, dim3(grid), dim3(BLK), 0, st, a);
+        return;
+    }
     static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
     if (!generic_only && a.k - a.s + 1 == 11 && a.s <= 13) hipLaunchKernelGGL(k_syncmers<11>, dim3(grid), dim3(BLK), 0, st, a);
     else hipLaunchKernelGGL(k_syncmers<0>, dim3(grid), dim3(BLK), 0, st, a);

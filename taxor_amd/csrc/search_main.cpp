@@ -387,11 +387,15 @@ int main(int argc, char **argv)
             t_index += now() - t0;
             trace("index resident in HBM");
             // threshold model (threshold.hpp:22-47)
-            const double ratio = taxor_threshold_ratio(view->kmer_size, cfg.error_rate, cfg.threshold);
-            if (cfg.threshold > 0.0 && cfg.threshold <= 1.0) printf("use percentage-model\t%g\n", cfg.threshold);
-            else printf("use syncmer model\n");
-            if (ratio < 0) die("no syncmer threshold model for k=" + std::to_string(view->kmer_size) + " and error rate " + std::to_string(cfg.error_rate));
-            taxor_gpu_search_params prm{ratio, 0, 0, 0};
+            taxor_gpu_search_params prm{};
+            if (taxor_threshold_select(view, cfg.error_rate, cfg.threshold, &prm) != TAXOR_OK)
+                die("no threshold model for k=" + std::to_string(view->kmer_size) + " and error rate " + std::to_string(cfg.error_rate));
+            switch (prm.model) {                                            // the reference's messages, threshold.hpp:32-46
+            case TAXOR_THR_PERCENTAGE: printf("use percentage-model\t%g\n", cfg.threshold); break;
+            case TAXOR_THR_SYNCMER: printf("use syncmer model\n"); break;
+            case TAXOR_THR_KMER: printf("use kmer-model\n"); break;
+            default: printf("use frac minhash\n"); break;
+            }
             std::vector<taxor_gpu_searcher *> sr(ng, nullptr);
             for (size_t g = 0; g < ng; ++g)
                 if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());

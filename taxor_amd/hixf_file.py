@@ -9,7 +9,7 @@ from ._lib import check
 
 
 def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None, window_size=None, scaling=1,
-               schema=None):
+               schema=None, use_syncmer=True):
     """ixfs: list of dicts {bins, stride, seg_len, seed, data, next_ixf, fname_idx} (host data required);
     species: list of dicts {organism_name, accession_id, taxid, taxnames_string, taxid_string, user_bin, seq_len}"""
     keep = []
@@ -20,7 +20,8 @@ def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None
         fn = np.ascontiguousarray(f["fname_idx"], dtype=np.int64)
         keep += [d, nx, fn]
         arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data, nx.ctypes.data, fn.ctypes.data)
-    view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1, scaling)
+    ws = window_size if window_size is not None else k
+    view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, ws)
     sp = (_lib.Species * len(species))()
     for i, x in enumerate(species):
         sp[i] = _lib.Species(x["organism_name"].encode(), x["accession_id"].encode(), x["taxid"].encode(),
@@ -28,7 +29,7 @@ def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None
     if filenames is None:
         filenames = [f"user_bin_{i}.fna" for i in range(n_user_bins)]
     fns = (C.c_char_p * len(filenames))(*[f.encode() for f in filenames])
-    meta = _lib.HixfMeta(window_size if window_size is not None else k, 1, 0, len(species), sp, len(filenames), fns)
+    meta = _lib.HixfMeta(ws, 1, 0, len(species), sp, len(filenames), fns)
     if schema is None:
         check(_lib.lib().taxor_hixf_store(str(path).encode(), C.byref(view), C.byref(meta)))
     else:

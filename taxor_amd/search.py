@@ -29,6 +29,17 @@ def threshold(hash_count, ratio):
     return int(_lib.lib().taxor_threshold(int(hash_count), float(ratio)))
 
 
+def threshold_kind(use_syncmer, kmer_size, window_size, percentage=-1.0):
+    """threshold::threshold's choice of model (threshold.hpp:22-47) -> _lib.THR_*"""
+    return int(_lib.lib().taxor_threshold_kind(1 if use_syncmer else 0, int(kmer_size), int(window_size), float(percentage)))
+
+
+def threshold_model(kind, count, kmer_size, error_rate=0.04, percentage=-1.0, scaling_factor=1.0):
+    """threshold::get for every kind (threshold.hpp:51-81), host arithmetic identical to the reference's"""
+    return int(_lib.lib().taxor_threshold_model(int(kind), int(count), int(kmer_size), float(error_rate), float(percentage),
+                                                float(scaling_factor)))
+
+
 def classify_filter(counts):
     c = np.ascontiguousarray(counts, dtype=np.uint32)
     keep = np.zeros(c.size, dtype=np.uint8)
@@ -61,7 +72,7 @@ def _results(res: _lib.Results) -> SearchResults:
 class GpuIndex:
     """A HIXF resident in one GPU's HBM."""
 
-    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1):
+    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None):
         """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)}"""
         L = _lib.lib()
         self._keep = []
@@ -77,7 +88,9 @@ class GpuIndex:
             self._keep += [nx, fn, d]
             arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"],
                                   d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data)
-        view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling)
+        self.use_syncmer = bool(use_syncmer)
+        self.window_size = int(window_size) if window_size is not None else k
+        view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, self.window_size)
         h = C.c_void_p()
         check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
         self._h = h
@@ -148,8 +161,15 @@ class Searcher:
     def __init__(self, index: GpuIndex, error_rate=0.04, percentage=-1.0, ratio=None, sub_batch_reads=0,
                  sub_batch_bases=0, time_kernels=False):
         self.index = index
-        self.ratio = threshold_ratio(index.k, error_rate, percentage) if ratio is None else float(ratio)
-        prm = _lib.SearchParams(self.ratio, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0)
+        prm = _lib.SearchParams(0.0, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0, _lib.THR_PERCENTAGE, error_rate)
+        if ratio is not None:          # explicit (size_t)(n * ratio), whatever the index
+            prm.ratio = float(ratio)
+        else:                          # the reference's choice: percentage / syncmer / k-mer / FracMinHash model
+            view = _lib.HixfView(0, None, index.n_user_bins, index.k, index.s, index.t, 1 if index.use_syncmer else 0, 1,
+                                 index.window_size)
+            if _lib.lib().taxor_threshold_select(C.byref(view), float(error_rate), float(percentage), C.byref(prm)) != 0:
+                raise ValueError(f"no threshold model for k={index.k}, error_rate={error_rate}")
+        self.ratio, self.model = prm.ratio, int(prm.model)
         h = C.c_void_p()
         check(_lib.lib().taxor_gpu_searcher_create(index._h, C.byref(prm), C.byref(h)))
         self._h = h

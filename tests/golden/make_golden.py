@@ -253,6 +253,118 @@ def mutate(rng, seq, e):
     return "".join(out)
 
 
+
+# ---- indexes built without --use-syncmer: seqan3::views::minimiser_hash + the k-mer / FracMinHash threshold models
+def adjust_seed(k):  # src/hixf/build/adjust_seed.hpp:40-44
+    return 0x8F3F73B5CF1C9ADE >> (64 - 2 * k)
+
+
+def minimiser_hash(seq, k, w):
+    """seqan3::views::minimiser_hash(ungapped{k}, window_size{w}, seed{adjust_seed(k)}) as called at
+    src/main/taxor_search.cpp:210-212 (un-vendored seqan3: restated from the published 3.x iterator, which keeps a
+    deque of the window's values and the offset of the current minimiser in it)."""
+    rank = {"A": 0, "C": 1, "G": 2, "T": 3}
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    seed = adjust_seed(k)
+    n = len(seq) - k + 1
+    if n <= 0:
+        return []
+
+    def kmer_hash(text):
+        v = 0
+        for ch in text:
+            v = v * 4 + rank[ch]
+        return v
+
+    fwd = [kmer_hash(seq[i:i + k]) ^ seed for i in range(n)]
+    rc_text = "".join(comp[c] for c in reversed(seq))            # views::complement | views::reverse
+    rc = [kmer_hash(rc_text[i:i + k]) ^ seed for i in range(n)][::-1]   # ... | kmer_hash | ^seed | views::reverse
+    values = [min(a, b) for a, b in zip(fwd, rc)]
+    window = min(w - k + 1, n)
+    dq = deque(values[:window])
+    # window_first: min_element with less_equal -> the rightmost minimum
+    m_val, m_off = dq[0], 0
+    for i, x in enumerate(dq):
+        if x <= m_val:
+            m_val, m_off = x, i
+    out = [m_val]
+    for x in values[window:]:
+        dq.popleft()
+        dq.append(x)
+        if m_off == 0:
+            m_val, m_off = dq[0], 0
+            for i, y in enumerate(dq):
+                if y <= m_val:
+                    m_val, m_off = y, i
+            out.append(m_val)
+        elif x < m_val:
+            m_val, m_off = x, len(dq) - 1
+            out.append(m_val)
+        else:
+            m_off -= 1
+    return out
+
+
+def f64_to_size(x):
+    """static_cast<size_t>(double) of the reference's stock x86-64 build (no -march: cvttsd2si sequence), stated
+    explicitly because negative / NaN inputs (very short reads) are undefined behaviour in C++"""
+    if x != x:
+        return 1 << 63
+    two63 = 9223372036854775808.0
+    if x >= two63:
+        y = x - two63
+        return 0 if y >= two63 else (int(y) ^ (1 << 63))
+    if x <= -two63:
+        return 1 << 63
+    return int(x) & M64
+
+
+def normal_cdf_inverse(p):  # src/hixf/search/gaussian_inverse.cpp:13-50
+    def ra(t):
+        c = (2.515517, 0.802853, 0.010328)
+        d = (1.432788, 0.189269, 0.001308)
+        return t - ((c[2] * t + c[1]) * t + c[0]) / (((d[2] * t + d[1]) * t + d[0]) * t + 1.0)
+    if p < 0.5:
+        return -ra(math.sqrt(-2.0 * math.log(p)))
+    return ra(math.sqrt(-2.0 * math.log(1.0 - p)))
+
+
+def _sqrt(x):
+    return math.sqrt(x) if x >= 0 else float("nan")
+
+
+def variance_nmut_kmer(r, k, n):  # src/hixf/search/kmer_model.cpp:32-39
+    q = 1.0 - math.pow(1.0 - r, k)
+    return (float(n) * (1.0 - q) * (q * (2.0 * float(k) + (2.0 / r) - 1.0) - 2.0 * float(k))
+            + float(k) * (float(k) - 1.0) * math.pow((1.0 - q), 2.0)
+            + (2.0 * (1.0 - q) / (math.pow(r, 2.0))) * ((1.0 + (float(k) - 1.0) * (1.0 - q)) * r - q))
+
+
+def threshold_kmer_model(n, k, err):  # threshold.hpp:62-66 + kmer_model.cpp:10-23
+    q = 1.0 - math.pow(1.0 - err, k)
+    z = normal_cdf_inverse(1.0 - (1 - 0.95) / 2.0)
+    high = f64_to_size(math.ceil(n * q + z * _sqrt(variance_nmut_kmer(err, k, n)))) if variance_nmut_kmer(err, k, n) >= 0 else (1 << 63)
+    return (n - high - f64_to_size(n * 0.0039)) & M64
+
+
+def threshold_fracminhash(n, k, err, sf):  # threshold.hpp:68-75 + fracminhash_model.cpp:8-33
+    z = normal_cdf_inverse(1.0 - (1.0 - 0.95) / 2.0)
+    q = 1.0 - math.pow(1.0 - err, k)
+    e_n = n * q
+    var_n = variance_nmut_kmer(err, k, n)
+    try:
+        term3 = var_n / math.pow(n, 2)
+        term2 = n * e_n - (math.pow(e_n, 2) + var_n)
+        den = sf * math.pow(n, 3) * math.pow(1.0 - math.pow(1.0 - sf, n), 2)
+        term1 = (1.0 - sf) / den
+        var = term1 * term2 + term3
+        clow = math.pow((1.0 - err), k) - z * _sqrt(var)
+        prod = clow * float(n)
+    except (ZeroDivisionError, ValueError, OverflowError):
+        return None                                       # IEEE inf/nan territory: left to the C restatement
+    return (f64_to_size(prod) - f64_to_size(n * 0.0039)) & M64
+
+
 def main():
     rng = random.Random(20250523)
     k, s, t = 22, 12, 5
@@ -354,6 +466,35 @@ def main():
            "root_counts_read1": counts0}
     json.dump(out, open(os.path.join(HERE, "toy_hixf.json"), "w"))
     print("golden vectors written:", sorted(f for f in os.listdir(HERE) if f.endswith(".json")))
+
+    # ---------------- minimiser / k-mer mode (indexes built without --use-syncmer) --------------------
+    mseqs = {
+        "random_400": rand_seq(rng, 400),
+        "homopolymer_A_90": "A" * 90,
+        "dinuc_AT_120": "AT" * 60,
+        "trinuc_CAG_150": "CAG" * 50,
+        "palindrome": "ACGTACGTACGTTGCATGCATGCAACGTACGTACGTTGCATGCATGCA" * 2,
+        "mixed_lowcomplex": rand_seq(rng, 70) + "C" * 45 + rand_seq(rng, 40) + "GA" * 25 + rand_seq(rng, 50),
+        "repeat_unit_7": rand_seq(rng, 7) * 20,
+        "len_lt_k": rand_seq(rng, 19),
+        "len_eq_k": rand_seq(rng, 20),
+        "len_between_k_and_w": rand_seq(rng, 26),
+        "len_eq_w": rand_seq(rng, 32),
+        "empty": "",
+    }
+    mini = {"cases": [], "thresholds": []}
+    for (kk, ww) in [(20, 20), (20, 32), (22, 22), (16, 24), (31, 40), (32, 32)]:
+        for name, sq in mseqs.items():
+            mini["cases"].append({"name": name, "k": kk, "w": ww, "seq": sq, "hashes": [str(h) for h in minimiser_hash(sq, kk, ww)]})
+    for kk in (20, 22, 31):
+        for err in (0.01, 0.04, 0.1):
+            for n in (0, 1, 2, 5, 10, 50, 100, 435, 1000, 4981, 9979, 99979):
+                mini["thresholds"].append({"model": "kmer", "k": kk, "err": err, "n": n, "thr": str(threshold_kmer_model(n, kk, err))})
+                for sf in (0.05, 0.125, 0.5):
+                    v = threshold_fracminhash(n, kk, err, sf)
+                    if v is not None:
+                        mini["thresholds"].append({"model": "fracminhash", "k": kk, "err": err, "n": n, "sf": sf, "thr": str(v)})
+    json.dump(mini, open(os.path.join(HERE, "minimisers.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":

@@ -112,3 +112,37 @@ def test_cli_errors(tmp_path):
     cp = subprocess.run([TAXOR, "search", "--output-file", str(out), "--index-file", str(idx_path), "--query-file", str(bad)],
                         capture_output=True, text=True, timeout=120)
     assert cp.returncode != 0 and "dna15" in cp.stderr
+
+
+@pytest.mark.parametrize("k,w,msg", [(20, 20, "use kmer-model"), (20, 30, "use frac minhash")])
+def test_cli_index_built_without_syncmers(tmp_path, k, w, msg):
+    """a .hixf with use_syncmer = 0: minimiser hashing + the k-mer / FracMinHash threshold model end to end"""
+    g, go = synth.random_genomes(7, 6000, seed=k + w)
+    planted = [orc.minimiser_hash(bytes(g[int(go[i]):int(go[i + 1])]), k, w) for i in range(7)]
+    lay = synth.make_layout(planted, root_bins=68, child_bins=40, n_children=3, seed=3)
+    host = synth.materialize_host(lay)
+    sp = make_species(lay)
+    idx_path = tmp_path / "kmer.hixf"
+    store_hixf(idx_path, host, lay["n_user_bins"], sp, k=k, s=0, t=0, window_size=w, use_syncmer=False)
+    bases, offs, origin = synth.synth_reads(g, go, 120, 1200, error_rate=0.01, frac_random=0.2, seed=6)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(120)] + [b"ACGTNNNNRYKM" * 30, b"ACGTACGT", bytes(g[:k])]
+    ids = [f"r{i}" for i in range(len(reads))]
+    fa = tmp_path / "r.fa"
+    with open(fa, "wb") as f:
+        for rid, r in zip(ids, reads):
+            f.write(b">" + rid.encode() + b"\n" + r + b"\n")
+    out = tmp_path / "o.tsv"
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out),
+                         "--batch-reads", "40", "--threads", "2"], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr
+    assert msg in cp.stdout
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    B = np.frombuffer(b"".join(orc.dna4_normalise(r) for r in reads), dtype=np.uint8)
+    O = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    nh, off, ub, cnt, _ = h.search_batch(B, O, k=k, threads=4, window=w)
+    want = HEADER
+    for i, rid in enumerate(ids):
+        tup = [(int(a), int(b)) for a, b in zip(ub[int(off[i]):int(off[i + 1])], cnt[int(off[i]):int(off[i + 1])])]
+        want += expected_lines(sp, rid, len(reads[i]), int(nh[i]), tup)
+    assert open(out).read() == want
+    assert want.count("\n") > 50 and "Organism" in want      # the control reads do classify

@@ -398,9 +398,9 @@ def test_index_validation_errors():
         with pytest.raises(TaxorError) as e:
             GpuIndex([d], bins)
         assert needle in str(e.value)
-    # unsupported modes are rejected loudly (out of scope: k-mer/minimiser indexes)
+    # a minimiser index whose window is shorter than k is rejected loudly (tests/test_gpu_minimiser.py has the rest)
     with pytest.raises(TaxorError):
-        GpuIndex([base], bins, use_syncmer=False)
+        GpuIndex([base], bins, use_syncmer=False, window_size=10)
     # a merged bin whose child is referenced twice is not a tree
     a = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.items()}
     a["fname_idx"][0] = -1

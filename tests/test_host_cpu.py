@@ -108,3 +108,24 @@ def test_layout_paths_cover_split_and_depth3():
         assert lay["planted_user_bin"][i] in ub.tolist()
         j = ub.tolist().index(lay["planted_user_bin"][i])
         assert ks.size <= cnt[j] <= ks.size + 16      # split bins add a few cross-part false positives
+
+
+def test_threshold_models_match_oracle():
+    """k-mer / FracMinHash threshold models (threshold.hpp:51-81) of the host library == oracle, including the wrapped
+    thresholds of very short reads"""
+    from taxor_amd import search as ts
+    from taxor_amd import _lib
+    rng = np.random.default_rng(9)
+    ns = [0, 1, 2, 3, 5, 7, 10, 20, 50, 99, 100, 435, 871, 4981, 9979, 99979, 1000000] + [int(x) for x in rng.integers(0, 200000, 300)]
+    for k in (16, 20, 22, 31, 32):
+        for err in (0.001, 0.01, 0.04, 0.1, 0.2, 0.5):
+            for n in ns:
+                assert ts.threshold_model(_lib.THR_KMER, n, k, err) == orc.threshold_model(orc.THR_KMER, n, k, err), (k, err, n)
+                for sf in (1e-3, 0.05, 1 / 7, 0.5, 0.999):
+                    a = ts.threshold_model(_lib.THR_FRACMINHASH, n, k, err, -1.0, sf)
+                    b = orc.threshold_model(orc.THR_FRACMINHASH, n, k, err, -1.0, sf)
+                    assert a == b, (k, err, n, sf)
+    assert ts.threshold_model(_lib.THR_PERCENTAGE, 435, 22, 0.04, 0.5) == 217
+    assert ts.threshold_model(_lib.THR_SYNCMER, 435, 22, 0.04) == 221
+    for use_syn, k, w, pct in ((1, 22, 22, -1.0), (0, 20, 20, -1.0), (0, 20, 32, -1.0), (0, 20, 20, 0.7), (1, 22, 22, 1.0), (0, 20, 21, 0.0)):
+        assert ts.threshold_kind(use_syn, k, w, pct) == orc.threshold_kind(use_syn, k, w, pct)

@@ -116,3 +116,37 @@ def test_classify_filter():
     keep = orc.classify_filter([100, 80, 79, 0])
     assert keep.tolist() == [True, True, False, False]
     assert orc.classify_filter([0, 0]).tolist() == [True, True]   # zero-hash quirk: 0 < 0*0.8 is false
+
+
+def test_minimiser_hash_golden(golden_dir):
+    """indexes built without --use-syncmer: seqan3 minimiser_hash restated twice (C oracle, Python deque iterator)"""
+    g = _load(golden_dir, "minimisers.json")
+    for c in g["cases"]:
+        got = orc.minimiser_hash(c["seq"].encode(), c["k"], c["w"])
+        assert got.tolist() == [int(h) for h in c["hashes"]], (c["name"], c["k"], c["w"])
+    # w == k: every canonical k-mer, one per position, no tie rule involved
+    seq = b"ACGTTGCAAGGCTTAACCGGTTACGATCGATCGGATCCA"
+    assert len(orc.minimiser_hash(seq, 20, 20)) == len(seq) - 19
+    # strand symmetry of the VALUES (not of the syncmer selection): a read and its reverse complement give the
+    # same multiset of canonical k-mer values
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    rc = seq.translate(comp)[::-1]
+    assert sorted(orc.minimiser_hash(seq, 20, 20).tolist()) == sorted(orc.minimiser_hash(rc, 20, 20).tolist())
+    assert orc.adjust_seed(20) == 0x8F3F73B5CF1C9ADE >> 24 and orc.adjust_seed(32) == 0x8F3F73B5CF1C9ADE
+
+
+def test_threshold_models_golden(golden_dir):
+    g = _load(golden_dir, "minimisers.json")
+    for t in g["thresholds"]:
+        kind = orc.THR_KMER if t["model"] == "kmer" else orc.THR_FRACMINHASH
+        got = orc.threshold_model(kind, t["n"], t["k"], t["err"], -1.0, t.get("sf", 1.0))
+        assert got == int(t["thr"]), t
+    # kind selection, threshold.hpp:22-47
+    assert orc.threshold_kind(True, 22, 22, -1.0) == orc.THR_SYNCMER
+    assert orc.threshold_kind(False, 20, 20, -1.0) == orc.THR_KMER
+    assert orc.threshold_kind(False, 20, 32, -1.0) == orc.THR_FRACMINHASH
+    assert orc.threshold_kind(False, 20, 20, 0.7) == orc.THR_PERCENTAGE and orc.threshold_kind(True, 22, 22, 1.0) == orc.THR_PERCENTAGE
+    # a 10-kb read at 4 % error keeps ~40 % of its 20-mers: the k-mer model asks for a little less than that
+    thr = orc.threshold_model(orc.THR_KMER, 9981, 20, 0.04)
+    assert 0.35 * 9981 < thr < 0.44 * 9981
+    assert abs(orc.lib().orc_normal_cdf_inverse(0.975) - 1.96) < 0.001
