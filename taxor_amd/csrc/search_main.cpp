@@ -7,6 +7,7 @@
 
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -252,6 +253,85 @@ int main(int argc, char **argv)
         printf("schema: n_before=%u n_after=%u idx_bins=%d idx_stride=%d idx_seg_len=%d%s idx_seed=%d\n", sc.n_before, sc.n_after,
                sc.idx_bins, sc.idx_stride, sc.idx_seg_len, sc.seg_len_is_rows ? "(rows)" : "", sc.idx_seed);
         return 0;
+    }
+    if (argc > 1 && strcmp(argv[1], "verify") == 0) {
+        // Positive control for an index whose provenance is not this library: error-free windows cut
+        // from a genome that IS in the index must find (nearly) all of their hashes in one user bin.  A match ratio near
+        // the false-positive floor instead means that the hash (wyhash / minimiser) or the IXF arithmetic (seed, row
+        // stride, segment length) read from the file does not describe this index -- the two un-vendored boundaries.
+        std::string index_file, genome_file;
+        uint64_t n_reads = 2000, read_len = 5000;
+        int device = 0;
+        for (int i = 2; i < argc; ++i) {
+            if (strcmp(argv[i], "--index-file") == 0 && i + 1 < argc) index_file = argv[++i];
+            else if (strcmp(argv[i], "--genome-file") == 0 && i + 1 < argc) genome_file = argv[++i];
+            else if (strcmp(argv[i], "--reads") == 0 && i + 1 < argc) n_reads = strtoull(argv[++i], nullptr, 10);
+            else if (strcmp(argv[i], "--read-len") == 0 && i + 1 < argc) read_len = strtoull(argv[++i], nullptr, 10);
+            else if (strcmp(argv[i], "--gpu") == 0 && i + 1 < argc) device = atoi(argv[++i]);
+        }
+        if (index_file.empty() || genome_file.empty() || !file_exists(index_file) || !file_exists(genome_file) || !n_reads || !read_len)
+            die("usage: taxor verify --index-file <x.hixf> --genome-file <fasta of a genome contained in the index> [--reads n] [--read-len l]");
+        taxor_hixf *h = nullptr;
+        if (taxor_hixf_load(index_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
+        const taxor_hixf_view *view = taxor_hixf_get_view(h);
+        taxor_gpu_index *gi = nullptr;
+        if (taxor_gpu_index_create(view, device, &gi) != TAXOR_OK) die(taxor_gpu_last_error());
+        taxor_gpu_search_params prm{};
+        prm.ratio = 0.05;                                  // report every bin holding >= 5 % of a window's hashes
+        prm.model = TAXOR_THR_PERCENTAGE;
+        taxor_gpu_searcher *sr = nullptr;
+        if (taxor_gpu_searcher_create(gi, &prm, &sr) != TAXOR_OK) die(taxor_gpu_last_error());
+        // windows: evenly spaced over the concatenated records, never across a record boundary
+        std::string genome, id, bases;
+        std::vector<uint64_t> rec_off{0};
+        try {
+            fastx::FastxReader rd;
+            if (!rd.open(genome_file)) die("cannot open " + genome_file);
+            while (rd.next(id, genome)) rec_off.push_back(genome.size());
+        } catch (const std::exception &e) { die(e.what()); }
+        std::vector<uint64_t> offsets{0};
+        for (size_t r = 0; r + 1 < rec_off.size(); ++r) {
+            const uint64_t len = rec_off[r + 1] - rec_off[r];
+            if (len < read_len) continue;
+            const uint64_t want = std::max<uint64_t>(1, n_reads * len / std::max<uint64_t>(1, genome.size()));
+            const uint64_t step = std::max<uint64_t>(1, (len - read_len) / want);
+            for (uint64_t p = 0; p + read_len <= len && offsets.size() <= n_reads; p += step) {
+                bases.append(genome, rec_off[r] + p, read_len);
+                offsets.push_back(bases.size());
+            }
+        }
+        if (offsets.size() < 2) die("no record of the genome file is as long as --read-len");
+        taxor_gpu_results res{};
+        if (taxor_gpu_search_batch(sr, bases.data(), offsets.data(), offsets.size() - 1, &res) != TAXOR_OK) die(taxor_gpu_last_error());
+        std::vector<double> best;
+        std::map<int64_t, uint64_t> votes;
+        uint64_t hashes = 0;
+        for (uint64_t r = 0; r < res.n_reads; ++r) {
+            uint32_t top = 0;
+            int64_t top_bin = -1;
+            for (uint64_t i = res.read_off[r]; i < res.read_off[r + 1]; ++i)
+                if (res.count[i] > top) { top = res.count[i]; top_bin = res.user_bin[i]; }
+            if (res.n_hashes[r]) best.push_back((double)top / (double)res.n_hashes[r]);
+            if (top_bin >= 0) ++votes[top_bin];
+            hashes += res.n_hashes[r];
+        }
+        std::sort(best.begin(), best.end());
+        const double median = best.empty() ? 0.0 : best[best.size() / 2], low = best.empty() ? 0.0 : best[best.size() / 20];
+        int64_t winner = -1;
+        uint64_t winner_votes = 0;
+        for (const auto &kv : votes)
+            if (kv.second > winner_votes) { winner = kv.first; winner_votes = kv.second; }
+        printf("windows %llu x %llu bp, %.1f hashes per window (%s, k=%u)\n", (unsigned long long)res.n_reads, (unsigned long long)read_len,
+               res.n_reads ? (double)hashes / (double)res.n_reads : 0.0, view->use_syncmer ? "open syncmers" : "minimisers", (unsigned)view->kmer_size);
+        printf("best-bin match ratio: median %.4f, 5th percentile %.4f (false-positive floor %.4f)\n", median, low, 1.0 / 256.0);
+        if (winner >= 0) printf("most frequent best user bin: %lld (%llu of %llu windows)\n", (long long)winner, (unsigned long long)winner_votes, (unsigned long long)res.n_reads);
+        const bool pass = median >= 0.9 && low >= 0.5;
+        printf("%s\n", pass ? "PASS: the index answers for this genome -- hashing and IXF arithmetic match the file"
+                            : "FAIL: an indexed genome must match itself; check `taxor probe` (seed / stride / segment length) and the hash");
+        taxor_gpu_searcher_destroy(sr);
+        taxor_gpu_index_destroy(gi);
+        taxor_hixf_free(h);
+        return pass ? 0 : 2;
     }
     if (argc > 1 && strcmp(argv[1], "reads") == 0) {                       // reader check: id, length, FNV-1a of every record
         Config cfg;

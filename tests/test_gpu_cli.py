@@ -146,3 +146,28 @@ def test_cli_index_built_without_syncmers(tmp_path, k, w, msg):
         want += expected_lines(sp, rid, len(reads[i]), int(nh[i]), tup)
     assert open(out).read() == want
     assert want.count("\n") > 50 and "Organism" in want      # the control reads do classify
+
+
+def test_cli_verify_positive_control(tmp_path):
+    """`taxor verify`: windows of an indexed genome must match themselves; a foreign genome (or an index whose
+    arithmetic is read wrongly) must be reported as FAIL"""
+    g, go, host, sp, idx_path = _setup(tmp_path, 33)
+    inside, outside = tmp_path / "in.fa", tmp_path / "out.fa"
+    with open(inside, "wb") as f:
+        f.write(b">genome_2 first half\n" + bytes(g[int(go[2]):int(go[2]) + 7000]) + b"\n>genome_2 second half\n" + bytes(g[int(go[2]) + 7000:int(go[3])]) + b"\n")
+    rng = np.random.default_rng(1)
+    with open(outside, "wb") as f:
+        f.write(b">foreign\n" + bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=15000)) + b"\n")
+    cp = subprocess.run([TAXOR, "verify", "--index-file", str(idx_path), "--genome-file", str(inside), "--reads", "200", "--read-len", "1500"],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0 and "PASS" in cp.stdout, cp.stdout + cp.stderr
+    assert "median 1.0000" in cp.stdout
+    cp = subprocess.run([TAXOR, "verify", "--index-file", str(idx_path), "--genome-file", str(outside), "--reads", "200", "--read-len", "1500"],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 2 and "FAIL" in cp.stdout, cp.stdout + cp.stderr
+    # the same fingerprints declared with another k: every hash differs -> FAIL
+    wrong = tmp_path / "wrong_k.hixf"
+    store_hixf(wrong, host, len(sp) if False else max(s["user_bin"] for s in sp) + 1, sp, k=24, s=12, t=6)
+    cp = subprocess.run([TAXOR, "verify", "--index-file", str(wrong), "--genome-file", str(inside), "--reads", "200", "--read-len", "1500"],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 2 and "FAIL" in cp.stdout, cp.stdout + cp.stderr
