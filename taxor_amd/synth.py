@@ -194,6 +194,97 @@ def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_ele
     return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth)
 
 
+def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 130, 300), max_ixfs=12):
+    """A random HIXF around the planted hash sets, for differential tests: random tree shape, bin counts that are not
+    multiples of 16 or 64, planted and decoy split runs of random length at random positions (so that runs straddle
+    16-bin units and 64-bin rows), merged bins anywhere, empty bins.  Same return format as make_layout."""
+    planted = [np.unique(np.ascontiguousarray(p, dtype=np.uint64)) for p in planted]
+    todo = list(range(len(planted)))
+    rng.shuffle(todo)
+    next_ub = [0]
+    planted_ub = [None] * len(planted)
+    ixfs = []
+
+    def new_ub():
+        next_ub[0] += 1
+        return next_ub[0] - 1
+
+    def node(depth):
+        me = len(ixfs)
+        bins = int(rng.choice(bins_choices))
+        f = dict(bins=bins, stride=_stride(bins), keys={}, fname_idx=np.full(bins, -2, dtype=np.int64), child_of={})
+        ixfs.append(f)
+        b = 0
+        while b < bins:
+            role = rng.random()
+            left = bins - b
+            if role < 0.18 and todo:                                   # planted genome, possibly split over a run
+                pi = todo.pop()
+                run = int(min(left, rng.integers(1, 7)))
+                ub = new_ub()
+                planted_ub[pi] = ub
+                for j in range(run):
+                    f["keys"][b + j] = planted[pi][j::run]
+                    f["fname_idx"][b + j] = ub
+                b += run
+            elif role < 0.30 and depth < max_depth and len(ixfs) < max_ixfs:   # merged bin -> child
+                f["fname_idx"][b] = -1
+                f["child_of"][b] = node(depth + 1)
+                b += 1
+            elif role < 0.45:                                          # decoy split run (random fill, never prunable early)
+                run = int(min(left, rng.integers(2, 24)))
+                ub = new_ub()
+                for j in range(run):
+                    f["fname_idx"][b + j] = ub
+                b += run
+            else:                                                      # decoy leaf
+                f["fname_idx"][b] = new_ub()
+                b += 1
+        return me
+
+    node(1)
+    while todo:                                                        # genomes that found no place: root leaves, overwriting decoys
+        pi = todo.pop()
+        f = ixfs[0]
+        cand = [b for b in range(f["bins"]) if b not in f["keys"] and b not in f["child_of"] and
+                (b == 0 or f["fname_idx"][b - 1] != f["fname_idx"][b]) and (b + 1 == f["bins"] or f["fname_idx"][b + 1] != f["fname_idx"][b])]
+        if not cand:
+            break
+        b = int(rng.choice(cand))
+        f["keys"][b] = planted[pi]
+        planted_ub[pi] = int(f["fname_idx"][b])
+
+    def all_keys(i):
+        parts = [k for k in ixfs[i]["keys"].values()]
+        for ch in ixfs[i]["child_of"].values():
+            parts.append(all_keys(ch))
+        return np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+
+    for i in range(len(ixfs) - 1, -1, -1):
+        for bb, ch in ixfs[i]["child_of"].items():
+            ixfs[i]["keys"][bb] = all_keys(ch)
+    out = []
+    depth = [1]
+
+    def walk(i, d):
+        depth[0] = max(depth[0], d)
+        for ch in ixfs[i]["child_of"].values():
+            walk(ch, d + 1)
+
+    walk(0, 1)
+    for i, f in enumerate(ixfs):
+        mx = max([len(k) for k in f["keys"].values()] + [1])
+        seg = seg_len_for(int(mx * float(rng.uniform(1.0, 1.5))) + 1)
+        nonempty = {bb: k for bb, k in f["keys"].items() if len(k)}
+        sd, cols = build_columns(nonempty, seg, int(rng.integers(1, 2**63)))
+        nx = np.full(f["bins"], i, dtype=np.int64)
+        for bb, ch in f["child_of"].items():
+            nx[bb] = ch
+        out.append(dict(bins=f["bins"], stride=f["stride"], seg_len=seg, seed=sd, next_ixf=nx, fname_idx=f["fname_idx"],
+                        columns=cols, fill_seed=int(rng.integers(1, 2**63)), key_sets={}))
+    return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth[0])
+
+
 def materialize_host(layout):
     """Random-fill every IXF on the host and write the planted columns -> list usable by GpuIndex and by
     a checker (small layouts only: allocates rows*stride bytes per IXF)."""

@@ -1,0 +1,78 @@
+"""One randomized differential trial: random genomes, a random HIXF around them (taxor_amd.synth.random_layout), random
+reads and search parameters; the HIP path (through the C ABI) must equal the CPU oracle tuple for tuple.
+Used by tests/test_gpu_fuzz.py (fixed seeds) and profiles/fuzz_parity.py (as long as you like)."""
+import numpy as np
+
+from oracle import oracle as orc
+from taxor_amd import GpuIndex, Searcher, synth
+
+
+def _rand_read(rng, g, go, kind):
+    if kind == 0:      # junk
+        return bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 3000))))
+    if kind == 1:      # low complexity
+        u = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(1, 9))))
+        return (u * 600)[:int(rng.integers(10, 2500))]
+    gi = int(rng.integers(0, go.size - 1))   # piece of a genome, optionally with IUPAC codes sprinkled in
+    a = int(rng.integers(int(go[gi]), int(go[gi + 1]) - 50))
+    b = min(int(go[gi + 1]), a + int(rng.integers(30, 6000)))
+    r = bytearray(bytes(g[a:b]))
+    if kind == 3:
+        for p in rng.integers(0, len(r), size=max(1, len(r) // 100)):
+            r[int(p)] = int(rng.choice(np.frombuffer(b"NRYKMSWBDHVacgtn", np.uint8)))
+    return bytes(r)
+
+
+def run_trial(seed, verbose=False):
+    rng = np.random.default_rng(seed)
+    syncmer = rng.random() < 0.7
+    if syncmer:
+        k, s = [(22, 12), (16, 8), (20, 10), (28, 14), (30, 12), (22, 16), (24, 9)][int(rng.integers(0, 7))]
+        w = k - s + 1
+        t = int(rng.integers(1, w + 1)) if rng.random() < 0.3 else (w // 2 if w > 1 else 1)   # taxor_build.cpp:510 default
+        t = max(t, 1)
+        win = 0
+    else:
+        k = int(rng.choice([16, 20, 22, 31, 32]))
+        win = k if rng.random() < 0.5 else k + int(rng.integers(1, 30))
+        s = t = 0
+    scaling = int(rng.choice([1, 1, 1, 2, 5]))
+    n_gen = int(rng.integers(2, 8))
+    g, go = synth.random_genomes(n_gen, int(rng.integers(2000, 9000)), seed=int(rng.integers(1, 2**31)))
+    planted = []
+    for i in range(n_gen):
+        seq = bytes(g[int(go[i]):int(go[i + 1])])
+        hs = orc.seq_to_syncmers(seq, k, s, t) if syncmer else orc.minimiser_hash(seq, k, win)
+        if scaling > 1:
+            hs = np.array([h for h in hs.tolist() if float(orc.wyhash(h)) <= float(2**64 - 1) / float(scaling)], dtype=np.uint64)
+        planted.append(hs)
+    lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 5)))
+    host = synth.materialize_host(lay)
+    idx = GpuIndex(host, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling)
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    n_syn = int(rng.integers(20, 200))
+    bases, offs, origin = synth.synth_reads(g, go, n_syn, int(rng.integers(200, 4000)), error_rate=float(rng.choice([0.0, 0.01, 0.03, 0.08])),
+                                            frac_random=0.1, seed=int(rng.integers(1, 2**31)))
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(n_syn)]
+    reads += [_rand_read(rng, g, go, int(rng.integers(0, 4))) for _ in range(int(rng.integers(5, 60)))]
+    reads += [b"", b"A" * int(rng.integers(1, 80))]
+    order = rng.permutation(len(reads))
+    reads = [reads[int(i)] for i in order]
+    B = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, np.uint8)
+    O = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    Bn = np.frombuffer(orc.dna4_normalise(B.tobytes()), dtype=np.uint8)
+    pct = float(rng.choice([-1.0, -1.0, 0.05, 0.3, 0.6, 1.0]))
+    err = float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.2])) if syncmer else float(rng.choice([0.01, 0.04, 0.1, 0.3]))
+    sub = int(rng.choice([0, 1, 7, 64]))
+    cfg = dict(seed=seed, syncmer=syncmer, k=k, s=s, t=t, window=win, scaling=scaling, n_ixf=len(host), depth=lay["depth"],
+               bins=[f["bins"] for f in host][:6], reads=len(reads), pct=pct, err=err, sub=sub)
+    if verbose:
+        print(cfg, flush=True)
+    sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub)
+    res = sr.search_batch(B, O)
+    nh, off, ub, cnt, _ = h.search_batch(Bn, O, k=k, s=s, t=t, err=err, percentage=pct, threads=4, scaling=scaling, window=win)
+    ok = (np.array_equal(res.n_hashes, nh) and np.array_equal(res.read_off, off) and np.array_equal(res.user_bin, ub) and
+          np.array_equal(res.count, cnt))
+    sr.close()
+    idx.close()
+    return ok, cfg, int(off[-1])
