@@ -46,7 +46,12 @@ def run_trial(seed, verbose=False):
         if scaling > 1:
             hs = np.array([h for h in hs.tolist() if float(orc.wyhash(h)) <= float(2**64 - 1) / float(scaling)], dtype=np.uint64)
         planted.append(hs)
-    lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 5)))
+    heavy = rng.random() < 0.08      # wide rows (several block passes, > 32 alive units possible) and reads whose probes
+    #                                  do not fit the LDS staging area
+    if heavy:
+        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 3)), bins_choices=(64, 1000, 2049, 4096), max_ixfs=4)
+    else:
+        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 5)))
     host = synth.materialize_host(lay)
     idx = GpuIndex(host, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling)
     h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
@@ -56,6 +61,11 @@ def run_trial(seed, verbose=False):
     reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(n_syn)]
     reads += [_rand_read(rng, g, go, int(rng.integers(0, 4))) for _ in range(int(rng.integers(5, 60)))]
     reads += [b"", b"A" * int(rng.integers(1, 80))]
+    if heavy:
+        for _ in range(6):
+            gi = int(rng.integers(0, n_gen))
+            reads.append(bytes(g[int(go[gi]):int(go[gi + 1])]) * int(rng.integers(2, 6)))      # long, repeats -> duplicates
+        reads.append(bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=30000)))
     order = rng.permutation(len(reads))
     reads = [reads[int(i)] for i in order]
     B = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, np.uint8)
@@ -65,7 +75,7 @@ def run_trial(seed, verbose=False):
     err = float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.2])) if syncmer else float(rng.choice([0.01, 0.04, 0.1, 0.3]))
     sub = int(rng.choice([0, 1, 7, 64]))
     cfg = dict(seed=seed, syncmer=syncmer, k=k, s=s, t=t, window=win, scaling=scaling, n_ixf=len(host), depth=lay["depth"],
-               bins=[f["bins"] for f in host][:6], reads=len(reads), pct=pct, err=err, sub=sub)
+               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub)
     if verbose:
         print(cfg, flush=True)
     sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub)
