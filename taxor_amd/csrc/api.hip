@@ -632,10 +632,10 @@ int ensure_scratch(taxor_gpu_searcher *s)
     if (s->d_hits.reserve(s->hit_cap)) return TAXOR_E_HIP;
     if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R))
         return TAXOR_E_HIP;
-    // dedup scratch for reads whose table does not fit LDS (4096 slots)
-    uint64_t ts = 64;
-    while (ts < 2 * s->max_read_slots) ts <<= 1;
-    if (syncmer_mode && ts > 4096) {
+    // dedup scratch in global memory, only for reads that could select more syncmers than the LDS passes cover
+    if (syncmer_mode && s->max_read_slots > SYNC_LDS_DEDUP_MAX) {
+        uint64_t ts = 64;
+        while (ts < 2 * s->max_read_slots) ts <<= 1;
         if (ts > (1ull << 31)) return fail(TAXOR_E_ARG, "read too long for the dedup table");
         if (s->gtab_stride < ts) s->gtab_stride = (uint32_t)ts;
         if (s->d_gtab.reserve((size_t)s->gtab_stride * (size_t)s->grid_sync)) return TAXOR_E_HIP;

@@ -63,6 +63,9 @@ struct Counters {
 };
 static constexpr int MAX_LEVELS = 16;
 
+// reads with at most this many selected syncmers dedup in LDS (partitioned passes); longer ones need SyncmerArgs::gtab
+static constexpr uint32_t SYNC_LDS_DEDUP_MAX = 66816;
+
 struct SyncmerArgs {
     const uint32_t *packed;   // 2-bit bases, 16 per word, first base in the top bits
     const uint64_t *poff;     // word offset of read r

@@ -400,56 +400,122 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
         }
 
         // ---- per-read dedup (ankerl::unordered_dense::set semantics, syncmer.cpp:157-165): keep the first
-        //      occurrence of every hash, preserve first-insertion order -------------------------------
+        //      occurrence of every hash, preserve first-insertion order.
+        //      The 4096-slot LDS table takes the candidates in P = ceil(n_sel / 1536) passes, pass p holding the
+        //      hashes of partition p (by their high bits; equal hashes share a partition), so reads of any length up
+        //      to ~750 kb dedup in LDS -- a per-read table in global memory costs one L2 atomic per candidate, and a
+        //      sub-batch of long reads is then bound by the chip's atomic rate.  Duplicates are rare: a pass that
+        //      meets none skips its lookup sweep, and a read without any is copied straight out. ---------------
         uint32_t n_dist = 0;
         if (n_sel > 0) {
-            uint32_t ts = 64;
-            while (ts < 2u * n_sel) ts <<= 1;
-            uint32_t *tab;
-            if (ts <= (uint32_t)SY_LDS_TAB) tab = sTab;
-            else if (ts <= a.gtab_stride) tab = a.gtab + (size_t)blockIdx.x * a.gtab_stride;
-            else {
-                if (tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW);
-                tab = sTab;
-                ts = SY_LDS_TAB;
-                n_sel = min(n_sel, (uint32_t)SY_LDS_TAB / 2u);
-            }
-            const uint32_t mask = ts - 1u;
-            for (uint32_t i = tid; i < ts; i += BLK) tab[i] = 0xFFFFFFFFu;
-            __syncthreads();
             auto cand_at = [&](uint32_t i) -> uint64_t { return i < (uint32_t)SY_LDS_CAND ? sCand[i] : cand[i]; };
-            for (uint32_t i = tid; i < n_sel; i += BLK) {
-                const uint64_t h = cand_at(i);
-                uint32_t q = dedup_slot(h, mask);
-                for (;;) {
-                    const uint32_t cur = atomicCAS(&tab[q], 0xFFFFFFFFu, i);
-                    if (cur == 0xFFFFFFFFu) break;
-                    if (cand_at(cur) == h) { atomicMin(&tab[q], i); break; }
-                    q = (q + 1u) & mask;
+            uint32_t *const sDupBits = sV;                               // the s-mer tile is dead by now: 1 bit per candidate
+            static_assert((uint32_t)(SY_C * SY_RS) * 32u == SYNC_LDS_DEDUP_MAX, "dup-bit capacity");
+            const bool in_lds = n_sel <= SYNC_LDS_DEDUP_MAX;
+            bool any_dup = false;                                        // block-uniform
+            if (in_lds) {
+                const uint32_t P = (n_sel + 1535u) / 1536u;
+                const uint32_t mask = (uint32_t)SY_LDS_TAB - 1u;
+                for (uint32_t i = tid; i < (n_sel + 31u) / 32u; i += BLK) sDupBits[i] = 0u;
+                for (uint32_t p = 0; p < P; ++p) {
+                    for (uint32_t i = tid; i < (uint32_t)SY_LDS_TAB; i += BLK) sTab[i] = 0xFFFFFFFFu;
+                    if (tid == 0) { sScr[6] = 0u; sScr[7] = 0u; }
+                    __syncthreads();
+                    bool dup = false;
+                    uint32_t fresh = 0;
+                    for (uint32_t i = tid; i < n_sel; i += BLK) {
+                        const uint64_t h = cand_at(i);
+                        if (P > 1u && __umulhi((uint32_t)(h >> 32), P) != p) continue;
+                        uint32_t q = dedup_slot(h, mask);
+                        for (;;) {
+                            const uint32_t cur = atomicCAS(&sTab[q], 0xFFFFFFFFu, i);
+                            if (cur == 0xFFFFFFFFu) { ++fresh; break; }
+                            if (cand_at(cur) == h) { atomicMin(&sTab[q], i); dup = true; break; }
+                            q = (q + 1u) & mask;
+                        }
+                    }
+                    if (dup) sScr[6] = 1u;
+                    if (fresh) atomicAdd(&sScr[7], fresh);
+                    __syncthreads();
+                    const bool pass_dup = sScr[6] != 0u;
+                    if (sScr[7] > 3584u && tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW); // cannot happen for mixed hashes
+                    if (pass_dup) {
+                        any_dup = true;
+                        for (uint32_t i = tid; i < n_sel; i += BLK) {
+                            const uint64_t h = cand_at(i);
+                            if (P > 1u && __umulhi((uint32_t)(h >> 32), P) != p) continue;
+                            uint32_t q = dedup_slot(h, mask);
+                            for (;;) {
+                                const uint32_t cur = sTab[q];
+                                if (cur == 0xFFFFFFFFu) break; // cannot happen for an inserted key
+                                if (cand_at(cur) == h) {
+                                    if (cur != i) atomicOr(&sDupBits[i >> 5], 1u << (i & 31u));
+                                    break;
+                                }
+                                q = (q + 1u) & mask;
+                            }
+                        }
+                    }
+                    __syncthreads();
                 }
-            }
-            __syncthreads();
-            for (uint32_t base = 0; base < n_sel; base += BLK) {
-                const uint32_t i = base + tid;
-                uint64_t h = 0;
-                uint32_t first = 0;
-                if (i < n_sel) {
-                    h = cand_at(i);
+            } else {
+                // longer than ~750 kb: per-block table in global memory (one pass)
+                uint32_t ts = 64;
+                while (ts < 2u * n_sel) ts <<= 1;
+                uint32_t *tab = a.gtab + (size_t)blockIdx.x * a.gtab_stride;
+                if (ts > a.gtab_stride) {
+                    if (tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW);
+                    n_sel = 0;
+                    ts = 64;
+                    tab = sTab;
+                }
+                const uint32_t mask = ts - 1u;
+                for (uint32_t i = tid; i < ts; i += BLK) tab[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                for (uint32_t i = tid; i < n_sel; i += BLK) {
+                    const uint64_t h = cand_at(i);
                     uint32_t q = dedup_slot(h, mask);
                     for (;;) {
-                        const uint32_t cur = tab[q];
-                        if (cur == 0xFFFFFFFFu) break; // cannot happen for an inserted key
-                        if (cand_at(cur) == h) { first = (cur == i); break; }
+                        const uint32_t cur = atomicCAS(&tab[q], 0xFFFFFFFFu, i);
+                        if (cur == 0xFFFFFFFFu) break;
+                        if (cand_at(cur) == h) { atomicMin(&tab[q], i); break; }
                         q = (q + 1u) & mask;
                     }
-                    // FracMinHash down-sampling of a scaled index: a pure function of the hash, so filtering the
-                    // first occurrences equals filtering the reference's set (taxor_search.cpp:223-233)
-                    if (first && a.scaling_limit > 0.0 && !((double)wyhash_u64(h) <= a.scaling_limit)) first = 0;
                 }
-                uint32_t tot;
-                const uint32_t rank = block_excl_add(first, sScr, &tot);
-                if (first) outh[n_dist + rank] = h;
-                n_dist += tot;
+                __syncthreads();
+                any_dup = true;                                          // flags are evaluated from the table below
+            }
+            if (!any_dup && !(a.scaling_limit > 0.0)) {
+                for (uint32_t i = tid; i < n_sel; i += BLK) outh[i] = cand_at(i);
+                n_dist = n_sel;
+            } else {
+                const uint32_t gmask = in_lds ? 0u : [&] { uint32_t ts = 64; while (ts < 2u * n_sel) ts <<= 1; return ts - 1u; }();
+                const uint32_t *gtab = a.gtab + (size_t)blockIdx.x * a.gtab_stride;
+                for (uint32_t base = 0; base < n_sel; base += BLK) {
+                    const uint32_t i = base + tid;
+                    uint64_t h = 0;
+                    uint32_t first = 0;
+                    if (i < n_sel) {
+                        h = cand_at(i);
+                        if (in_lds) first = ((sDupBits[i >> 5] >> (i & 31u)) & 1u) ^ 1u;
+                        else {
+                            uint32_t q = dedup_slot(h, gmask);
+                            for (;;) {
+                                const uint32_t cur = gtab[q];
+                                if (cur == 0xFFFFFFFFu) break;
+                                if (cand_at(cur) == h) { first = (cur == i); break; }
+                                q = (q + 1u) & gmask;
+                            }
+                        }
+                        // FracMinHash down-sampling of a scaled index: a pure function of the hash, so filtering the
+                        // first occurrences equals filtering the reference's set (taxor_search.cpp:223-233)
+                        if (first && a.scaling_limit > 0.0 && !((double)wyhash_u64(h) <= a.scaling_limit)) first = 0;
+                    }
+                    uint32_t tot;
+                    const uint32_t rank = block_excl_add(first, sScr, &tot);
+                    if (first) outh[n_dist + rank] = h;
+                    n_dist += tot;
+                }
             }
         }
         if (tid == 0) {

@@ -105,13 +105,18 @@ def test_syncmers_vs_oracle_ragged_and_tie_heavy(kst):
     idx.close()
 
 
-def test_syncmers_long_reads_global_dedup_table():
-    """reads whose dedup table exceeds LDS (n_sel > 4096) take the global-memory table"""
+def test_syncmers_long_reads_partitioned_and_global_dedup():
+    """reads with more selected syncmers than one LDS table holds dedup in partitioned passes (with and without
+    duplicates); beyond ~750 kb the per-block table in global memory takes over"""
     rng = np.random.default_rng(11)
     unit = bytes(rng.choice(list(b"ACGT"), size=30000).astype(np.uint8))
+    mb = bytes(rng.choice(list(b"ACGT"), size=900000).astype(np.uint8))
     reads = [bytes(rng.choice(list(b"ACGT"), size=300000).astype(np.uint8)),
              unit * 6,                                   # every hash occurs 6 times
-             bytes(rng.choice(list(b"ACGT"), size=70000).astype(np.uint8))]
+             bytes(rng.choice(list(b"ACGT"), size=70000).astype(np.uint8)),
+             unit[:25000] + unit[:700] + unit[20000:],   # a few duplicates in a read of two passes
+             mb + mb[100000:400000],                     # 1.2 Mb: global table, with duplicates
+             bytes(rng.choice(list(b"ACGT"), size=18000).astype(np.uint8))]
     idx = _dummy_index()
     sr = Searcher(idx, ratio=0.5)
     hoff, hashes = sr.seq_to_syncmers(*_cat(reads))
