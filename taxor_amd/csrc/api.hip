@@ -6,6 +6,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1011,11 +1012,20 @@ extern "C" int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, 
                                       taxor_gpu_results *out)
 {
     // streamed: the bases of sub-batch i+1 are copied and packed while sub-batch i is being classified
+    static const bool trace = getenv("TAXOR_TRACE_BATCH") != nullptr;   // phase times of this call on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     if (int rc = prepare_batch(s, bases, offsets, n_reads, true)) return rc;
+    const double t_prep = ms_since(t0);
     // (page-locking the caller's buffer for the duration of the call was measured and is slower: the registration
     // costs more than the pageable staging it saves -- 55 vs 50 ms for 1.3 GB)
     if (int rc = run_pipeline(s, n_reads ? bases + offsets[0] : nullptr)) return rc;
-    return taxor_gpu_batch_fetch(s, out);
+    const double t_enq = ms_since(t0);
+    const int rc = taxor_gpu_batch_fetch(s, out);
+    if (trace)
+        fprintf(stderr, "[search_batch] %llu reads: layout+per-read arrays %.2f ms, pipeline enqueued (incl. blocking copies) at %.2f ms, "
+                        "results on the host at %.2f ms\n", (unsigned long long)n_reads, t_prep, t_enq, ms_since(t0));
+    return rc;
 }
 
 // =========================================================================================================
