@@ -334,7 +334,14 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
         t0 = time.perf_counter()
         h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=ncpu)
         extra = {"all_cores": {"value": round(int(offs[n]) / (time.perf_counter() - t0) / 1e6, 3), "cores": ncpu}}
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "")
+    except OSError:
+        pass
     return {**extra, "value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
+            "cpu_model": model, "hardware_threads": ncpu,
             "sample": f"first {n} of the step's reads ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
                       f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
 
