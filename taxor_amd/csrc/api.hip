@@ -596,11 +596,35 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
     // processing order inside each sub-batch: longest reads first (stable), so the dynamic work cursors hand out
     // the expensive items early and no long read is left alone at the tail of a launch
     order.resize(n_reads);
+    static const bool no_order = getenv("TAXOR_NO_ORDER") != nullptr; // A/B knob for measurements
+    std::vector<uint32_t> tmp;
     for (const SubBatch &sb : s->subs) {
         uint32_t *o = order.data() + sb.first;
+        const uint32_t *len = rlen.data() + sb.first;
         for (uint32_t i = 0; i < sb.n; ++i) o[i] = i;
-        if (!getenv("TAXOR_NO_ORDER")) // A/B knob for measurements
-            std::stable_sort(o, o + sb.n, [&](uint32_t a, uint32_t b) { return rlen[sb.first + a] > rlen[sb.first + b]; });
+        if (no_order || sb.n < 2) continue;
+        uint32_t lo = len[0], hi = len[0];
+        for (uint32_t i = 1; i < sb.n; ++i) { lo = std::min(lo, len[i]); hi = std::max(hi, len[i]); }
+        if (lo == hi) continue;                                       // equal lengths: input order is the order
+        if (sb.n < 4096) {
+            std::stable_sort(o, o + sb.n, [&](uint32_t a, uint32_t b) { return len[a] > len[b]; });
+            continue;
+        }
+        // stable LSD radix sort by descending length (two 16-bit digits of hi - len): O(n), this runs per batch on the
+        // host before anything is enqueued
+        tmp.resize(sb.n);
+        uint32_t *src = o, *dst = tmp.data();
+        for (int pass = 0; pass < 2; ++pass) {
+            const int shift = 16 * pass;
+            if (pass == 1 && ((hi - lo) >> 16) == 0) break;
+            static thread_local std::vector<uint32_t> cnt;
+            cnt.assign(65537, 0u);
+            for (uint32_t i = 0; i < sb.n; ++i) ++cnt[(((hi - len[src[i]]) >> shift) & 0xFFFFu) + 1];
+            for (uint32_t d = 0; d < 65536; ++d) cnt[d + 1] += cnt[d];
+            for (uint32_t i = 0; i < sb.n; ++i) dst[cnt[((hi - len[src[i]]) >> shift) & 0xFFFFu]++] = src[i];
+            std::swap(src, dst);
+        }
+        if (src != o) std::copy(src, src + sb.n, o);
     }
     s->packed_word_count = words + 16;
     s->packed_in_bytes = 0;
