@@ -73,6 +73,8 @@ typedef struct taxor_gpu_index taxor_gpu_index;
 
 int taxor_gpu_index_create(const taxor_hixf_view *view, int device, taxor_gpu_index **out);
 void taxor_gpu_index_destroy(taxor_gpu_index *idx);
+/* current hash seed of one IXF (construction on the device may have redrawn it) */
+uint64_t taxor_gpu_index_ixf_seed(const taxor_gpu_index *idx, uint64_t ixf);
 /* bytes of fingerprint data resident in HBM */
 uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx);
 /* number of leaf runs (= tuples a threshold-0 read produces) and IXF tree depth */
@@ -98,6 +100,13 @@ int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8
  * IXF carries *seed_out (also written into the resident index); *rounds_out = peeling rounds of the slowest chunk. */
 int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
                               uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out);
+/* The whole hierarchy at once (the back end of hierarchical_build.cpp:27-236): key_off[total_bins + 1] indexes `keys`
+ * per technical bin in the index's bin order (all bins of IXF 0, then IXF 1, ...); LEAF bins bring their keys
+ * (distinct within a bin; a split user bin brings one part per technical bin), MERGED bins bring none -- their key set
+ * is the union of everything in their child IXF, computed on the device (sort + unique), bottom-up.  Every IXF is
+ * then constructed as by taxor_gpu_index_build_ixf (its seed may be redrawn).  Unions are limited to 2^32 keys. */
+int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
+                               uint32_t *rounds_out);
 
 /* ------------------------------------------------------------------------------------------------
  * Searcher = one GPU-side "membership agent" + the per-read driver state.

@@ -72,6 +72,8 @@ SIGNATURES = {
     "taxor_gpu_last_error": (C.c_char_p, []),
     "taxor_gpu_index_create": (C.c_int, [C.POINTER(HixfView), C.c_int, C.POINTER(_P)]),
     "taxor_gpu_index_destroy": (None, [_P]),
+    "taxor_gpu_index_build_hixf": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "taxor_gpu_index_ixf_seed": (C.c_uint64, [_P, C.c_uint64]),
     "taxor_gpu_index_data_bytes": (C.c_uint64, [_P]),
     "taxor_gpu_gather_ceiling": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "taxor_gpu_index_leaf_runs": (C.c_uint64, [_P]),

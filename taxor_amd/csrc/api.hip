@@ -79,6 +79,7 @@ struct taxor_gpu_index {
     int k = 0, s = 0, t = 0;
     uint32_t scaling = 1;
     int w_min = 0;           // > 0: index built without --use-syncmer, minimiser window size (== k: every k-mer)
+    std::vector<uint32_t> h_binfo, h_bin_base;   // host copies for the hierarchical builder (bin_base has n_ixf + 1 entries)
 };
 
 struct SubBatch {
@@ -255,6 +256,10 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
             binfo[bb + b] = info;
         }
     }
+    idx->h_binfo = binfo;
+    idx->h_bin_base.resize(n + 1);
+    for (uint64_t i = 0; i < n; ++i) idx->h_bin_base[i] = idx->h_ixf[i].bin_base;
+    idx->h_bin_base[n] = (uint32_t)tb;
     {
         std::vector<uint8_t> seen(n, 0);
         struct Frame { uint64_t ixf, bin; uint32_t depth; };
@@ -345,6 +350,16 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_
     return 0;
 }
 
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_tree(taxor_gpu_index *idx, uint64_t *n_ixf, const uint32_t **bin_base,
+                                                                      const uint32_t **binfo)
+{
+    if (!idx) return -1;
+    *n_ixf = idx->h_ixf.size();
+    *bin_base = idx->h_bin_base.data();
+    *binfo = idx->h_binfo.data();
+    return 0;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed)
 {
     if (!idx || ixf >= idx->h_ixf.size()) return -1;
@@ -353,6 +368,10 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_
 }
 
 extern "C" uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx) { return idx ? idx->data_bytes : 0; }
+extern "C" uint64_t taxor_gpu_index_ixf_seed(const taxor_gpu_index *idx, uint64_t ixf)
+{
+    return idx && ixf < idx->h_ixf.size() ? idx->h_ixf[ixf].seed : 0;
+}
 extern "C" uint64_t taxor_gpu_index_leaf_runs(const taxor_gpu_index *idx) { return idx ? idx->leaf_runs : 0; }
 extern "C" uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx) { return idx ? idx->depth : 0; }
 

@@ -18,11 +18,17 @@
 //
 // The fingerprints differ from a sequential peel (any peeling order yields a valid filter); every key of every bin
 // matches, which is what the tests check through the query kernels and the CPU oracle.
+//
+// taxor_gpu_index_build_hixf builds a whole hierarchy bottom-up: the keys stay on the device, a merged bin's key set
+// is the sorted, duplicate-free union of everything in its child IXF (keyset.hip), and every IXF goes through the
+// same peeling.
 #include "../../include/taxor_gpu.h"
 #include "ixf_arith.h"
 #include "kernels.h"
+#include "keyset.h"
 
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -50,6 +56,19 @@ struct BuildArgs {
     uint64_t *st_slot;
     uint32_t *st_n;            // entries logged so far
 };
+
+// chunk-local bin of every key: off[nb+1] are the chunk's bin boundaries inside its contiguous key range
+__global__ __launch_bounds__(BB) void k_build_key_bin(const uint64_t *off, uint32_t nb, uint64_t n_keys, uint32_t *key_bin)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n_keys; i += (uint64_t)gridDim.x * BB) {
+        uint32_t lo = 0, hi = nb;                     // last bin whose start is <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (off[mid] <= i) lo = mid; else hi = mid;
+        }
+        key_bin[i] = lo;
+    }
+}
 
 __global__ __launch_bounds__(BB) void k_build_count(const BuildArgs a)
 {
@@ -180,9 +199,13 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_
                                                                           int *device);
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed);
 
-extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
-                                         uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out)
+namespace {
+
+// d_keys: the bins' key lists concatenated ON THE DEVICE (distinct within a bin); key_off[bins+1] on the host
+int build_ixf_device(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *d_all_keys, const uint64_t *key_off, uint64_t seed0,
+                     uint64_t *seed_out, uint32_t *rounds_out)
 {
+    const uint64_t *keys = d_all_keys;
     uint8_t *data = nullptr;
     uint64_t stride = 0, seg_len = 0, bins = 0;
     int device = 0;
@@ -209,11 +232,11 @@ extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, con
     if (chunk_bins * rows >= (1ull << 32)) chunk_bins = std::max<uint64_t>(1, ((1ull << 32) - 1) / rows); // work-list counters are u32
 
     uint32_t *d_cnt = nullptr, *d_key_bin = nullptr, *d_ctr = nullptr, *d_bin_ids = nullptr;
-    uint64_t *d_xr = nullptr, *d_wl0 = nullptr, *d_wl1 = nullptr, *d_keys = nullptr, *d_st_key = nullptr, *d_st_slot = nullptr;
+    uint64_t *d_xr = nullptr, *d_wl0 = nullptr, *d_wl1 = nullptr, *d_st_key = nullptr, *d_st_slot = nullptr, *d_off = nullptr;
     uint8_t *d_single = nullptr;
     auto cleanup = [&] {
         for (void *p : {(void *)d_cnt, (void *)d_key_bin, (void *)d_ctr, (void *)d_bin_ids, (void *)d_xr, (void *)d_wl0, (void *)d_wl1,
-                        (void *)d_keys, (void *)d_st_key, (void *)d_st_slot, (void *)d_single})
+                        (void *)d_st_key, (void *)d_st_slot, (void *)d_single, (void *)d_off})
             if (p) (void)hipFree(p);
     };
     const uint64_t n_slots_max = chunk_bins * rows;
@@ -224,6 +247,7 @@ extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, con
     B_TRY(hipMalloc((void **)&d_wl1, n_slots_max * 8));
     B_TRY(hipMalloc((void **)&d_ctr, 64));
     B_TRY(hipMalloc((void **)&d_bin_ids, chunk_bins * 4));
+    B_TRY(hipMalloc((void **)&d_off, (chunk_bins + 1) * 8));
 
     uint64_t seed = seed0;
     uint32_t max_rounds = 0;
@@ -231,23 +255,20 @@ extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, con
         bool failed = false;
         for (size_t c0 = 0; c0 < work.size() && !failed; c0 += chunk_bins) {
             const size_t nb = std::min<size_t>(chunk_bins, work.size() - c0);
-            // gather the chunk's keys
-            std::vector<uint64_t> hk;
-            std::vector<uint32_t> hb;
-            for (size_t i = 0; i < nb; ++i) {
-                const uint32_t b = work[c0 + i];
-                hk.insert(hk.end(), keys + key_off[b], keys + key_off[b + 1]);
-                hb.insert(hb.end(), key_off[b + 1] - key_off[b], (uint32_t)i);
-            }
-            const uint64_t nk = hk.size();
+            // bins are taken in bin order, and bins without keys have empty ranges: the chunk's keys are one contiguous
+            // range of the concatenated device array
+            const uint64_t k0 = key_off[work[c0]], nk = key_off[work[c0 + nb - 1] + 1] - k0;
+            const uint64_t *d_keys = keys + k0;
+            std::vector<uint64_t> hoff(nb + 1);
+            for (size_t i = 0; i < nb; ++i) hoff[i] = key_off[work[c0 + i]] - k0;
+            hoff[nb] = nk;
             if (nk >= (1ull << 32)) { cleanup(); return bfail(TAXOR_E_ARG, "build_ixf: more than 2^32 keys in one chunk of bins"); }
-            if (d_keys) { (void)hipFree(d_keys); (void)hipFree(d_key_bin); (void)hipFree(d_st_key); (void)hipFree(d_st_slot); d_keys = nullptr; d_key_bin = nullptr; d_st_key = nullptr; d_st_slot = nullptr; }
-            B_TRY(hipMalloc((void **)&d_keys, nk * 8));
+            if (d_key_bin) { (void)hipFree(d_key_bin); (void)hipFree(d_st_key); (void)hipFree(d_st_slot); d_key_bin = nullptr; d_st_key = nullptr; d_st_slot = nullptr; }
             B_TRY(hipMalloc((void **)&d_key_bin, nk * 4));
             B_TRY(hipMalloc((void **)&d_st_key, nk * 8));
             B_TRY(hipMalloc((void **)&d_st_slot, nk * 8));
-            B_TRY(hipMemcpy(d_keys, hk.data(), nk * 8, hipMemcpyHostToDevice));
-            B_TRY(hipMemcpy(d_key_bin, hb.data(), nk * 4, hipMemcpyHostToDevice));
+            B_TRY(hipMemcpy(d_off, hoff.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_build_key_bin, dim3(2048), dim3(BB), 0, nullptr, d_off, (uint32_t)nb, nk, d_key_bin);
             B_TRY(hipMemcpy(d_bin_ids, work.data() + c0, nb * 4, hipMemcpyHostToDevice));
             const uint64_t n_slots = nb * rows;
             B_TRY(hipMemset(d_cnt, 0, n_slots * 4));
@@ -311,4 +332,119 @@ extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, con
     }
     cleanup();
     return bfail(TAXOR_E_INTERNAL, "build_ixf: no seed peeled every bin in 32 attempts (duplicate keys inside a bin?)");
+}
+
+} // namespace
+
+extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
+                                         uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out)
+{
+    uint8_t *data = nullptr;
+    uint64_t stride = 0, seg_len = 0, bins = 0;
+    int device = 0;
+    if (!idx || !key_off || taxor_index_ixf_info(idx, ixf, &data, &stride, &seg_len, &bins, &device))
+        return bfail(TAXOR_E_ARG, "build_ixf: bad index / IXF id");
+    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_ixf: hipSetDevice failed");
+    const uint64_t total = key_off[bins] - key_off[0];
+    if (total && !keys) return bfail(TAXOR_E_ARG, "build_ixf: null keys");
+    uint64_t *d_keys = nullptr;
+    if (total) {
+        if (hipMalloc((void **)&d_keys, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_ixf: no device memory for the keys");
+        if (hipMemcpy(d_keys, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_keys);
+            return bfail(TAXOR_E_HIP, "build_ixf: key upload failed");
+        }
+    }
+    std::vector<uint64_t> off(bins + 1);
+    for (uint64_t b = 0; b <= bins; ++b) off[b] = key_off[b] - key_off[0];
+    const int rc = build_ixf_device(idx, ixf, d_keys, off.data(), seed0, seed_out, rounds_out);
+    if (d_keys) (void)hipFree(d_keys);
+    return rc;
+}
+
+// library-internal: tree of the resident index (api.hip)
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_tree(taxor_gpu_index *idx, uint64_t *n_ixf, const uint32_t **bin_base,
+                                                                      const uint32_t **binfo);
+
+extern "C" int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
+                                          uint32_t *rounds_out)
+{
+    uint64_t n_ixf = 0;
+    const uint32_t *bin_base = nullptr, *binfo = nullptr;
+    if (!idx || !key_off || taxor_index_tree(idx, &n_ixf, &bin_base, &binfo)) return bfail(TAXOR_E_ARG, "build_hixf: bad index");
+    uint8_t *data = nullptr;
+    uint64_t stride = 0, seg_len = 0, bins = 0;
+    int device = 0;
+    taxor_index_ixf_info(idx, 0, &data, &stride, &seg_len, &bins, &device);
+    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_hixf: hipSetDevice failed");
+    const uint64_t total_bins = bin_base[n_ixf];
+    for (uint64_t g = 0; g < total_bins; ++g) {
+        if (key_off[g + 1] < key_off[g]) return bfail(TAXOR_E_ARG, "build_hixf: key_off not monotone");
+        if ((binfo[g] & BINFO_MERGED) && key_off[g + 1] != key_off[g])
+            return bfail(TAXOR_E_ARG, "build_hixf: a merged bin must not bring keys of its own (they come from its child)");
+    }
+    const uint64_t total = key_off[total_bins] - key_off[0];
+    if (total && !keys) return bfail(TAXOR_E_ARG, "build_hixf: null keys");
+    uint64_t *d_leaf = nullptr;
+    if (total) {
+        if (hipMalloc((void **)&d_leaf, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys");
+        if (hipMemcpy(d_leaf, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_leaf);
+            return bfail(TAXOR_E_HIP, "build_hixf: key upload failed");
+        }
+    }
+    uint32_t max_rounds = 0;
+    std::string err;
+    int err_code = TAXOR_OK;
+    struct DevKeys { uint64_t *p = nullptr; uint64_t n = 0; };
+    // post-order: children first; returns the union of everything below IXF i (not needed for the root)
+    std::function<bool(uint64_t, bool, DevKeys *)> build = [&](uint64_t i, bool want_union, DevKeys *out) -> bool {
+        taxor_index_ixf_info(idx, i, &data, &stride, &seg_len, &bins, &device);
+        const uint64_t nb = bins, g0 = bin_base[i];
+        std::vector<DevKeys> child(nb);
+        std::vector<uint64_t> off(nb + 1, 0);
+        bool ok = true;
+        for (uint64_t b = 0; b < nb && ok; ++b) {
+            if (binfo[g0 + b] & BINFO_MERGED) ok = build(binfo[g0 + b] & 0x3FFFFFFFu, true, &child[b]);
+            off[b + 1] = off[b] + ((binfo[g0 + b] & BINFO_MERGED) ? child[b].n : key_off[g0 + b + 1] - key_off[g0 + b]);
+        }
+        uint64_t *d_all = nullptr;
+        if (ok && off[nb]) {
+            if (hipMalloc((void **)&d_all, off[nb] * 8) != hipSuccess) { err = "build_hixf: no device memory for the keys of one IXF"; err_code = TAXOR_E_NOMEM; ok = false; }
+            for (uint64_t b = 0; b < nb && ok;) {              // runs of leaf bins are contiguous in the caller's array
+                if (binfo[g0 + b] & BINFO_MERGED) {
+                    if (child[b].n && hipMemcpyAsync(d_all + off[b], child[b].p, child[b].n * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) ok = false;
+                    ++b;
+                } else {
+                    uint64_t e = b;
+                    while (e < nb && !(binfo[g0 + e] & BINFO_MERGED)) ++e;
+                    const uint64_t n = off[e] - off[b];
+                    if (n && hipMemcpyAsync(d_all + off[b], d_leaf + (key_off[g0 + b] - key_off[0]), n * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) ok = false;
+                    b = e;
+                }
+            }
+            if (!ok && err.empty()) { err = "build_hixf: device copy failed"; err_code = TAXOR_E_HIP; }
+            if (ok && hipDeviceSynchronize() != hipSuccess) { err = "build_hixf: device copy failed"; err_code = TAXOR_E_HIP; ok = false; }
+        }
+        for (auto &c : child)
+            if (c.p) (void)hipFree(c.p);
+        if (ok) {
+            uint64_t seed = 0;
+            uint32_t rounds = 0;
+            const int rc = build_ixf_device(idx, i, d_all, off.data(), seed0 + 0x9E3779B97F4A7C15ull * i, &seed, &rounds);
+            if (rc != TAXOR_OK) { err_code = rc; ok = false; }     // message already set
+            max_rounds = std::max(max_rounds, rounds);
+        }
+        if (ok && want_union && off[nb]) {
+            const hipError_t e = sort_unique_u64(d_all, off[nb], &out->p, &out->n, nullptr);
+            if (e != hipSuccess) { err = std::string("build_hixf: key union failed: ") + hipGetErrorString(e); err_code = TAXOR_E_HIP; ok = false; }
+        }
+        if (d_all) (void)hipFree(d_all);
+        return ok;
+    };
+    const bool ok = build(0, false, nullptr);
+    if (d_leaf) (void)hipFree(d_leaf);
+    if (rounds_out) *rounds_out = max_rounds;
+    if (!ok) return err.empty() ? err_code : bfail(err_code, err);
+    return TAXOR_OK;
 }

@@ -148,6 +148,25 @@ class GpuIndex:
                                                    C.byref(seed), C.byref(rounds)))
         return int(seed.value), int(rounds.value)
 
+    def build_hixf(self, leaf_keys, seed0=1):
+        """GPU construction of the whole hierarchy: leaf_keys = {(ixf, bin): uint64 keys} for leaf bins only; merged
+        bins receive the union of their child IXF on the device.  Returns the number of peeling rounds of the slowest IXF."""
+        parts, sizes = [], []
+        for i, (bins, _, _) in enumerate(self.shapes):
+            for b in range(bins):
+                k = np.ascontiguousarray(leaf_keys.get((i, b), np.zeros(0, np.uint64)), dtype=np.uint64)
+                parts.append(k)
+                sizes.append(k.size)
+        off = np.zeros(len(sizes) + 1, dtype=np.uint64)
+        np.cumsum(np.array(sizes, dtype=np.uint64), out=off[1:])
+        keys = np.concatenate(parts) if parts else np.zeros(0, np.uint64)
+        rounds = C.c_uint32()
+        check(_lib.lib().taxor_gpu_index_build_hixf(self._h, _p(keys) if keys.size else None, _p(off), int(seed0), C.byref(rounds)))
+        return int(rounds.value)
+
+    def ixf_seed(self, ixf):
+        return int(_lib.lib().taxor_gpu_index_ixf_seed(self._h, ixf))
+
     def download_ixf(self, ixf):
         bins, stride, seg = self.shapes[ixf]
         out = np.empty(3 * seg * stride, dtype=np.uint8)

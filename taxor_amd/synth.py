@@ -260,6 +260,8 @@ def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 1
             parts.append(all_keys(ch))
         return np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
 
+    for f in ixfs:                                                     # what a build front end hands to the builder
+        f["leaf_keys"] = {bb: k for bb, k in f["keys"].items() if len(k)}
     for i in range(len(ixfs) - 1, -1, -1):
         for bb, ch in ixfs[i]["child_of"].items():
             ixfs[i]["keys"][bb] = all_keys(ch)
@@ -281,7 +283,7 @@ def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 1
         for bb, ch in f["child_of"].items():
             nx[bb] = ch
         out.append(dict(bins=f["bins"], stride=f["stride"], seg_len=seg, seed=sd, next_ixf=nx, fname_idx=f["fname_idx"],
-                        columns=cols, fill_seed=int(rng.integers(1, 2**63)), key_sets={}))
+                        columns=cols, fill_seed=int(rng.integers(1, 2**63)), key_sets={}, leaf_keys=f["leaf_keys"]))
     return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth[0])
 
 

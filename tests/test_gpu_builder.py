@@ -118,3 +118,91 @@ def test_layout_built_on_gpu_equals_oracle_search():
     assert hit > 0.8 * (origin >= 0).sum()
     sr.close()
     idx.close()
+
+
+def _tree_layout(rng, n_genomes=10, glen=5000):
+    """random hierarchy with LEAF key sets only (what a build front end hands over after the layout step)"""
+    g, go = synth.random_genomes(n_genomes, glen, seed=int(rng.integers(1, 2**31)))
+    planted = [orc.seq_to_syncmers(bytes(g[int(go[i]):int(go[i + 1])])) for i in range(n_genomes)]
+    while True:     # a hierarchy worth building: several IXFs, most genomes placed
+        lay = synth.random_layout(planted, rng, max_depth=4)
+        if len(lay["ixfs"]) >= 3 and sum(p is not None for p in lay["planted_user_bin"]) >= n_genomes - 2:
+            return g, go, planted, lay
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_hierarchical_build_on_gpu(seed):
+    """taxor_gpu_index_build_hixf: leaf key sets in, merged bins = union of their child IXF computed on the device,
+    every IXF peeled on the device.  Checked three ways: every leaf key is found in its bin and in the merged bin of
+    every ancestor (oracle on the downloaded bytes), searches agree with the oracle, and with a host-built index of
+    the same layout they report the same user bins for the control reads."""
+    rng = np.random.default_rng(seed)
+    g, go, planted, lay = _tree_layout(rng)
+    ix = lay["ixfs"]
+    # leaf keys per (ixf, bin) from the layout's columns' key sets: rebuild them from the planted assignment
+    leaf = {}
+    for i, f in enumerate(ix):
+        for b, keys in f.get("leaf_keys", {}).items():
+            leaf[(i, b)] = keys
+    assert leaf, "layout carries no leaf keys"
+    # rows sized for the unions: merged bins hold whole subtrees
+    def subtree_keys(i):
+        ks = [k for (ii, b), k in leaf.items() if ii == i]
+        for b in range(ix[i]["bins"]):
+            if ix[i]["fname_idx"][b] == -1:
+                ks.append(subtree_keys(int(ix[i]["next_ixf"][b])))
+        return np.unique(np.concatenate(ks)) if ks else np.zeros(0, np.uint64)
+    shapes = []
+    for i, f in enumerate(ix):
+        biggest = max([len(k) for (ii, b), k in leaf.items() if ii == i] +
+                      [len(subtree_keys(int(f["next_ixf"][b]))) for b in range(f["bins"]) if f["fname_idx"][b] == -1] + [1])
+        shapes.append(dict(bins=f["bins"], stride=f["stride"], seg_len=synth.seg_len_for(biggest), seed=7 + i,
+                           next_ixf=f["next_ixf"], fname_idx=f["fname_idx"], data=None))
+    idx = GpuIndex(shapes, lay["n_user_bins"])
+    for i in range(len(shapes)):
+        idx.fill_random(i, 100 + i)
+    rounds = idx.build_hixf(leaf, seed0=11)
+    assert rounds >= 1
+    host = [dict(s, seed=idx.ixf_seed(i), data=idx.download_ixf(i)) for i, s in enumerate(shapes)]
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    # (1) membership: leaf keys in their bin, and in the merged bin of the parent, grandparent, ...
+    parent = {}
+    for i, f in enumerate(host):
+        for b in range(f["bins"]):
+            if f["fname_idx"][b] == -1:
+                parent[int(f["next_ixf"][b])] = (i, b)
+    for (i, b), keys in leaf.items():
+        cnt = h.ixf_bulk_count(i, keys)
+        assert cnt[b] == len(keys)
+        node = i
+        while node in parent:
+            pi, pb = parent[node]
+            assert h.ixf_bulk_count(pi, keys)[pb] == len(keys), (i, b, pi, pb)
+            node = pi
+    # (2) search parity on the GPU-built index, (3) control reads classify
+    bases, offs, origin = synth.synth_reads(g, go, 200, 1500, error_rate=0.01, frac_random=0.1, seed=seed)
+    sr = Searcher(idx, error_rate=0.04)
+    res = sr.search_batch(bases, offs)
+    Bn = np.frombuffer(orc.dna4_normalise(bases.tobytes()), dtype=np.uint8)
+    nh, off, ub, cnt, _ = h.search_batch(Bn, offs, threads=4)
+    assert np.array_equal(res.read_off, off) and np.array_equal(res.user_bin, ub) and np.array_equal(res.count, cnt)
+    hit = tot = 0
+    for r in range(200):
+        if origin[r] >= 0 and lay["planted_user_bin"][origin[r]] is not None:
+            tot += 1
+            hit += lay["planted_user_bin"][origin[r]] in ub[int(off[r]):int(off[r + 1])].tolist()
+    assert tot > 50 and hit > 0.8 * tot, (hit, tot)
+    sr.close()
+    idx.close()
+
+
+def test_hierarchical_build_rejects_keys_on_merged_bins():
+    nx = np.array([1, 0, 0, 0], dtype=np.int64)
+    fn = np.array([-1, 0, 1, 2], dtype=np.int64)
+    shapes = [dict(bins=4, stride=64, seg_len=64, seed=1, next_ixf=nx, fname_idx=fn, data=None),
+              dict(bins=4, stride=64, seg_len=64, seed=2, next_ixf=np.full(4, 1, np.int64), fname_idx=np.array([3, 4, 5, 6], np.int64), data=None)]
+    idx = GpuIndex(shapes, 7)
+    with pytest.raises(TaxorError):
+        idx.build_hixf({(0, 0): np.arange(5, dtype=np.uint64)})
+    idx.build_hixf({(1, 1): np.arange(1, 40, dtype=np.uint64), (0, 2): np.arange(100, 130, dtype=np.uint64)})
+    idx.close()
