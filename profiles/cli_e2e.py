@@ -59,6 +59,33 @@ for extra in configs:
     print(" ".join(extra) or "(default batch)", "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end")
     print(cp.stdout.strip().replace("\n", " | "))
     print(cp.stderr.strip()[:1500])
+# gzip input: one stream inflates on one thread, several files inflate concurrently
+n_gz = 8
+per = n_reads // 5 // n_gz            # a fifth of the reads, in eight files
+parts = []
+for j in range(n_gz):
+    pth = os.path.join(tmp, f"part{j}.fastq")
+    with open(pth, "wb") as f:
+        for i in range(j * per, (j + 1) * per):
+            f.write(b"@read_%d\n" % i)
+            f.write(bb[i * read_len:(i + 1) * read_len])
+            f.write(b"\n+\n")
+            f.write(qual)
+            f.write(b"\n")
+    parts.append(pth)
+procs = [subprocess.Popen(["gzip", "-1", "-f", pth]) for pth in parts]
+for pr in procs:
+    pr.wait()
+gz = [pth + ".gz" for pth in parts]
+subprocess.run("cat " + " ".join(gz) + " > " + os.path.join(tmp, "all.fastq.gz"), shell=True, check=True)
+gz_bases = n_gz * per * read_len
+for label, qf in (("one gzip file (8 members)", os.path.join(tmp, "all.fastq.gz")), ("eight gzip files", ",".join(gz))):
+    t0 = time.time()
+    cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", qf,
+                         "--output-file", out, "--threads", "32"], capture_output=True, text=True)
+    dt = time.time() - t0
+    print(label, "rc", cp.returncode, f"wall {dt:.2f}s -> {gz_bases/dt/1e6:.0f} Mbp/s end to end")
+    print(cp.stdout.strip().replace("\n", " | "))
 lines = sum(1 for _ in open(out))
 print("tsv lines", lines)
 subprocess.run(["rm", "-rf", tmp])

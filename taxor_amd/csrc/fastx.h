@@ -1,12 +1,15 @@
 // fastx.h -- FASTA / FASTQ record readers feeding `taxor search` (the reference reads its queries with
 // seqan3::sequence_file_input, src/main/taxor_search.cpp:181-184,315-321: ids are the full header line, sequences
 // are dna4).  Two sources produce the same numbered batches of records:
-//   * FastxReader       : sequential, over zlib (plain or .gz, any stream);
+//   * FastxReader       : sequential, over zlib (plain or .gz, any stream); a multi-member gzip file is inflated
+//                         by several threads underneath (gzmembers.h) and parsed by one;
 //   * RangedFastx       : a plain file cut into byte ranges that start at record boundaries; each range is read
 //                         (pread into a small per-thread buffer: no page-table traffic) and parsed by its own
 //                         FastxReader, as many at a time as --threads allows.
 // Errors are thrown as std::runtime_error.
 #pragma once
+
+#include "gzmembers.h"
 
 #include <zlib.h>
 
@@ -26,7 +29,9 @@ namespace fastx {
 
 // one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
 struct Batch {
-    uint64_t seq = 0;   // position of this chunk in the input
+    uint64_t seq = 0;   // position of this chunk in its query file
+    uint32_t file = 0;  // position of the query file in --query-file
+    bool end_of_file = false;   // marker that follows the last chunk of a file (seq = number of chunks), carries no records
     std::vector<std::string> ids;
     std::string bases;
     std::vector<uint64_t> offsets;
@@ -49,6 +54,7 @@ struct FastxReader {
     std::string pending; // header line read ahead (FASTA)
     int fd = -1;         // range mode: bytes [rpos, rend) of a plain file, read with pread
     uint64_t rpos = 0, rend = 0;
+    GzMembers *members = nullptr;   // multi-member gzip inflated in parallel (gzmembers.h)
 
     void open_range(int fd_, uint64_t b, uint64_t e)
     {
@@ -72,7 +78,9 @@ struct FastxReader {
     {
         if (eof) return false;
         long n;
-        if (fd >= 0) {
+        if (members) {
+            n = (long)members->read(buf.data(), buf.size());
+        } else if (fd >= 0) {
             const uint64_t want = std::min<uint64_t>(buf.size(), rend - rpos);
             n = want ? (long)pread(fd, buf.data(), want, (off_t)rpos) : 0;
             if (n > 0) rpos += (uint64_t)n;

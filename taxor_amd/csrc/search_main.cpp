@@ -8,6 +8,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -154,8 +155,24 @@ void trace(const char *what)
 // the next byte range of about cfg.batch_reads records; anything else (gzip, pipes) goes through the sequential
 // zlib reader, which cuts batches at exactly cfg.batch_reads records.  Returns the wall time spent producing.
 double produce_batches(const std::string &query, const Config &cfg, bool allow_ranges, BatchPool &pool,
-                       const std::function<void(std::unique_ptr<Batch>)> &push)
+                       const std::function<void(std::unique_ptr<Batch>)> &push_, uint32_t file = 0, unsigned parse_threads = 0,
+                       const std::function<void()> &gate = nullptr)
 {
+    std::atomic<uint64_t> n_pushed{0};
+    auto push = [&](std::unique_ptr<Batch> b) {
+        b->file = file;
+        b->end_of_file = false;
+        ++n_pushed;
+        push_(std::move(b));
+    };
+    auto finish = [&] {      // tells the consumer how many chunks this file had
+        auto m = std::make_unique<Batch>();
+        m->file = file;
+        m->seq = n_pushed.load();
+        m->end_of_file = true;
+        m->offsets.assign(1, 0);
+        push_(std::move(m));
+    };
     const double t_begin = now();
     double blocked = 0;   // time the sequential reader spent waiting for the consumers
     fastx::RangedFastx rf;
@@ -166,7 +183,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
     if (ranged) {
         if (cfg.batch_reads) rf.plan(cfg.batch_reads, std::min<uint64_t>(cfg.batch_bases, 1ull << 30));
         else rf.range_bytes = rf.kind == '@' ? (128u << 20) : (64u << 20);
-        const unsigned nt = std::max(1u, std::min(cfg.threads, 16u));
+        const unsigned nt = parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, 16u));
         std::vector<std::thread> th;
         for (unsigned t = 0; t < nt; ++t)
             th.emplace_back([&] {
@@ -174,6 +191,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                 std::string id;
                 uint64_t b, e, seq;
                 for (;;) {
+                    if (gate) gate();
                     auto bt = pool.get();                   // buffer first: ranges are then taken in the order they can be filled
                     try {
                         if (!rf.next_range(b, e, seq)) { pool.put(std::move(bt)); break; }
@@ -198,16 +216,26 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                 }
             });
         for (auto &t : th) t.join();
+        finish();
         return now() - t_begin;
     }
     fastx::FastxReader rd;
-    if (!rd.open(query)) die("cannot open query file " + query);
+    fastx::GzMembers members;
+    bool multi = false;
+    try {
+        multi = allow_ranges && members.open(query, parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, 16u)));
+    } catch (const std::exception &ex) { die(ex.what()); }
+    if (multi) {
+        rd.members = &members;
+        rd.buf.resize(8u << 20);
+    } else if (!rd.open(query)) die("cannot open query file " + query);
     std::string id;
     bool more = true;
     uint64_t seq = 0;
     const uint64_t batch_reads = cfg.batch_reads ? cfg.batch_reads : 65536;
     try {
         while (more) {
+            if (gate) gate();
             auto b = pool.get();
             b->seq = seq++;
             b->ids.clear();
@@ -223,6 +251,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             blocked += now() - t1;
         }
     } catch (const std::exception &ex) { die(ex.what()); }
+    finish();
     return now() - t_begin - blocked;
 }
 
@@ -348,6 +377,7 @@ int main(int argc, char **argv)
         BatchPool pool;
         pool.cap = ~size_t(0);                                        // this check keeps every batch
         const double dt = produce_batches(cfg.query_file, cfg, allow_ranges, pool, [&](std::unique_ptr<Batch> b) {
+            if (b->end_of_file) return;
             std::lock_guard<std::mutex> lk(mu);
             got.emplace(b->seq, std::move(b));
         });
@@ -442,144 +472,197 @@ int main(int argc, char **argv)
     uint64_t n_batches = 0;
     uint64_t total_reads = 0, total_bases = 0;
     std::mutex stat_mu;
-    for (const auto &query : query_files) {
-        for (const auto &hixf_file : index_files) {                        // :344-358
-            double t0 = now();
-            taxor_hixf *h = nullptr;
-            if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
-            trace("index file loaded");
-            const taxor_hixf_view *view = taxor_hixf_get_view(h);
-            // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
-            // replicated, batches are sharded); replicas are uploaded concurrently
-            const size_t ng = cfg.gpus.size();
-            std::vector<taxor_gpu_index *> gidx(ng, nullptr);
-            {
-                std::vector<std::thread> up;
-                std::vector<std::string> errs(ng);
-                for (size_t g = 0; g < ng; ++g)
-                    up.emplace_back([&, g] {
-                        if (taxor_gpu_index_create(view, cfg.gpus[g], &gidx[g]) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
-                    });
-                for (auto &t : up) t.join();
-                for (const auto &e : errs)
-                    if (!e.empty()) die(e);
-            }
-            t_index += now() - t0;
-            trace("index resident in HBM");
-            // threshold model (threshold.hpp:22-47)
-            taxor_gpu_search_params prm{};
-            if (taxor_threshold_select(view, cfg.error_rate, cfg.threshold, &prm) != TAXOR_OK)
-                die("no threshold model for k=" + std::to_string(view->kmer_size) + " and error rate " + std::to_string(cfg.error_rate));
-            switch (prm.model) {                                            // the reference's messages, threshold.hpp:32-46
-            case TAXOR_THR_PERCENTAGE: printf("use percentage-model\t%g\n", cfg.threshold); break;
-            case TAXOR_THR_SYNCMER: printf("use syncmer model\n"); break;
-            case TAXOR_THR_KMER: printf("use kmer-model\n"); break;
-            default: printf("use frac minhash\n"); break;
-            }
-            std::vector<taxor_gpu_searcher *> sr(ng, nullptr);
+    // One index, all of `queries`: the index is loaded and uploaded once; query files are read concurrently (a gzip
+    // stream inflates on one thread, so several files are the only way to read gzip input faster) and written in the
+    // order they were given.
+    auto search_files = [&](const std::string &hixf_file, const std::vector<std::string> &queries, bool last) {
+        double t0 = now();
+        taxor_hixf *h = nullptr;
+        if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
+        trace("index file loaded");
+        const taxor_hixf_view *view = taxor_hixf_get_view(h);
+        // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
+        // replicated, batches are sharded); replicas are uploaded concurrently
+        const size_t ng = cfg.gpus.size();
+        std::vector<taxor_gpu_index *> gidx(ng, nullptr);
+        {
+            std::vector<std::thread> up;
+            std::vector<std::string> errs(ng);
             for (size_t g = 0; g < ng; ++g)
-                if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());
+                up.emplace_back([&, g] {
+                    if (taxor_gpu_index_create(view, cfg.gpus[g], &gidx[g]) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                });
+            for (auto &t : up) t.join();
+            for (const auto &e : errs)
+                if (!e.empty()) die(e);
+        }
+        t_index += now() - t0;
+        trace("index resident in HBM");
+        // threshold model (threshold.hpp:22-47)
+        taxor_gpu_search_params prm{};
+        if (taxor_threshold_select(view, cfg.error_rate, cfg.threshold, &prm) != TAXOR_OK)
+            die("no threshold model for k=" + std::to_string(view->kmer_size) + " and error rate " + std::to_string(cfg.error_rate));
+        switch (prm.model) {                                            // the reference's messages, threshold.hpp:32-46
+        case TAXOR_THR_PERCENTAGE: printf("use percentage-model\t%g\n", cfg.threshold); break;
+        case TAXOR_THR_SYNCMER: printf("use syncmer model\n"); break;
+        case TAXOR_THR_KMER: printf("use kmer-model\n"); break;
+        default: printf("use frac minhash\n"); break;
+        }
+        std::vector<taxor_gpu_searcher *> sr(ng, nullptr);
+        for (size_t g = 0; g < ng; ++g)
+            if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());
 
-            // Overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
-            //   reader thread(s)  : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321);
-            //                       plain files are parsed by up to --threads threads (fastx.h)
-            //   one thread per GPU: chunk -> GPU (streamed upload, kernels, fetch)   (:325)
-            //   writer thread     : tuples -> 0.8*max filter -> TSV lines -> file, in chunk order (:266-311)
-            // Output stays in input order (the reference's order at --threads 1).
-            BoundedQueue<std::unique_ptr<Batch>> q_in(ng + 1), q_out(2 * ng + 2);
-            double t_reads_local = 0;
-            BatchPool pool;
-            pool.cap = std::min(cfg.threads, 16u) + 3 * ng + 3;      // being parsed + q_in + on a GPU + q_out / writer
-            std::thread reader([&] {
-                t_reads_local = produce_batches(query, cfg, true, pool, [&](std::unique_ptr<Batch> b) { q_in.push(std::move(b)); });
-                q_in.close();
-                trace("reader done");
-            });
-            std::thread writer([&] {
-                std::unique_ptr<Batch> b;
-                std::map<uint64_t, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
-                uint64_t next_seq = 0;
-                std::string text;
-                std::vector<char> line(4096);
-                while (q_out.pop(b)) {
-                    pending.emplace(b->seq, std::move(b));
-                    while (!pending.empty() && pending.begin()->first == next_seq) {
-                        std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
-                        pending.erase(pending.begin());
-                        ++next_seq;
-                        text.clear();
-                        for (size_t r = 0; r < cur->ids.size(); ++r) {
-                            const uint64_t lo = cur->read_off[r], n = cur->read_off[r + 1] - lo;
-                            const uint64_t rl = cur->offsets[r + 1] - cur->offsets[r];
-                            uint64_t need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
-                                                              cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
-                            if (need > line.size()) {
-                                line.resize(need + 1024);
-                                need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
-                                                         cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
-                            }
-                            text.append(line.data(), need);
+        // Overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
+        //   reader threads    : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321);
+        //                       plain files are parsed by up to --threads threads (fastx.h), several files at a time
+        //   one thread per GPU: chunk -> GPU (streamed upload, kernels, fetch)   (:325)
+        //   writer thread     : tuples -> 0.8*max filter -> TSV lines -> file, in file and chunk order (:266-311)
+        // Output stays in input order (the reference's order at --threads 1).
+        const size_t nf = queries.size();
+        const unsigned readers = (unsigned)std::max<size_t>(1, std::min<size_t>({nf, cfg.threads, 8}));
+        const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 16u) / readers);
+        BoundedQueue<std::unique_ptr<Batch>> q_in(ng + 1), q_out(2 * ng + 2);
+        BatchPool pool;
+        pool.cap = readers * parse_threads + 3 * ng + 3 + 2 * readers; // being parsed + q_in + on a GPU + q_out / writer + look-ahead
+        // a file that is not being written yet may run at most two chunks ahead, so that the file whose turn it is can
+        // always get buffers
+        std::mutex fmu;
+        std::condition_variable fcv;
+        size_t current_file = 0;
+        std::vector<int> ahead(nf, 0);
+        std::atomic<size_t> next_file{0};
+        std::vector<double> reader_time(readers, 0.0);
+        std::vector<std::thread> reader_threads;
+        for (unsigned rt = 0; rt < readers; ++rt)
+            reader_threads.emplace_back([&, rt] {
+                for (;;) {
+                    const size_t f = next_file.fetch_add(1);
+                    if (f >= nf) break;
+                    auto gate = [&, f] {
+                        std::unique_lock<std::mutex> lk(fmu);
+                        fcv.wait(lk, [&] { return f == current_file || ahead[f] < 2; });
+                    };
+                    reader_time[rt] += produce_batches(queries[f], cfg, true, pool, [&, f](std::unique_ptr<Batch> b) {
+                        if (!b->end_of_file) {
+                            std::lock_guard<std::mutex> lk(fmu);
+                            ++ahead[f];
                         }
-                        fwrite(text.data(), 1, text.size(), out);
-                        pool.put(std::move(cur));
-                    }
+                        q_in.push(std::move(b));
+                    }, (uint32_t)f, parse_threads, gate);
                 }
             });
-            std::vector<std::thread> workers;
-            for (size_t g = 0; g < ng; ++g)
-                workers.emplace_back([&, g] {
-                    std::unique_ptr<Batch> b;
-                    while (q_in.pop(b)) {
-                        const double t1 = now();
-                        if (b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
-                            taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
-                            b->pinned = &b->bases[0];       // recycled with the batch: pinned once, DMA source from then on
-                        const double t2 = now();
-                        taxor_gpu_results res{};
-                        if (taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
-                        const double t3 = now();
-                        b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
-                        b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
-                        b->count.assign(res.count, res.count + res.n_tuples);
-                        b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
-                        {
-                            std::lock_guard<std::mutex> lk(stat_mu);
-                            t_pin += t2 - t1;
-                            t_search += t3 - t2;
-                            ++n_batches;
-                            t_compute += now() - t1;
-                            total_reads += b->ids.size();
-                            total_bases += b->bases.size();
-                        }
-                        q_out.push(std::move(b));
+        std::thread reader([&] {
+            for (auto &t : reader_threads) t.join();
+            q_in.close();
+            trace("readers done");
+        });
+        std::thread writer([&] {
+            std::unique_ptr<Batch> b;
+            std::map<std::pair<uint32_t, uint64_t>, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
+            uint32_t cur_file = 0;
+            uint64_t next_seq = 0;
+            std::string text;
+            std::vector<char> line(4096);
+            while (q_out.pop(b)) {
+                const auto key = std::make_pair(b->file, b->seq);
+                pending.emplace(key, std::move(b));
+                while (!pending.empty() && pending.begin()->first == std::make_pair(cur_file, next_seq)) {
+                    std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
+                    pending.erase(pending.begin());
+                    if (cur->end_of_file) {                 // every chunk of this file is written: the next file's turn
+                        ++cur_file;
+                        next_seq = 0;
+                        std::lock_guard<std::mutex> lk(fmu);
+                        current_file = cur_file;
+                        fcv.notify_all();
+                        continue;
                     }
-                });
-            for (auto &t : workers) t.join();
-            trace("GPU workers done");
-            q_out.close();
-            reader.join();
-            writer.join();
-            trace("writer done");
-            t_reads += t_reads_local;
-            for (size_t g = 0; g < ng; ++g) {
-                taxor_gpu_searcher_destroy(sr[g]);
-                taxor_gpu_index_destroy(gidx[g]);
+                    ++next_seq;
+                    text.clear();
+                    for (size_t r = 0; r < cur->ids.size(); ++r) {
+                        const uint64_t lo = cur->read_off[r], n = cur->read_off[r + 1] - lo;
+                        const uint64_t rl = cur->offsets[r + 1] - cur->offsets[r];
+                        uint64_t need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
+                                                          cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
+                        if (need > line.size()) {
+                            line.resize(need + 1024);
+                            need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
+                                                     cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
+                        }
+                        text.append(line.data(), need);
+                    }
+                    fwrite(text.data(), 1, text.size(), out);
+                    {
+                        std::lock_guard<std::mutex> lk(fmu);
+                        --ahead[cur->file];
+                        fcv.notify_all();
+                    }
+                    pool.put(std::move(cur));
+                }
             }
-            trace("GPU memory released");
-            taxor_hixf_free(h);
-            trace("host index released");
-            const bool last = &query == &query_files.back() && &hixf_file == &index_files.back();
-            if (last) {
-                // the process is about to end: unpinning and unmapping gigabytes of staging buffers page by page
-                // would only delay the exit (~0.1 s per GB)
-                for (auto &b : pool.free_) (void)b.release();
-            } else {
-                for (auto &b : pool.free_)
-                    if (b->pinned) taxor_gpu_host_unregister(b->pinned);
-            }
-            pool.free_.clear();
-            trace("batch buffers released");
+        });
+        std::vector<std::thread> workers;
+        for (size_t g = 0; g < ng; ++g)
+            workers.emplace_back([&, g] {
+                std::unique_ptr<Batch> b;
+                while (q_in.pop(b)) {
+                    if (b->end_of_file) { q_out.push(std::move(b)); continue; }
+                    const double t1 = now();
+                    if (b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
+                        taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
+                        b->pinned = &b->bases[0];       // recycled with the batch: pinned once, DMA source from then on
+                    const double t2 = now();
+                    taxor_gpu_results res{};
+                    if (taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                    const double t3 = now();
+                    b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
+                    b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
+                    b->count.assign(res.count, res.count + res.n_tuples);
+                    b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
+                    {
+                        std::lock_guard<std::mutex> lk(stat_mu);
+                        t_pin += t2 - t1;
+                        t_search += t3 - t2;
+                        ++n_batches;
+                        t_compute += now() - t1;
+                        total_reads += b->ids.size();
+                        total_bases += b->bases.size();
+                    }
+                    q_out.push(std::move(b));
+                }
+            });
+        for (auto &t : workers) t.join();
+        trace("GPU workers done");
+        q_out.close();
+        reader.join();
+        writer.join();
+        trace("writer done");
+        t_reads += *std::max_element(reader_time.begin(), reader_time.end());
+        for (size_t g = 0; g < ng; ++g) {
+            taxor_gpu_searcher_destroy(sr[g]);
+            taxor_gpu_index_destroy(gidx[g]);
         }
+        trace("GPU memory released");
+        taxor_hixf_free(h);
+        trace("host index released");
+        if (last) {
+            // the process is about to end: unpinning and unmapping gigabytes of staging buffers page by page
+            // would only delay the exit (~0.1 s per GB)
+            for (auto &b : pool.free_) (void)b.release();
+        } else {
+            for (auto &b : pool.free_)
+                if (b->pinned) taxor_gpu_host_unregister(b->pinned);
+        }
+        pool.free_.clear();
+        trace("batch buffers released");
+    };
+    if (index_files.size() == 1) {
+        search_files(index_files[0], query_files, true);
+    } else {
+        // several indexes: the reference's order, every query file against every index in turn (:344-358)
+        for (size_t qi = 0; qi < query_files.size(); ++qi)
+            for (size_t ii = 0; ii < index_files.size(); ++ii)
+                search_files(index_files[ii], {query_files[qi]}, qi + 1 == query_files.size() && ii + 1 == index_files.size());
     }
     fclose(out);
     trace("output closed");

@@ -132,3 +132,43 @@ def test_damaged_input_fails_loudly(tmp_path, text, msg):
     for m in (("--sequential",), ("--threads", "2")):
         cp = subprocess.run([EXE, "reads", "--query-file", str(p), *m], capture_output=True, text=True)
         assert cp.returncode != 0 and msg in cp.stderr, (m, cp.stderr)
+
+
+def test_multi_member_gzip_is_inflated_in_parallel_and_in_order(tmp_path):
+    """bgzip-like / concatenated gzip files: members are found speculatively and inflated by several threads; the
+    records must come out exactly as from a sequential read.  Includes members of very different sizes, an empty
+    member, a header whose FNAME field contains a fake member magic, and trailing zero padding."""
+    import io
+    import zlib
+    rng = np.random.default_rng(7)
+    recs = make_records(rng, 900, lo=0, hi=700)
+    text = io.BytesIO()
+    for i, s in recs:
+        text.write(b"@" + i.encode() + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n")
+    raw = text.getvalue()
+    cuts = sorted(set([0, 10, 11, 5000, 5000, 40000, 90000, 90001, len(raw) // 2, len(raw) - 7, len(raw)] +
+                      [int(x) for x in rng.integers(0, len(raw), 25)]))
+    blob = b""
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        blob += gzip.compress(raw[a:b], compresslevel=int(rng.integers(1, 9)))
+    blob += gzip.compress(b"")                                            # an empty member is legal
+    # a member whose header carries a file name that looks like another member header
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    tail_text = b"@last_read extra\nACGTACGTAC\n+\nIIIIIIIIII\n"
+    body = co.compress(tail_text) + co.flush()
+    hdr = b"\x1f\x8b\x08\x08" + b"\x00" * 4 + b"\x00\x03" + b"\x1f\x8b\x08\x01fakefakefake" + b"\x00"
+    blob += hdr + body + (zlib.crc32(tail_text) & 0xFFFFFFFF).to_bytes(4, "little") + (len(tail_text) & 0xFFFFFFFF).to_bytes(4, "little")
+    blob += b"\x00" * 37                                                  # zero padding after the last member
+    p = tmp_path / "multi.fastq.gz"
+    p.write_bytes(blob)
+    assert gzip.decompress(blob[:-37]) == raw + tail_text      # python agrees that this is a valid file
+    want = expected(recs + [("last_read extra", b"ACGTACGTAC")])
+    for m in (("--threads", "1"), ("--threads", "4"), ("--threads", "8", "--batch-reads", "50"), ("--sequential",)):
+        assert run_reads(p, *m)[0] == want, m
+    # corrupt member in the middle: loud failure, not silence
+    bad = bytearray(blob)
+    bad[len(blob) // 2] ^= 0x55
+    q = tmp_path / "bad.fastq.gz"
+    q.write_bytes(bytes(bad))
+    cp = subprocess.run([EXE, "reads", "--query-file", str(q), "--threads", "4"], capture_output=True, text=True)
+    assert cp.returncode != 0 or cp.stdout != "".join(f"{i}\t{n}\t{h:016x}\n" for i, n, h in want)

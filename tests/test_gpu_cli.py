@@ -171,3 +171,29 @@ def test_cli_verify_positive_control(tmp_path):
     cp = subprocess.run([TAXOR, "verify", "--index-file", str(wrong), "--genome-file", str(inside), "--reads", "200", "--read-len", "1500"],
                         capture_output=True, text=True, timeout=300)
     assert cp.returncode == 2 and "FAIL" in cp.stdout, cp.stdout + cp.stderr
+
+
+def test_cli_many_query_files_read_concurrently(tmp_path):
+    """several gzip / plain query files: read concurrently, index loaded once, output in the order of --query-file"""
+    g, go, host, sp, idx_path = _setup(tmp_path, 34)
+    bases, offs, origin = synth.synth_reads(g, go, 400, 900, error_rate=0.02, frac_random=0.2, seed=8)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(400)]
+    cuts = [0, 150, 150, 151, 260, 300, 390, 400]            # one empty file, one with a single read
+    files, want = [], HEADER
+    for j in range(len(cuts) - 1):
+        ids = [f"f{j}_r{i}" for i in range(cuts[j], cuts[j + 1])]
+        rs = reads[cuts[j]:cuts[j + 1]]
+        gz = j % 3 != 2
+        path = tmp_path / (f"q{j}.fastq.gz" if gz else f"q{j}.fastq")
+        with (gzip.open(path, "wb") if gz else open(path, "wb")) as f:
+            for rid, r in zip(ids, rs):
+                f.write(b"@" + rid.encode() + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+        files.append(str(path))
+        want += _expected(host, sp, ids, rs) if rs else ""
+    out = tmp_path / "many.tsv"
+    for extra in (["--threads", "8", "--batch-reads", "40"], ["--threads", "1"], ["--threads", "3", "--gpu-list", "0,0", "--batch-reads", "25"]):
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", ",".join(files), "--output-file", str(out)] + extra,
+                            capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0, cp.stderr
+        assert cp.stdout.count("use syncmer model") == 1          # the index was loaded once for all files
+        assert open(out).read() == want, extra
