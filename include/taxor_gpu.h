@@ -155,6 +155,13 @@ typedef struct {
 int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets,
                            uint64_t n_reads, taxor_gpu_results *out);
 
+/* The same call in two halves, for a host that wants to read / parse its next chunk while this one is classified
+ * (the reference's chunk loop is synchronous, taxor_search.cpp:315-326): _begin enqueues everything and returns --
+ * immediately when `bases` is registered memory (below), after the last host-to-device copy otherwise; `bases` and
+ * `offsets` must stay valid until _end, which waits and hands out the results like taxor_gpu_search_batch. */
+int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out);
+
 /* Optional: pin a host buffer that the caller passes to taxor_gpu_search_batch / taxor_gpu_batch_upload again and
  * again (a recycled staging buffer, like the reference's per-chunk `records` vector, taxor_search.cpp:319).  Copies
  * from registered memory are direct DMA; for pageable memory the runtime locks and unlocks the pages on every call

@@ -89,6 +89,8 @@ SIGNATURES = {
     "taxor_threshold_select": (C.c_int, [C.POINTER(HixfView), C.c_double, C.c_double, C.POINTER(SearchParams)]),
     "taxor_gpu_host_register": (C.c_int, [_P, C.c_uint64]),
     "taxor_gpu_host_unregister": (C.c_int, [_P]),
+    "taxor_gpu_search_batch_begin": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "taxor_gpu_search_batch_end": (C.c_int, [_P, C.POINTER(Results)]),
     "taxor_gpu_search_batch": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(Results)]),
     "taxor_gpu_batch_upload": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "taxor_gpu_batch_run": (C.c_int, [_P]),

@@ -1051,23 +1051,30 @@ extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *o
     return TAXOR_OK;
 }
 
+extern "C" int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    // streamed: the bases of sub-batch i+1 are copied and packed while sub-batch i is being classified
+    if (int rc = prepare_batch(s, bases, offsets, n_reads, true)) return rc;
+    // (page-locking the caller's buffer for the duration of the call was measured and is slower: the registration
+    // costs more than the pageable staging it saves -- 55 vs 50 ms for 1.3 GB; a caller that re-uses its buffer
+    // registers it once with taxor_gpu_host_register, and then this call returns as soon as everything is enqueued)
+    return run_pipeline(s, n_reads ? bases + offsets[0] : nullptr);
+}
+
+extern "C" int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out) { return taxor_gpu_batch_fetch(s, out); }
+
 extern "C" int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                                       taxor_gpu_results *out)
 {
-    // streamed: the bases of sub-batch i+1 are copied and packed while sub-batch i is being classified
     static const bool trace = getenv("TAXOR_TRACE_BATCH") != nullptr;   // phase times of this call on stderr
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-    if (int rc = prepare_batch(s, bases, offsets, n_reads, true)) return rc;
-    const double t_prep = ms_since(t0);
-    // (page-locking the caller's buffer for the duration of the call was measured and is slower: the registration
-    // costs more than the pageable staging it saves -- 55 vs 50 ms for 1.3 GB)
-    if (int rc = run_pipeline(s, n_reads ? bases + offsets[0] : nullptr)) return rc;
+    if (int rc = taxor_gpu_search_batch_begin(s, bases, offsets, n_reads)) return rc;
     const double t_enq = ms_since(t0);
-    const int rc = taxor_gpu_batch_fetch(s, out);
+    const int rc = taxor_gpu_search_batch_end(s, out);
     if (trace)
-        fprintf(stderr, "[search_batch] %llu reads: layout+per-read arrays %.2f ms, pipeline enqueued (incl. blocking copies) at %.2f ms, "
-                        "results on the host at %.2f ms\n", (unsigned long long)n_reads, t_prep, t_enq, ms_since(t0));
+        fprintf(stderr, "[search_batch] %llu reads: pipeline enqueued (layout, per-read arrays, blocking copies of pageable bases) at "
+                        "%.2f ms, results on the host at %.2f ms\n", (unsigned long long)n_reads, t_enq, ms_since(t0));
     return rc;
 }
 

@@ -213,6 +213,18 @@ class Searcher:
         check(_lib.lib().taxor_gpu_search_batch(self._h, _p(b), _p(o), o.size - 1, C.byref(res)))
         return _results(res)
 
+    def search_batch_begin(self, bases, offsets):
+        """enqueue the drop-in call; keep the arrays alive until search_batch_end()"""
+        b, o = self._batch(bases, offsets)
+        self._inflight = (b, o)
+        check(_lib.lib().taxor_gpu_search_batch_begin(self._h, _p(b), _p(o), o.size - 1))
+
+    def search_batch_end(self) -> SearchResults:
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_search_batch_end(self._h, C.byref(res)))
+        self._inflight = None
+        return _results(res)
+
     # --- phases -------------------------------------------------------------------------------------------
     def upload(self, bases, offsets):
         b, o = self._batch(bases, offsets)

@@ -554,3 +554,31 @@ def test_gather_ceiling_runs_on_every_row_width():
         gbps, row_bytes = idx.gather_ceiling(0, want_bytes=1 << 28, reps=2)
         assert row_bytes == (bins + 15) // 16 * 16 and gbps > 1.0
         idx.close()
+
+
+def test_search_batch_begin_end_overlaps_two_searchers():
+    """the drop-in call in two halves: two batches in flight on two searchers of one index, pageable and registered
+    host buffers; results equal the blocking call"""
+    import ctypes as C
+    from taxor_amd import _lib
+    g, go, lay, host = _planted_setup(9)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    b1, o1, _ = synth.synth_reads(g, go, 700, 2500, error_rate=0.02, frac_random=0.2, seed=1)
+    b2, o2, _ = synth.synth_reads(g, go, 900, 1200, error_rate=0.03, frac_random=0.1, seed=2)
+    s1, s2 = Searcher(idx, sub_batch_reads=128), Searcher(idx, sub_batch_reads=300)
+    want1, want2 = s1.search_batch(b1, o1), s2.search_batch(b2, o2)
+    assert _lib.lib().taxor_gpu_host_register(b2.ctypes.data, b2.size) == 0
+    for _ in range(3):
+        s1.search_batch_begin(b1, o1)
+        s2.search_batch_begin(b2, o2)
+        r2 = s2.search_batch_end()
+        r1 = s1.search_batch_end()
+        for got, want in ((r1, want1), (r2, want2)):
+            assert np.array_equal(got.read_off, want.read_off) and np.array_equal(got.user_bin, want.user_bin)
+            assert np.array_equal(got.count, want.count) and np.array_equal(got.n_hashes, want.n_hashes)
+    assert _lib.lib().taxor_gpu_host_unregister(b2.ctypes.data) == 0
+    with pytest.raises(TaxorError):
+        Searcher(idx).search_batch_end()                    # nothing in flight
+    s1.close()
+    s2.close()
+    idx.close()
