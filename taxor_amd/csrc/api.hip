@@ -564,7 +564,7 @@ int ev_end(taxor_gpu_searcher *s, size_t slot, hipStream_t st = nullptr)
 // host-side layout of a batch: packed offsets, candidate slots, sub-batch partition
 int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_reads, std::vector<uint64_t> &poff,
                  std::vector<uint32_t> &rlen, std::vector<uint64_t> &hoff, std::vector<uint32_t> &hcap,
-                 std::vector<uint32_t> &order, uint32_t first_div)
+                 std::vector<uint32_t> &order, uint32_t first_div, bool ramp)
 {
     const taxor_gpu_index *idx = s->idx;
     const int w = idx->k - idx->s + 1;
@@ -588,8 +588,23 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         // 128-B aligned regions: no line shared between reads.  Minimiser mode emits at most one value per window.
         const uint64_t cap = round_up((idx->w_min > 0 ? nwin : nwin / gap) + 2, 16);
         // the first sub-batch's syncmer kernel has nothing to hide behind: keep it a quarter the size
-        const uint64_t lim_reads = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_reads / first_div, 1) : s->prm.sub_batch_reads;
-        const uint64_t lim_bases = s->subs.empty() ? std::max<uint64_t>(s->prm.sub_batch_bases / first_div, 1) : s->prm.sub_batch_bases;
+        // Resident batch: only the first sub-batch may be smaller (first_div).  Streamed batch: sub-batch i+1 is ready
+        // when its bases have crossed PCIe (serially, behind all earlier ones) and its syncmer kernel has run, and it
+        // should be ready before sub-batch i is classified -- which allows a growth of ~1.27x per sub-batch at 48 GB/s
+        // of PCIe against ~35 Gbp/s of classification, so the sizes ramp 1/first_div, x1.25, x1.25, ... up to the full
+        // size instead of jumping there (a jump leaves the GPU idle for most of the second sub-batch's copy).
+        uint64_t lim_reads = s->prm.sub_batch_reads, lim_bases = s->prm.sub_batch_bases;
+        if (ramp) {
+            double f = 1.0 / (double)first_div;
+            for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= 1.25;
+            if (f < 1.0) {
+                lim_reads = std::max<uint64_t>((uint64_t)((double)lim_reads * f), 1);
+                lim_bases = std::max<uint64_t>((uint64_t)((double)lim_bases * f), 1);
+            }
+        } else if (s->subs.empty()) {
+            lim_reads = std::max<uint64_t>(lim_reads / first_div, 1);
+            lim_bases = std::max<uint64_t>(lim_bases / first_div, 1);
+        }
         if (r > sub_first && (r - sub_first >= lim_reads || sub_bases + len > lim_bases)) {
             s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[r] - offsets[0]});
             s->max_slots = std::max(s->max_slots, sub_slots);
@@ -859,7 +874,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     std::vector<uint64_t> poff, hoff;
     std::vector<uint32_t> rlen, hcap, order;
     // streamed: the first sub-batch's PCIe copy has nothing to hide behind either, so it is a quarter the size
-    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? std::max(s->first_div, 4u) : s->first_div))
+    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? std::max(s->first_div, 8u) : s->first_div, streamed))
         return rc;
     s->n_reads = n_reads;
     s->h_rlen = rlen;
