@@ -39,6 +39,48 @@ def build(force=False):
     return _SO
 
 
+_REF_SO = os.path.join(_HERE, "_ref", "libtaxor_ref.so")
+_ref = None
+
+
+def ref_lib(reference_root="/root/reference"):
+    """oracle/_ref/libtaxor_ref.so: the standalone-compilable pieces of the REAL reference (see ref_driver.cpp), built
+    here when /root/reference is present; on the GPU box the prebuilt file travels with the repository.  None if
+    neither is available."""
+    global _ref
+    if _ref is not None:
+        return _ref
+    src = os.path.join(_HERE, "ref_driver.cpp")
+    if os.path.isdir(os.path.join(reference_root, "src")) and (
+            not os.path.exists(_REF_SO) or os.path.getmtime(src) > os.path.getmtime(_REF_SO)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "ref", f"REF={reference_root}"])
+    if not os.path.exists(_REF_SO):
+        return None
+    L = C.CDLL(_REF_SO)
+    L.ref_syncmer_match_ratio.restype = C.c_double
+    L.ref_syncmer_match_ratio.argtypes = [C.c_size_t, C.c_double]
+    L.ref_nmut_kmer_ci_high.restype = C.c_size_t
+    L.ref_nmut_kmer_ci_high.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double]
+    L.ref_containment_index_ci_low.restype = C.c_double
+    L.ref_containment_index_ci_low.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+    L.ref_normal_cdf_inverse.restype = C.c_double
+    L.ref_normal_cdf_inverse.argtypes = [C.c_double]
+    L.ref_adjust_seed.restype = C.c_uint64
+    L.ref_adjust_seed.argtypes = [C.c_uint8]
+    L.ref_xor_build.restype = C.c_void_p
+    L.ref_xor_build.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_xor_contain.restype = C.c_int
+    L.ref_xor_contain.argtypes = [C.c_void_p, C.c_uint64]
+    L.ref_xor_fingerprints.restype = C.POINTER(C.c_uint8)
+    L.ref_xor_fingerprints.argtypes = [C.c_void_p]
+    L.ref_xor_probe.restype = None
+    L.ref_xor_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.ref_xor_free.restype = None
+    L.ref_xor_free.argtypes = [C.c_void_p]
+    _ref = L
+    return _ref
+
+
 class _Ixf(C.Structure):
     _fields_ = [("bins", C.c_uint64), ("stride", C.c_uint64), ("seg_len", C.c_uint64),
                 ("seed", C.c_uint64), ("data", C.c_void_p)]
@@ -76,6 +118,10 @@ def lib():
         L.orc_threshold_kind.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double]
         L.orc_threshold_model.restype = C.c_size_t
         L.orc_threshold_model.argtypes = [C.c_int, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double]
+        L.orc_nmut_kmer_ci_high.restype = C.c_size_t
+        L.orc_nmut_kmer_ci_high.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double]
+        L.orc_containment_index_ci_low.restype = C.c_double
+        L.orc_containment_index_ci_low.argtypes = [C.c_double, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
         L.orc_normal_cdf_inverse.restype = C.c_double
         L.orc_normal_cdf_inverse.argtypes = [C.c_double]
         L.orc_adjust_seed.restype = C.c_uint64

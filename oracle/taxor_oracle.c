@@ -301,7 +301,7 @@ static double orc_expected_nmut_kmer_squared(double r, size_t kmer_size, size_t 
 }
 
 /* calculate_nmut_kmer_CI(...).second, kmer_model.cpp:10-23 (only the upper bound is used, threshold.hpp:65) */
-static size_t orc_nmut_kmer_ci_high(double r, size_t kmer_size, size_t kmer_count, double confidence)
+size_t orc_nmut_kmer_ci_high(double r, size_t kmer_size, size_t kmer_count, double confidence)
 {
     double q = 1.0 - pow(1.0 - r, kmer_size);
     double varN = orc_variance_nmut_kmer(r, kmer_size, kmer_count);                    /* same expression, :13-15 */
@@ -311,7 +311,7 @@ static size_t orc_nmut_kmer_ci_high(double r, size_t kmer_size, size_t kmer_coun
 }
 
 /* calculate_containment_index_CI(...).first, fracminhash_model.cpp:8-33 */
-static double orc_containment_index_ci_low(double r, size_t kmer_size, size_t kmer_count, double scaling_factor, double confidence)
+double orc_containment_index_ci_low(double r, size_t kmer_size, size_t kmer_count, double scaling_factor, double confidence)
 {
     double z_alpha = orc_normal_cdf_inverse(1.0 - (1.0 - confidence) / 2.0);
     double term3 = orc_variance_nmut_kmer(r, kmer_size, kmer_count) / pow(kmer_count, 2);

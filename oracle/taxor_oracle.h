@@ -6,24 +6,35 @@
  * the checker for the HIP path -- only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
  * may load it.  The product library (libtaxor_gpu.so) never links, loads or calls anything in oracle/.
  *
- * PINNING STATUS -- "parity unpinned" at three boundaries:
- *   The reference has no tests, golden vectors or fixtures, and it cannot be built
- *   in this image: every translation unit on the path includes seqan3 / cereal / ankerl headers that are
- *   fetched by git at configure time and are absent here (src/seqan/CMakeLists.txt.in:7-62,
- *   src/hashing/CMakeLists.txt.in:6-15).  Building it against hand-written stand-ins for those headers
- *   is not a reference build, so there is no oracle/_ref.  Consequently:
+ * PINNING STATUS
+ *   The reference has no tests, golden vectors or fixtures, and its search path cannot be
+ *   built in this image: syncmer.cpp, hierarchical_interleaved_xor_filter.hpp, threshold.hpp and taxor_search.cpp
+ *   include seqan3 / cereal / ankerl headers that are fetched by git at configure time and are absent here
+ *   (src/seqan/CMakeLists.txt.in:7-62, src/hashing/CMakeLists.txt.in:6-15); building them against hand-written
+ *   stand-ins would not be a reference build.
+ *   PINNED against the reference's own code (oracle/_ref/libtaxor_ref.so, built by `make ref` straight from the
+ *   reference's files that need nothing but the standard library; tests/test_oracle_ref.py):
+ *     - orc_syncmer_match_ratio / orc_threshold        = src/hixf/search/syncmer_model.hpp, every (k, error rate)
+ *     - orc_nmut_kmer_ci_high, orc_containment_index_ci_low, orc_normal_cdf_inverse (and so orc_threshold_model)
+ *                                                      = kmer_model.cpp, fracminhash_model.cpp, gaussian_inverse.cpp,
+ *                                                        including the NaN / negative casts of very short reads
+ *     - orc_adjust_seed                                = src/hixf/build/adjust_seed.hpp
+ *     - orc_ixf_probe / orc_ixf_seg_len / lookup rule  = src/main/xorfilter.hpp + hashutil.hpp, the in-repo XOR-filter
+ *                                                        prototype (same rows, fingerprint, sizing; a filter it builds
+ *                                                        answers identically through orc_ixf_bulk_count)
+ *   "parity unpinned" at three boundaries that live in absent third-party code:
  *     (1) orc_wyhash_u64   -- restates the PUBLISHED algorithm of martinus/unordered_dense v3.0.1
  *         (`detail::wyhash::hash(uint64_t)` = mix(x, 0x9E3779B97F4A7C15), mix = lo64 ^ hi64 of the
  *         128-bit product); call site src/hashing/syncmer.cpp:73-77.                 parity unpinned
- *     (2) orc_ixf_*        -- restates the interleaved XOR filter of the author's seqan3 fork
- *         (JensUweUlrich/seqan3@master, un-vendored, un-pinned) from the in-repo evidence
- *         src/main/xorfilter.hpp:22-68,338-350 + src/main/hashutil.hpp:50-61.        parity unpinned
+ *     (2) orc_ixf_* as the INTERLEAVED filter of the author's seqan3 fork (JensUweUlrich/seqan3@master, un-vendored,
+ *         un-pinned): that its per-bin arithmetic is the prototype's (pinned above), that rows are interleaved as
+ *         data[row*stride + bin] with stride = ceil(bins/64)*64, and how it serialises.  parity unpinned
  *     (3) orc_minimiser_hash -- restates seqan3::views::minimiser_hash (same un-vendored fork), used for
  *         indexes built without --use-syncmer; call sites src/main/taxor_search.cpp:210-212,241-256.
  *         Window > k: which of several equal minima is kept is recalled, not read.   parity unpinned
- *   Everything else (syncmer selector, HIXF traversal/tally, thresholds, classification call, TSV) is
- *   restated from code that IS in /root/reference and is cross-checked against a second, independent
- *   pure-Python restatement (tests/golden/make_golden.py) whose outputs are committed under tests/golden/.
+ *   Everything else (syncmer selector, HIXF traversal/tally, classification call, TSV) is restated from code
+ *   that IS in /root/reference and is cross-checked against a second, independent pure-Python restatement
+ *   (tests/golden/make_golden.py) whose outputs are committed under tests/golden/.
  */
 #ifndef TAXOR_ORACLE_H
 #define TAXOR_ORACLE_H
@@ -69,6 +80,10 @@ int orc_threshold_kind(int use_syncmer, size_t kmer_size, size_t window_size, do
 size_t orc_threshold_model(int kind, size_t minimiser_count, size_t kmer_size, double error_rate, double percentage,
                            double scaling_factor);
 double orc_normal_cdf_inverse(double p);
+/* the two model components, exported so that tests can hold them against the reference's own translation units
+ * (oracle/_ref, see ref_driver.cpp): calculate_nmut_kmer_CI(...).second and calculate_containment_index_CI(...).first */
+size_t orc_nmut_kmer_ci_high(double r, size_t kmer_size, size_t kmer_count, double confidence);
+double orc_containment_index_ci_low(double r, size_t kmer_size, size_t kmer_count, double scaling_factor, double confidence);
 
 /* hixf::adjust_seed (adjust_seed.hpp:40-44) and seqan3::views::minimiser_hash as the reference calls it
  * (taxor_search.cpp:210-212): values in emission order, duplicates kept.  See the .c for the pinning status. */
