@@ -302,12 +302,12 @@ def materialize_host(layout):
     return res
 
 
-def device_index(layout, k=22, s=12, t=5, device=0):
+def device_index(layout, k=22, s=12, t=5, device=0, use_syncmer=True, window_size=None, scaling=1):
     """Create the index directly in HBM: rows are filled by a device kernel, planted columns uploaded."""
     from .search import GpuIndex
     ixfs = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"],
                  next_ixf=f["next_ixf"], fname_idx=f["fname_idx"], data=None) for f in layout["ixfs"]]
-    idx = GpuIndex(ixfs, layout["n_user_bins"], k, s, t, device)
+    idx = GpuIndex(ixfs, layout["n_user_bins"], k, s, t, device, use_syncmer=use_syncmer, window_size=window_size, scaling=scaling)
     for i, f in enumerate(layout["ixfs"]):
         idx.fill_random(i, f["fill_seed"])
         for b, col in f["columns"].items():
