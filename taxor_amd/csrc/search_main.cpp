@@ -5,6 +5,7 @@
 #include "../../include/taxor_gpu.h"
 #include "fastx.h"
 
+#include <sys/resource.h>
 #include <sys/stat.h>
 
 #include <algorithm>
@@ -671,6 +672,12 @@ int main(int argc, char **argv)
                 t_search, t_compute - t_pin - t_search);
     printf("Index I/O\tReads I/O\tCompute\n%.2f\t%.2f\t%.2f\n", t_index, t_reads, t_compute);   // :328-336
     printf("%llu reads, %llu bases classified\n", (unsigned long long)total_reads, (unsigned long long)total_bases);
+    {   // the reference's main() closes with the process's CPU time and peak resident set (main.cpp:37-49,79-84)
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        const double cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
+        printf("CPU time  : %g sec\nPeak RSS  : %d MByte\n", cpu, (int)((size_t)ru.ru_maxrss * 1024 / (1024 * 1024)));
+    }
     fflush(stdout);
     fflush(stderr);
     _exit(0);   // everything is written and closed; skip the runtime's and the allocator's teardown
