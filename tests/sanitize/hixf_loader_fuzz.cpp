@@ -1,0 +1,53 @@
+// AddressSanitizer / UBSan driver for the .hixf loader, the probe and the TSV formatter (host code only, no GPU):
+// usage: hixf_loader_fuzz <valid.hixf> <data_lo> <data_hi> <trials> <scratch file>
+// mutates the file (bit flips, huge integers, truncation, insertions, deletions outside [data_lo, data_hi)) and loads it.
+#include <taxor_gpu.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <random>
+#include <string>
+extern "C" void taxor_set_last_error(const char *m) { (void)m; }
+int main(int argc, char **argv) {
+    FILE *f = fopen(argv[1], "rb"); fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> raw(n); if (fread(raw.data(), 1, n, f) != (size_t)n) return 1; fclose(f);
+    long data_lo = atol(argv[2]), data_hi = atol(argv[3]);
+    int trials = atoi(argv[4]);
+    std::mt19937_64 rng(7);
+    int ok = 0, err = 0;
+    std::vector<long> meta; for (long i = 0; i < n; ++i) if (i < data_lo || i >= data_hi) meta.push_back(i);
+    for (int t = 0; t < trials; ++t) {
+        std::vector<unsigned char> b = raw;
+        switch (t % 5) {
+        case 0: for (int j = 0; j < 1 + (int)(rng() % 3); ++j) b[meta[rng() % meta.size()]] ^= (unsigned char)(1 + rng() % 255); break;
+        case 1: { long p = meta[rng() % meta.size()] & ~7L; unsigned long long v[] = {0, 1, 1ull << 63, ~0ull, 1ull << 40, 1ull << 31, 65};
+                  unsigned long long x = v[rng() % 7]; if (p + 8 <= (long)b.size()) memcpy(&b[p], &x, 8); break; }
+        case 2: b.resize(1 + rng() % b.size()); break;
+        case 3: { long p = rng() % b.size(); std::vector<unsigned char> g(1 + rng() % 64); for (auto &c : g) c = (unsigned char)rng(); b.insert(b.begin() + p, g.begin(), g.end()); break; }
+        case 4: { long p = meta[rng() % meta.size()]; long len = 1 + rng() % 32; if (p + len < (long)b.size()) b.erase(b.begin() + p, b.begin() + p + len); break; }
+        }
+        FILE *o = fopen(argv[5], "wb"); fwrite(b.data(), 1, b.size(), o); fclose(o);
+        taxor_hixf *h = nullptr;
+        int rc = taxor_hixf_load(argv[5], &h);
+        if (rc == TAXOR_OK) {
+            const taxor_hixf_view *v = taxor_hixf_get_view(h);
+            unsigned long long sum = 0;
+            for (size_t i = 0; i < v->n_ixf; ++i) {   // touch every byte the view claims
+                const taxor_ixf_view &x = v->ixf[i];
+                size_t sz = 3 * x.seg_len * x.stride;
+                sum += x.data[0] + x.data[sz - 1];
+                for (size_t j = 0; j < x.bins; ++j) sum += x.next_ixf[j] + x.fname_idx[j];
+            }
+            const taxor_hixf_meta *m = taxor_hixf_get_meta(h);
+            for (size_t i = 0; i < m->n_species; ++i) sum += strlen(m->species[i].organism_name) + strlen(m->species[i].taxid_string);
+            // format a line with arbitrary user bins
+            int64_t ub[2] = {0, (int64_t)v->n_user_bins - 1}; unsigned ct[2] = {5, 4}; char buf[8192];
+            taxor_format_read(h, "r", 1, 100, 10, ub, ct, 2, buf, sizeof buf);
+            taxor_ixf_schema sc; char rep[4096]; taxor_hixf_probe(argv[5], &sc, rep, sizeof rep);
+            if (sum == 42) puts("");
+            taxor_hixf_free(h); ++ok;
+        } else { taxor_ixf_schema sc; char rep[4096]; taxor_hixf_probe(argv[5], &sc, rep, sizeof rep); ++err; }
+    }
+    printf("ok=%d err=%d\n", ok, err);
+}
