@@ -415,10 +415,12 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
             bool any_dup = false;                                        // block-uniform
             if (in_lds) {
                 const uint32_t P = (n_sel + 1535u) / 1536u;
-                const uint32_t mask = (uint32_t)SY_LDS_TAB - 1u;
+                uint32_t ts = 64;                                        // a short read clears and probes a short table
+                while (ts < 2u * n_sel && ts < (uint32_t)SY_LDS_TAB) ts <<= 1;
+                const uint32_t mask = ts - 1u;
                 for (uint32_t i = tid; i < (n_sel + 31u) / 32u; i += BLK) sDupBits[i] = 0u;
                 for (uint32_t p = 0; p < P; ++p) {
-                    for (uint32_t i = tid; i < (uint32_t)SY_LDS_TAB; i += BLK) sTab[i] = 0xFFFFFFFFu;
+                    for (uint32_t i = tid; i < ts; i += BLK) sTab[i] = 0xFFFFFFFFu;
                     if (tid == 0) { sScr[6] = 0u; sScr[7] = 0u; }
                     __syncthreads();
                     bool dup = false;
