@@ -103,6 +103,7 @@ struct taxor_gpu_searcher {
     Counters h_ctr{};
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
+    bool auto_sub_reads = true; // sub_batch_reads was left to the library: short reads get more of them per sub-batch
     bool prune = true;   // TAXOR_QUERY_PRUNE=0 disables the threshold-aware pruning (A/B measurements)
     size_t lds_query = 0;
 
@@ -466,6 +467,7 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     auto s = new taxor_gpu_searcher();
     s->idx = idx;
     s->prm = *prm;
+    s->auto_sub_reads = s->prm.sub_batch_reads == 0;
     if (s->prm.sub_batch_reads == 0) s->prm.sub_batch_reads = 32768;
     if (s->prm.sub_batch_bases == 0) s->prm.sub_batch_bases = 1ull << 29;
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
@@ -486,7 +488,7 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     s->grid_sync = syncmers_grid(idx->device);
     if (const char *e = getenv("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
     if (const char *e = getenv("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
-    if (const char *e = getenv("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) s->prm.sub_batch_reads = (uint32_t)v; }
+    if (const char *e = getenv("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) { s->prm.sub_batch_reads = (uint32_t)v; s->auto_sub_reads = false; } }
     {   // syncmer launches that run beside a query kernel keep to two blocks per CU: at full occupancy (three) the
         // query kernel stalls for as long as the syncmer kernel runs (measured); with one or two it is not slowed
         hipDeviceProp_t p;
@@ -580,6 +582,13 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
     s->max_sub_reads = 0;
     uint64_t words = 0, sub_slots = 0, sub_bases = 0;
     uint32_t sub_first = 0;
+    // a sub-batch of 32768 reads of 1 kb is 33 Mbases: three query launches and four finalize kernels per millisecond
+    // of work.  With the size left to the library, short reads get up to 131072 per sub-batch (~128 Mbases).
+    uint64_t full_reads = s->prm.sub_batch_reads;
+    if (s->auto_sub_reads && n_reads) {
+        const uint64_t mean_len = std::max<uint64_t>(1, (offsets[n_reads] - offsets[0]) / n_reads);
+        while (full_reads < 131072 && full_reads * mean_len < (1ull << 27)) full_reads *= 2;
+    }
     for (uint64_t r = 0; r < n_reads; ++r) {
         if (offsets[r + 1] < offsets[r]) return fail(TAXOR_E_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
         const uint64_t len = offsets[r + 1] - offsets[r];
@@ -593,7 +602,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         // should be ready before sub-batch i is classified -- which allows a growth of ~1.27x per sub-batch at 48 GB/s
         // of PCIe against ~35 Gbp/s of classification, so the sizes ramp 1/first_div, x1.25, x1.25, ... up to the full
         // size instead of jumping there (a jump leaves the GPU idle for most of the second sub-batch's copy).
-        uint64_t lim_reads = s->prm.sub_batch_reads, lim_bases = s->prm.sub_batch_bases;
+        uint64_t lim_reads = full_reads, lim_bases = s->prm.sub_batch_bases;
         if (ramp) {
             double f = 1.0 / (double)first_div;
             for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= 1.25;
