@@ -746,6 +746,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.q_out = s->d_q[(lvl + 1) & 1].p;
         q.n_level0 = n_reads;
         q.order0 = d_order;
+        static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_QUERY_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        q.cursor_chunk = lvl >= 1 ? (chunk_env ? chunk_env : 4u) : 1u;
         size_t slot;
         if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
         launch_query_level(q, s->grid_query, s->lds_query, s->st);

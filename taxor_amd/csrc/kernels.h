@@ -108,6 +108,7 @@ struct QueryArgs {
     uint32_t q_cap, hit_cap;
     uint32_t map_words;       // words of the alive-unit bitmap in LDS (query_lds_map_words(max_stride))
     uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)
+    uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
 };
 
 struct FinalizeArgs {

@@ -698,6 +698,7 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
 // ------------------------------------------------------------------------------------------------------
 static constexpr int Q_HT = 240;   // hashes per probe tile when one thread sees every hash (byte counters stay < 256)
 static constexpr int Q_HT2 = 480;  // probe tile when hashes are split over G >= 2 thread groups
+static constexpr int Q_OB = 64;    // child pushes / hit records buffered in LDS before they are appended globally
 static constexpr int Q_CAP = 1024; // LDS probe capacity: reads with n_h <= Q_CAP stage all their probes once per work item
 
 __device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
@@ -859,12 +860,47 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
     const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0;
     unsigned long long st_bytes = 0, st_touched = 0, st_work = 0;
 
+    // Returning atomics on one word are served serially by one L2 channel, ~13 ns each.  A launch of small work items
+    // (deeper levels, short reads) issues one per item on the work cursor and one per item on the hit / queue append
+    // word, and either alone caps it at ~76 M items/s however many blocks are resident (every block then spends its
+    // time queueing for the word).  So: `cursor_chunk` items per cursor atomic, and child pushes / hit records are
+    // collected in LDS across items and appended a few dozen at a time.
+    __shared__ uint4 sOutH[Q_OB];
+    __shared__ uint2 sOutQ[Q_OB];
+    if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
+    auto flush_out = [&](bool force) {          // block-uniform; the caller has just passed a barrier
+        const uint32_t nq = min(sScal[2], (uint32_t)Q_OB), nh = min(sScal[3], (uint32_t)Q_OB);
+        if (!(force ? (nq | nh) != 0u : (nq >= (uint32_t)Q_OB / 2u || nh >= (uint32_t)Q_OB / 2u))) return;
+        if (tid == 0) {
+            sScal[4] = nq ? atomicAdd(&a.ctr->q_n[lvl + 1].v, nq) : 0u;
+            sScal[5] = nh ? atomicAdd(&a.ctr->n_hits.v, nh) : 0u;
+        }
+        __syncthreads();
+        const uint32_t bq = sScal[4], bh = sScal[5];
+        for (uint32_t i = tid; i < nq; i += BLK) {
+            if (bq + i < a.q_cap) a.q_out[bq + i] = sOutQ[i];
+            else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+        }
+        for (uint32_t i = tid; i < nh; i += BLK) {
+            if (bh + i < a.hit_cap) a.hits[bh + i] = sOutH[i];
+            else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
+        }
+        __syncthreads();
+        if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
+    };
+
+    const uint32_t chunk = a.cursor_chunk ? a.cursor_chunk : 1u;
+    uint32_t item = 0, item_end = 0;
     for (;;) {
         __syncthreads();
-        if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, 1u);
-        __syncthreads();
-        const uint32_t item = sScal[0];
-        if (item >= n_items) break;
+        if (item == item_end) {
+            flush_out(false);
+            if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, chunk);
+            __syncthreads();
+            item = sScal[0];
+            item_end = min(item + chunk, n_items);
+            if (item >= n_items) break;
+        }
         uint32_t r, v;
         if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
         else { r = a.order0 ? a.order0[item] : item; v = 0; }
@@ -996,23 +1032,34 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
                     push_hit = (uint64_t)sum >= thr;               // :328
                 }
             }
-            const uint32_t qs = wave_append(push_child, &a.ctr->q_n[lvl + 1].v);
+            const uint32_t qs = wave_append(push_child, &sScal[2]);             // LDS slot; a full buffer spills
             if (push_child) {
-                if (qs < a.q_cap) a.q_out[qs] = make_uint2(r, info & 0x3FFFFFFFu);
-                else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+                const uint2 rec = make_uint2(r, info & 0x3FFFFFFFu);
+                if (qs < (uint32_t)Q_OB) sOutQ[qs] = rec;
+                else {
+                    const uint32_t g = atomicAdd(&a.ctr->q_n[lvl + 1].v, 1u);
+                    if (g < a.q_cap) a.q_out[g] = rec;
+                    else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+                }
             }
-            const uint32_t hs = wave_append(push_hit, &a.ctr->n_hits.v);
+            const uint32_t hs = wave_append(push_hit, &sScal[3]);
             if (push_hit) {
-                if (hs < a.hit_cap) {
-                    a.hits[hs] = make_uint4(r, D.bin_base + b, sum, 0u);
-                    atomicAdd(&a.read_hits[r], 1u);
-                } else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
+                const uint4 rec = make_uint4(r, D.bin_base + b, sum, 0u);
+                atomicAdd(&a.read_hits[r], 1u);
+                if (hs < (uint32_t)Q_OB) sOutH[hs] = rec;
+                else {                                                           // e.g. a threshold-0 read reporting every leaf run
+                    const uint32_t g = atomicAdd(&a.ctr->n_hits.v, 1u);
+                    if (g < a.hit_cap) a.hits[g] = rec;
+                    else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
+                }
             }
         }
         st_bytes += (unsigned long long)n * 3ull * D.bins;
         st_touched += touched;
         st_work += 1ull;
+        ++item;
     }
+    flush_out(true);           // the break above is taken by the whole block right after a barrier
     if (tid == 0 && st_work) { // one set of statistics atomics per block, not per work item
         atomicAdd(&a.ctr->query_bytes, st_bytes);
         atomicAdd(&a.ctr->touched_bytes, st_touched);
