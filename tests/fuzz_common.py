@@ -1,6 +1,6 @@
 """One randomized differential trial: random genomes, a random HIXF around them (taxor_amd.synth.random_layout), random
 reads and search parameters; the HIP path (through the C ABI) must equal the CPU oracle tuple for tuple.
-Used by tests/test_gpu_fuzz.py (fixed seeds) and profiles/fuzz_parity.py (as long as you like)."""
+Used by tests/test_gpu_fuzz.py (fixed seeds) and tests/fuzz_parity.py (as long as you like)."""
 import numpy as np
 
 from oracle import oracle as orc

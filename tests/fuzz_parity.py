@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Long randomized differential run (GPU vs CPU oracle): python profiles/fuzz_parity.py [seconds] [first_seed]"""
+"""Long randomized differential run (GPU vs CPU oracle): python tests/fuzz_parity.py [seconds] [first_seed]"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from tests.fuzz_common import run_trial  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
