@@ -7,7 +7,7 @@
  * (user_bin, count) tuples come out.  This header replaces exactly that seam; every entry point cites
  * the reference interface it stands in for.  Plain pointers and sizes only, no C++/torch types, no
  * exceptions: every function returns 0 on success or a negative taxor_status, and
- * taxor_gpu_last_error() returns the message (the reference prints "[TAXOR SEARCH ERROR] ..." and
+ * taxor_gpu_last_error() returns the message of the calling thread's last failure (the reference prints "[TAXOR SEARCH ERROR] ..." and
  * returns -1, taxor_search.cpp:380-384).
  *
  * Threading: an index is immutable after creation and may be shared; a searcher is single-caller, like
