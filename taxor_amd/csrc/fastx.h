@@ -92,23 +92,30 @@ struct FastxReader {
         len = (size_t)n;
         return true;
     }
-    // next line -> appended to `out` (if non-null); returns false at end of input with nothing read
-    bool line_to(std::string *out)
+    // next line -> appended to `out` (if non-null); returns false at end of input with nothing read.  *count (if
+    // non-null) receives the line's length without its line terminator.
+    bool line_to(std::string *out, size_t *count = nullptr)
     {
         bool any = false;
+        size_t total = 0;
+        char last = 0;
         for (;;) {
             if (pos == len && !refill()) {
                 if (any && out && !out->empty() && out->back() == '\r') out->pop_back();
+                if (count) *count = total - (last == '\r' ? 1 : 0);
                 return any;
             }
             const char *s = buf.data() + pos;
             const char *e = (const char *)memchr(s, '\n', len - pos);
             const size_t n = e ? (size_t)(e - s) : len - pos;
             if (out) out->append(s, n);
+            if (n) last = s[n - 1];
+            total += n;
             any = any || n || e;
             pos += n + (e ? 1 : 0);
             if (e) {
                 if (out && !out->empty() && out->back() == '\r') out->pop_back();
+                if (count) *count = total - (last == '\r' ? 1 : 0);
                 return true;
             }
         }
@@ -142,9 +149,25 @@ struct FastxReader {
         }
         if (line[0] == '@') {
             id.assign(line, 1, std::string::npos);
+            // like seqan3's format_fastq: the sequence runs until the line that starts with '+' (usually one line),
+            // the quality string is as long as the sequence (so a quality line may start with '@' or '+')
+            const size_t seq_begin = bases.size();
             if (!line_to(&bases)) throw std::runtime_error("truncated FASTQ record: " + id);
-            if (!getline(line) || line.empty() || line[0] != '+') throw std::runtime_error("malformed FASTQ record: " + id);
-            if (!line_to(nullptr)) throw std::runtime_error("truncated FASTQ record: " + id);   // quality: skipped, never copied
+            for (;;) {
+                if (pos == len && !refill()) throw std::runtime_error("truncated FASTQ record: " + id);
+                if (buf[pos] == '+') break;
+                line_to(&bases);
+            }
+            line_to(nullptr);                                                                    // the '+' line
+            const size_t want = bases.size() - seq_begin;
+            size_t got = 0, n = 0;
+            do {                                                                                 // quality: skipped, never copied
+                if (!line_to(nullptr, &n)) {
+                    if (got < want) throw std::runtime_error("truncated FASTQ record: " + id);
+                    break;
+                }
+                got += n;
+            } while (got < want);
             return true;
         }
         throw std::runtime_error("query file is neither FASTA nor FASTQ");
@@ -217,6 +240,19 @@ struct RangedFastx {
         cur = i;
         kind = win[i];
         if (kind != '>' && kind != '@') throw std::runtime_error("query file is neither FASTA nor FASTQ");
+        if (kind == '@') {
+            // the range cutter (resync below) relies on four-line records; a file that wraps its sequences over several
+            // lines (legal FASTQ, seqan3 reads it) goes through the sequential reader instead
+            const char *p = win.data() + i, *e = win.data() + n;
+            for (int rec = 0; rec < 16 && p < e; ++rec) {
+                const char *l3 = next_line(next_line(p, e), e);
+                if (l3 >= e) break;
+                if (*l3 != '+') return false;
+                const char *nx = next_line(next_line(l3, e), e);
+                if (nx < e && *nx != '@' && *nx != '\n' && *nx != '\r') return false;
+                p = nx;
+            }
+        }
         return true;
     }
     // file offset of the first record that starts after the line containing offset `from`

@@ -238,6 +238,11 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         while (more) {
             if (gate) gate();
             auto b = pool.get();
+            // a batch recycled from the ranged reader of an earlier plain file may still be page-locked; this reader
+            // appends without a size bound, so the string can reallocate: give the registration up first (a stale
+            // registration over freed memory would be a DMA source) and do not pin batches of this path again
+            if (b->pinned) { taxor_gpu_host_unregister(b->pinned); b->pinned = nullptr; }
+            b->may_pin = false;
             b->seq = seq++;
             b->ids.clear();
             b->bases.clear();
@@ -254,6 +259,29 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
     } catch (const std::exception &ex) { die(ex.what()); }
     finish();
     return now() - t_begin - blocked;
+}
+
+// seqan3's FASTA/FASTQ readers drop white space and digits inside sequences (numbered or column-formatted files).  The
+// parsers here append sequence lines raw -- a scan per byte would halve their rate for files that never need it -- and
+// the device reports any character outside dna15 (TAXOR_E_ALPHABET); only then is the batch cleaned, in place, and run
+// again.  Returns false if there was nothing to remove (the batch really holds a foreign character).
+bool strip_space_and_digits(Batch &b)
+{
+    char *d = &b.bases[0];
+    size_t w = 0;
+    bool any = false;
+    for (size_t r = 0; r + 1 < b.offsets.size(); ++r) {
+        const size_t lo = b.offsets[r], hi = b.offsets[r + 1];
+        b.offsets[r] = w;
+        for (size_t i = lo; i < hi; ++i) {
+            const unsigned char c = (unsigned char)d[i];
+            if (c == ' ' || (c >= '\t' && c <= '\r') || (c >= '0' && c <= '9')) { any = true; continue; }
+            d[w++] = (char)c;
+        }
+    }
+    b.offsets.back() = w;
+    b.bases.resize(w);          // shrinks: never reallocates, a page-locked buffer stays where it is
+    return any;
 }
 
 uint64_t fnv1a(const char *p, size_t n)
@@ -614,7 +642,10 @@ int main(int argc, char **argv)
                         b->pinned = &b->bases[0];       // recycled with the batch: pinned once, DMA source from then on
                     const double t2 = now();
                     taxor_gpu_results res{};
-                    if (taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                    int rc = taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res);
+                    if (rc == TAXOR_E_ALPHABET && strip_space_and_digits(*b))
+                        rc = taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res);
+                    if (rc != TAXOR_OK) die(taxor_gpu_last_error());
                     const double t3 = now();
                     b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
                     b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);

@@ -123,7 +123,7 @@ def test_long_records_span_many_ranges(tmp_path):
 @pytest.mark.parametrize("text,msg", [
     (b"@r1\nACGT\n+\nIIII\n@r2\nACGT\n", "FASTQ record: r2"),
     (b"@r1\nACGT\n+\nIIII\n@r2\nACGT\n+\n", "truncated FASTQ record: r2"),
-    (b"@r1\nACGT\nIIII\n@r2\nAC\n+\nII\n", "malformed"),
+    (b"@r1\nACGT\nIIII\n@r2\nAC\n+\nII\n", "truncated FASTQ record: r1"),   # no '+' line: the sequence runs on
     (b"hello\nworld\n", "neither FASTA nor FASTQ"),
 ])
 def test_damaged_input_fails_loudly(tmp_path, text, msg):
@@ -132,6 +132,29 @@ def test_damaged_input_fails_loudly(tmp_path, text, msg):
     for m in (("--sequential",), ("--threads", "2")):
         cp = subprocess.run([EXE, "reads", "--query-file", str(p), *m], capture_output=True, text=True)
         assert cp.returncode != 0 and msg in cp.stderr, (m, cp.stderr)
+
+
+def test_multi_line_fastq_like_seqan3(tmp_path):
+    """FASTQ whose sequence and quality strings wrap over several lines (seqan3's format_fastq reads the sequence up to
+    the '+' line and then as many quality characters as the sequence has): not cut into byte ranges -- the four-line
+    resync rule does not hold -- but read by the sequential reader, whatever --threads says."""
+    rng = np.random.default_rng(11)
+    recs = make_records(rng, 120, lo=1, hi=900)
+    qchars = np.frombuffer(b"@+!I5>#", np.uint8)
+    p = tmp_path / "wrapped.fastq"
+    with open(p, "wb") as f:
+        for j, (i, s) in enumerate(recs):
+            q = bytes(rng.choice(qchars, size=len(s)))
+            w = int(rng.integers(20, 80))
+            f.write(b"@" + i.encode() + b"\n")
+            for a in range(0, len(s), w):
+                f.write(s[a:a + w] + b"\n")
+            f.write(b"+\n")
+            for a in range(0, len(q), w):
+                f.write(q[a:a + w] + b"\n")
+    want = expected(recs)
+    for m in MODES:
+        assert run_reads(p, *m)[0] == want, m
 
 
 def test_multi_member_gzip_is_inflated_in_parallel_and_in_order(tmp_path):

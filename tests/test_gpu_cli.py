@@ -197,3 +197,53 @@ def test_cli_many_query_files_read_concurrently(tmp_path):
         assert cp.returncode == 0, cp.stderr
         assert cp.stdout.count("use syncmer model") == 1          # the index was loaded once for all files
         assert open(out).read() == want, extra
+
+
+def test_cli_plain_then_large_gzip_batch(tmp_path):
+    """A batch buffer page-locked while a plain file was read (ranged parser) is recycled for a gzip file whose batch
+    outgrows it (sequential reader): the registration must be dropped before the buffer is refilled."""
+    g, go, host, sp, idx_path = _setup(tmp_path, 35)
+    bases, offs, origin = synth.synth_reads(g, go, 3300, 1500, error_rate=0.02, frac_random=0.2, seed=9)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(3300)]
+    ids = [f"q{i}" for i in range(3300)]
+    plain, gz = tmp_path / "a.fastq", tmp_path / "b.fastq.gz"
+    with open(plain, "wb") as f:                                   # 300 reads = 0.45 MB: fits the 2 MB minimum reserve
+        for rid, r in zip(ids[:300], reads[:300]):
+            f.write(b"@" + rid.encode() + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    with gzip.open(gz, "wb", compresslevel=1) as f:                # one 4.5 MB batch: the recycled string must grow
+        for rid, r in zip(ids[300:], reads[300:]):
+            f.write(b"@" + rid.encode() + b"\n" + r + b"\n+\n" + b"I" * len(r) + b"\n")
+    out = tmp_path / "o.tsv"
+    want = HEADER + _expected(host, sp, ids, reads)
+    for extra in (["--threads", "1"], ["--threads", "4"]):
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{plain},{gz},{plain}",
+                             "--output-file", str(out), "--batch-reads", "100000"] + extra, capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0, cp.stderr
+        assert open(out).read() == want + _expected(host, sp, ids[:300], reads[:300])
+
+
+def test_cli_sequences_with_spaces_and_digits(tmp_path):
+    """seqan3 drops white space and digits inside sequences (numbered / column-formatted files); the CLI cleans a batch
+    only when the device reports a character outside dna15, and a really foreign character still fails"""
+    g, go, host, sp, idx_path = _setup(tmp_path, 36)
+    bases, offs, origin = synth.synth_reads(g, go, 60, 1300, error_rate=0.02, frac_random=0.2, seed=10)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(60)]
+    ids = [f"gb_{i}" for i in range(60)]
+    fa = tmp_path / "numbered.fa"
+    with open(fa, "wb") as f:
+        for rid, r in zip(ids, reads):
+            f.write(b">" + rid.encode() + b"\n")
+            for a in range(0, len(r), 60):                          # GenBank-like: position, blocks of ten
+                row = r[a:a + 60]
+                f.write(b"%9d " % (a + 1) + b" ".join(row[j:j + 10] for j in range(0, len(row), 10)) + b"\t\n")
+    out = tmp_path / "o.tsv"
+    for extra in (["--threads", "1"], ["--threads", "4", "--batch-reads", "7"]):
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out)] + extra,
+                            capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0, cp.stderr
+        assert open(out).read() == HEADER + _expected(host, sp, ids, reads)
+    bad = tmp_path / "bad.fa"
+    open(bad, "wb").write(b">x\nACGT ACGT 12 ACGTACGTACGTACGTACGT#ACGT\n")
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(bad), "--output-file", str(out)],
+                        capture_output=True, text=True, timeout=120)
+    assert cp.returncode != 0 and "dna15" in cp.stderr
