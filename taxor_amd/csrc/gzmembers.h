@@ -66,8 +66,22 @@ public:
         size_t max_gap = 0;
         for (size_t i = 0; i < cand_.size(); ++i)
             max_gap = std::max(max_gap, (i + 1 < cand_.size() ? cand_[i + 1] : size_) - cand_[i]);
-        if (max_gap > (256u << 20)) return false;                   // members that large: a few of them would not fit in memory
+        if (max_gap > kMaxMember) return false;                   // members that large: a few of them would not fit in memory
         res_.resize(cand_.size());
+        // Candidates are only byte patterns (about one false `1f 8b 08` per 2^27 bytes of deflate data), so a large
+        // single-member file can pass the tests above.  Commit to parallel mode only if the first member really ends
+        // on another candidate (or at the end of the file) within the size limit; its output is kept, not redone.
+        {
+            Result r0;
+            inflate_member(0, cand_[1], r0);
+            const bool chained = r0.state == 2 && (r0.end >= size_ || std::binary_search(cand_.begin(), cand_.end(), r0.end) ||
+                                                   only_zeros_from(r0.end));
+            if (!chained) return false;
+            res_[0].out.swap(r0.out);
+            res_[0].end = r0.end;
+            res_[0].state = 2;
+            next_task_ = 1;
+        }
         window_ = std::max(4u, 2 * threads);
         for (unsigned t = 0; t < std::max(1u, threads); ++t) th_.emplace_back([this] { worker(); });
         return true;
@@ -96,6 +110,13 @@ private:
         size_t end = 0;
         int state = 0;   // 0 not started, 1 running, 2 inflated, 3 not a member / corrupt
     };
+
+    bool only_zeros_from(size_t p) const
+    {
+        for (; p < size_; ++p)
+            if (map_[p] != 0) return false;
+        return true;
+    }
 
     bool header_at(size_t p) const
     {
@@ -137,13 +158,19 @@ private:
         r.state = 3;
         if (inflateInit2(&zs, 15 + 16) != Z_OK) return;
         zs.next_in = const_cast<Bytef *>(map_ + p);
-        size_t avail = size_ - p;
+        // a real member is at most kMaxMember compressed bytes long (open() checked the candidate gaps); a false
+        // candidate that happens to parse as deflate data must not run through the rest of the file, and no member may
+        // grow its output without bound
+        size_t avail = std::min(size_ - p, kMaxMember + (1u << 16));
         r.out.resize(std::max<size_t>(1u << 16, 4 * guess));
         size_t produced = 0;
         for (;;) {
             const uInt in_chunk = (uInt)std::min<size_t>(avail, 1u << 30);
             zs.avail_in = in_chunk;
-            if (produced == r.out.size()) r.out.resize(r.out.size() * 2);
+            if (produced == r.out.size()) {
+                if (produced >= kMaxOutput) break;
+                r.out.resize(std::min(r.out.size() * 2, kMaxOutput));
+            }
             const uInt out_chunk = (uInt)std::min<size_t>(r.out.size() - produced, 1u << 30);
             zs.next_out = (Bytef *)&r.out[produced];
             zs.avail_out = out_chunk;
@@ -152,12 +179,12 @@ private:
             avail -= in_chunk - zs.avail_in;
             if (rc == Z_STREAM_END) {
                 r.out.resize(produced);
-                r.end = size_ - avail;
+                r.end = (size_t)(zs.next_in - map_);
                 r.state = 2;
                 break;
             }
             if (rc != Z_OK && rc != Z_BUF_ERROR) break;              // not a deflate stream: a false candidate
-            if (rc == Z_BUF_ERROR && zs.avail_in == 0 && avail == 0) break; // truncated
+            if (zs.avail_in == 0 && avail == 0 && rc != Z_STREAM_END && zs.avail_out != 0) break; // truncated, or longer than a member may be
         }
         inflateEnd(&zs);
         if (r.state != 2) r.out.clear();
@@ -191,6 +218,9 @@ private:
         cur_pos_ = 0;
         return true;
     }
+
+    static constexpr size_t kMaxMember = 256u << 20;      // compressed bytes of one member in parallel mode
+    static constexpr size_t kMaxOutput = 4ull << 30;      // inflated bytes of one member
 
     const unsigned char *map_ = nullptr;
     size_t size_ = 0;

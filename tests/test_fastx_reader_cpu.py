@@ -195,3 +195,17 @@ def test_multi_member_gzip_is_inflated_in_parallel_and_in_order(tmp_path):
     q.write_bytes(bytes(bad))
     cp = subprocess.run([EXE, "reads", "--query-file", str(q), "--threads", "4"], capture_output=True, text=True)
     assert cp.returncode != 0 or cp.stdout != "".join(f"{i}\t{n}\t{h:016x}\n" for i, n, h in want)
+
+
+def test_single_member_gzip_with_false_member_headers(tmp_path):
+    """a one-member .gz whose (stored) data contains byte patterns that look like member headers: the speculative
+    member search must not be fooled into a wrong split"""
+    rng = np.random.default_rng(13)
+    recs = [(f"r{i} \x1f\x8b\x08\x00 tag", bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300))) for i in range(40)]
+    raw = b"".join(b"@" + i.encode("latin1") + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in recs)
+    p = tmp_path / "stored.fastq.gz"
+    p.write_bytes(gzip.compress(raw, compresslevel=0))
+    cp = subprocess.run([EXE, "reads", "--query-file", str(p), "--threads", "4"], capture_output=True)
+    assert cp.returncode == 0, cp.stderr
+    rows = [l.split(b"\t") for l in cp.stdout.split(b"\n") if l]
+    assert [(r[0], int(r[1]), int(r[2], 16)) for r in rows] == [(i.encode("latin1"), len(s), fnv1a(s)) for i, s in recs]
