@@ -201,7 +201,7 @@ def test_single_member_gzip_with_false_member_headers(tmp_path):
     """a one-member .gz whose (stored) data contains byte patterns that look like member headers: the speculative
     member search must not be fooled into a wrong split"""
     rng = np.random.default_rng(13)
-    recs = [(f"r{i} \x1f\x8b\x08\x00 tag", bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300))) for i in range(40)]
+    recs = [(f"r{i} \x1f\x8b\x08\x01 tag", bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=300))) for i in range(40)]
     raw = b"".join(b"@" + i.encode("latin1") + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in recs)
     p = tmp_path / "stored.fastq.gz"
     p.write_bytes(gzip.compress(raw, compresslevel=0))
