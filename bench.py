@@ -5,19 +5,37 @@
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One step = one pass of the hot path (syncmers -> dedup -> threshold -> level-synchronous HIXF query -> DFS
-ordered per-read tuples) over one batch of synthetic long reads that is already resident in HBM (2-bit
-packed); with N>1 every rank holds a replica of the index, classifies its own shard of reads (weak scaling)
-and the per-read results are gathered on rank 0 over RCCL inside the timed region.
+ordered per-read tuples) over one batch of synthetic long reads that is already resident in HBM (2-bit packed).
+`--batches` DISTINCT batches are resident and the steps rotate through them, so no step re-reads the rows its
+predecessor touched.  With N>1 every rank holds a replica of the index, classifies its own shard of reads and the
+per-read results are gathered on rank 0 over RCCL inside the timed region (`--scaling weak`: per-GPU work fixed;
+`--scaling strong`: the N=1 batch is cut into N shards).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     : k_query_level (dominant kernel) algorithmic gather bytes / its HIP-event time vs 8 TB/s HBM
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline     : k_query_level (dominant kernel).  achieved = bytes the kernel REQUESTED (device-counted) / its
+                 HIP-event time, frac = achieved / 8 TB/s (<= 1 by construction).  The reference's formulation
+                 counts every hash against every bin (n_h*3*bins per visited IXF); threshold-aware
+                 pruning requests fewer bytes with identical results, so the algorithmic rate is reported
+                 separately (algorithmic_GBps, vs_dense) and `unpruned` holds the same steps with pruning switched
+                 off, where requested == algorithmic and the contract formula is physical.
+                 traffic = HBM bytes per launch from two live rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
+                 correction, WRITE_SIZE) over one step of the same workload, run as child processes before this
+                 process touches the GPU; null when rocprofv3 is unavailable (never a constant from a file).
   cpu_baseline : the CPU oracle (oracle/, a port of the reference path) timed on this box's host cores on a
                  bounded sample of the same reads and index; also used to re-check parity on that sample.
+  sustained    : >= 10 M reads fed from HOST buffers through taxor_gpu_search_batch_begin/_end (PCIe inside),
+                 rotating through the same distinct batches; never reported as `value`.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -38,7 +56,7 @@ WORKLOADS = {
     "viral": dict(root_bins=256, child_bins=64, n_children=252, total_bytes=373e6, root_frac=0.40,
                   reads=131072, read_len=5000, genomes=64, genome_len=100000),
     "tiny": dict(root_bins=64, child_bins=32, n_children=8, total_bytes=8e6, root_frac=0.40,
-                 reads=2048, read_len=3000, genomes=8, genome_len=50000),
+                 reads=2048, read_len=3000, genomes=16, genome_len=50000),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -48,33 +66,215 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("TAXOR_BENCH_WORKLOAD", "gtdb"), choices=sorted(WORKLOADS))
+    ap.add_argument("--root-bins", type=int, default=0, help="root t_max (taxor_build.cpp:177-184: 64..4096); 0 = workload default")
     ap.add_argument("--reads", type=int, default=0, help="reads per step and GPU (0 = workload default)")
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--genomes", type=int, default=0, help="planted genomes (0 = workload default)")
     ap.add_argument("--genome-len", type=int, default=0)
-    ap.add_argument("--read-error", type=float, default=0.02)
+    ap.add_argument("--family-size", type=int, default=16,
+                    help="planted genomes come in families of this many related strains (99.7-93.6 %% identical) laid out in "
+                         "adjacent bins of several child IXFs; 1 = unrelated genomes (the round-1 workload)")
+    ap.add_argument("--read-error", type=float, default=0.02,
+                    help="per-base error of the synthetic reads.  BASELINE.md section 3 names 0.04, but with uniformly placed errors only "
+                         "(1-0.036)^22 = 45 %% of a read's 22-mers survive that, below the 0.508 the reference's model demands at "
+                         "--error-rate 0.04, so nothing would classify; 0.02 (68 %% survive) exercises the whole traversal.  DESIGN.md "
+                         "section 5 reports both.")
     ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate through")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
     ap.add_argument("--len-mix", default="", help="'ont': skewed read lengths 1-100 kb (same total bases) instead of a fixed length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-dropin", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurement: "
-                    "profiling passes then contain only the timed steps' launches")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
+    ap.add_argument("--no-unpruned", action="store_true", help="skip the pruning-off pass")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the gather-ceiling microkernel")
+    ap.add_argument("--sustained-reads", type=int, default=10_000_000, help="host-fed reads of the `sustained` figure (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--traffic-bytes", type=float, default=None,
-                    help="HBM bytes per k_query_level launch from a separate rocprofv3 --pmc pass")
-    args = ap.parse_args()
+    ap.add_argument("--traffic", default="live", choices=("live", "none"),
+                    help="live: two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) over one step before the run")
+    ap.add_argument("--dump-results", default="", help="rank 0 writes the last step's (gathered) CSR results to this .npz (tests)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# live HBM traffic: rocprofv3 --pmc passes over one step of the same workload, as child processes, BEFORE this process
+# initialises the GPU (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; FETCH_SIZE is in KB and
+# reports half the bytes of wide coalesced reads on gfx950 -> doubled; counters get --kernel-trace only)
+# ---------------------------------------------------------------------------------------------------------------------
+def live_traffic(args):
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "1", "--warmup", "0",
+             "--workload", args.workload, "--family-size", str(args.family_size), "--read-error", str(args.read_error),
+             "--error-rate", str(args.error_rate), "--batches", "1"]
+    for flag, v in (("--reads", args.reads), ("--read-len", args.read_len), ("--genomes", args.genomes),
+                    ("--genome-len", args.genome_len), ("--root-bins", args.root_bins)):
+        if v:
+            child += [flag, str(v)]
+    if args.len_mix:
+        child += ["--len-mix", args.len_mix]
+    per_launch = {}
+    launches = None
+    tmp = tempfile.mkdtemp(prefix="taxor_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
+            t0 = time.time()
+            try:
+                cp = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420,
+                                    start_new_session=True)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {counter} pass timed out"
+            if cp.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {cp.returncode}): {cp.stderr.decode(errors='replace')[-300:]}"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"rocprofv3 --pmc {counter}: no counter_collection.csv"
+            tot, ids = 0.0, set()
+            for f in files:
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and "k_query_level" in r.get("Kernel_Name", ""):
+                        tot += float(r["Counter_Value"])
+                        ids.add(r.get("Dispatch_Id"))
+            if not ids:
+                return None, f"rocprofv3 --pmc {counter}: no k_query_level dispatch in the trace"
+            per_launch[counter] = tot * 1024.0 * corr / len(ids)     # KB -> bytes, gfx950 correction
+            launches = len(ids)
+            log(f"rocprofv3 --pmc {counter}: {len(ids)} k_query_level launches, {per_launch[counter]/1e9:.3f} GB per launch "
+                f"(corrected x{corr:g}), {time.time()-t0:.0f}s")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"], \
+        f"live rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, separate passes over one step " \
+        f"({launches} launches) of this workload in this invocation"
+
+
+def build_workload(args, local_rank, rank, world):
+    """planted genomes, index resident in HBM, and this rank's distinct read batches"""
+    from taxor_amd import GpuIndex, Searcher, synth
+    wl = dict(WORKLOADS[args.workload])
+    if args.root_bins:
+        wl["root_bins"] = args.root_bins
+    n_reads = args.reads or wl["reads"]
+    read_len = args.read_len or wl["read_len"]
+    n_genomes = args.genomes or wl["genomes"]
+    genome_len = args.genome_len or wl["genome_len"]
+    fam_size = max(1, min(args.family_size, n_genomes))
+    k, s, t = 22, 12, 5
+    ncpu = os.cpu_count() or 8
+
+    # ---- planted genomes and their syncmer hashes (hashed on the GPU; same seed on every rank) -------------
+    t0 = time.time()
+    if fam_size > 1:
+        n_genomes = (n_genomes // fam_size) * fam_size
+        g, go, family = synth.family_genomes(n_genomes // fam_size, fam_size, genome_len, seed=synth.DEFAULT_SEED)
+    else:
+        g, go = synth.random_genomes(n_genomes, genome_len, seed=synth.DEFAULT_SEED)
+        family = None
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins, k, s, t,
+                     device=local_rank)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(n_genomes)]
+    hs.close()
+    dummy.close()
+    log(f"{n_genomes} genomes x {genome_len} bp ({'families of %d' % fam_size if fam_size > 1 else 'unrelated'}) hashed on GPU: "
+        f"{int(hoff[-1])} syncmers, {time.time()-t0:.1f}s")
+
+    # ---- footprint-faithful layout -----------------------------------------------------------------------------
+    t0 = time.time()
+    spread = 4
+    n_children = min(wl["n_children"], wl["root_bins"] - 8)
+    root_rows = wl["total_bytes"] * wl["root_frac"] / max(64, wl["root_bins"])
+    child_rows = wl["total_bytes"] * (1 - wl["root_frac"]) / ((n_children + 1) * max(64, wl["child_bins"]))
+    root_max = max(int((root_rows - 32) / 1.23), 8)
+    child_max = max(int((child_rows - 32) / 1.23), 8)
+    biggest = max(len(p) for p in planted)
+    if fam_size > 1:
+        per_child = -(-fam_size // spread) + 1
+        need_root = biggest * per_child
+    else:
+        need_root = max(sum(len(p) for p in planted[2:]) // max(1, min(n_children, len(planted) - 2)) * 2, biggest)
+    root_max = max(root_max, need_root)
+    child_max = max(child_max, biggest + 1024)
+    if fam_size > 1:
+        lay = synth.make_family_layout(planted, family, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
+                                       n_children=n_children, spread=spread, root_max_elems=root_max,
+                                       child_max_elems=child_max, seed=synth.DEFAULT_SEED, build="gpu")
+    else:
+        lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
+                                n_children=n_children, root_max_elems=root_max, child_max_elems=child_max,
+                                seed=synth.DEFAULT_SEED, build="gpu")
+    idx = synth.device_index(lay, k, s, t, device=local_rank)   # planted columns constructed on the GPU
+    log(f"index in HBM: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs, depth {idx.depth}, root {wl['root_bins']} bins, "
+        f"children {wl['child_bins']} bins, {time.time()-t0:.1f}s")
+
+    # ---- this rank's distinct batches (seed + rank + batch) ----------------------------------------------------
+    t0 = time.time()
+    if args.scaling == "strong" and world > 1:
+        from taxor_amd import distributed as td
+        lo, hi = td.shard_range(n_reads, rank, world)
+    else:
+        lo, hi = 0, n_reads
+    batches, origins = [], []
+    for b in range(max(1, args.batches)):
+        seed = synth.DEFAULT_SEED + 1000 * b + (rank if args.scaling == "weak" else 0)
+        if args.len_mix == "ont":
+            # ONT-like skew with the same total bases: 1, 3, 10, 30, 100 kb carrying 10/20/40/20/10 % of the bases, shuffled
+            total = n_reads * read_len
+            parts = []
+            for L, frac in ((1000, 0.1), (3000, 0.2), (10000, 0.4), (30000, 0.2), (100000, 0.1)):
+                cnt = max(1, int(total * frac / L))
+                bb, oo, _ = synth.synth_reads(g, go, cnt, L, error_rate=args.read_error, frac_random=0.1, seed=seed + L, threads=ncpu)
+                parts += [(bb, int(oo[i]), int(oo[i + 1])) for i in range(cnt)]
+            perm = np.random.default_rng(seed).permutation(len(parts))
+            bases = np.concatenate([parts[i][0][parts[i][1]:parts[i][2]] for i in perm])
+            offs = np.concatenate([[0], np.cumsum([parts[i][2] - parts[i][1] for i in perm])]).astype(np.uint64)
+            origin = None
+        else:
+            bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
+                                                    seed=seed, threads=ncpu)
+        if (lo, hi) != (0, offs.size - 1):          # strong scaling: this rank's contiguous shard of the common batch
+            lo_, hi_ = (lo, hi) if not args.len_mix else td.shard_range(offs.size - 1, rank, world)
+            bases, offs = bases[int(offs[lo_]):int(offs[hi_])], offs[lo_:hi_ + 1] - offs[lo_]
+            origin = origin[lo_:hi_] if origin is not None else None
+        batches.append((np.ascontiguousarray(bases), np.ascontiguousarray(offs)))
+        origins.append(origin)
+    log(f"{len(batches)} distinct batches of {batches[0][1].size - 1} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
+    return wl, idx, lay, batches, dict(n_reads=n_reads, read_len=read_len, n_genomes=n_genomes, genome_len=genome_len,
+                                       fam_size=fam_size, ncpu=ncpu, origins=origins)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    # live PMC passes run as child processes before anything here touches the GPU
+    traffic, traffic_src = None, "not collected (--traffic none, a child run, or N > 1)"
+    if args.traffic == "live" and not args.pmc_child and world == 1:
+        try:
+            traffic, traffic_src = live_traffic(args)
+        except Exception as e:      # the profiler is an aid: its failure must not take the benchmark down
+            traffic, traffic_src = None, f"rocprofv3 pass raised {type(e).__name__}: {e}"
+        if traffic is None:
+            log("traffic:", traffic_src)
 
     import torch                      # first: its bundled HIP runtime is the one the process uses
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -92,83 +292,24 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from taxor_amd import GpuIndex, Searcher, synth
+    from taxor_amd import Searcher
 
-    wl = dict(WORKLOADS[args.workload])
-    n_reads = args.reads or wl["reads"]
-    read_len = args.read_len or wl["read_len"]
-    args.genomes = args.genomes or wl["genomes"]
-    args.genome_len = args.genome_len or wl["genome_len"]
-    k, s, t = 22, 12, 5
-    ncpu = os.cpu_count() or 8
+    wl, idx, lay, batches, info = build_workload(args, local_rank, rank, world)
+    n_reads, read_len, ncpu = info["n_reads"], info["read_len"], info["ncpu"]
+    shard_reads = [b[1].size - 1 for b in batches]
+    shard_bases = [int(b[1][-1]) for b in batches]
 
-    # ---- planted genomes and their syncmer hashes (hashed on the GPU; same seed on every rank) -------------
-    t0 = time.time()
-    g, go = synth.random_genomes(args.genomes, args.genome_len, seed=synth.DEFAULT_SEED)
-    bins = 64
-    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
-                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins, k, s, t,
-                     device=local_rank)
-    hs = Searcher(dummy, ratio=0.5)
-    hoff, hashes = hs.seq_to_syncmers(g, go)
-    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(args.genomes)]
-    hs.close()
-    dummy.close()
-    log(f"{args.genomes} genomes x {args.genome_len} bp hashed on GPU: {int(hoff[-1])} syncmers, {time.time()-t0:.1f}s")
-
-    # ---- footprint-faithful layout -----------------------------------------------------------------------------
-    t0 = time.time()
-    root_rows = wl["total_bytes"] * wl["root_frac"] / wl["root_bins"]
-    child_rows = wl["total_bytes"] * (1 - wl["root_frac"]) / ((wl["n_children"] + 1) * max(64, wl["child_bins"]))
-    root_max = max(int((root_rows - 32) / 1.23), 8)
-    child_max = max(int((child_rows - 32) / 1.23), 8)
-    need_root = max(sum(len(p) for p in planted[2:]) // max(1, min(wl["n_children"], len(planted) - 2)) * 2,
-                    max(len(p) for p in planted))
-    root_max = max(root_max, need_root)
-    child_max = max(child_max, max(len(p) for p in planted) + 1024)
-    lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
-                            n_children=wl["n_children"], root_max_elems=root_max, child_max_elems=child_max,
-                            seed=synth.DEFAULT_SEED, build="gpu")
-    idx = synth.device_index(lay, k, s, t, device=local_rank)   # planted columns constructed on the GPU
-    log(f"index in HBM: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs, depth {idx.depth}, root {wl['root_bins']} bins, "
-        f"children {wl['child_bins']} bins, {time.time()-t0:.1f}s")
-
-    # ---- reads of this rank's shard (seed + rank), resident in HBM before the timed region -----------------------
-    t0 = time.time()
-    if args.len_mix == "ont":
-        # ONT-like skew with the same total bases: 1, 3, 10, 30, 100 kb carrying 10/20/40/20/10 % of the bases, shuffled
-        total = n_reads * read_len
-        parts = []
-        for L, frac in ((1000, 0.1), (3000, 0.2), (10000, 0.4), (30000, 0.2), (100000, 0.1)):
-            cnt = max(1, int(total * frac / L))
-            b, o, _ = synth.synth_reads(g, go, cnt, L, error_rate=args.read_error, frac_random=0.1,
-                                        seed=synth.DEFAULT_SEED + rank + L, threads=ncpu)
-            parts += [(b, int(o[i]), int(o[i + 1])) for i in range(cnt)]
-        perm = np.random.default_rng(synth.DEFAULT_SEED + rank).permutation(len(parts))
-        bases = np.concatenate([parts[i][0][parts[i][1]:parts[i][2]] for i in perm])
-        offs = np.concatenate([[0], np.cumsum([parts[i][2] - parts[i][1] for i in perm])]).astype(np.uint64)
-        origin = None
-        n_reads = len(parts)
-        read_len = int(offs[-1]) / n_reads
-    else:
-        bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
-                                                seed=synth.DEFAULT_SEED + rank, threads=ncpu)
-    log(f"{n_reads} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
-    sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
-    # the drop-in call with host buffers (bases cross PCIe inside the call, streamed per sub-batch); reported as
-    # pcie_inclusive, never as `value`
-    t_dropin = None
-    if not args.no_dropin:
-        sr.search_batch(bases, offs)
-        t0 = time.time()
-        sr.search_batch(bases, offs)
-        t_dropin = time.time() - t0
-    sr.upload(bases, offs)
+    # one searcher per resident batch: each keeps its packed reads (and its scratch) in HBM
+    searchers = []
+    for bases, offs in batches:
+        sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+        sr.upload(bases, offs)
+        searchers.append(sr)
 
     from taxor_amd import distributed as td
     gathered = {}
 
-    def gather_results():
+    def gather_results(sr):
         """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
         if world == 1:
             return
@@ -184,116 +325,230 @@ def main():
             ro, ub, ct, nh = ro.cpu(), ub.cpu(), ct.cpu(), nh.cpu()
         gathered["last"] = td.gather_csr(ro, ub, ct, nh, dst=0)
 
-    def step():
+    def step(i, pool):
+        sr = pool[i % len(pool)]
         sr.run()
         sr.sync()
-        gather_results()
+        gather_results(sr)
+        return sr
 
-    for _ in range(args.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    q_ms = q_bytes = q_touched = 0.0
-    q_launches = 0
-    for _ in range(args.steps):
-        step()
-        st = sr.stats()
-        q_ms += st["query_ms"]
-        q_bytes += st["query_bytes"]
-        q_touched += st["query_touched_bytes"]
-        q_launches += st["query_launches"]
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64,
-                          device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    st = sr.stats()
+    def timed(pool, steps, warmup):
+        for i in range(warmup):
+            step(i, pool)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = dict(q_ms=0.0, q_bytes=0.0, q_touched=0.0, launches=0, bases=0, sync_ms=0.0, query_ms=0.0, fin_ms=0.0, total_ms=0.0,
+                   hashes=0, tuples=0, work=0, reads=0, alg=0)
+        for i in range(steps):
+            sr = step(warmup + i, pool)
+            st = sr.stats()
+            acc["q_ms"] += st["query_ms"]
+            acc["q_bytes"] += st["query_bytes"]
+            acc["q_touched"] += st["query_touched_bytes"]
+            acc["launches"] += st["query_launches"]
+            acc["bases"] += st["n_bases"]
+            acc["sync_ms"] += st["syncmer_ms"]
+            acc["fin_ms"] += st["finalize_ms"]
+            acc["total_ms"] += st["total_ms"]
+            acc["hashes"] += st["n_hashes"]
+            acc["tuples"] += st["n_tuples"]
+            acc["work"] += st["n_work_items"]
+            acc["reads"] += st["n_reads"]
+            acc["alg"] += st["algorithmic_bytes"]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([elapsed, float(acc["bases"])], dtype=torch.float64,
+                              device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
+            elapsed, acc["all_bases"] = float(tt[0].item()), float(tt[1].item())
+        else:
+            acc["all_bases"] = float(acc["bases"])
+        return elapsed, acc
+
+    elapsed, acc = timed(searchers, args.steps, args.warmup)
     if world > 1 and rank == 0:
         g_off, g_ub, g_cnt, g_nh = gathered["last"]
-        assert g_nh.numel() == n_reads * world and g_off.numel() == n_reads * world + 1
-        assert int(g_off[-1]) == g_ub.numel() == g_cnt.numel()
-    total_bases = float(n_reads) * read_len * world * args.steps
-    value = total_bases / elapsed / 1e6
+        assert g_off.numel() == g_nh.numel() + 1 and int(g_off[-1]) == g_ub.numel() == g_cnt.numel()
+        want = n_reads if args.scaling == "strong" else n_reads * world
+        assert g_nh.numel() == want, (g_nh.numel(), want)
+    value = acc["all_bases"] / elapsed / 1e6
+    if args.dump_results and rank == 0:
+        if world > 1:
+            d_off, d_ub, d_cnt, d_nh = (x.cpu().numpy() for x in gathered["last"])
+        else:
+            r_ = searchers[(args.warmup + args.steps - 1) % len(searchers)].fetch()
+            d_off, d_ub, d_cnt, d_nh = r_.read_off, r_.user_bin, r_.count, r_.n_hashes
+        np.savez(args.dump_results, read_off=d_off.astype(np.int64), user_bin=d_ub.astype(np.int64), count=d_cnt.astype(np.int64),
+                 n_hashes=d_nh.astype(np.int64))
+
+    if args.pmc_child:                 # profiled child: the launches above are all the parent wanted
+        for sr in searchers:
+            sr.close()
+        idx.close()
+        return
 
     out = None
     if rank == 0:
-        # measured gather ceiling: random whole-row reads of the same IXFs by a kernel that does nothing
-        # else; outside the timed region
-        ceiling = {}
-        for name, ixf in (("root", 0), ("child", 1 if idx.n_ixf > 1 else 0)):
-            gbps, row_bytes = idx.gather_ceiling(ixf, want_bytes=16 << 30, reps=3)
-            ceiling[name] = {"ixf": ixf, "row_bytes": row_bytes, "GBps": round(gbps, 1)}
-        achieved = q_bytes / (q_ms * 1e-3) / 1e9 if q_ms > 0 else 0.0
-        res = sr.fetch()
+        q_s = acc["q_ms"] * 1e-3
+        requested = acc["q_touched"] / q_s / 1e9 if q_s > 0 else 0.0
+        algorithmic = acc["q_bytes"] / q_s / 1e9 if q_s > 0 else 0.0
+        launches = max(1, acc["launches"])
+        roof = {"bound": "hbm", "achieved": round(requested, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(requested / HBM_PEAK_GBS, 4),
+                "traffic": None if traffic is None else round(traffic, 1), "traffic_source": traffic_src,
+                "kernel": "k_query_level",
+                "note": "achieved = bytes k_query_level requested (device-counted) / its HIP-event time on the searcher's "
+                        "stream.  algorithmic_* = the reference's n_h*3*bins per visited IXF (SURVEY 8(d)); pruning asks for "
+                        "fewer bytes with identical tuples, so vs_dense > 1 is saved work, not bandwidth.  `unpruned`: same "
+                        "steps with pruning off, where the contract formula (algorithmic bytes / time) is physical.",
+                "launches": acc["launches"], "avg_launch_ms": round(acc["q_ms"] / launches, 4),
+                "requested_bytes_per_launch": round(acc["q_touched"] / launches, 1),
+                "algorithmic_bytes_per_launch": round(acc["q_bytes"] / launches, 1),
+                "algorithmic_GBps": round(algorithmic, 1),
+                "vs_dense": round(acc["q_bytes"] / max(1.0, acc["q_touched"]), 4)}
+        if traffic is not None:
+            roof["traffic_over_requested"] = round(traffic / max(1.0, acc["q_touched"] / launches), 4)
+
+        # ---- the contract formula on a kernel that does all the algorithmic work: pruning off -------------------
+        if not args.no_unpruned and world == 1:
+            os.environ["TAXOR_QUERY_PRUNE"] = "0"
+            try:
+                pool = []
+                for bases, offs in batches[:2]:
+                    s2 = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+                    s2.upload(bases, offs)
+                    pool.append(s2)
+            finally:
+                del os.environ["TAXOR_QUERY_PRUNE"]
+            e2, a2 = timed(pool, max(2, min(args.steps, 4)), 1)
+            q2 = a2["q_ms"] * 1e-3
+            assert a2["q_touched"] == a2["q_bytes"]
+            roof["unpruned"] = {"achieved": round(a2["q_bytes"] / q2 / 1e9, 1), "frac": round(a2["q_bytes"] / q2 / 1e9 / HBM_PEAK_GBS, 4),
+                                "avg_launch_ms": round(a2["q_ms"] / max(1, a2["launches"]), 4),
+                                "algorithmic_bytes_per_launch": round(a2["q_bytes"] / max(1, a2["launches"]), 1),
+                                "value_Mbp_s": round(a2["all_bases"] / e2 / 1e6, 2),
+                                "note": "TAXOR_QUERY_PRUNE=0: every hash against every bin of every visited IXF, like the reference"}
+            ra, rb = pool[0].fetch(), searchers[0].fetch()      # both hold batch 0: pruning must not change a single tuple
+            same = (np.array_equal(ra.read_off, rb.read_off) and np.array_equal(ra.user_bin, rb.user_bin)
+                    and np.array_equal(ra.count, rb.count) and np.array_equal(ra.n_hashes, rb.n_hashes))
+            if not same:
+                raise SystemExit("PARITY FAILURE: pruning changed the results")
+            for s2 in pool:
+                s2.close()
+
+        # measured gather ceiling: random whole-row reads of the same IXFs by a kernel that does nothing else
+        if not args.no_ceiling:
+            ceiling = {}
+            for name, ixf in (("root", 0), ("child", 1 if idx.n_ixf > 1 else 0)):
+                gbps, row_bytes = idx.gather_ceiling(ixf, want_bytes=16 << 30, reps=3)
+                ceiling[name] = {"ixf": ixf, "row_bytes": row_bytes, "GBps": round(gbps, 1)}
+            roof["gather_ceiling"] = ceiling
+
+        last = searchers[(args.warmup + args.steps - 1) % len(searchers)]
+        res = last.fetch()
+        st = last.stats()
         classified = int(((res.read_off[1:] - res.read_off[:-1]) > 0).sum())
+        nr = max(1, acc["reads"])
+        fam = f"{info['n_genomes'] // info['fam_size']} families x {info['fam_size']} strains" if info["fam_size"] > 1 else f"{info['n_genomes']} unrelated genomes"
         out = {
             "metric": "Mbp/s classified (taxor search) vs GTDB k22/s12", "value": round(value, 2), "unit": "Mbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-class synthetic HIXF k22/s12/t5, {idx.data_bytes/1e9:.1f} GB resident, "
-                                   f"root {wl['root_bins']} bins / children {wl['child_bins']} bins / depth {idx.depth}, "
-                                   f"{n_reads} reads x {read_len} bp per GPU per step",
+            "config": {"workload": f"{args.workload}-class HIXF k22/s12 {idx.data_bytes/1e9:.0f} GB in HBM, root {wl['root_bins']} bins, "
+                                   f"{shard_reads[0]} reads x {int(read_len)} bp/GPU/step, {fam}",
                        "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "root_bins": wl["root_bins"],
-                       "child_bins": wl["child_bins"], "reads_per_gpu": n_reads, "read_len": read_len,
-                       "read_error": args.read_error, "search_error_rate": args.error_rate,
-                       "planted_genomes": args.genomes, "sharding": "reads by rank, index replicated",
-                       "hashes_per_read": round(st["n_hashes"] / max(1, n_reads), 1),
-                       "tuples_per_read": round(st["n_tuples"] / max(1, n_reads), 3),
-                       "reads_with_hits": classified, "work_items_per_read": round(st["n_work_items"] / max(1, n_reads), 3)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic_from_profiles(args), "kernel": "k_query_level",
-                         "note": "achieved = algorithmic bytes (sum n_h*3*bins over visited IXFs, SURVEY 8(d)) / HIP-event "
-                                 "time; threshold-aware pruning requests fewer bytes than that (requested_*), so "
-                                 "achieved can exceed the HBM peak while requested_GBps cannot",
-                         "launches": q_launches, "avg_launch_ms": round(q_ms / max(1, q_launches), 4),
-                         "algorithmic_bytes_per_launch": round(q_bytes / max(1, q_launches), 1),
-                         "requested_bytes_per_launch": round(q_touched / max(1, q_launches), 1),
-                         "requested_GBps": round(q_touched / (q_ms * 1e-3) / 1e9, 1) if q_ms > 0 else 0.0,
-                         "gather_ceiling": ceiling,
-                         "whole_step_achieved": round(st["algorithmic_bytes"] * args.steps / elapsed / 1e9 / 1.0, 1)},
-            "stage_ms_last_step": {"syncmers": round(st["syncmer_ms"], 3), "query": round(st["query_ms"], 3),
-                                   "finalize": round(st["finalize_ms"], 3), "total": round(st["total_ms"], 3)},
-            "pcie_inclusive": None if t_dropin is None else {"seconds": round(t_dropin, 4), "value": round(float(n_reads) * read_len / t_dropin / 1e6, 2),
-                               "unit": "Mbp/s",
-                               "note": "taxor_gpu_search_batch on host buffers: ASCII bases from pageable memory, streamed "
-                                       "H2D + on-device pack overlapped with compute, results fetched to host; per GPU"},
+                       "child_bins": wl["child_bins"], "depth": idx.depth, "reads_per_gpu": shard_reads[0], "read_len": read_len,
+                       "distinct_batches": len(batches), "read_error": args.read_error, "search_error_rate": args.error_rate,
+                       "planted_genomes": info["n_genomes"], "family_size": info["fam_size"],
+                       "sharding": "reads by rank, index replicated",
+                       "hashes_per_read": round(acc["hashes"] / nr, 1),
+                       "tuples_per_read": round(acc["tuples"] / nr, 3),
+                       "reads_with_hits_last_step": classified, "work_items_per_read": round(acc["work"] / nr, 3)},
+            "roofline": roof,
+            "whole_step": {"algorithmic_GBps": round(acc["alg"] / elapsed / 1e9, 1),
+                           "note": "SURVEY 8(d) A(read) summed over the timed steps / wall time (includes syncmers and CSR assembly)"},
+            "stage_ms_per_step": {"syncmers": round(acc["sync_ms"] / args.steps, 3), "query": round(acc["q_ms"] / args.steps, 3),
+                                  "finalize": round(acc["fin_ms"] / args.steps, 3), "total": round(acc["total_ms"] / args.steps, 3),
+                                  "note": "HIP-event sums per stream; syncmers of sub-batch i+1 overlap the query of sub-batch i"},
         }
+        if world == 1 and not args.no_dropin:
+            out["pcie_inclusive"], out["sustained"] = dropin_measurements(args, idx, batches, read_len)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu)
+            out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu)
         print(json.dumps(out), flush=True)
-    sr.close()
+    for sr in searchers:
+        sr.close()
     idx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def traffic_from_profiles(args):
-    """HBM bytes per k_query_level launch from the separate rocprofv3 --pmc passes (profiles/run_profiles.sh):
-    FETCH_SIZE (doubled, gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE.  None if never collected for
-    this workload at its default size."""
-    if args.traffic_bytes is not None:
-        return args.traffic_bytes
-    if args.reads or args.read_len or args.len_mix:
-        return None
-    p = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-    if os.path.exists(p):
-        with open(p) as f:
-            return json.load(f).get("k_query_level_bytes_per_launch")
-    return None
+def dropin_measurements(args, idx, batches, read_len):
+    """The drop-in boundary with HOST buffers: (a) one taxor_gpu_search_batch call on pageable memory; (b) the sustained
+    rate over >= --sustained-reads reads, rotating through the distinct batches from page-locked staging buffers with two
+    searchers in flight (what the CLI's GPU workers do), results fetched to the host every call."""
+    from taxor_amd import Searcher, _lib
+    import ctypes as C
+    sr = Searcher(idx, error_rate=args.error_rate)
+    bases, offs = batches[0]
+    sr.search_batch(bases, offs)
+    t0 = time.perf_counter()
+    sr.search_batch(bases, offs)
+    dt = time.perf_counter() - t0
+    single = {"seconds": round(dt, 4), "value": round(float(offs[-1]) / dt / 1e6, 2), "unit": "Mbp/s",
+              "note": "one taxor_gpu_search_batch on host buffers: ASCII bases from pageable memory, streamed H2D + on-device "
+                      "pack overlapped with compute, results fetched to host; per GPU"}
+    sustained = None
+    if args.sustained_reads > 0:
+        L = _lib.lib()
+        for b, _ in batches:
+            L.taxor_gpu_host_register(b.ctypes.data_as(C.c_void_p), b.nbytes)
+        per = sum(o.size - 1 for _, o in batches)
+        rounds = max(1, -(-args.sustained_reads // per))
+        order = [i % len(batches) for i in range(rounds * len(batches))]
+        workers = [sr, Searcher(idx, error_rate=args.error_rate)]
+        tuples = [0, 0]
+
+        def run(w):
+            for j in range(w, len(order), len(workers)):
+                b, o = batches[order[j]]
+                r = workers[w].search_batch(b, o)
+                tuples[w] += int(r.user_bin.size)
+
+        for w in range(len(workers)):          # warm both searchers' scratch
+            workers[w].search_batch(*batches[w % len(batches)])
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=run, args=(w,)) for w in range(len(workers))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        nb = sum(int(batches[i][1][-1]) for i in order)
+        nr = sum(batches[i][1].size - 1 for i in order)
+        sustained = {"reads": nr, "calls": len(order), "distinct_batches": len(batches), "seconds": round(dt, 3),
+                     "value": round(nb / dt / 1e6, 2), "unit": "Mbp/s", "tuples": int(sum(tuples)),
+                     "note": "host-fed: page-locked ASCII staging buffers -> taxor_gpu_search_batch (H2D, pack, search, D2H of "
+                             "the CSR) with two searchers in flight on one GPU; PCIe inside the timed region"}
+        for b, _ in batches:
+            L.taxor_gpu_host_unregister(b.ctypes.data_as(C.c_void_p))
+        workers[1].close()
+    sr.close()
+    return single, sustained
 
 
-def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
+def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu):
     """The CPU oracle (a port of the reference path) on a bounded sample of the same reads + index, same box."""
     from oracle import oracle as orc
+    bases, offs = batch
     threads = min(ncpu, 32)                      # the reference caps --threads at 32 (taxor_search.cpp:51-55)
     # host copy of the IXFs the sample can visit: the root plus every IXF holding a planted path; the rest get
     # untouched virtual memory (never read: the traversal enters a child only when its merged bin passes the
@@ -312,17 +567,17 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
     except MemoryError as e:
         return {"value": None, "unit": "Mbp/s", "cores": threads, "kind": "port", "sample": f"skipped: {e}"}
 
-    def run(n):
+    def run(n, th):
         t0 = time.perf_counter()
-        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=threads)
+        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=th)
         return time.perf_counter() - t0, o
 
     n = min(256 * threads // 8 + 64, len(offs) - 1)
-    dt, o = run(n)
+    dt, o = run(n, threads)
     n2 = int(min(len(offs) - 1, max(n, n * args.cpu_seconds / max(dt, 1e-3))))
     if n2 > n:
         n = n2
-        dt, o = run(n)
+        dt, o = run(n, threads)
     nh, off, ub, cnt, _ = o
     lo = int(res.read_off[n])
     same = (np.array_equal(res.n_hashes[:n], nh) and np.array_equal(res.read_off[: n + 1], off)
@@ -331,9 +586,8 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
         raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
     extra = {}
     if ncpu > threads:      # also at all hardware threads (the reference itself caps --threads at 32)
-        t0 = time.perf_counter()
-        h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=ncpu)
-        extra = {"all_cores": {"value": round(int(offs[n]) / (time.perf_counter() - t0) / 1e6, 3), "cores": ncpu}}
+        dta, _ = run(n, ncpu)
+        extra = {"all_cores": {"value": round(int(offs[n]) / dta / 1e6, 3), "cores": ncpu}}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -342,7 +596,7 @@ def cpu_baseline(args, idx, lay, res, bases, offs, read_len, ncpu):
         pass
     return {**extra, "value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
             "cpu_model": model, "hardware_threads": ncpu,
-            "sample": f"first {n} of the step's reads ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
+            "sample": f"first {n} reads of the last timed batch ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
                       f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
 
 

@@ -204,6 +204,12 @@ typedef struct {
     float total_ms;
 } taxor_gpu_run_stats;
 int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out);
+/* Measurement aid: a searcher created while TAXOR_PROFILE_PHASES=1 is set launches instrumented instantiations of the
+ * two big kernels (s_memtime marks at their phase boundaries, summed over blocks).  Returns and clears 16 cycle sums:
+ * [0..7] k_syncmers (cursor, staging, s-mer values, window argmins, selection, hash emit, dedup, copy-out),
+ * [8..15] k_query_level (cursor+flush, metadata+probe staging, dense gathers, prune check, sparse gathers, tally,
+ * final flush, -).  Results are unchanged; throughput is not (the marks cost a few percent). */
+int taxor_gpu_phase_profile(taxor_gpu_searcher *s, uint64_t *cycles16);
 
 /* ------------------------------------------------------------------------------------------------
  * Stage entry points (used by the parity tests; each stage is checked on its own against the oracle).

@@ -99,6 +99,7 @@ SIGNATURES = {
     "taxor_gpu_batch_result_sizes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "taxor_gpu_batch_export_device": (C.c_int, [_P, _P, _P, _P, _P]),
     "taxor_gpu_batch_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
+    "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),
     "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),

@@ -100,6 +100,7 @@ struct taxor_gpu_searcher {
     hipEvent_t ev_reset = nullptr;
     DBuf<uint32_t> d_sync_cursor;
     Counters *d_ctr = nullptr;
+    unsigned long long *d_prof = nullptr;   // TAXOR_PROFILE_PHASES=1: per-phase cycle sums of the two big kernels
     Counters h_ctr{};
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
@@ -486,6 +487,13 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         return fail(TAXOR_E_ARG, "searcher_create: an IXF with %u-byte rows does not fit the LDS tally", idx->max_stride);
     }
     s->grid_sync = syncmers_grid(idx->device);
+    if (const char *e = getenv("TAXOR_PROFILE_PHASES")) {
+        if (atoi(e) != 0 && (hipMalloc((void **)&s->d_prof, 16 * sizeof(unsigned long long)) != hipSuccess ||
+                             hipMemset(s->d_prof, 0, 16 * sizeof(unsigned long long)) != hipSuccess)) {
+            taxor_gpu_searcher_destroy(s);
+            return fail(TAXOR_E_HIP, "searcher_create: profile buffer");
+        }
+    }
     if (const char *e = getenv("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
     if (const char *e = getenv("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
     if (const char *e = getenv("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) { s->prm.sub_batch_reads = (uint32_t)v; s->auto_sub_reads = false; } }
@@ -525,6 +533,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
     for (auto ev : s->ev) (void)hipEventDestroy(ev);
     if (s->d_ctr) (void)hipFree(s->d_ctr);
+    if (s->d_prof) (void)hipFree(s->d_prof);
     if (s->st) (void)hipStreamDestroy(s->st);
     delete s;
 }
@@ -739,6 +748,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.hit_cap = s->hit_cap;
     q.map_words = query_map_words(idx->max_stride);
     q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
+    q.prof = s->d_prof;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
         q.level = lvl;
@@ -820,6 +830,7 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.t = idx->t;
     a.w_min = idx->w_min;
     a.thr_on_device = s->prm.model == TAXOR_THR_PERCENTAGE ? 1 : 0;
+    a.prof = s->d_prof;
     size_t slot;
     if (ev_begin(s, 0, &slot, st)) return TAXOR_E_HIP;
     launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
@@ -1023,6 +1034,17 @@ extern "C" int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats 
 {
     if (!s || !out || !s->synced) return fail(TAXOR_E_ARG, "batch_stats: no completed run");
     *out = s->stats;
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_phase_profile(taxor_gpu_searcher *s, uint64_t *cycles16)
+{
+    if (!s || !cycles16) return fail(TAXOR_E_ARG, "phase_profile: null argument");
+    if (!s->d_prof) return fail(TAXOR_E_ARG, "phase_profile: searcher was created without TAXOR_PROFILE_PHASES=1");
+    HIP_TRY(hipSetDevice(s->idx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(cycles16, s->d_prof, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(s->d_prof, 0, 16 * sizeof(uint64_t)));
     return TAXOR_OK;
 }
 

@@ -238,7 +238,11 @@ int taxor_synth_reads(const char *genomes, const uint64_t *genome_off, uint64_t 
     auto comp = [](char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; };
     auto work = [&](uint64_t lo, uint64_t hi) {
         for (uint64_t i = lo; i < hi; ++i) {
-            uint64_t st = seed * 0xD1342543DE82EF95ull + i * 0x9E3779B97F4A7C15ull + 1;
+            // every read gets its own stream: the state is a hash of (seed, i).  (splitmix64 advances its state by a
+            // constant, so seeding read i with seed + i * that constant made read i replay read 0's stream i draws
+            // later -- error positions were then correlated across reads and the error rate varied along the read.)
+            uint64_t s0 = seed ^ (i * 0xD1342543DE82EF95ull + 0x2545F4914F6CDD1Dull);
+            uint64_t st = splitmix64(s0) ^ (splitmix64(s0) << 1);
             char *out = bases + i * read_len;
             offsets[i] = i * read_len;
             const double u0 = (double)(splitmix64(st) >> 11) * (1.0 / 9007199254740992.0);

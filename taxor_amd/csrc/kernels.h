@@ -87,6 +87,7 @@ struct SyncmerArgs {
     int k, s, t;
     int w_min;                // > 0: minimiser / k-mer mode with this window size (index built without --use-syncmer)
     int thr_on_device;        // minimiser mode: 1 = thr = (size_t)(nh * ratio) here; 0 = the host applies a model
+    unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };
 
 struct QueryArgs {
@@ -109,6 +110,7 @@ struct QueryArgs {
     uint32_t map_words;       // words of the alive-unit bitmap in LDS (query_lds_map_words(max_stride))
     uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)
     uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
+    unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };
 
 struct FinalizeArgs {

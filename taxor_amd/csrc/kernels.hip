@@ -224,8 +224,19 @@ __device__ __forceinline__ uint32_t dedup_slot(uint64_t h, uint32_t mask)
 // (value<<5 | 31-offset).  FW == 0: generic window length, per-window scan in LDS.
 static constexpr int SY_RS = SY_T / SY_C + 5; // row stride (words) of the transposed s-mer tile; odd -> no bank conflicts
 
-template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
+// PROF: the same kernel with s_memtime marks at its phase boundaries (block-uniform, scalar), summed per launch into
+// a.prof -- a measurement aid compiled as a separate instantiation, the production kernel carries none of it.
+#define PMARK(i)                                                                                        \
+    if constexpr (PROF) {                                                                               \
+        const uint64_t now_ = __builtin_amdgcn_s_memtime();                                             \
+        pacc[i] += now_ - plast;                                                                        \
+        plast = now_;                                                                                   \
+    }
+
+template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_syncmers(const SyncmerArgs a)
 {
+    uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
     __shared__ uint32_t sW[SY_WORDS];
     __shared__ uint32_t sV[SY_C * SY_RS];
     __shared__ __attribute__((aligned(16))) uint8_t sLm[SY_T];
@@ -247,6 +258,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
         __syncthreads();
         if (sRead >= a.n_reads) break;
         const uint32_t r = a.order ? a.order[sRead] : sRead;
+        PMARK(0)                                                     // 0: work cursor
 
         const uint32_t L = a.rlen[r];
         const uint32_t *__restrict__ pk = a.packed + a.poff[r];
@@ -267,6 +279,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                 sW[i] = wi < nwords ? pk[wi] : 0u;
             }
             __syncthreads();
+            PMARK(1)                                                 // 1: per-read metadata + staging the packed words
             // ---- canonical s-mer values (syncmer.cpp:103-110; the s-mer "hash" is the raw 2-bit value)
             const int nv = min(SY_T + w - 1, (int)L - s + 1 - x0); // valid s-mer starts in this tile
             const int nw_tile = min(SY_T, nwin - x0);
@@ -285,6 +298,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                     sV[(i & (SY_C - 1)) * SY_RS + (i >> 3)] = v;
                 }
                 __syncthreads();
+                PMARK(2)                                             // 2: canonical s-mer values -> LDS
                 constexpr int NV = FW + SY_C - 1;
                 uint32_t kl[NV], kr[NV];
 #pragma unroll
@@ -356,6 +370,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                     }
                 }
             }
+            PMARK(3)                                                 // 3: window argmins (min trees / scan)
             const int anchor = block_excl_max(last_anchor, (int *)sScr);
             uint32_t selmask = 0;
             int p; // tile-local s-mer start currently tracked (may be -1: last position of the previous tile)
@@ -375,6 +390,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
             }
             __syncthreads();
             if (xs < nw_tile && xs + SY_C >= nw_tile) sCarry = p + x0; // owner of the tile's last window
+            PMARK(4)                                                 // 4: anchor scan + chain walk + selection
             // ---- emit wyhash(canonical k-mer) of the selected windows, in window order --------------
             uint32_t tot;
             uint32_t pos = n_sel + block_excl_add((uint32_t)__popc(selmask), sScr, &tot);
@@ -392,6 +408,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                 ++pos;
             }
             n_sel += tot;
+            PMARK(5)                                                 // 5: emit wyhash(canonical k-mer)
         }
         __syncthreads();
         if (n_sel > cap) { // capacity bound (nwin / min(t, w-t+1) + 2) violated: internal invariant
@@ -487,6 +504,7 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
                 __syncthreads();
                 any_dup = true;                                          // flags are evaluated from the table below
             }
+            PMARK(6)                                                 // 6: dedup table passes
             if (!any_dup && !(a.scaling_limit > 0.0)) {
                 for (uint32_t i = tid; i < n_sel; i += BLK) outh[i] = cand_at(i);
                 n_dist = n_sel;
@@ -525,6 +543,11 @@ template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers(const Syncme
             a.thr[r] = (uint64_t)((double)n_dist * a.ratio);                    // threshold.hpp:60,76-79
             atomicAdd(&a.ctr->n_hashes, (unsigned long long)n_dist);
         }
+        PMARK(7)                                                     // 7: copy out / ordered compaction
+    }
+    if constexpr (PROF) {
+        if (tid == 0 && a.prof)
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[i], (unsigned long long)pacc[i]);
     }
 }
 
@@ -667,7 +690,7 @@ int syncmers_grid(int device)
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers<11>, BLK, 0) != hipSuccess || per < 1) per = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers<11, false>, BLK, 0) != hipSuccess || per < 1) per = 2;
     if (const char *e = getenv("TAXOR_SYNC_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
@@ -680,8 +703,10 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
         return;
     }
     static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
-    if (!generic_only && a.k - a.s + 1 == 11 && a.s <= 13) hipLaunchKernelGGL(k_syncmers<11>, dim3(grid), dim3(BLK), 0, st, a);
-    else hipLaunchKernelGGL(k_syncmers<0>, dim3(grid), dim3(BLK), 0, st, a);
+    if (!generic_only && a.k - a.s + 1 == 11 && a.s <= 13) {
+        if (a.prof) hipLaunchKernelGGL((k_syncmers<11, true>), dim3(grid), dim3(BLK), 0, st, a);
+        else hipLaunchKernelGGL((k_syncmers<11, false>), dim3(grid), dim3(BLK), 0, st, a);
+    } else hipLaunchKernelGGL((k_syncmers<0, false>), dim3(grid), dim3(BLK), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -843,8 +868,10 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
     }
 }
 
-template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
+template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
 {
+    uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
     uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_CAP * sizeof(uint4));       // [0] item, [1] n alive units
@@ -901,6 +928,7 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
             item_end = min(item + chunk, n_items);
             if (item >= n_items) break;
         }
+        PMARK(0)                                                     // 0: work cursor + output flushes
         uint32_t r, v;
         if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
         else { r = a.order0 ? a.order0[item] : item; v = 0; }
@@ -942,9 +970,11 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
                 sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
         __syncthreads();
+        PMARK(1)                                                     // 1: item metadata, clearing the tally, probe staging
         query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC, staged);
         touched += (uint64_t)dense_end * 3ull * stride;
         __syncthreads();
+        PMARK(2)                                                     // 2: dense phase (row gathers)
 
         if (dense_end < n) {
             const uint64_t rem = n - dense_end;
@@ -970,6 +1000,7 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
                 }
             }
             __syncthreads();
+            PMARK(3)                                                 // 3: which runs can still reach the threshold
             const uint32_t n_alive = sScal[1];
             if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
                 query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC, staged);
@@ -1012,6 +1043,7 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
             }
         }
         __syncthreads();
+        PMARK(4)                                                     // 4: sparse phase (surviving units only)
 
         if (a.counts_out)
             for (uint32_t b = tid; b < D.bins; b += BLK) a.counts_out[b] = sC[b];
@@ -1058,8 +1090,14 @@ template <bool NT, int U> __global__ __launch_bounds__(BLK) void k_query_level(c
         st_touched += touched;
         st_work += 1ull;
         ++item;
+        PMARK(5)                                                     // 5: run tally, child pushes, hit records
     }
     flush_out(true);           // the break above is taken by the whole block right after a barrier
+    PMARK(6)
+    if constexpr (PROF) {
+        if (tid == 0 && a.prof)
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.prof[8 + i], (unsigned long long)pacc[i]);
+    }
     if (tid == 0 && st_work) { // one set of statistics atomics per block, not per work item
         atomicAdd(&a.ctr->query_bytes, st_bytes);
         atomicAdd(&a.ctr->touched_bytes, st_touched);
@@ -1087,6 +1125,10 @@ void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStrea
 {
     static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
     static const int unroll = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
+    if (a.prof) {
+        hipLaunchKernelGGL((k_query_level<true, 2, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+        return;
+    }
     if (unroll == 2) {
         if (nt) hipLaunchKernelGGL((k_query_level<true, 2>), dim3(grid), dim3(BLK), lds_bytes, st, a);
         else hipLaunchKernelGGL((k_query_level<false, 2>), dim3(grid), dim3(BLK), lds_bytes, st, a);

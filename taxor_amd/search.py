@@ -246,6 +246,13 @@ class Searcher:
         check(_lib.lib().taxor_gpu_batch_stats(self._h, C.byref(st)))
         return {f: getattr(st, f) for f, _ in _lib.RunStats._fields_}
 
+    def phase_profile(self):
+        """per-phase cycle sums of k_syncmers [0..7] and k_query_level [8..15] since the last call (needs a searcher
+        created under TAXOR_PROFILE_PHASES=1)"""
+        out = np.zeros(16, dtype=np.uint64)
+        check(_lib.lib().taxor_gpu_phase_profile(self._h, _p(out)))
+        return out
+
     def result_sizes(self):
         a, b = C.c_uint64(), C.c_uint64()
         check(_lib.lib().taxor_gpu_batch_result_sizes(self._h, C.byref(a), C.byref(b)))

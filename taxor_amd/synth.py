@@ -160,7 +160,14 @@ def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_ele
         planted_ub[deep_member] = ub
         ixfs[gi]["keys"][2] = planted[deep_member]
         ixfs[gi]["fname_idx"][2] = ub
-    # --- decoy leaves get their own user bins; merged bins hold the union of their child's keys ---
+    out = _finalize_layout(ixfs, new_ub, rng, build)
+    depth = 3 if deep_member is not None else 2
+    return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth)
+
+
+def _finalize_layout(ixfs, new_ub, rng, build):
+    """decoy leaves get their own user bins; merged bins hold the union of their child's keys; XOR-filter columns are
+    constructed (build="host") or left to the device builder as key sets (build="gpu")"""
     for f in ixfs:
         for bb in range(f["bins"]):
             if f["fname_idx"][bb] == -2:
@@ -190,8 +197,113 @@ def make_layout(planted, root_bins=64, child_bins=64, n_children=4, root_max_ele
         out.append(dict(bins=f["bins"], stride=f["stride"], seg_len=seg, seed=sd, next_ixf=nx,
                         fname_idx=f["fname_idx"], columns=cols, fill_seed=int(rng.integers(1, 2**63)),
                         key_sets=nonempty if build != "host" else {}))
-    depth = 3 if deep_member is not None else 2
-    return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth)
+    return out
+
+
+def family_genomes(n_families, family_size, length, seed=DEFAULT_SEED, ladder=(0.001, 0.002, 0.004, 0.008, 0.016, 0.032)):
+    """Families of related genomes (strains of one species): every family has a random ancestor, sibling j carries
+    substitutions at rate ladder[j % len(ladder)] against it, so two siblings are about 1 - (d_i + d_j) identical --
+    99.7 % down to 93.6 % with the default ladder (strains of a species; GTDB clusters species at 95 % ANI).  A read of one sibling then reaches the threshold in several of its
+    siblings' bins and in every merged bin above them, like reads against a real, taxonomically clustered index.
+    Returns (bases uint8[n*length], offsets uint64[n+1], family int32[n])."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = n_families * family_size
+    codes = np.empty(n * length, dtype=np.uint8)
+    fam = np.empty(n, dtype=np.int32)
+    for f in range(n_families):
+        anc = rng.integers(0, 4, size=length, dtype=np.uint8)
+        for j in range(family_size):
+            g = f * family_size + j
+            fam[g] = f
+            d = ladder[j % len(ladder)]
+            sib = anc.copy()
+            pos = np.flatnonzero(rng.random(length) < d)
+            sib[pos] = (sib[pos] + rng.integers(1, 4, size=pos.size, dtype=np.uint8)) & 3   # always a different base
+            codes[g * length:(g + 1) * length] = sib
+    offs = (np.arange(n + 1, dtype=np.uint64) * np.uint64(length))
+    return acgt[codes], offs, fam
+
+
+def make_family_layout(planted, family, root_bins=64, child_bins=64, n_children=8, spread=4, root_max_elems=None,
+                       child_max_elems=None, seed=DEFAULT_SEED, build="host"):
+    """HIXF layout for families of related genomes (family_genomes): the members of a family sit in ADJACENT bins of
+    `spread` different child IXFs (a taxonomically clustered layout keeps relatives together, and a large clade fills
+    several merged bins), every third member is split over two technical bins, member 0 of family 0 is a split root
+    leaf over three technical bins, member 0 of family 1 a plain root leaf, and the last member of family 0 sits in a
+    grandchild behind a merged bin of its child (depth-3 chain).  A read of one member so passes the threshold in
+    several merged bins of the root and in several leaf runs below each.  Same return format as make_layout."""
+    planted = [np.unique(np.ascontiguousarray(p, dtype=np.uint64)) for p in planted]
+    P = len(planted)
+    family = np.asarray(family)
+    n_fam = int(family.max()) + 1
+    assert P >= 3 and n_children >= spread >= 1 and root_bins >= 4 + n_children
+    rng = np.random.default_rng(seed)
+    next_ub = [0]
+
+    def new_ub():
+        next_ub[0] += 1
+        return next_ub[0] - 1
+
+    planted_ub = [None] * P
+    ixfs = []
+
+    def new_ixf(bins, max_elems):
+        ixfs.append(dict(bins=bins, stride=_stride(bins), keys={}, next_ixf=None,
+                         fname_idx=np.full(bins, -2, dtype=np.int64), child_of={}, max_elems=max_elems))
+        return len(ixfs) - 1
+
+    root = new_ixf(root_bins, root_max_elems)
+    members = [list(np.flatnonzero(family == f)) for f in range(n_fam)]
+    # root leaves: a split run of three and a plain leaf
+    ub = new_ub()
+    m = members[0].pop(0)
+    planted_ub[m] = ub
+    for j in range(3):
+        ixfs[root]["keys"][j] = planted[m][j::3]
+        ixfs[root]["fname_idx"][j] = ub
+    if n_fam > 1:
+        ub = new_ub()
+        m = members[1].pop(0)
+        planted_ub[m] = ub
+        ixfs[root]["keys"][3] = planted[m]
+        ixfs[root]["fname_idx"][3] = ub
+    children = []
+    for c in range(n_children):
+        ci = new_ixf(child_bins, child_max_elems)
+        children.append(ci)
+        ixfs[root]["fname_idx"][4 + c] = -1
+        ixfs[root]["child_of"][4 + c] = ci
+    deep_member = members[0].pop() if len(members[0]) >= 2 else None
+    slot = [1] * n_children                                   # bin 0 of every child stays a decoy
+    n_split = 0
+    for f in range(n_fam):
+        for j, m in enumerate(members[f]):
+            c = (f * spread + j % spread) % n_children        # family f occupies children f*spread .. f*spread+spread-1
+            ci = children[c]
+            ub = new_ub()
+            planted_ub[m] = ub
+            run = 2 if j % 3 == 2 else 1
+            assert slot[c] + run < child_bins - 2, "child_bins too small for the planted families"
+            for r in range(run):
+                ixfs[ci]["keys"][slot[c]] = planted[m][r::run]
+                ixfs[ci]["fname_idx"][slot[c]] = ub
+                slot[c] += 1
+            n_split += run == 2
+    depth = 2
+    if deep_member is not None:
+        gi = new_ixf(child_bins, child_max_elems)
+        c0 = children[0]
+        mb = child_bins - 2
+        ixfs[c0]["fname_idx"][mb] = -1
+        ixfs[c0]["child_of"][mb] = gi
+        ub = new_ub()
+        planted_ub[deep_member] = ub
+        ixfs[gi]["keys"][2] = planted[deep_member]
+        ixfs[gi]["fname_idx"][2] = ub
+        depth = 3
+    out = _finalize_layout(ixfs, new_ub, rng, build)
+    return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth, split_runs=n_split + 1)
 
 
 def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 130, 300), max_ixfs=12):

@@ -1,0 +1,65 @@
+"""bench.py's N>1 flow on a one-GPU box: two ranks launched by torch.distributed.run exactly like the driver launches
+them, both on GPU 0 (TAXOR_BENCH_SAME_GPU=1) with the gloo backend standing in for RCCL (RCCL refuses two ranks on one
+device).  The CSR gathered on rank 0 -- real library output exported from the device, not fake tensors -- must equal
+what a single rank computes for the same reads."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(n, extra, dump):
+    common = ["bench.py", "--gpus", str(n), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--batches", "2",
+              "--traffic", "none", "--no-cpu-baseline", "--no-dropin", "--no-unpruned", "--no-ceiling", "--dump-results", str(dump)] + extra
+    env = dict(os.environ, TAXOR_BENCH_BACKEND="gloo", TAXOR_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1")
+    if n == 1:
+        cmd = [sys.executable] + common
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + common
+    cp = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, cp.stdout            # exactly ONE JSON line, from rank 0
+    return json.loads(lines[0]), np.load(dump)
+
+
+def test_two_ranks_strong_scaling_equals_one_rank(tmp_path):
+    j1, r1 = _run(1, ["--scaling", "strong"], tmp_path / "n1.npz")
+    j2, r2 = _run(2, ["--scaling", "strong"], tmp_path / "n2.npz")
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    for key in ("read_off", "user_bin", "count", "n_hashes"):
+        assert np.array_equal(r1[key], r2[key]), key
+    assert r1["user_bin"].size > 0
+    # the same total work, so the two lines describe the same number of bases per step
+    assert abs(j1["value"] * j1["ms_per_step"] - j2["value"] * j2["ms_per_step"]) / (j1["value"] * j1["ms_per_step"]) < 2e-2          # value and ms_per_step are rounded in the line
+
+
+def test_three_ranks_weak_scaling_gathers_every_shard(tmp_path):
+    j1, r1 = _run(1, [], tmp_path / "n1.npz")
+    j3, r3 = _run(3, [], tmp_path / "n3.npz")
+    assert j3["n_gpus"] == 3 and j3["scaling"] == "weak"
+    n = r1["n_hashes"].size
+    assert r3["n_hashes"].size == 3 * n and r3["read_off"].size == 3 * n + 1
+    # rank 0's shard of the weak run is the single-rank batch (seed + rank with rank = 0)
+    t = int(r1["read_off"][-1])
+    assert np.array_equal(r3["n_hashes"][:n], r1["n_hashes"]) and np.array_equal(r3["read_off"][:n + 1], r1["read_off"])
+    assert np.array_equal(r3["user_bin"][:t], r1["user_bin"]) and np.array_equal(r3["count"][:t], r1["count"])
+    assert int(r3["read_off"][-1]) == r3["user_bin"].size > t
+    # weak scaling: three times the bases per step
+    assert abs(j3["value"] * j3["ms_per_step"] / (j1["value"] * j1["ms_per_step"]) - 3.0) < 6e-2

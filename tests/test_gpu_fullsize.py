@@ -92,3 +92,135 @@ def test_viral_class_one_million_reads():
     assert (per[planted_reads] > 0).mean() > 0.9
     assert (per[~planted_reads] > 0).mean() < 0.01
     idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] and configs[3] at full size: RefSeq-class (9.9 GB) and GTDB-class (113 GB) indexes resident
+# in HBM, 10 M synthetic 10 kb reads each (ten batches of 1 M, like the CLI feeds them), the workload bench.py measures
+# (families of related strains, read error 0.04).  Bit-exact oracle samples at the first / middle / last reads, pruning
+# on/off equality over ALL reads, sub-batch invariance and idempotence, counter checksums, positive/negative controls.
+# ---------------------------------------------------------------------------------------------------------------------
+def _digest(res):
+    """order-sensitive checksum of a CSR result (a checksum of checksums over batches is compared between runs)"""
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    for a in (res.read_off, res.user_bin, res.count, res.n_hashes):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def _full_size_class(workload, min_index_bytes, max_index_bytes):
+    import psutil
+    import torch
+
+    import bench
+
+    free_hbm, _ = torch.cuda.mem_get_info(0)
+    if free_hbm < max_index_bytes + 40e9:
+        pytest.skip(f"needs {max_index_bytes/1e9 + 40:.0f} GB of free HBM, have {free_hbm/1e9:.0f}")
+    n_batches, reads_per_batch, read_len = 10, 1_000_000, 10_000
+    avail = psutil.virtual_memory().available
+    while n_batches > 1 and n_batches * reads_per_batch * read_len * 1.3 + 60e9 > avail:
+        n_batches -= 1                                           # the GPU pool's hosts have 3 TB; a small host runs fewer batches
+    args = bench.parse_args(["--workload", workload, "--reads", str(reads_per_batch), "--read-len", str(read_len),
+                             "--batches", str(n_batches)])
+    wl, idx, lay, batches, info = bench.build_workload(args, 0, 0, 1)
+    assert min_index_bytes < idx.data_bytes < max_index_bytes
+    assert info["fam_size"] == 16 and lay["depth"] == 3 and lay["split_runs"] > 8
+
+    host = None
+    checks = []           # (batch, lo, hi) oracle samples: first, middle and last reads of the 10 M
+    S = 1500
+    checks.append((0, 0, S))
+    checks.append((n_batches // 2, reads_per_batch // 2, reads_per_batch // 2 + S))
+    checks.append((n_batches - 1, reads_per_batch - S, reads_per_batch))
+
+    sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+    os.environ["TAXOR_QUERY_PRUNE"] = "0"
+    try:
+        dense = Searcher(idx, error_rate=args.error_rate, sub_batch_reads=65536)
+    finally:
+        del os.environ["TAXOR_QUERY_PRUNE"]
+    planted_ub = np.array([u if u is not None else -1 for u in lay["planted_user_bin"]], dtype=np.int64)
+    total_reads = total_tuples = total_hashes = 0
+    hit_own = n_planted = n_random = random_hit = 0
+    digests, digests_dense = [], []
+    samples = {}
+    for b, (bases, offs) in enumerate(batches):
+        sr.upload(bases, offs)
+        sr.run()
+        res = sr.fetch()
+        st = sr.stats()
+        n = offs.size - 1
+        assert st["n_reads"] == n and st["n_bases"] == int(offs[-1])
+        assert st["n_hashes"] == int(res.n_hashes.astype(np.int64).sum())
+        assert st["n_tuples"] == res.user_bin.size == int(res.read_off[-1])
+        assert np.all(np.diff(res.read_off.astype(np.int64)) >= 0)
+        assert st["query_touched_bytes"] < st["query_bytes"]                  # pruning removed traffic
+        total_reads += n
+        total_tuples += res.user_bin.size
+        total_hashes += st["n_hashes"]
+        digests.append(_digest(res))
+        # pruning off, another sub-batch partition: the identical CSR for every one of the 10 M reads
+        dense.upload(bases, offs)
+        dense.run()
+        rd = dense.fetch()
+        sd = dense.stats()
+        assert sd["query_touched_bytes"] == sd["query_bytes"] == st["query_bytes"]
+        digests_dense.append(_digest(rd))
+        if b == 0:
+            sr.run()                                                            # idempotence on the resident batch
+            assert _csr_equal(res, sr.fetch())
+        # controls: a planted read reports its own genome's user bin; random reads report nothing
+        origin = info["origins"][b]
+        per = np.diff(res.read_off.astype(np.int64))
+        is_planted = origin >= 0
+        own = planted_ub[np.where(is_planted, origin, 0)]
+        rid = np.repeat(np.arange(n), per)
+        got_own = np.zeros(n, dtype=bool)
+        got_own[rid[res.user_bin == own[rid]]] = True
+        hit_own += int((got_own & is_planted).sum())
+        n_planted += int(is_planted.sum())
+        n_random += int((~is_planted).sum())
+        random_hit += int((per[~is_planted] > 0).sum())
+        for (cb, lo, hi) in checks:
+            if cb == b and (cb, lo) not in samples:
+                a, e = int(res.read_off[lo]), int(res.read_off[hi])
+                samples[(cb, lo)] = (bases[int(offs[lo]):int(offs[hi])].copy(), offs[lo:hi + 1] - offs[lo], res.n_hashes[lo:hi].copy(),
+                                     res.read_off[lo:hi + 1] - res.read_off[lo], res.user_bin[a:e].copy(), res.count[a:e].copy())
+    sr.close()
+    dense.close()
+    assert total_reads == n_batches * reads_per_batch
+    assert digests == digests_dense, "pruning / sub-batch partition changed results"
+    assert len(set(digests)) == n_batches                                       # ten DISTINCT batches
+    assert hit_own / n_planted > 0.8, hit_own / n_planted
+    assert random_hit / max(1, n_random) < 0.01
+    assert total_tuples / total_reads > 2.0                                     # related strains: several tuples per read
+    batches.clear()
+
+    # the oracle, bit for bit, on the samples (host copy of the IXFs the traversal can enter)
+    needed = {0} | {i for i, f in enumerate(lay["ixfs"]) if f.get("key_sets") or f["columns"]}
+    host = []
+    for i, f in enumerate(lay["ixfs"]):
+        nbytes = 3 * f["seg_len"] * f["stride"]
+        data = idx.download_ixf(i) if i in needed else np.empty(nbytes, dtype=np.uint8)    # untouched virtual memory
+        host.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], data=data))
+    h = orc.Hixf(host, [f["next_ixf"] for f in lay["ixfs"]], [f["fname_idx"] for f in lay["ixfs"]])
+    assert len(samples) == len(set((c[0], c[1]) for c in checks))
+    for key, (sb, so, g_nh, g_off, g_ub, g_cnt) in samples.items():
+        nh, off, ub, cnt, _ = h.search_batch(sb, so, err=args.error_rate, threads=min(64, os.cpu_count() or 8))
+        assert np.array_equal(g_nh, nh), key
+        assert np.array_equal(g_off, off), key
+        assert np.array_equal(g_ub, ub) and np.array_equal(g_cnt, cnt), key
+        assert ub.size > 0
+    idx.close()
+
+
+def test_refseq_class_ten_million_reads():
+    """BASELINE.json configs[2]: RefSeq-ABFV-class k22/s12 index (9.9 GB, README.md:52) resident in HBM, 10 M x 10 kb"""
+    _full_size_class("refseq", 9.0e9, 11e9)
+
+
+def test_gtdb_class_ten_million_reads():
+    """BASELINE.json configs[3]: GTDB-220-class k22/s12 index (113 GB, README.md:51) resident in one GPU's HBM, 10 M x 10 kb"""
+    _full_size_class("gtdb", 105e9, 120e9)
