@@ -304,6 +304,8 @@ def main():
     for bases, offs in batches:
         sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
         sr.upload(bases, offs)
+        sr.run()          # set-up, untimed: sizes this searcher's result buffers for its batch (an overflow reruns the
+        sr.sync()         # batch once with grown buffers; that must not land in another searcher's timed step)
         searchers.append(sr)
 
     from taxor_amd import distributed as td
@@ -386,6 +388,23 @@ def main():
             d_off, d_ub, d_cnt, d_nh = r_.read_off, r_.user_bin, r_.count, r_.n_hashes
         np.savez(args.dump_results, read_off=d_off.astype(np.int64), user_bin=d_ub.astype(np.int64), count=d_cnt.astype(np.int64),
                  n_hashes=d_nh.astype(np.int64))
+
+    # N > 1: the drop-in call with HOST buffers on every rank at the same time -- the ranks share the host's memory
+    # bandwidth and PCIe root complexes, which is where a sharded run is won or lost (the resident-batch `value` is not)
+    per_rank = None
+    if world > 1 and not args.no_dropin and not args.pmc_child:
+        dist.barrier()
+        small = argparse.Namespace(**vars(args))
+        small.sustained_reads = max(1, args.sustained_reads // 4)
+        single, sustained = dropin_measurements(small, idx, batches, read_len)
+        mine = torch.tensor([single["value"], sustained["value"] if sustained else 0.0], dtype=torch.float64,
+                            device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        if rank == 0:
+            per_rank = {"single_call_Mbp_s": [round(float(v[0]), 1) for v in allv], "sustained_Mbp_s": [round(float(v[1]), 1) for v in allv],
+                        "sustained_sum_Mbp_s": round(float(sum(v[1] for v in allv)), 1),
+                        "note": "taxor_gpu_search_batch on host buffers, all ranks at once; per-rank rates, PCIe inside"}
 
     if args.pmc_child:                 # profiled child: the launches above are all the parent wanted
         for sr in searchers:
@@ -480,6 +499,8 @@ def main():
         }
         if world == 1 and not args.no_dropin:
             out["pcie_inclusive"], out["sustained"] = dropin_measurements(args, idx, batches, read_len)
+        if per_rank is not None:
+            out["pcie_inclusive_per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu)
         print(json.dumps(out), flush=True)
@@ -585,9 +606,10 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu):
     if not same:
         raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
     extra = {}
-    if ncpu > threads:      # also at all hardware threads (the reference itself caps --threads at 32)
-        dta, _ = run(n, ncpu)
-        extra = {"all_cores": {"value": round(int(offs[n]) / dta / 1e6, 3), "cores": ncpu}}
+    if ncpu > threads:      # also at all hardware threads (the reference itself caps --threads at 32);
+        na = max(1, n // 4)  # a quarter of the sample: beyond 32 threads the port gets slower (remote-socket row reads)
+        dta, _ = run(na, ncpu)
+        extra = {"all_cores": {"value": round(int(offs[na]) / dta / 1e6, 3), "cores": ncpu, "reads": na}}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:

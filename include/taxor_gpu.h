@@ -159,6 +159,10 @@ int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint6
  * (the reference's chunk loop is synchronous, taxor_search.cpp:315-326): _begin enqueues everything and returns --
  * immediately when `bases` is registered memory (below), after the last host-to-device copy otherwise; `bases` and
  * `offsets` must stay valid until _end, which waits and hands out the results like taxor_gpu_search_batch. */
+/* Exception: with the KMER and FRACMINHASH threshold models (indexes built without --use-syncmer) _begin is NOT
+ * asynchronous -- each sub-batch's hash counts come back to the host, the model is evaluated there in the reference's
+ * double arithmetic, and the thresholds go up again before that sub-batch's query is enqueued, so _begin returns only
+ * after the last sub-batch's hashing has finished (the GPU keeps classifying the previous sub-batch meanwhile). */
 int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out);
 
@@ -228,6 +232,33 @@ int taxor_gpu_bulk_contains(taxor_gpu_searcher *s, const uint64_t *hashes, uint6
                             taxor_gpu_results *out);
 
 /* ------------------------------------------------------------------------------------------------
+ * Diagnosis of an index this library did not write (`taxor verify --variants`).  The arithmetic of
+ * seqan3::interleaved_xor_filter is un-vendored in the reference; taxor_amd/csrc/ixf_arith.h holds this library's
+ * reading (evidence: src/main/xorfilter.hpp:36-45,60-68,338-350, src/main/hashutil.hpp:50-61).  A variant describes
+ * another reading of the same raw fingerprint bytes; the scan probes IXF `ixf` of a resident index under every variant
+ * with hash lists cut from a genome that is in the index and reports, per (variant, list), the best-bin match ratio:
+ * ~1.0 under the file's true arithmetic, ~2^-8 otherwise.  best_ratio[n_variants * n_lists], variant-major.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed;
+    uint64_t seg_len;   /* rows per hash segment */
+    uint64_t stride;    /* bytes per fingerprint row */
+    uint8_t key_hash;   /* 0 murmur64 finaliser (hashutil.hpp:50-57), 1 none, 2 wyhash mix, 3 splitmix64 finaliser */
+    uint8_t seed_mode;  /* 0 h(key + seed) (hashutil.hpp:59-61), 1 h(key ^ seed), 2 h(key) + seed, 3 seed unused */
+    uint8_t rot;        /* row i uses rotl64(h, rot * i); 21 in xorfilter.hpp:42-45 */
+    uint8_t reduce;     /* 0 ((u32)rot * seg_len) >> 32 (xorfilter.hpp:36-40), 1 (u32)rot % seg_len, 2 mulhi64(rot, seg_len) */
+    uint8_t fp_mode;    /* 0 (u8)(h ^ h>>32) (xorfilter.hpp:60-62), 1 (u8)h, 2 (u8)(h>>56), 3 (u8)(h>>32) */
+    uint8_t layout;     /* 0 data[row*stride + bin] (interleaved), 1 data[bin*rows + row] */
+    uint8_t pad[2];
+} taxor_ixf_variant;
+/* this library's reading for the given seed / segment length / stride */
+void taxor_ixf_variant_default(taxor_ixf_variant *out, uint64_t seed, uint64_t seg_len, uint64_t stride);
+int taxor_gpu_ixf_variant_scan(taxor_gpu_index *idx, uint64_t ixf, const taxor_ixf_variant *variants, uint32_t n_variants,
+                               const uint64_t *hashes, const uint64_t *hash_off, uint64_t n_lists, float *best_ratio);
+/* one-line description of a variant; returns the length written */
+uint64_t taxor_ixf_variant_describe(const taxor_ixf_variant *v, char *buf, uint64_t cap);
+
+/* ------------------------------------------------------------------------------------------------
  * .hixf on-disk format (drop-in): cereal BinaryOutputArchive of taxor_index<hixf_t>, native little endian,
  * no header (src/main/store_index.hpp:24-27).  Envelope order is pinned by src/main/index.hpp:208-244,
  * src/taxonomy/Species.hpp:40-50 and hierarchical_interleaved_xor_filter.hpp:152-158,277-282; the record of
@@ -249,6 +280,10 @@ typedef struct {
     uint64_t n_user_bin_filenames;
     const char *const *user_bin_filenames;   /* hixf.hpp:280; bin_path (index.hpp:226) is written as one
                                                 single-element vector per filename, like taxor_build.cpp:519-523 */
+    uint8_t foreign_schema;                  /* set by taxor_hixf_load: the IXF records did not follow this library's
+                                                own layout and were read through the probed one -- the file was written
+                                                by other software, whose IXF arithmetic this library has not been
+                                                verified against (run `taxor verify`) */
 } taxor_hixf_meta;
 
 typedef struct taxor_hixf taxor_hixf;  /* a parsed .hixf held in host memory (mmap) */

@@ -38,6 +38,10 @@ dt = (time.perf_counter() - t0) / steps
 st = sr.stats()
 res = sr.fetch()
 hit = sum(1 for r in range(n_reads) if origin[r] >= 0 and lay["planted_user_bin"][origin[r]] in res.user_bin[int(res.read_off[r]):int(res.read_off[r + 1])].tolist())
+prof = sr.phase_profile() if os.environ.get("TAXOR_PROFILE_PHASES") else None
+if prof is not None:
+    p = prof[8:].astype(float); print("-- k_query_level phases:", ", ".join(f"{100*v/p.sum():.1f}%" for v in p))
+print(f"algorithmic {st['query_bytes']/1e9:.1f} GB requested {st['query_touched_bytes']/1e9:.1f} GB per step")
 print(f"k={k} window={w} model={sr.model}: index {idx.data_bytes/1e9:.2f} GB, {n_reads} x {read_len} bp, {st['n_hashes']/n_reads:.0f} hashes/read, "
       f"{n_reads*read_len/dt/1e6:.0f} Mbp/s ({dt*1e3:.1f} ms/step; hashing {st['syncmer_ms']:.1f} ms, query {st['query_ms']:.1f} ms), "
       f"requested {st['query_touched_bytes']/(st['query_ms']*1e-3)/1e9:.0f} GB/s, planted reads classified {hit}/{int((origin >= 0).sum())}")

@@ -57,13 +57,19 @@ class Species(C.Structure):
 class HixfMeta(C.Structure):
     _fields_ = [("window_size", C.c_uint64), ("parts", C.c_uint8), ("compressed", C.c_uint8),
                 ("n_species", C.c_uint64), ("species", C.POINTER(Species)), ("n_user_bin_filenames", C.c_uint64),
-                ("user_bin_filenames", C.POINTER(C.c_char_p))]
+                ("user_bin_filenames", C.POINTER(C.c_char_p)), ("foreign_schema", C.c_uint8)]
 
 
 class IxfSchema(C.Structure):
     _fields_ = [("n_before", C.c_uint32), ("n_after", C.c_uint32), ("idx_bins", C.c_int32), ("idx_stride", C.c_int32),
                 ("idx_seg_len", C.c_int32), ("idx_seed", C.c_int32), ("seg_len_is_rows", C.c_uint32),
                 ("default_seed", C.c_uint64)]
+
+
+class IxfVariant(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("seg_len", C.c_uint64), ("stride", C.c_uint64), ("key_hash", C.c_uint8),
+                ("seed_mode", C.c_uint8), ("rot", C.c_uint8), ("reduce", C.c_uint8), ("fp_mode", C.c_uint8),
+                ("layout", C.c_uint8), ("pad", C.c_uint8 * 2)]
 
 
 # every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
@@ -104,6 +110,9 @@ SIGNATURES = {
                                      C.POINTER(C.POINTER(C.c_uint64))]),
     "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),
     "taxor_gpu_bulk_contains": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(Results)]),
+    "taxor_ixf_variant_default": (None, [C.POINTER(IxfVariant), C.c_uint64, C.c_uint64, C.c_uint64]),
+    "taxor_gpu_ixf_variant_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(IxfVariant), C.c_uint32, _P, _P, C.c_uint64, _P]),
+    "taxor_ixf_variant_describe": (C.c_uint64, [C.POINTER(IxfVariant), C.c_char_p, C.c_uint64]),
     "taxor_hixf_load": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "taxor_ixf_schema_default": (None, [C.POINTER(IxfSchema)]),
     "taxor_hixf_probe": (C.c_int, [C.c_char_p, C.POINTER(IxfSchema), C.c_char_p, C.c_uint64]),

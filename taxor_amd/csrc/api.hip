@@ -102,14 +102,14 @@ struct taxor_gpu_searcher {
     Counters *d_ctr = nullptr;
     unsigned long long *d_prof = nullptr;   // TAXOR_PROFILE_PHASES=1: per-phase cycle sums of the two big kernels
     Counters h_ctr{};
-    int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0;
+    int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0, grid_query_short = 0;   // query blocks: 3 per CU, 4 for short reads
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
     bool auto_sub_reads = true; // sub_batch_reads was left to the library: short reads get more of them per sub-batch
     bool prune = true;   // TAXOR_QUERY_PRUNE=0 disables the threshold-aware pruning (A/B measurements)
     size_t lds_query = 0;
 
     // batch-resident input
-    uint64_t n_reads = 0, n_bases = 0;
+    uint64_t n_reads = 0, n_bases = 0, mean_read_len = 1u << 20;
     DBuf<uint8_t> d_ascii;
     DBuf<uint64_t> d_aoff, d_poff, d_hoff;
     DBuf<uint32_t> d_packed, d_rlen, d_hcap, d_nh, d_order;
@@ -505,7 +505,8 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         s->grid_sync_overlap = hipGetDeviceProperties(&p, idx->device) == hipSuccess ? p.multiProcessorCount * per : s->grid_sync;
         if (s->grid_sync_overlap > s->grid_sync) s->grid_sync_overlap = s->grid_sync;
     }
-    s->grid_query = query_grid(idx->device, s->lds_query);
+    s->grid_query = query_grid(idx->device, s->lds_query, 3);
+    s->grid_query_short = query_grid(idx->device, s->lds_query, 4);
     *out = s;
     return TAXOR_OK;
 }
@@ -701,8 +702,11 @@ int ensure_scratch(taxor_gpu_searcher *s)
         s->ev_query_done.push_back(b);
         s->ev_pack_done.push_back(c);
     }
-    const uint64_t qmin = std::max<uint64_t>(4ull * R, idx->h_ixf.size() + 64);
-    const uint64_t hmin = std::max<uint64_t>(4ull * R, idx->leaf_runs + 64);
+    // Initial capacities: a read of a clade with many indexed relatives reports a tuple per relative and enters several
+    // child IXFs (8 tuples / 3 children per read on the family workload), and an overflow costs a rerun of the whole
+    // batch; these buffers are small (8 B per queue entry, 16 B per hit), so start generously.
+    const uint64_t qmin = std::max<uint64_t>(8ull * R, idx->h_ixf.size() + 64);
+    const uint64_t hmin = std::max<uint64_t>(16ull * R, idx->leaf_runs + 64);
     if (s->q_cap < qmin) s->q_cap = (uint32_t)std::min<uint64_t>(qmin, 0x7FFFFFFFu);
     if (s->hit_cap < hmin) s->hit_cap = (uint32_t)std::min<uint64_t>(hmin, 0x7FFFFFFFu);
     if (s->d_q[0].reserve(s->q_cap) || s->d_q[1].reserve(s->q_cap)) return TAXOR_E_HIP;
@@ -717,7 +721,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
         if (s->gtab_stride < ts) s->gtab_stride = (uint32_t)ts;
         if (s->d_gtab.reserve((size_t)s->gtab_stride * (size_t)s->grid_sync)) return TAXOR_E_HIP;
     }
-    const uint64_t tmin = std::max<uint64_t>(4 * s->n_reads + 1024, idx->leaf_runs + 64);
+    const uint64_t tmin = std::max<uint64_t>(12 * s->n_reads + 1024, idx->leaf_runs + 64);   // 16 B per tuple
     if (s->tuple_cap < tmin) s->tuple_cap = tmin;
     if (s->d_out_ub.reserve(s->tuple_cap) || s->d_out_cnt.reserve(s->tuple_cap) || s->d_out_key.reserve(s->tuple_cap))
         return TAXOR_E_HIP;
@@ -747,6 +751,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.q_cap = s->q_cap;
     q.hit_cap = s->hit_cap;
     q.map_words = query_map_words(idx->max_stride);
+    q.max_stride = idx->max_stride;
     q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
     q.prof = s->d_prof;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
@@ -757,10 +762,12 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.n_level0 = n_reads;
         q.order0 = d_order;
         static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_QUERY_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
-        q.cursor_chunk = lvl >= 1 ? (chunk_env ? chunk_env : 4u) : 1u;
+        // levels below the root: small items, four per cursor atomic; the root level too when the reads are short (a
+        // long read is ~30 us of work and chunks of those would leave blocks idle at the tail of the launch)
+        q.cursor_chunk = chunk_env ? chunk_env : ((lvl >= 1 || s->mean_read_len < 3000) ? 4u : 1u);
         size_t slot;
         if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
-        launch_query_level(q, s->grid_query, s->lds_query, s->st);
+        launch_query_level(q, s->mean_read_len < 6000 ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
         if (ev_end(s, slot)) return TAXOR_E_HIP;
         s->stats.query_launches++;
     }
@@ -825,6 +832,10 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.gtab_stride = s->gtab_stride;
     a.ctr = s->d_ctr;
     a.n_reads = sb.n;
+    {   // short reads: eight per cursor atomic (metadata + first words prefetched); long reads one (load balance at the tail)
+        static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_SYNC_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        a.chunk = chunk_env ? chunk_env : (s->mean_read_len < 2500 ? 8u : (s->mean_read_len < 6000 ? 4u : 1u));
+    }
     a.k = idx->k;
     a.s = idx->s;
     a.t = idx->t;
@@ -902,6 +913,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     s->h_rlen = rlen;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     s->n_bases = nb;
+    s->mean_read_len = n_reads ? nb / n_reads : (1u << 20);
     if (s->d_ascii.reserve(nb + 64) || s->d_aoff.reserve(n_reads + 1) || s->d_poff.reserve(n_reads + 1) ||
         s->d_hoff.reserve(n_reads + 1) || s->d_rlen.reserve(n_reads + 1) || s->d_hcap.reserve(n_reads + 1) ||
         s->d_nh.reserve(n_reads + 1) || s->d_thr.reserve(n_reads + 1) || s->d_order.reserve(n_reads + 1) ||
@@ -958,9 +970,13 @@ int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
             HIP_TRY(hipEventRecord(s->ev_pack_done[i], s->st_copy));
             HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_pack_done[i], 0));
         }
-        if (i >= 2) HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_query_done[i - 2], 0));
-        if (int rc = launch_syncmers_sub(s, sb, i, buf, s->st_sync, i > 0)) return rc;
-        HIP_TRY(hipEventRecord(s->ev_sync_done[i], s->st_sync));
+        // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
+        static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
+        hipStream_t ss = no_overlap ? s->st : s->st_sync;
+        if (host_ascii && no_overlap) HIP_TRY(hipStreamWaitEvent(ss, s->ev_pack_done[i], 0));
+        if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss, s->ev_query_done[i - 2], 0));
+        if (int rc = launch_syncmers_sub(s, sb, i, buf, ss, i > 0 && !no_overlap)) return rc;
+        HIP_TRY(hipEventRecord(s->ev_sync_done[i], ss));
         HIP_TRY(hipStreamWaitEvent(s->st, s->ev_sync_done[i], 0));
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
         if (int rc = run_query(s, s->d_hashes[buf].p, s->d_hoff.p + sb.first, s->d_nh.p + sb.first, s->d_thr.p + sb.first,
@@ -1172,6 +1188,7 @@ int stage_hash_list(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, u
     s->ran = s->synced = false;
     s->n_reads = 1;
     s->n_bases = 0;
+    s->mean_read_len = 1u << 20;
     s->subs.clear();
     s->max_slots = n + 64;
     s->max_read_slots = 16;

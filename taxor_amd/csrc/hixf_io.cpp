@@ -448,7 +448,9 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
     // the records did not fit this library's schema: probe the file and retry with what it found
     taxor_ixf_schema probed;
     if (taxor_hixf_probe(path, &probed, nullptr, 0) != TAXOR_OK) return TAXOR_E_IO;
-    return load_with(path, probed, out, nullptr);
+    const int rc2 = load_with(path, probed, out, nullptr);
+    if (rc2 == TAXOR_OK) (*out)->meta.foreign_schema = 1;
+    return rc2;
 }
 
 extern "C" void taxor_hixf_free(taxor_hixf *h)

@@ -84,6 +84,7 @@ struct SyncmerArgs {
     uint32_t *cursor;         // dynamic work cursor of this launch (zeroed by the host)
     const uint32_t *order;    // processing order: longest reads first, so that no long read is left for the tail
     uint32_t n_reads;
+    uint32_t chunk;           // reads per cursor atomic (short reads: 8, so that their metadata and words are prefetched)
     int k, s, t;
     int w_min;                // > 0: minimiser / k-mer mode with this window size (index built without --use-syncmer)
     int thr_on_device;        // minimiser mode: 1 = thr = (size_t)(nh * ratio) here; 0 = the host applies a model
@@ -108,6 +109,7 @@ struct QueryArgs {
     const uint32_t *order0;   // level 0: item i is read order0[i] (longest first); nullptr = identity
     uint32_t q_cap, hit_cap;
     uint32_t map_words;       // words of the alive-unit bitmap in LDS (query_lds_map_words(max_stride))
+    uint32_t max_stride;      // widest row of the index: sizes the per-bin LDS arrays
     uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)
     uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
@@ -138,7 +140,7 @@ void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t
 void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st);
 int syncmers_grid(int device);
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
-int query_grid(int device, size_t lds_bytes);
+int query_grid(int device, size_t lds_bytes, int want_per_cu);
 size_t query_lds_bytes(uint32_t max_stride);
 uint32_t query_map_words(uint32_t max_stride);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);

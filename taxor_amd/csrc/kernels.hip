@@ -185,6 +185,7 @@ static constexpr int SY_T = BLK * SY_C;        // windows per tile
 static constexpr int SY_WORDS = SY_T / 16 + 8; // packed words staged per tile
 static constexpr int SY_LDS_TAB = 4096;        // dedup slots held in LDS
 static constexpr int SY_LDS_CAND = 2048;       // candidate hashes held in LDS (the rest spill to global)
+static constexpr int SY_CHUNK_MAX = 8;         // reads taken per cursor atomic, at most
 
 __device__ __forceinline__ uint32_t revcomp32(uint32_t x, int nb)
 {
@@ -246,40 +247,89 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
     __shared__ uint32_t sScr[8];
     __shared__ int sCarry;
     __shared__ uint32_t sRead;
+    // Per-read metadata of a cursor chunk, fetched by one lane per read: the chain  cursor -> order -> (length, offsets,
+    // capacity) -> packed words  is four dependent global round trips, which is most of what a SHORT read costs
+    // (10 us per 1-kb read at two blocks per CU).  A chunk pays the first three once; the packed words of the next tile
+    // -- of this read, or the first tile of the next read of the chunk -- are loaded into a register while the current
+    // tile is processed, so staging them finds them there.
+    struct ReadMeta { uint64_t poff, hoff; uint32_t r, L, cap, pad; };
+    __shared__ ReadMeta sMeta[SY_CHUNK_MAX];
+    static_assert(SY_WORDS <= BLK, "one staged word per thread");
 
     const int k = a.k, s = a.s, t = a.t;
     const int w = k - s + 1;
     const uint32_t smask = (s < 16) ? ((1u << (2 * s)) - 1u) : 0xFFFFFFFFu;
     const uint32_t tid = threadIdx.x;
+    const uint32_t chunk = min(max(a.chunk, 1u), (uint32_t)SY_CHUNK_MAX);
+    uint32_t ri = 0, chunk_n = 0;      // position in / reads of the current chunk (block-uniform)
+    uint32_t nextW = 0;                // prefetched word tid of the next staging event
+    bool have_next = false;            // block-uniform
 
     for (;;) {
         __syncthreads();
-        if (tid == 0) sRead = atomicAdd(a.cursor, 1u);
-        __syncthreads();
-        if (sRead >= a.n_reads) break;
-        const uint32_t r = a.order ? a.order[sRead] : sRead;
-        PMARK(0)                                                     // 0: work cursor
+        if (ri == chunk_n) {
+            if (tid == 0) sRead = atomicAdd(a.cursor, chunk);
+            __syncthreads();
+            const uint32_t first = sRead;
+            if (first >= a.n_reads) break;
+            chunk_n = min(chunk, a.n_reads - first);
+            ri = 0;
+            have_next = false;
+            if (tid < chunk_n) {
+                const uint32_t r_ = a.order ? a.order[first + tid] : first + tid;
+                ReadMeta m;
+                m.r = r_;
+                m.L = a.rlen[r_];
+                m.poff = a.poff[r_];
+                m.hoff = a.hoff[r_];
+                m.cap = a.hcap[r_];
+                m.pad = 0;
+                sMeta[tid] = m;
+            }
+            __syncthreads();
+        }
+        const uint32_t r = sMeta[ri].r;
+        PMARK(0)                                                     // 0: work cursor + chunk metadata
 
-        const uint32_t L = a.rlen[r];
-        const uint32_t *__restrict__ pk = a.packed + a.poff[r];
+        const uint32_t L = sMeta[ri].L;
+        const uint32_t *__restrict__ pk = a.packed + sMeta[ri].poff;
         const uint32_t nwords = (((L + 15u) >> 4) + 3u) & ~3u;
-        uint64_t *__restrict__ cand = a.cand + a.hoff[r];
-        uint64_t *__restrict__ outh = a.hashes + a.hoff[r];
-        const uint32_t cap = a.hcap[r];
+        uint64_t *__restrict__ cand = a.cand + sMeta[ri].hoff;
+        uint64_t *__restrict__ outh = a.hashes + sMeta[ri].hoff;
+        const uint32_t cap = sMeta[ri].cap;
         const int nwin = (int)L - k + 1; // number of k-mer windows (<= 0: none)
         uint32_t n_sel = 0;              // block-uniform
+        // first tile of the next read of this chunk (prefetched during this read's last tile)
+        const bool nx_ok = ri + 1u < chunk_n && (int)sMeta[ri + 1u < chunk_n ? ri + 1u : ri].L - k + 1 > 0;
+        const uint32_t *__restrict__ nx_pk = a.packed + sMeta[ri + 1u < chunk_n ? ri + 1u : ri].poff;
+        const uint32_t nx_words = (((sMeta[ri + 1u < chunk_n ? ri + 1u : ri].L + 15u) >> 4) + 3u) & ~3u;
+        ++ri;
 
         if (tid == 0) sCarry = 0;
         for (int x0 = 0; x0 < nwin; x0 += SY_T) {
             __syncthreads();
             // ---- stage packed words of the tile ---------------------------------------------------
             const uint32_t wbase = (uint32_t)x0 >> 4;
-            for (uint32_t i = tid; i < (uint32_t)SY_WORDS; i += BLK) {
-                const uint32_t wi = wbase + i;
-                sW[i] = wi < nwords ? pk[wi] : 0u;
+            if (tid < (uint32_t)SY_WORDS) {
+                uint32_t wv = nextW;
+                if (!have_next) {
+                    const uint32_t wi = wbase + tid;
+                    wv = wi < nwords ? pk[wi] : 0u;
+                }
+                sW[tid] = wv;
             }
             __syncthreads();
-            PMARK(1)                                                 // 1: per-read metadata + staging the packed words
+            // the words of the next staging event: in flight while this tile is processed
+            have_next = false;
+            if (x0 + SY_T < nwin) {
+                const uint32_t wi = (((uint32_t)x0 + (uint32_t)SY_T) >> 4) + tid;
+                if (tid < (uint32_t)SY_WORDS) nextW = wi < nwords ? pk[wi] : 0u;
+                have_next = true;
+            } else if (nx_ok) {
+                if (tid < (uint32_t)SY_WORDS) nextW = tid < nx_words ? nx_pk[tid] : 0u;
+                have_next = true;
+            }
+            PMARK(1)                                                 // 1: staging the packed words
             // ---- canonical s-mer values (syncmer.cpp:103-110; the s-mer "hash" is the raw 2-bit value)
             const int nv = min(SY_T + w - 1, (int)L - s + 1 - x0); // valid s-mer starts in this tile
             const int nw_tile = min(SY_T, nwin - x0);
@@ -424,7 +474,32 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
         //      sub-batch of long reads is then bound by the chip's atomic rate.  Duplicates are rare: a pass that
         //      meets none skips its lookup sweep, and a read without any is copied straight out. ---------------
         uint32_t n_dist = 0;
-        if (n_sel > 0) {
+        if (n_sel > 0 && n_sel <= (uint32_t)BLK) {
+            // short read (up to ~2.8 kb at k22/s12): one candidate per thread, compared with every earlier one.  The
+            // loop is uniform and its LDS reads are broadcasts -- no table to clear, no atomics, one barrier; the hash
+            // table below costs a short read several times its selection work.
+            const uint64_t h = tid < n_sel ? sCand[tid] : 0ull;
+            bool dupf = false;
+            for (uint32_t j0 = 0; j0 + 1u < n_sel; j0 += 8u) {        // eight independent LDS reads per trip (a loop of
+                uint64_t o[8];                                       // single dependent reads is all LDS latency);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = sCand[j0 + (uint32_t)u];   // j0 + 7 < 264 <= SY_LDS_CAND: in bounds
+#pragma unroll
+                for (int u = 0; u < 8; ++u) dupf |= (j0 + (uint32_t)u < tid) && (o[u] == h);   // j < tid < n_sel
+            }
+            bool first = tid < n_sel && !dupf;
+            if (first && a.scaling_limit > 0.0 && !((double)wyhash_u64(h) <= a.scaling_limit)) first = false;   // taxor_search.cpp:223-233
+            PMARK(6)
+            if (!__syncthreads_or((tid < n_sel && !first) ? 1 : 0)) {
+                if (tid < n_sel) outh[tid] = h;
+                n_dist = n_sel;
+            } else {
+                uint32_t tot;
+                const uint32_t rank = block_excl_add(first ? 1u : 0u, sScr, &tot);
+                if (first) outh[rank] = h;
+                n_dist = tot;
+            }
+        } else if (n_sel > 0) {
             auto cand_at = [&](uint32_t i) -> uint64_t { return i < (uint32_t)SY_LDS_CAND ? sCand[i] : cand[i]; };
             uint32_t *const sDupBits = sV;                               // the s-mer tile is dead by now: 1 bit per candidate
             static_assert((uint32_t)(SY_C * SY_RS) * 32u == SYNC_LDS_DEDUP_MAX, "dup-bit capacity");
@@ -454,7 +529,12 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
                         }
                     }
                     if (dup) sScr[6] = 1u;
-                    if (fresh) atomicAdd(&sScr[7], fresh);
+                    {   // one LDS atomic per wave, not per lane (64 lanes on one address serialise)
+                        uint32_t f = fresh;
+#pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) f += __shfl_xor(f, d);
+                        if (lane_id() == 0 && f) atomicAdd(&sScr[7], f);
+                    }
                     __syncthreads();
                     const bool pass_dup = sScr[6] != 0u;
                     if (sScr[7] > 3584u && tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW); // cannot happen for mixed hashes
@@ -767,7 +847,18 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
 //   [.., +Q_MAXU*4)                    list of alive 16-bin units
 //   [.., +map_words*4)                 bitmap of alive units (map_words = max_units/32 rounded up to 4 words)
 //   [.., +max_stride*4)                per-bin counts
+//   [.., +max_stride*4)                per-bin info words (binfo) of the current IXF
 static constexpr int Q_MAXU = 32;   // more alive units than this -> finish the item densely
+static constexpr int Q_CHUNK_MAX = 8; // work items taken per cursor atomic, at most
+
+// what a block needs to know about a work item, fetched for a whole cursor chunk at once (one lane per item) so that
+// the dependent loads  cursor -> (read, IXF) -> descriptor / hash count / threshold / hash offset  are paid once per
+// chunk and not once per item by every thread
+struct ItemMeta {
+    IxfDesc D;
+    uint64_t thr, hoff;
+    uint32_t r, n;
+};
 
 __host__ __device__ inline size_t query_lds_map_words(uint32_t max_stride) { return (((size_t)max_stride / 16 + 31) / 32 + 3) & ~(size_t)3; }
 
@@ -775,7 +866,7 @@ uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_w
 
 size_t query_lds_bytes(uint32_t max_stride)
 {
-    return (size_t)Q_CAP * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 4;
+    return (size_t)Q_CAP * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 8;
 }
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
@@ -878,6 +969,8 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
     uint32_t *sUnits = sScal + 16;
     uint32_t *sMap = sUnits + Q_MAXU;
     uint32_t *sC = sMap + a.map_words;
+    uint32_t *sInfo = sC + a.max_stride;
+    __shared__ ItemMeta sItems[Q_CHUNK_MAX];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lvl = a.level;
@@ -916,31 +1009,52 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
     };
 
-    const uint32_t chunk = a.cursor_chunk ? a.cursor_chunk : 1u;
-    uint32_t item = 0, item_end = 0;
+    const uint32_t chunk = min(max(a.cursor_chunk, 1u), (uint32_t)Q_CHUNK_MAX);
+    uint32_t item = 0, item_end = 0, item0 = 0;
     for (;;) {
         __syncthreads();
         if (item == item_end) {
             flush_out(false);
             if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, chunk);
             __syncthreads();
-            item = sScal[0];
+            item = item0 = sScal[0];
             item_end = min(item + chunk, n_items);
             if (item >= n_items) break;
+            if (tid < item_end - item) {                             // one lane per item of the chunk
+                uint32_t r_, v_;
+                if (a.q_in) { const uint2 it = a.q_in[item + tid]; r_ = it.x; v_ = it.y; }
+                else { r_ = a.order0 ? a.order0[item + tid] : item + tid; v_ = 0; }
+                ItemMeta m;
+                m.D = a.ixf[v_];
+                m.thr = a.thr[r_];
+                m.hoff = a.hoff[r_];
+                m.r = r_;
+                m.n = a.nh[r_];
+                sItems[tid] = m;
+            }
+            __syncthreads();
         }
-        PMARK(0)                                                     // 0: work cursor + output flushes
-        uint32_t r, v;
-        if (a.q_in) { const uint2 it = a.q_in[item]; r = it.x; v = it.y; }
-        else { r = a.order0 ? a.order0[item] : item; v = 0; }
-
-        const IxfDesc D = a.ixf[v];
-        const uint32_t n = a.nh[r];
-        const uint64_t thr = a.thr[r];
-        const uint64_t *__restrict__ hp = a.hashes + a.hoff[r];
+        PMARK(0)                                                     // 0: work cursor, chunk metadata, output flushes
+        const IxfDesc D = sItems[item - item0].D;
+        const uint32_t r = sItems[item - item0].r, n = sItems[item - item0].n;
+        const uint64_t thr = sItems[item - item0].thr;
+        const uint64_t *__restrict__ hp = a.hashes + sItems[item - item0].hoff;
         const uint32_t stride = D.stride;
         const uint32_t *__restrict__ bi = a.binfo + D.bin_base;
         const uint32_t nb_round = (D.bins + 63u) & ~63u;
 
+        // The per-bin info words are read twice per item (pruning check, tally): out of LDS, not out of L2 -- a global
+        // load per phase is a round trip of its own, which is most of what a small item costs.  Rows of up to 1024 bins
+        // take them through registers so that these loads and the hash loads of the probe staging below fly together.
+        const bool info_regs = nb_round <= 4u * BLK;
+        uint32_t infoReg[4] = {0u, 0u, 0u, 0u};
+        if (info_regs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = tid + (uint32_t)j * BLK;
+                if (b < D.bins) infoReg[j] = bi[b];
+            }
+        }
         for (uint32_t i = tid; i < stride; i += BLK) sC[i] = 0;
         for (uint32_t i = tid; i < a.map_words; i += BLK) sMap[i] = 0;
         if (tid == 0) sScal[1] = 0;
@@ -969,8 +1083,17 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
                 const ixf_probe p = ixf_probe_key(hp[i], D.seed, D.seg_len);
                 sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
+        if (info_regs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t b = tid + (uint32_t)j * BLK;
+                if (b < nb_round) sInfo[b] = infoReg[j];
+            }
+        } else {
+            for (uint32_t b = tid; b < nb_round; b += BLK) sInfo[b] = b < D.bins ? bi[b] : 0u;
+        }
         __syncthreads();
-        PMARK(1)                                                     // 1: item metadata, clearing the tally, probe staging
+        PMARK(1)                                                     // 1: clearing the tally, bin info + probe staging
         query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC, staged);
         touched += (uint64_t)dense_end * 3ull * stride;
         __syncthreads();
@@ -980,12 +1103,12 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
             const uint64_t rem = n - dense_end;
             for (uint32_t b = tid; b < nb_round; b += BLK) {
                 if (b < D.bins) {
-                    const uint32_t info = bi[b];
+                    const uint32_t info = sInfo[b];
                     if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
                         int bb = (int)b;
                         uint64_t sum = sC[bb];
                         if (!(info & BINFO_MERGED))
-                            while (bb > 0 && (bi[bb - 1] >> 30) == 0u) sum += sC[--bb];
+                            while (bb > 0 && (sInfo[bb - 1] >> 30) == 0u) sum += sC[--bb];
                         const uint64_t len = (uint64_t)b - (uint64_t)bb + 1u;
                         if (sum + rem * len >= thr) {
                             for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
@@ -1018,23 +1141,44 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
                         }
                         __syncthreads();
                     }
+                    // one task = (hash, alive unit): three 16-B loads from three different rows.  A thread has only a few
+                    // tasks (rem * n_alive / 256) and each is a full memory round trip, so four are issued together (twelve
+                    // loads in flight per lane); one at a time this phase is a chain of dependent latencies.
                     const uint32_t tasks = nt * n_alive;
-                    for (uint32_t task = tid; task < tasks; task += BLK) {
-                        const uint32_t i = task / n_alive, j = task - i * n_alive;
-                        const uint32_t x = sUnits[j];
-                        const uint4 p = pr[i];
-                        const uint8_t *base = D.data + (size_t)x * 16u;
-                        const uint4 r0 = ld16<NT>(base + (size_t)p.x * stride), r1 = ld16<NT>(base + (size_t)p.y * stride),
-                                    r2 = ld16<NT>(base + (size_t)p.z * stride);
-                        const uint32_t z[4] = {zero_bytes01(r0.x ^ r1.x ^ r2.x ^ p.w), zero_bytes01(r0.y ^ r1.y ^ r2.y ^ p.w),
-                                               zero_bytes01(r0.z ^ r1.z ^ r2.z ^ p.w), zero_bytes01(r0.w ^ r1.w ^ r2.w ^ p.w)};
+                    constexpr int SU = 4;
+                    for (uint32_t task0 = tid; task0 < tasks; task0 += BLK * SU) {
+                        uint4 r0[SU], r1[SU], r2[SU];
+                        uint32_t xs[SU], fp4[SU];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            uint32_t m = z[q];
-                            while (m) {
-                                const int bit = __ffs((int)m) - 1; // 0, 8, 16 or 24
-                                m &= m - 1u;
-                                atomicAdd(&sC[x * 16u + 4u * (uint32_t)q + ((uint32_t)bit >> 3)], 1u);
+                        for (int u = 0; u < SU; ++u) {
+                            const uint32_t task = task0 + (uint32_t)u * BLK;
+                            xs[u] = 0xFFFFFFFFu;
+                            r0[u] = r1[u] = r2[u] = make_uint4(0, 0, 0, 0);
+                            fp4[u] = 0;
+                            if (task < tasks) {
+                                const uint32_t i = task / n_alive, j = task - i * n_alive;
+                                xs[u] = sUnits[j];
+                                const uint4 p = pr[i];
+                                fp4[u] = p.w;
+                                const uint8_t *base = D.data + (size_t)xs[u] * 16u;
+                                r0[u] = ld16<NT>(base + (size_t)p.x * stride);
+                                r1[u] = ld16<NT>(base + (size_t)p.y * stride);
+                                r2[u] = ld16<NT>(base + (size_t)p.z * stride);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < SU; ++u) {
+                            if (xs[u] == 0xFFFFFFFFu) continue;
+                            const uint32_t z[4] = {zero_bytes01(r0[u].x ^ r1[u].x ^ r2[u].x ^ fp4[u]), zero_bytes01(r0[u].y ^ r1[u].y ^ r2[u].y ^ fp4[u]),
+                                                   zero_bytes01(r0[u].z ^ r1[u].z ^ r2[u].z ^ fp4[u]), zero_bytes01(r0[u].w ^ r1[u].w ^ r2[u].w ^ fp4[u])};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                uint32_t m = z[q];
+                                while (m) {
+                                    const int bit = __ffs((int)m) - 1; // 0, 8, 16 or 24
+                                    m &= m - 1u;
+                                    atomicAdd(&sC[xs[u] * 16u + 4u * (uint32_t)q + ((uint32_t)bit >> 3)], 1u);
+                                }
                             }
                         }
                     }
@@ -1053,14 +1197,14 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
             bool push_child = false, push_hit = false;
             uint32_t sum = 0, info = 0;
             if (b < D.bins) {
-                info = bi[b];
+                info = sInfo[b];
                 if (info & BINFO_MERGED) {
                     sum = sC[b];                                   // merged bins are runs of their own
                     push_child = (uint64_t)sum >= thr;             // :321
                 } else if (info & BINFO_END) {
                     int bb = (int)b;
                     sum = sC[bb];
-                    while (bb > 0 && (bi[bb - 1] >> 30) == 0u) sum += sC[--bb]; // split bin: :315,325-326
+                    while (bb > 0 && (sInfo[bb - 1] >> 30) == 0u) sum += sC[--bb]; // split bin: :315,325-326
                     push_hit = (uint64_t)sum >= thr;               // :328
                 }
             }
@@ -1105,18 +1249,18 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
     }
 }
 
-int query_grid(int device, size_t lds_bytes)
+int query_grid(int device, size_t lds_bytes, int want_per_cu)
 {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<false, 4>, BLK, lds_bytes) != hipSuccess || per < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<true, 2, false>, BLK, lds_bytes) != hipSuccess || per < 1)
         per = 2;
     // Measured: HBM streaming saturates from two resident blocks per CU (1 -> -4 %, 2 = 3 = 4), but the per-item
-    // latency-bound phases (metadata fetch, probe staging, pruning check, tally) hide better with three, which
-    // matters for short reads and small child IXFs (+14 % viral-class, +23 % at 1 kb reads).  Three blocks of the
-    // 2x-unrolled kernel (88 VGPRs) still leave registers and LDS for two syncmer blocks of the next sub-batch.
-    if (per > 3) per = 3;
+    // latency-bound phases (metadata fetch, probe staging, pruning check, tally) hide better with more: three for long
+    // reads (+14 % viral-class over two), four for short reads, whose items spend half their time outside the gather
+    // loop (1-kb reads +4 % unrelated / +11 % family workload over three; 10-kb reads unchanged).  The caller asks.
+    if (per > want_per_cu) per = want_per_cu;
     if (const char *e = getenv("TAXOR_QUERY_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }

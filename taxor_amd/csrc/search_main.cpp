@@ -95,6 +95,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     std::vector<int> gpus{0};   // devices that classify batches in parallel, each with its own index replica
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
+    std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
 };
 
 std::vector<std::string> str_split(const std::string &s, char delim)         // taxor_search.cpp:82-95
@@ -135,7 +136,8 @@ void usage()
             "  --gpu <id>               device ordinal (default 0)\n"
             "  --gpus <n>               use devices 0..n-1: the index is replicated, batches of reads are sharded\n"
             "  --gpu-list <a,b,..>      explicit device list (a device may be listed twice)\n"
-            "  --batch-reads <n>        reads per GPU batch (default: about 128 MB of query file, 65536 reads for gzip)\n");
+            "  --batch-reads <n>        reads per GPU batch (default: about 128 MB of query file, 65536 reads for gzip)\n"
+            "  --expect <tsv>           compare the output per read with a TSV the reference wrote for the same input (exit 3 if it differs)\n");
 }
 
 double now()
@@ -284,6 +286,68 @@ bool strip_space_and_digits(Batch &b)
     return any;
 }
 
+// `--expect ref.tsv`: compare this run's output with a TSV the reference produced for the same reads and index
+// (the day a published .hixf and its reference output are at hand).  The reference writes the lines
+// of one read together but, with --threads > 1, the reads in no particular order (sync_out.hpp:24-29): reads are
+// matched by id, the lines of a read are compared in order (the HIXF's DFS order).  Returns the number of differing reads.
+uint64_t compare_tsv(const std::string &ours, const std::string &expect)
+{
+    auto load = [](const std::string &path, std::map<std::string, std::vector<std::string>> &by_read, std::vector<std::string> &order) {
+        FILE *f = fopen(path.c_str(), "rb");
+        if (!f) die("cannot open " + path);
+        std::string line;
+        std::vector<char> buf(1 << 20);
+        std::string carry;
+        size_t n;
+        auto take = [&](const std::string &l) {
+            if (l.empty() || l[0] == '#') return;
+            const size_t tab = l.find('\t');
+            const std::string id = l.substr(0, tab);
+            auto it = by_read.find(id);
+            if (it == by_read.end()) { it = by_read.emplace(id, std::vector<std::string>()).first; order.push_back(id); }
+            it->second.push_back(l);
+        };
+        while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) {
+            size_t a = 0;
+            for (size_t i = 0; i < n; ++i)
+                if (buf[i] == '\n') {
+                    carry.append(buf.data() + a, i - a);
+                    if (!carry.empty() && carry.back() == '\r') carry.pop_back();
+                    take(carry);
+                    carry.clear();
+                    a = i + 1;
+                }
+            carry.append(buf.data() + a, n - a);
+        }
+        if (!carry.empty()) take(carry);
+        fclose(f);
+    };
+    std::map<std::string, std::vector<std::string>> a, b;
+    std::vector<std::string> oa, ob;
+    load(ours, a, oa);
+    load(expect, b, ob);
+    uint64_t same = 0, differ = 0, only_ours = 0, only_expect = 0, shown = 0;
+    for (const auto &id : oa) {
+        const auto it = b.find(id);
+        if (it == b.end()) { ++only_ours; continue; }
+        if (it->second == a[id]) { ++same; continue; }
+        ++differ;
+        if (shown++ < 10) {
+            printf("read %s differs:\n", id.c_str());
+            for (const auto &l : a[id]) printf("  ours    %s\n", l.c_str());
+            for (const auto &l : it->second) printf("  expect  %s\n", l.c_str());
+        }
+    }
+    for (const auto &id : ob)
+        if (!a.count(id)) ++only_expect;
+    printf("compared with %s: %llu reads identical, %llu differ, %llu only in this run, %llu only in the expected file\n", expect.c_str(),
+           (unsigned long long)same, (unsigned long long)differ, (unsigned long long)only_ours, (unsigned long long)only_expect);
+    const uint64_t bad = differ + only_ours + only_expect;
+    printf("%s\n", bad == 0 ? "PASS: per-read output identical to the expected TSV"
+                            : "FAIL: output differs from the expected TSV (run `taxor verify` to test the index arithmetic)");
+    return bad;
+}
+
 uint64_t fnv1a(const char *p, size_t n)
 {
     uint64_t h = 1469598103934665603ull;
@@ -320,7 +384,9 @@ int main(int argc, char **argv)
         std::string index_file, genome_file;
         uint64_t n_reads = 2000, read_len = 5000;
         int device = 0;
+        bool scan_variants = false;
         for (int i = 2; i < argc; ++i) {
+            if (strcmp(argv[i], "--variants") == 0) { scan_variants = true; continue; }
             if (strcmp(argv[i], "--index-file") == 0 && i + 1 < argc) index_file = argv[++i];
             else if (strcmp(argv[i], "--genome-file") == 0 && i + 1 < argc) genome_file = argv[++i];
             else if (strcmp(argv[i], "--reads") == 0 && i + 1 < argc) n_reads = strtoull(argv[++i], nullptr, 10);
@@ -386,6 +452,69 @@ int main(int argc, char **argv)
         const bool pass = median >= 0.9 && low >= 0.5;
         printf("%s\n", pass ? "PASS: the index answers for this genome -- hashing and IXF arithmetic match the file"
                             : "FAIL: an indexed genome must match itself; check `taxor probe` (seed / stride / segment length) and the hash");
+        if (scan_variants || !pass) {
+            // Which reading of the un-vendored IXF arithmetic does this file follow?  Probe the raw bytes of the root IXF
+            // (every indexed genome is in one of its bins, as a leaf or inside a merged bin) under a family of variants.
+            const uint64_t n_lists = std::min<uint64_t>(24, offsets.size() - 1);
+            const uint64_t *hoff = nullptr, *hs = nullptr;
+            if (taxor_gpu_syncmers(sr, bases.data(), offsets.data(), n_lists, &hoff, &hs) != TAXOR_OK) die(taxor_gpu_last_error());
+            const taxor_ixf_view &root = view->ixf[0];
+            const uint64_t data_len = 3 * root.seg_len * root.stride;
+            std::vector<uint64_t> seeds{root.seed};
+            for (uint64_t sd : {13572355802537770549ull, 0ull})
+                if (std::find(seeds.begin(), seeds.end(), sd) == seeds.end()) seeds.push_back(sd);
+            std::vector<std::pair<uint64_t, uint64_t>> shapes;          // (stride, seg_len)
+            for (uint64_t st : {root.stride, root.bins}) {
+                if (!st) continue;
+                for (uint64_t sg : {root.seg_len, data_len / st / 3}) {
+                    if (!sg) continue;
+                    if (std::find(shapes.begin(), shapes.end(), std::make_pair(st, sg)) == shapes.end()) shapes.push_back({st, sg});
+                }
+            }
+            std::vector<taxor_ixf_variant> vs;
+            for (uint64_t sd : seeds)
+                for (const auto &sh : shapes)
+                    for (int kh = 0; kh < 4; ++kh)
+                        for (int sm = 0; sm < 3; ++sm)
+                            for (int rot : {21, 16, 32})
+                                for (int red = 0; red < 3; ++red)
+                                    for (int fp = 0; fp < 4; ++fp)
+                                        for (int lay = 0; lay < 2; ++lay) {
+                                            if (sd == 0 && sm != 0) continue;        // without a seed the three seed modes coincide
+                                            taxor_ixf_variant v;
+                                            taxor_ixf_variant_default(&v, sd, sh.second, sh.first);
+                                            v.key_hash = (uint8_t)kh; v.seed_mode = (uint8_t)sm; v.rot = (uint8_t)rot;
+                                            v.reduce = (uint8_t)red; v.fp_mode = (uint8_t)fp; v.layout = (uint8_t)lay;
+                                            vs.push_back(v);
+                                        }
+            std::vector<float> ratio(vs.size() * n_lists);
+            if (taxor_gpu_ixf_variant_scan(gi, 0, vs.data(), (uint32_t)vs.size(), hs, hoff, n_lists, ratio.data()) != TAXOR_OK) die(taxor_gpu_last_error());
+            std::vector<std::pair<float, size_t>> rank;
+            for (size_t i = 0; i < vs.size(); ++i) {
+                std::vector<float> r(ratio.begin() + i * n_lists, ratio.begin() + (i + 1) * n_lists);
+                std::sort(r.begin(), r.end());
+                rank.push_back({r[r.size() / 2], i});
+            }
+            std::sort(rank.begin(), rank.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            printf("variant scan of the root IXF (%zu readings of the fingerprint array, %llu hash lists): median best-bin match ratio\n", vs.size(),
+                   (unsigned long long)n_lists);
+            char desc[512];
+            taxor_ixf_variant mine;
+            taxor_ixf_variant_default(&mine, root.seed, root.seg_len, root.stride);
+            for (size_t i = 0; i < std::min<size_t>(5, rank.size()); ++i) {
+                const taxor_ixf_variant &v = vs[rank[i].second];
+                taxor_ixf_variant_describe(&v, desc, sizeof desc);
+                const bool is_mine = memcmp(&v, &mine, sizeof v) == 0;
+                printf("  %.4f  %s%s\n", rank[i].first, desc, is_mine ? "   [this library's reading, ixf_arith.h]" : "");
+            }
+            if (!rank.empty() && rank[0].first >= 0.9f) {
+                const bool is_mine = memcmp(&vs[rank[0].second], &mine, sizeof mine) == 0;
+                printf("%s\n", is_mine ? "the file follows this library's reading of the IXF arithmetic"
+                                       : "the file follows ANOTHER reading of the IXF arithmetic (first line): change taxor_amd/csrc/ixf_arith.h accordingly");
+            } else {
+                printf("no variant answers: the key hash (wyhash / minimiser value) or the genome is not what the index holds\n");
+            }
+        }
         taxor_gpu_searcher_destroy(sr);
         taxor_gpu_index_destroy(gi);
         taxor_hixf_free(h);
@@ -461,6 +590,7 @@ int main(int argc, char **argv)
             if (cfg.gpus.empty()) die("--gpu-list is empty");
         }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
+        else if (k == "--expect") cfg.expect_file = val();
         else if (k == "-h" || k == "--help") { usage(); return 0; }
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
@@ -490,6 +620,7 @@ int main(int argc, char **argv)
     }
     for (const auto &f : query_files)
         if (!file_exists(f)) die("Please check the given input query files. \nThe following query file does not exist: " + f);
+    if (!cfg.expect_file.empty() && !file_exists(cfg.expect_file)) die("The expected-output file does not exist: " + cfg.expect_file);
     printf("done!\n");
     trace("input checked");
 
@@ -510,6 +641,11 @@ int main(int argc, char **argv)
         if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
         trace("index file loaded");
         const taxor_hixf_view *view = taxor_hixf_get_view(h);
+        if (taxor_hixf_get_meta(h)->foreign_schema)
+            fprintf(stderr, "[TAXOR SEARCH WARNING] %s was not written by this library (its IXF records follow another layout, read by probing).\n"
+                            "  The arithmetic of seqan3's interleaved_xor_filter is not part of the reference sources; this build's reading of it has\n"
+                            "  not been checked against this file.  Run `taxor verify --index-file %s --genome-file <a genome in the index>` first:\n"
+                            "  a wrong reading still loads and classifies at the false-positive floor.\n", hixf_file.c_str(), hixf_file.c_str());
         // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
         // replicated, batches are sharded); replicas are uploaded concurrently
         const size_t ng = cfg.gpus.size();
@@ -709,7 +845,9 @@ int main(int argc, char **argv)
         const double cpu = ru.ru_utime.tv_sec + ru.ru_stime.tv_sec + 1e-6 * (ru.ru_utime.tv_usec + ru.ru_stime.tv_usec);
         printf("CPU time  : %g sec\nPeak RSS  : %d MByte\n", cpu, (int)((size_t)ru.ru_maxrss * 1024 / (1024 * 1024)));
     }
+    int rc = 0;
+    if (!cfg.expect_file.empty()) rc = compare_tsv(cfg.report_file, cfg.expect_file) ? 3 : 0;
     fflush(stdout);
     fflush(stderr);
-    _exit(0);   // everything is written and closed; skip the runtime's and the allocator's teardown
+    _exit(rc);  // everything is written and closed; skip the runtime's and the allocator's teardown
 }

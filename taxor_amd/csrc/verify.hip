@@ -1,0 +1,166 @@
+// verify.hip -- diagnosis aid for indexes this library did not write.
+//
+// The arithmetic of seqan3::interleaved_xor_filter<uint8_t> is un-vendored in the reference; the
+// product's reading of it lives in ixf_arith.h.  When `taxor verify` finds that an indexed genome does not answer, this
+// scan tells WHICH reading the file follows: the same raw fingerprint bytes of one IXF are probed under a family of
+// arithmetic variants (how the seed enters, which mixer, rotation step, range reduction, fingerprint fold, row stride,
+// segment length, row- or bin-major layout), each scored by the best-bin match ratio of hash lists taken from a genome
+// that IS in the index.  The right variant scores ~1.0, every other one sits at the 2^-8 false-positive floor.
+// Not on the search path; a plain kernel (one block per (hash list, variant), a thread per bin).
+#include "../../include/taxor_gpu.h"
+#include "ixf_arith.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const char *msg);
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_gpu_index *idx, uint64_t ixf, uint8_t **data,
+                                                                          uint64_t *stride, uint64_t *seg_len, uint64_t *bins,
+                                                                          int *device);
+
+namespace {
+
+using namespace taxor;
+
+__device__ __forceinline__ uint64_t variant_hash(const taxor_ixf_variant &v, uint64_t key)
+{
+    uint64_t x = key;
+    if (v.seed_mode == 0) x = key + v.seed;                       // hashutil.hpp:59-61: murmur64(key + seed)
+    else if (v.seed_mode == 1) x = key ^ v.seed;
+    uint64_t h;
+    switch (v.key_hash) {
+    case 0: h = murmur64(x); break;
+    case 1: h = x; break;                                         // no mixer
+    case 2: h = wyhash_u64(x); break;
+    default: {                                                    // splitmix64 finaliser
+        uint64_t z = x + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h = z ^ (z >> 31);
+    }
+    }
+    if (v.seed_mode == 2) h += v.seed;                            // seed added after the mixer
+    return h;
+}
+
+__global__ __launch_bounds__(256) void k_variant_scan(const uint8_t *__restrict__ data, uint64_t data_len, uint32_t bins,
+                                                      const taxor_ixf_variant *__restrict__ variants,
+                                                      const uint64_t *__restrict__ hashes, const uint64_t *__restrict__ hoff,
+                                                      float *__restrict__ best_ratio, uint32_t n_lists)
+{
+    __shared__ uint32_t sBest;
+    const uint32_t list = blockIdx.x, vi = blockIdx.y;
+    const taxor_ixf_variant v = variants[vi];
+    const uint64_t h0 = hoff[list], n = hoff[list + 1] - h0;
+    if (threadIdx.x == 0) sBest = 0;
+    __syncthreads();
+    const uint64_t rows = 3 * v.seg_len;
+    uint32_t best = 0;
+    for (uint32_t b = threadIdx.x; b < bins; b += 256) {
+        uint32_t cnt = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t h = variant_hash(v, hashes[h0 + i]);
+            uint8_t fp;
+            switch (v.fp_mode) {
+            case 0: fp = (uint8_t)(h ^ (h >> 32)); break;          // xorfilter.hpp:60-62
+            case 1: fp = (uint8_t)h; break;
+            case 2: fp = (uint8_t)(h >> 56); break;
+            default: fp = (uint8_t)(h >> 32); break;
+            }
+            uint8_t x = fp;
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint64_t rot = rotl64(h, (unsigned)v.rot * (unsigned)j);
+                uint64_t r;
+                if (v.reduce == 0) r = ((uint64_t)(uint32_t)rot * v.seg_len) >> 32;           // xorfilter.hpp:36-40
+                else if (v.reduce == 1) r = (uint64_t)(uint32_t)rot % v.seg_len;
+                else r = __umul64hi(rot, v.seg_len);
+                r += (uint64_t)j * v.seg_len;
+                const uint64_t addr = v.layout == 0 ? r * v.stride + b : (uint64_t)b * rows + r;
+                if (addr >= data_len) { ok = false; break; }
+                x ^= data[addr];
+            }
+            cnt += (ok && x == 0) ? 1u : 0u;
+        }
+        best = max(best, cnt);
+    }
+    atomicMax(&sBest, best);
+    __syncthreads();
+    if (threadIdx.x == 0) best_ratio[(size_t)vi * n_lists + list] = n ? (float)sBest / (float)n : 0.f;
+}
+
+int vfail(int code, const std::string &msg)
+{
+    taxor_set_last_error(msg.c_str());
+    return code;
+}
+
+} // namespace
+
+extern "C" int taxor_gpu_ixf_variant_scan(taxor_gpu_index *idx, uint64_t ixf, const taxor_ixf_variant *variants, uint32_t n_variants,
+                                          const uint64_t *hashes, const uint64_t *hash_off, uint64_t n_lists, float *best_ratio)
+{
+    if (!idx || !variants || !n_variants || !hashes || !hash_off || !n_lists || !best_ratio)
+        return vfail(TAXOR_E_ARG, "ixf_variant_scan: null or empty argument");
+    uint8_t *data;
+    uint64_t stride, seg_len, bins;
+    int device;
+    if (taxor_index_ixf_info(idx, ixf, &data, &stride, &seg_len, &bins, &device) != 0) return vfail(TAXOR_E_ARG, "ixf_variant_scan: bad IXF id");
+    for (uint32_t i = 0; i < n_variants; ++i)
+        if (variants[i].seg_len == 0 || variants[i].stride == 0) return vfail(TAXOR_E_ARG, "ixf_variant_scan: variant with zero segment length or stride");
+    if (n_lists > 65535 || n_variants > 65535) return vfail(TAXOR_E_ARG, "ixf_variant_scan: more than 65535 lists or variants");
+    const uint64_t data_len = 3 * seg_len * stride, nh = hash_off[n_lists];
+    taxor_ixf_variant *d_v = nullptr;
+    uint64_t *d_h = nullptr, *d_off = nullptr;
+    float *d_out = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_v, n_variants * sizeof(taxor_ixf_variant));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_h, std::max<uint64_t>(nh, 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, (n_lists + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n_variants * n_lists * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_v, variants, n_variants * sizeof(taxor_ixf_variant), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nh) e = hipMemcpy(d_h, hashes, nh * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, hash_off, (n_lists + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_variant_scan, dim3((uint32_t)n_lists, n_variants), dim3(256), 0, nullptr, data, data_len, (uint32_t)bins, d_v,
+                           d_h, d_off, d_out, (uint32_t)n_lists);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(best_ratio, d_out, (size_t)n_variants * n_lists * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_v);
+    (void)hipFree(d_h);
+    (void)hipFree(d_off);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return vfail(TAXOR_E_HIP, std::string("ixf_variant_scan: ") + hipGetErrorString(e));
+    return TAXOR_OK;
+}
+
+extern "C" void taxor_ixf_variant_default(taxor_ixf_variant *out, uint64_t seed, uint64_t seg_len, uint64_t stride)
+{
+    if (!out) return;
+    *out = taxor_ixf_variant{};
+    out->seed = seed;
+    out->seg_len = seg_len;
+    out->stride = stride;
+    out->rot = 21;
+}
+
+extern "C" uint64_t taxor_ixf_variant_describe(const taxor_ixf_variant *v, char *buf, uint64_t cap)
+{
+    if (!v || !buf || !cap) return 0;
+    static const char *hash_name[] = {"murmur64", "identity", "wyhash-mix", "splitmix64"};
+    static const char *seed_name[] = {"h(key + seed)", "h(key ^ seed)", "h(key) + seed", "h(key), seed unused"};
+    static const char *red_name[] = {"(u32)rot * seg >> 32", "(u32)rot % seg", "mulhi64(rot, seg)"};
+    static const char *fp_name[] = {"(u8)(h ^ h>>32)", "(u8)h", "(u8)(h>>56)", "(u8)(h>>32)"};
+    const int n = snprintf(buf, cap, "%s as %s, seed %llu, row_i = %s + i*seg with rot = rotl(h, %u*i), fingerprint %s, seg_len %llu, row stride %llu, %s",
+                           hash_name[v->key_hash & 3], seed_name[v->seed_mode & 3], (unsigned long long)v->seed, red_name[v->reduce % 3],
+                           (unsigned)v->rot, fp_name[v->fp_mode & 3], (unsigned long long)v->seg_len, (unsigned long long)v->stride,
+                           v->layout == 0 ? "data[row*stride + bin]" : "data[bin*rows + row]");
+    return n < 0 ? 0 : (uint64_t)n;
+}

@@ -71,6 +71,7 @@ class HixfFile:
         self.use_syncmer, self.scaling = bool(v.use_syncmer), v.scaling
         self.n_user_bins = int(v.n_user_bins)
         self.window_size = int(m.window_size)
+        self.foreign_schema = bool(m.foreign_schema)
         self.ixfs = []
         for i in range(v.n_ixf):
             f = v.ixf[i]

@@ -25,7 +25,8 @@ def _free_port():
 
 def _run(n, extra, dump):
     common = ["bench.py", "--gpus", str(n), "--workload", "tiny", "--steps", "2", "--warmup", "1", "--batches", "2",
-              "--traffic", "none", "--no-cpu-baseline", "--no-dropin", "--no-unpruned", "--no-ceiling", "--dump-results", str(dump)] + extra
+              "--traffic", "none", "--no-cpu-baseline", "--no-unpruned", "--no-ceiling", "--sustained-reads", "8192",
+              "--dump-results", str(dump)] + extra
     env = dict(os.environ, TAXOR_BENCH_BACKEND="gloo", TAXOR_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1")
     if n == 1:
         cmd = [sys.executable] + common
@@ -54,6 +55,9 @@ def test_three_ranks_weak_scaling_gathers_every_shard(tmp_path):
     j1, r1 = _run(1, [], tmp_path / "n1.npz")
     j3, r3 = _run(3, [], tmp_path / "n3.npz")
     assert j3["n_gpus"] == 3 and j3["scaling"] == "weak"
+    pr = j3["pcie_inclusive_per_rank"]                 # every rank ran the host-fed call concurrently
+    assert len(pr["sustained_Mbp_s"]) == 3 and all(v > 0 for v in pr["sustained_Mbp_s"] + pr["single_call_Mbp_s"])
+    assert "pcie_inclusive" in j1 and j1["sustained"]["reads"] >= 8192
     n = r1["n_hashes"].size
     assert r3["n_hashes"].size == 3 * n and r3["read_off"].size == 3 * n + 1
     # rank 0's shard of the weak run is the single-rank batch (seed + rank with rank = 0)

@@ -247,3 +247,123 @@ def test_cli_sequences_with_spaces_and_digits(tmp_path):
     cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(bad), "--output-file", str(out)],
                         capture_output=True, text=True, timeout=120)
     assert cp.returncode != 0 and "dna15" in cp.stderr
+
+
+def _foreign_xor_column(keys, seed, seg_len):
+    """XOR-filter column of one bin under ANOTHER reading of the un-vendored IXF arithmetic than ixf_arith.h's:
+    murmur64(key ^ seed) instead of (key + seed), rows by modulo instead of multiply-shift, fingerprint = low byte."""
+    M = (1 << 64) - 1
+
+    def murmur64(h):
+        h ^= h >> 33
+        h = (h * 0xff51afd7ed558ccd) & M
+        h ^= h >> 33
+        h = (h * 0xc4ceb9fe1a85ec53) & M
+        return h ^ (h >> 33)
+
+    def probe(key):
+        h = murmur64((int(key) ^ seed) & M)
+        rows = []
+        for i in range(3):
+            rot = ((h << (21 * i)) | (h >> (64 - 21 * i))) & M if i else h
+            rows.append((rot & 0xFFFFFFFF) % seg_len + i * seg_len)
+        return rows, h & 0xFF
+
+    pr = {int(k): probe(k) for k in keys}
+    deg, acc = {}, {}
+    for k, (rows, _) in pr.items():
+        for r in rows:
+            deg[r] = deg.get(r, 0) + 1
+            acc[r] = acc.get(r, 0) ^ k
+    stack, queue = [], [r for r, d in deg.items() if d == 1]
+    while queue:
+        r = queue.pop()
+        if deg.get(r, 0) != 1:
+            continue
+        k = acc[r]
+        stack.append((k, r))
+        for q in pr[k][0]:
+            deg[q] -= 1
+            acc[q] ^= k
+            if deg[q] == 1:
+                queue.append(q)
+    if len(stack) != len(pr):
+        return None
+    col = np.zeros(3 * seg_len, dtype=np.uint8)
+    for k, r in reversed(stack):
+        rows, fp = pr[k]
+        col[r] = fp ^ col[rows[0]] ^ col[rows[1]] ^ col[rows[2]] ^ col[r]
+    return col
+
+
+def test_cli_verify_variant_scan_names_a_foreign_arithmetic(tmp_path):
+    """`taxor verify --variants`: an index whose fingerprints follow another reading of the IXF arithmetic than this
+    library's must FAIL the positive control and the scan must name that reading; the library's own index must be
+    recognised as the library's reading."""
+    g, go = synth.random_genomes(1, 12000, seed=77)
+    genome = bytes(g)
+    keys = np.unique(orc.seq_to_syncmers(genome))
+    bins, stride = 40, 64
+    seg = synth.seg_len_for(len(keys) + 50)
+    rng = np.random.default_rng(5)
+    col = None
+    for seed in (0x1234567890ABCDEF, 0x0FEDCBA987654321, 0x55AA55AA55AA55AA):
+        col = _foreign_xor_column(keys, seed, seg)
+        if col is not None:
+            break
+    assert col is not None
+    data = rng.integers(0, 256, size=(3 * seg, stride), dtype=np.uint8)
+    data[:, 7] = col
+    host = [dict(bins=bins, stride=stride, seg_len=seg, seed=seed, data=data.reshape(-1), next_ixf=np.zeros(bins, np.int64),
+                 fname_idx=np.arange(bins, dtype=np.int64))]
+    sp = [dict(organism_name=f"O{i}", accession_id=f"A{i}", taxid=str(i), taxnames_string="n", taxid_string="t", user_bin=i, seq_len=1)
+          for i in range(bins)]
+    foreign = tmp_path / "foreign.hixf"
+    store_hixf(foreign, host, bins, sp)
+    fa = tmp_path / "g.fa"
+    fa.write_bytes(b">g\n" + genome + b"\n")
+    cp = subprocess.run([TAXOR, "verify", "--index-file", str(foreign), "--genome-file", str(fa), "--reads", "60", "--read-len", "1500"],
+                        capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 2 and "FAIL" in cp.stdout, cp.stdout + cp.stderr
+    assert "ANOTHER reading" in cp.stdout, cp.stdout
+    first = [l for l in cp.stdout.splitlines() if l.startswith("  1.0000")][0]
+    assert "murmur64 as h(key ^ seed)" in first and "(u32)rot % seg" in first and "fingerprint (u8)h," in first and "data[row*stride + bin]" in first, first
+    assert f"seed {seed}" in first and "rotl(h, 21*i)" in first
+    # the library's own files: recognised as such
+    g2, go2, host2, sp2, own = _setup(tmp_path, 37)
+    fa2 = tmp_path / "g2.fa"
+    fa2.write_bytes(b">g\n" + bytes(g2[int(go2[3]):int(go2[4])]) + b"\n")
+    cp = subprocess.run([TAXOR, "verify", "--variants", "--index-file", str(own), "--genome-file", str(fa2), "--reads", "60", "--read-len", "1500"],
+                        capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0 and "PASS" in cp.stdout and "the file follows this library's reading" in cp.stdout, cp.stdout + cp.stderr
+
+
+def test_cli_expect_tsv_compares_per_read(tmp_path):
+    """`--expect ref.tsv`: per-read comparison with a TSV written for the same input -- reads in any order (the reference
+    writes them in completion order when --threads > 1), lines of a read in order; a changed count must be reported"""
+    g, go, host, sp, idx_path = _setup(tmp_path, 38)
+    bases, offs, origin = synth.synth_reads(g, go, 120, 1400, error_rate=0.02, frac_random=0.2, seed=12)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(120)]
+    ids = [f"e{i}" for i in range(120)]
+    fa = tmp_path / "r.fa"
+    with open(fa, "wb") as f:
+        for rid, r in zip(ids, reads):
+            f.write(b">" + rid.encode() + b"\n" + r + b"\n")
+    per_read = [_expected(host, sp, [rid], [r]) for rid, r in zip(ids, reads)]
+    order = np.random.default_rng(3).permutation(120)
+    ref = tmp_path / "ref.tsv"
+    ref.write_text(HEADER + "".join(per_read[i] for i in order))             # the reference's order: arbitrary
+    out = tmp_path / "o.tsv"
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out), "--expect", str(ref)],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0 and "120 reads identical, 0 differ" in cp.stdout and "PASS" in cp.stdout, cp.stdout + cp.stderr
+    hit = next(i for i in range(120) if "\t-\t" not in per_read[i])
+    cols = per_read[hit].split("\n")[0].split("\t")
+    cols[7] = str(int(cols[7]) + 1)                                             # QHASH_MATCH off by one
+    bad = list(per_read)
+    bad[hit] = "\t".join(cols) + "\n" + "\n".join(per_read[hit].split("\n")[1:])
+    ref.write_text(HEADER + "".join(bad[i] for i in order if i != 5))            # and one read missing
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out), "--expect", str(ref)],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 3 and "118 reads identical, 1 differ, 1 only in this run" in cp.stdout and "FAIL" in cp.stdout, cp.stdout
+    assert f"read {ids[hit]} differs" in cp.stdout

@@ -157,6 +157,10 @@ def test_probe_recovers_foreign_ixf_schemas(tmp_path):
             assert np.array_equal(a["data"], b["data"]), name
             assert np.array_equal(a["next_ixf"], b["next_ixf"]) and np.array_equal(a["fname_idx"], b["fname_idx"])
         assert h.species == sp
+        # a file whose records needed the probed layout is flagged: `taxor search` warns that it was written by other
+        # software and that `taxor verify` should run first
+        assert h.foreign_schema == (sc is not None and (sc.n_before, sc.n_after, sc.idx_bins, sc.idx_stride, sc.idx_seg_len, sc.idx_seed)
+                                    != (dflt.n_before, dflt.n_after, dflt.idx_bins, dflt.idx_stride, dflt.idx_seg_len, dflt.idx_seed)), name
         h.close()
         h2 = HixfFile(p, schema=got)
         assert len(h2.ixfs) == len(host)
@@ -210,3 +214,60 @@ def test_loader_survives_random_corruption(tmp_path):
         h.close()
         outcomes["ok"] += 1
     assert outcomes["err"] > 100          # most corruptions of the metadata are detected
+
+
+def parse_search_results_like_taxor_profile(text):
+    """src/main/taxor_profile.cpp:93-163 (parse_search_results) restated: the header line is skipped; fields are split
+    at tabs; the read id is cut at its first blank; a '-' in column 1 is a miss whose read length sits in column 5; a hit
+    line is read at the indices 1, 3, 4, 5, 6, 7 (accession, taxid, ref_len, query_len, hash count, hash match) and 9 / 8
+    (tax id path / tax name path); a miss is not added to a read that already has a reference assignment."""
+    results, taxpath = {}, {}
+    for n, line in enumerate(text.split("\n")):
+        if n == 0 or not line:
+            continue
+        f = line.split("\t")                                        # :111-116
+        read_id = f[0].split(" ")[0] if " " in f[0] else f[0]       # :120-123
+        if f[1] == "-":                                             # :126-130
+            res = dict(accession_id="-", query_len=int(f[5]))
+        else:                                                       # :131-145
+            res = dict(accession_id=f[1], tax_id=f[3], ref_len=int(f[4]), query_len=int(f[5]),
+                       query_hash_count=int(f[6]), query_hash_match=int(f[7]))
+            taxpath.setdefault(f[1], (f[9], f[8]))
+        lst = results.setdefault(read_id, [])                       # :147-150
+        if lst and res["accession_id"] == "-":                      # :153-156
+            continue
+        lst.append(res)
+    return results, taxpath
+
+
+def test_tsv_is_what_taxor_profile_parses(tmp_path):
+    """the search TSV is `taxor profile`'s input.  The text written by the library's formatter must
+    parse with the column indices taxor_profile.cpp uses -- a 6-column miss line with the read length at index 5, a
+    10-column hit line -- and carry the values the searcher produced."""
+    lay, host, _ = small_layout()
+    sp = make_species(lay)
+    p = tmp_path / "toy.hixf"
+    store_hixf(p, host, lay["n_user_bins"], sp)
+    h = HixfFile(p)
+    text = HEADER
+    want = {}
+    cases = [("read_1 runid=7 ch=3", 5000, 430, [(2, 300), (5, 290), (1, 100)]),      # three tuples, one below 0.8*max
+             ("read_2", 7123, 612, []),                                                  # miss
+             ("read_3\twith_tab", 900, 77, [(0, 40)])]                                   # header text is copied verbatim
+    for rid, rlen, nh, tup in cases:
+        text += h.format_read(rid, rlen, nh, [a for a, _ in tup], [b for _, b in tup])
+        want[rid.split(" ")[0]] = (rlen, nh, tup)
+    h.close()
+    header_cols = HEADER.rstrip("\n").split("\t")
+    assert len(header_cols) == 10 and header_cols[5] == "QUERY_LEN" and header_cols[6] == "QHASH_COUNT" and header_cols[7] == "QHASH_MATCH"
+    results, taxpath = parse_search_results_like_taxor_profile(text)
+    r1 = results["read_1"]
+    assert [x["accession_id"] for x in r1] == [sp[2]["accession_id"], sp[5]["accession_id"]]      # 100 < 0.8*300 dropped
+    assert all(x["query_len"] == 5000 and x["query_hash_count"] == 430 for x in r1)
+    assert [x["query_hash_match"] for x in r1] == [300, 290]
+    assert r1[0]["ref_len"] == sp[2]["seq_len"] and r1[0]["tax_id"] == sp[2]["taxid"]
+    assert taxpath[sp[2]["accession_id"]] == (sp[2]["taxid_string"], sp[2]["taxnames_string"])
+    assert results["read_2"] == [dict(accession_id="-", query_len=7123)]
+    # an id containing a tab shifts the columns in the reference's own output as well (it writes the id verbatim,
+    # taxor_search.cpp:270,287): the formatter must not "repair" it
+    assert "read_3\twith_tab\t" in text
