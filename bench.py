@@ -222,8 +222,8 @@ def build_workload(args, local_rank, rank, world):
 
     # ---- this rank's distinct batches (seed + rank + batch) ----------------------------------------------------
     t0 = time.time()
+    from taxor_amd import distributed as td
     if args.scaling == "strong" and world > 1:
-        from taxor_amd import distributed as td
         lo, hi = td.shard_range(n_reads, rank, world)
     else:
         lo, hi = 0, n_reads
@@ -245,7 +245,7 @@ def build_workload(args, local_rank, rank, world):
         else:
             bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
                                                     seed=seed, threads=ncpu)
-        if (lo, hi) != (0, offs.size - 1):          # strong scaling: this rank's contiguous shard of the common batch
+        if args.scaling == "strong" and world > 1:  # this rank's contiguous shard of the common batch
             lo_, hi_ = (lo, hi) if not args.len_mix else td.shard_range(offs.size - 1, rank, world)
             bases, offs = bases[int(offs[lo_]):int(offs[hi_])], offs[lo_:hi_ + 1] - offs[lo_]
             origin = origin[lo_:hi_] if origin is not None else None
@@ -396,7 +396,11 @@ def main():
         dist.barrier()
         small = argparse.Namespace(**vars(args))
         small.sustained_reads = max(1, args.sustained_reads // 4)
-        single, sustained = dropin_measurements(small, idx, batches, read_len)
+        try:
+            single, sustained = dropin_measurements(small, idx, batches, read_len)
+        except Exception as e:       # an aid: its failure on one rank must not desynchronise the collective below
+            log(f"host-fed measurement failed: {type(e).__name__}: {e}")
+            single, sustained = {"value": 0.0}, None
         mine = torch.tensor([single["value"], sustained["value"] if sustained else 0.0], dtype=torch.float64,
                             device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
         allv = [torch.zeros_like(mine) for _ in range(world)]

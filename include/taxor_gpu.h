@@ -159,10 +159,12 @@ int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint6
  * (the reference's chunk loop is synchronous, taxor_search.cpp:315-326): _begin enqueues everything and returns --
  * immediately when `bases` is registered memory (below), after the last host-to-device copy otherwise; `bases` and
  * `offsets` must stay valid until _end, which waits and hands out the results like taxor_gpu_search_batch. */
-/* Exception: with the KMER and FRACMINHASH threshold models (indexes built without --use-syncmer) _begin is NOT
- * asynchronous -- each sub-batch's hash counts come back to the host, the model is evaluated there in the reference's
- * double arithmetic, and the thresholds go up again before that sub-batch's query is enqueued, so _begin returns only
- * after the last sub-batch's hashing has finished (the GPU keeps classifying the previous sub-batch meanwhile). */
+/* Exception: with the FRACMINHASH threshold model (minimiser indexes with window > k, or scaling > 1) _begin is NOT
+ * asynchronous -- each sub-batch's minimiser counts come back to the host, the model is evaluated there in the
+ * reference's double arithmetic, and the thresholds go up again before that sub-batch's query is enqueued, so _begin
+ * returns only after the last sub-batch's hashing has finished (the GPU keeps classifying the previous sub-batch
+ * meanwhile).  The KMER model (window == k) depends on the read length alone and is evaluated before anything is
+ * enqueued. */
 int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out);
 

@@ -93,6 +93,8 @@ struct taxor_gpu_searcher {
     taxor_gpu_search_params prm{};
     std::vector<uint32_t> h_rlen, h_nh_sub;   // k-mer / FracMinHash threshold models are evaluated on the host
     std::vector<uint64_t> h_thr_sub;
+    bool thr_precomputed = false;             // k-mer model: the count is L-k+1, so the thresholds went up with the batch
+    std::vector<uint64_t> thr_memo;           // k-mer model: threshold by k-mer count (index 0 unused marker = ~0)
     hipStream_t st = nullptr;       // query + CSR assembly; the stream callers synchronise on
     hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
     hipStream_t st_copy = nullptr;  // H2D of the next sub-batch's bases + packing (streamed search_batch)
@@ -767,7 +769,11 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.cursor_chunk = chunk_env ? chunk_env : ((lvl >= 1 || s->mean_read_len < 3000) ? 4u : 1u);
         size_t slot;
         if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
-        launch_query_level(q, s->mean_read_len < 6000 ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
+        // four blocks per CU for short reads and for every level below the root (small items: half their time is spent
+        // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
+        static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
+        const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4);
+        launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
         if (ev_end(s, slot)) return TAXOR_E_HIP;
         s->stats.query_launches++;
     }
@@ -847,7 +853,7 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
     if (ev_end(s, slot, st)) return TAXOR_E_HIP;
     HIP_TRY(hipGetLastError());
-    if (s->prm.model == TAXOR_THR_KMER || s->prm.model == TAXOR_THR_FRACMINHASH) {
+    if ((s->prm.model == TAXOR_THR_KMER || s->prm.model == TAXOR_THR_FRACMINHASH) && !s->thr_precomputed) {
         // threshold::get of the k-mer / FracMinHash models (threshold.hpp:62-75) is a page of double arithmetic with
         // pow / log / sqrt whose result is truncated to an integer: evaluated on the host, with the host's libm, so
         // that it is the reference's value bit for bit.  The GPU keeps classifying the previous sub-batch meanwhile.
@@ -929,6 +935,29 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         HIP_TRY(hipMemcpyAsync(s->d_rlen.p, rlen.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
         HIP_TRY(hipMemcpyAsync(s->d_hcap.p, hcap.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
         HIP_TRY(hipMemcpyAsync(s->d_order.p, order.data(), n_reads * sizeof(uint32_t), hipMemcpyHostToDevice, s->st));
+    }
+    // k-mer model (window == k, scaling 1): every k-mer of the read counts, so hash_count = L - k + 1 is known here and
+    // threshold::get (threshold.hpp:62-66) -- a function of the count alone -- is evaluated for the whole batch now,
+    // memoised per count; nothing blocks between a sub-batch's hashing and its query.  (The FracMinHash model needs the
+    // number of minimisers the device finds: launch_syncmers_sub fetches it per sub-batch.)
+    s->thr_precomputed = false;
+    std::vector<uint64_t> thr_h;
+    if (s->prm.model == TAXOR_THR_KMER && s->idx->w_min == s->idx->k && s->idx->scaling <= 1 && n_reads) {
+        thr_h.resize(n_reads);
+        const uint64_t k = (uint64_t)s->idx->k;
+        for (uint64_t r = 0; r < n_reads; ++r) {
+            const uint64_t n = rlen[r] >= k ? rlen[r] - k + 1 : 0;
+            if (n >= s->thr_memo.size()) s->thr_memo.resize(n + 1, ~0ull);
+            uint64_t &m = s->thr_memo[n];
+            if (m == ~0ull) {
+                const double sf = (double)n / ((double)rlen[r] - (double)k + 1.0);               // taxor_search.cpp:263
+                m = taxor_threshold_model(TAXOR_THR_KMER, n, (uint32_t)k, s->prm.error_rate, -1.0, sf);
+                if (m == ~0ull) m = ~0ull - 1;   // keep the marker free (a threshold that large is unreachable either way)
+            }
+            thr_h[r] = m;
+        }
+        HIP_TRY(hipMemcpyAsync(s->d_thr.p, thr_h.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
+        s->thr_precomputed = true;
     }
     HIP_TRY(hipStreamSynchronize(s->st)); // the pageable host vectors above may now die
     return ensure_scratch(s);

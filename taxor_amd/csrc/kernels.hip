@@ -885,9 +885,6 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
         const uint32_t u = u0 + (tid - g * upass);
         const bool active = g < G;
         const uint8_t *__restrict__ base = D.data + (size_t)u * 16u;
-        uint32_t acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0;
 
         // a tile bounds the per-thread increments of the packed byte counters (<= 240); when the probes are not
         // pre-staged it is also what fits the staging loop
@@ -940,21 +937,20 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
                     for (int j = 0; j < U - 1; ++j)
                         if (ok[j]) probe_accumulate(acc8, ra[j], rb[j], rc[j], p[j].w);
                 }
-                // widen the packed byte counters (<= 240 per byte) into 32-bit counters
+                // the packed byte counters (<= 240 per byte) of this tile go straight into the LDS tally: almost always one
+                // tile per item, and sixteen 32-bit accumulators held across the loop are sixteen registers the loads need
                 const uint32_t wv[4] = {acc8.x, acc8.y, acc8.z, acc8.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    acc[4 * q + 0] += wv[q] & 0xFFu;
-                    acc[4 * q + 1] += (wv[q] >> 8) & 0xFFu;
-                    acc[4 * q + 2] += (wv[q] >> 16) & 0xFFu;
-                    acc[4 * q + 3] += wv[q] >> 24;
+                    if (wv[q] == 0u) continue;
+                    const uint32_t b0 = wv[q] & 0xFFu, b1 = (wv[q] >> 8) & 0xFFu, b2 = (wv[q] >> 16) & 0xFFu, b3 = wv[q] >> 24;
+                    uint32_t *c = &sC[u * 16u + 4u * (uint32_t)q];
+                    if (b0) atomicAdd(c + 0, b0);
+                    if (b1) atomicAdd(c + 1, b1);
+                    if (b2) atomicAdd(c + 2, b2);
+                    if (b3) atomicAdd(c + 3, b3);
                 }
             }
-        }
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (acc[j]) atomicAdd(&sC[u * 16u + (uint32_t)j], acc[j]);
         }
     }
 }
@@ -1268,7 +1264,9 @@ int query_grid(int device, size_t lds_bytes, int want_per_cu)
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
 {
     static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
-    static const int unroll = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
+    static const int unroll0 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
+    static const int unroll1 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
+    const int unroll = (a.level >= 1 && unroll1) ? unroll1 : unroll0;
     if (a.prof) {
         hipLaunchKernelGGL((k_query_level<true, 2, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
         return;
