@@ -84,6 +84,8 @@ struct taxor_gpu_index {
 
 struct SubBatch {
     uint32_t first, n;
+    uint32_t n_long = 0;     // the first n_long reads of the processing order go to the block-per-read syncmer kernel, the rest
+                             // (candidate capacity <= SYNC_WAVE_CAND, ~2.5 kb) to the wave-per-read one
     uint64_t slots;          // candidate/hash slots of this sub-batch
     uint64_t a_begin, a_end; // ASCII byte range of its reads within the batch
 };
@@ -97,6 +99,8 @@ struct taxor_gpu_searcher {
     std::vector<uint64_t> thr_memo;           // k-mer model: threshold by k-mer count (index 0 unused marker = ~0)
     hipStream_t st = nullptr;       // query + CSR assembly; the stream callers synchronise on
     hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
+    hipStream_t st_sync2 = nullptr; // its short reads (k_syncmers_wave), concurrent with the long ones on st_sync
+    hipEvent_t ev_wave = nullptr;
     hipStream_t st_copy = nullptr;  // H2D of the next sub-batch's bases + packing (streamed search_batch)
     std::vector<hipEvent_t> ev_sync_done, ev_query_done, ev_pack_done;
     hipEvent_t ev_reset = nullptr;
@@ -104,6 +108,7 @@ struct taxor_gpu_searcher {
     Counters *d_ctr = nullptr;
     unsigned long long *d_prof = nullptr;   // TAXOR_PROFILE_PHASES=1: per-phase cycle sums of the two big kernels
     Counters h_ctr{};
+    int grid_wave = 0, grid_wave_overlap = 0;   // k_syncmers_wave: full occupancy / beside a query kernel
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0, grid_query_short = 0;   // query blocks: 3 per CU, 4 for short reads
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
     bool auto_sub_reads = true; // sub_batch_reads was left to the library: short reads get more of them per sub-batch
@@ -476,6 +481,8 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_wave, hipEventDisableTiming);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
@@ -507,6 +514,12 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         s->grid_sync_overlap = hipGetDeviceProperties(&p, idx->device) == hipSuccess ? p.multiProcessorCount * per : s->grid_sync;
         if (s->grid_sync_overlap > s->grid_sync) s->grid_sync_overlap = s->grid_sync;
     }
+    s->grid_wave = syncmers_wave_grid(idx->device, 8);
+    {
+        int per = 2;
+        if (const char *e = getenv("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+        s->grid_wave_overlap = syncmers_wave_grid(idx->device, per);
+    }
     s->grid_query = query_grid(idx->device, s->lds_query, 3);
     s->grid_query_short = query_grid(idx->device, s->lds_query, 4);
     *out = s;
@@ -518,6 +531,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     if (!s) return;
     (void)hipSetDevice(s->idx->device);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
+    if (s->st_sync2) (void)hipStreamSynchronize(s->st_sync2);
     if (s->st_sync) (void)hipStreamSynchronize(s->st_sync);
     if (s->st) (void)hipStreamSynchronize(s->st);
     s->d_ascii.release(); s->d_aoff.release(); s->d_poff.release(); s->d_hoff.release();
@@ -531,6 +545,8 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
+    if (s->st_sync2) (void)hipStreamDestroy(s->st_sync2);
+    if (s->ev_wave) (void)hipEventDestroy(s->ev_wave);
     s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
     s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release();
     s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
@@ -627,7 +643,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
             lim_bases = std::max<uint64_t>(lim_bases / first_div, 1);
         }
         if (r > sub_first && (r - sub_first >= lim_reads || sub_bases + len > lim_bases)) {
-            s->subs.push_back({sub_first, (uint32_t)(r - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[r] - offsets[0]});
+            s->subs.push_back({sub_first, (uint32_t)(r - sub_first), (uint32_t)(r - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[r] - offsets[0]});
             s->max_slots = std::max(s->max_slots, sub_slots);
             s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(r - sub_first));
             sub_first = (uint32_t)r;
@@ -644,7 +660,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         s->max_read_slots = std::max(s->max_read_slots, cap);
     }
     if (n_reads > sub_first) {
-        s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[n_reads] - offsets[0]});
+        s->subs.push_back({sub_first, (uint32_t)(n_reads - sub_first), (uint32_t)(n_reads - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[n_reads] - offsets[0]});
         s->max_slots = std::max(s->max_slots, sub_slots);
         s->max_sub_reads = std::max(s->max_sub_reads, (uint32_t)(n_reads - sub_first));
     }
@@ -653,7 +669,19 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
     order.resize(n_reads);
     static const bool no_order = getenv("TAXOR_NO_ORDER") != nullptr; // A/B knob for measurements
     std::vector<uint32_t> tmp;
-    for (const SubBatch &sb : s->subs) {
+    const bool wave_ok = idx->w_min == 0 && syncmers_wave_applies(idx->k, idx->s);
+    auto split_long_short = [&](SubBatch &sb) {   // the order is longest first: the short reads are a suffix of it
+        const uint32_t *o = order.data() + sb.first;
+        const uint32_t *cp = hcap.data() + sb.first;
+        sb.n_long = sb.n;
+        if (!wave_ok) return;
+        uint32_t nl = 0;
+        while (nl < sb.n && cp[o[nl]] > SYNC_WAVE_CAND) ++nl;
+        for (uint32_t i = nl; i < sb.n; ++i)
+            if (cp[o[i]] > SYNC_WAVE_CAND) return;       // not sorted by length (TAXOR_NO_ORDER): block kernel for all
+        sb.n_long = nl;
+    };
+    for (SubBatch &sb : s->subs) {
         uint32_t *o = order.data() + sb.first;
         const uint32_t *len = rlen.data() + sb.first;
         for (uint32_t i = 0; i < sb.n; ++i) o[i] = i;
@@ -681,6 +709,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         }
         if (src != o) std::copy(src, src + sb.n, o);
     }
+    for (SubBatch &sb : s->subs) split_long_short(sb);
     s->packed_word_count = words + 16;
     s->packed_in_bytes = 0;
     for (uint64_t r = 0; r < n_reads; ++r) s->packed_in_bytes += (rlen[r] + 3u) / 4u; // ceil(L/4), SURVEY 8(d)
@@ -694,7 +723,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
     const bool syncmer_mode = idx->w_min == 0;  // minimiser mode writes its hashes directly: no candidates, no dedup
     for (int b = 0; b < 2; ++b)
         if ((syncmer_mode && s->d_cand[b].reserve(s->max_slots + 64)) || s->d_hashes[b].reserve(s->max_slots + 64)) return TAXOR_E_HIP;
-    if (s->d_sync_cursor.reserve(s->subs.size() + 1)) return TAXOR_E_HIP;
+    if (s->d_sync_cursor.reserve(2 * (s->subs.size() + 1))) return TAXOR_E_HIP;      // block kernel + wave kernel per sub-batch
     while (s->ev_sync_done.size() < s->subs.size() + 1) {
         hipEvent_t a, b, c;
         HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -816,8 +845,9 @@ int reset_sub_counters(taxor_gpu_searcher *s, bool whole)
 
 // syncmer kernel of sub-batch `sub_i` into scratch buffer `buf`, on stream `st`
 int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i, int buf, hipStream_t st,
-                        bool overlapped = false)
+                        bool overlapped = false, hipStream_t st_short = nullptr)
 {
+    if (!st_short) st_short = st;   // the wave-per-read kernel of the short reads: its own stream when the caller has one
     const taxor_gpu_index *idx = s->idx;
     SyncmerArgs a{};
     a.packed = s->d_packed.p;
@@ -827,7 +857,7 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.hcap = s->d_hcap.p + sb.first;
     a.cand = s->d_cand[buf].p;
     a.hashes = s->d_hashes[buf].p;
-    a.cursor = s->d_sync_cursor.p + sub_i;
+    a.cursor = s->d_sync_cursor.p + 2 * sub_i;
     a.order = s->d_order.p ? s->d_order.p + sb.first : nullptr;
     a.nh = s->d_nh.p + sb.first;
     a.thr = s->d_thr.p + sb.first;
@@ -850,7 +880,26 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.prof = s->d_prof;
     size_t slot;
     if (ev_begin(s, 0, &slot, st)) return TAXOR_E_HIP;
-    launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
+    const uint32_t n_long = idx->w_min > 0 ? sb.n : sb.n_long;
+    if (n_long) {
+        a.n_reads = n_long;
+        launch_syncmers(a, overlapped ? s->grid_sync_overlap : s->grid_sync, st);
+    }
+    if (n_long < sb.n) {      // short reads: one wavefront per read (k_syncmers_wave), behind the long ones on the same stream
+        SyncmerArgs b = a;
+        b.order = a.order + n_long;
+        b.n_reads = sb.n - n_long;
+        b.cursor = a.cursor + 1;
+        b.chunk = 4;
+        b.prof = nullptr;
+        // beside the block kernel, not behind it: the few very long reads of an ONT-like mix keep single blocks busy
+        // for milliseconds, and the short reads fill the rest of the chip meanwhile
+        launch_syncmers_wave(b, overlapped ? s->grid_wave_overlap : s->grid_wave, st_short);
+        if (st_short != st) {
+            HIP_TRY(hipEventRecord(s->ev_wave, st_short));
+            HIP_TRY(hipStreamWaitEvent(st, s->ev_wave, 0));
+        }
+    }
     if (ev_end(s, slot, st)) return TAXOR_E_HIP;
     HIP_TRY(hipGetLastError());
     if ((s->prm.model == TAXOR_THR_KMER || s->prm.model == TAXOR_THR_FRACMINHASH) && !s->thr_precomputed) {
@@ -973,9 +1022,10 @@ int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
     s->stats = taxor_gpu_run_stats{};
     size_t tot_slot;
     if (reset_sub_counters(s, true)) return TAXOR_E_HIP;
-    HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, (s->subs.size() + 1) * sizeof(uint32_t), s->st));
+    HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, 2 * (s->subs.size() + 1) * sizeof(uint32_t), s->st));
     HIP_TRY(hipEventRecord(s->ev_reset, s->st));
     HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_reset, 0));
+    HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_reset, 0));
     HIP_TRY(hipStreamWaitEvent(s->st_copy, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
     if (s->subs.empty()) { // zero reads: CSR = [0]
@@ -998,13 +1048,16 @@ int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(s->ev_pack_done[i], s->st_copy));
             HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_pack_done[i], 0));
+            HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_pack_done[i], 0));
         }
         // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
         static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
         hipStream_t ss = no_overlap ? s->st : s->st_sync;
         if (host_ascii && no_overlap) HIP_TRY(hipStreamWaitEvent(ss, s->ev_pack_done[i], 0));
+        hipStream_t ss2 = no_overlap ? s->st : s->st_sync2;
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss, s->ev_query_done[i - 2], 0));
-        if (int rc = launch_syncmers_sub(s, sb, i, buf, ss, i > 0 && !no_overlap)) return rc;
+        if (i >= 2 && ss2 != ss) HIP_TRY(hipStreamWaitEvent(ss2, s->ev_query_done[i - 2], 0));
+        if (int rc = launch_syncmers_sub(s, sb, i, buf, ss, i > 0 && !no_overlap, ss2)) return rc;
         HIP_TRY(hipEventRecord(s->ev_sync_done[i], ss));
         HIP_TRY(hipStreamWaitEvent(s->st, s->ev_sync_done[i], 0));
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
@@ -1187,7 +1240,7 @@ extern "C" int taxor_gpu_syncmers(taxor_gpu_searcher *s, const char *bases, cons
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
         if (i && reset_sub_counters(s, false)) return TAXOR_E_HIP;
-        HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, sizeof(uint32_t), s->st));
+        HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, 2 * sizeof(uint32_t), s->st));
         if (int rc = launch_syncmers_sub(s, sb, 0, 0, s->st)) return rc;
         bool rerun;
         if (int rc = check_flags(s, &rerun)) return rc;

@@ -65,6 +65,8 @@ static constexpr int MAX_LEVELS = 16;
 
 // reads with at most this many selected syncmers dedup in LDS (partitioned passes); longer ones need SyncmerArgs::gtab
 static constexpr uint32_t SYNC_LDS_DEDUP_MAX = 66816;
+// reads with at most this many candidate slots (hcap) may go to the wave-per-read syncmer kernel
+static constexpr uint32_t SYNC_WAVE_CAND = 512;
 
 struct SyncmerArgs {
     const uint32_t *packed;   // 2-bit bases, 16 per word, first base in the top bits
@@ -138,6 +140,10 @@ struct FinalizeArgs {
 void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,
                       uint32_t n_reads, Counters *ctr, hipStream_t st, int max_grid = 0);
 void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st);
+// short reads (hcap <= SYNC_WAVE_CAND), k - s + 1 == 11: one wavefront per read
+void launch_syncmers_wave(const SyncmerArgs &a, int grid, hipStream_t st);
+int syncmers_wave_grid(int device, int want_per_cu);
+bool syncmers_wave_applies(int k, int s);
 int syncmers_grid(int device);
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
 int query_grid(int device, size_t lds_bytes, int want_per_cu);

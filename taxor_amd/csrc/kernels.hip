@@ -633,6 +633,251 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
 
 
 // ------------------------------------------------------------------------------------------------------
+// k_syncmers_wave -- the same selection for SHORT reads (at most WV_CAND candidate slots: ~2.5 kb at k22/s12), one
+// wavefront per read, four reads per block at a time.  A 1-kb read fills less than half of the block kernel's
+// 2048-window tile and pays ~ten block barriers and a four-deep chain of dependent global loads per read; here the
+// tile is 512 windows (64 lanes x 8), scans are wave scans, the tracked position is carried in a register, dedup is the
+// all-pairs comparison, and nothing ever waits for another wave.  LDS is private per wave; a wave's LDS operations
+// complete in program order, so the only "barrier" is a compiler-level one.  Results are identical to k_syncmers
+// (tests/test_gpu_parity.py runs both on the same reads).
+// ------------------------------------------------------------------------------------------------------
+static constexpr int WV_C = 8;                      // windows per lane
+static constexpr int WV_T = 64 * WV_C;              // windows per tile
+static constexpr int WV_WORDS = WV_T / 16 + 8;      // packed words per tile (<= 64: one per lane)
+static constexpr int WV_RS = 64 + 5;                // row stride of the transposed s-mer tile (odd)
+static constexpr int WV_PER_BLOCK = BLK / 64;
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int FW> __global__ __launch_bounds__(BLK) void k_syncmers_wave(const SyncmerArgs a)
+{
+    static_assert(FW >= 8 && FW <= 16 && WV_WORDS <= 64, "fast path only");
+    __shared__ uint32_t sWall[WV_PER_BLOCK][WV_WORDS];
+    __shared__ uint32_t sVall[WV_PER_BLOCK][WV_C * WV_RS];
+    __shared__ __attribute__((aligned(16))) uint8_t sLmAll[WV_PER_BLOCK][WV_T];
+    __shared__ __attribute__((aligned(16))) uint8_t sRmAll[WV_PER_BLOCK][WV_T];
+    __shared__ uint64_t sCandAll[WV_PER_BLOCK][SYNC_WAVE_CAND];
+    const uint32_t wid = threadIdx.x >> 6, lane = lane_id();
+    uint32_t *sW = sWall[wid];
+    uint32_t *sV = sVall[wid];
+    uint8_t *sLm = sLmAll[wid];
+    uint8_t *sRm = sRmAll[wid];
+    uint64_t *sCand = sCandAll[wid];
+
+    const int k = a.k, s = a.s, t = a.t;
+    const uint32_t smask = (s < 16) ? ((1u << (2 * s)) - 1u) : 0xFFFFFFFFu;
+    const uint32_t chunk = min(max(a.chunk, 1u), 16u);
+    unsigned long long hashes_total = 0;
+
+    for (;;) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(a.cursor, chunk);
+        first = __shfl(first, 0);
+        if (first >= a.n_reads) break;
+        const uint32_t chunk_n = min(chunk, a.n_reads - first);
+        // one lane per read of the chunk fetches its metadata; the others get it by shuffle
+        uint32_t m_r = 0, m_L = 0, m_cap = 0, m_plo = 0, m_phi = 0, m_hlo = 0, m_hhi = 0;
+        if (lane < chunk_n) {
+            m_r = a.order ? a.order[first + lane] : first + lane;
+            m_L = a.rlen[m_r];
+            m_cap = a.hcap[m_r];
+            const uint64_t po = a.poff[m_r], ho = a.hoff[m_r];
+            m_plo = (uint32_t)po; m_phi = (uint32_t)(po >> 32);
+            m_hlo = (uint32_t)ho; m_hhi = (uint32_t)(ho >> 32);
+        }
+        for (uint32_t ri = 0; ri < chunk_n; ++ri) {
+            const uint32_t r = __shfl(m_r, (int)ri), L = __shfl(m_L, (int)ri), cap = min(__shfl(m_cap, (int)ri), (uint32_t)SYNC_WAVE_CAND);
+            const uint64_t po = ((uint64_t)__shfl(m_phi, (int)ri) << 32) | __shfl(m_plo, (int)ri);
+            const uint64_t ho = ((uint64_t)__shfl(m_hhi, (int)ri) << 32) | __shfl(m_hlo, (int)ri);
+            const uint32_t *__restrict__ pk = a.packed + po;
+            uint64_t *__restrict__ outh = a.hashes + ho;
+            const uint32_t nwords = (((L + 15u) >> 4) + 3u) & ~3u;
+            const int nwin = (int)L - k + 1;
+            uint32_t n_sel = 0;     // wave-uniform
+            int carry = 0;          // tracked position (absolute) of the previous tile's last window, wave-uniform
+
+            for (int x0 = 0; x0 < nwin; x0 += WV_T) {
+                wave_lds_sync();
+                const uint32_t wbase = (uint32_t)x0 >> 4;
+                if (lane < (uint32_t)WV_WORDS) {
+                    const uint32_t wi = wbase + lane;
+                    sW[lane] = wi < nwords ? pk[wi] : 0u;
+                }
+                wave_lds_sync();
+                const int nv = min(WV_T + FW - 1, (int)L - s + 1 - x0);
+                const int nw_tile = min(WV_T, nwin - x0);
+                for (int i = (int)lane; i < WV_T + FW - 1; i += 64) {
+                    uint32_t v = 0x07FFFFFFu;
+                    if (i < nv) {
+                        const uint32_t pos = (uint32_t)(x0 + i);
+                        const uint32_t f = (uint32_t)extract_bases(sW, (pos >> 4) - wbase, pos & 15u, s) & smask;
+                        v = min(f, revcomp32(f, s));
+                    }
+                    sV[(i & (WV_C - 1)) * WV_RS + (i >> 3)] = v;
+                }
+                wave_lds_sync();
+                // leftmost / rightmost argmin of this lane's eight windows (same sparse-table minima as k_syncmers)
+                constexpr int NV = FW + WV_C - 1;
+                const int xs = (int)lane * WV_C;
+                int lmr[WV_C], rmr[WV_C], last_anchor = -1;
+                {
+                    uint32_t kl[NV], kr[NV];
+#pragma unroll
+                    for (int c = 0; c < NV; ++c) {
+                        const uint32_t v = sV[(c & (WV_C - 1)) * WV_RS + (int)lane + (c >> 3)];
+                        kl[c] = (v << 5) | (uint32_t)c;
+                        kr[c] = (v << 5) | (uint32_t)(31 - c);
+                    }
+                    uint32_t l2[NV - 1], r2[NV - 1], l4[NV - 3], r4[NV - 3], l8[WV_C + FW - 8], r8[WV_C + FW - 8];
+#pragma unroll
+                    for (int c = 0; c < NV - 1; ++c) { l2[c] = min(kl[c], kl[c + 1]); r2[c] = min(kr[c], kr[c + 1]); }
+#pragma unroll
+                    for (int c = 0; c < NV - 3; ++c) { l4[c] = min(l2[c], l2[c + 2]); r4[c] = min(r2[c], r2[c + 2]); }
+#pragma unroll
+                    for (int c = 0; c < WV_C + FW - 8; ++c) { l8[c] = min(l4[c], l4[c + 4]); r8[c] = min(r4[c], r4[c + 4]); }
+                    uint64_t packL = 0, packR = 0;
+#pragma unroll
+                    for (int c = 0; c < WV_C; ++c) {
+                        const uint32_t ml = min(l8[c], l8[c + FW - 8]);
+                        const uint32_t mr = min(r8[c], r8[c + FW - 8]);
+                        lmr[c] = (int)(ml & 31u) - c;
+                        rmr[c] = 31 - (int)(mr & 31u) - c;
+                        packL |= (uint64_t)(uint32_t)lmr[c] << (8 * c);
+                        packR |= (uint64_t)(uint32_t)rmr[c] << (8 * c);
+                        const int xl = xs + c;
+                        if (xl < nw_tile && (lmr[c] == rmr[c] || x0 + xl == 0)) last_anchor = xl;
+                    }
+                    *reinterpret_cast<uint64_t *>(&sLm[xs]) = packL;
+                    *reinterpret_cast<uint64_t *>(&sRm[xs]) = packR;
+                }
+                // nearest earlier anchor: exclusive prefix max over the lanes
+                int anchor = wave_incl_max(last_anchor);
+                anchor = __shfl_up(anchor, 1);
+                if (lane == 0) anchor = -1;
+                wave_lds_sync();
+                uint32_t selmask = 0;
+                int p = 0;
+                if (xs < nw_tile) {
+                    p = anchor >= 0 ? anchor + (int)sLm[anchor] : carry - x0;
+                    while (p < xs) p = (p + 1) + (int)sRm[p + 1];
+#pragma unroll
+                    for (int c = 0; c < WV_C; ++c) {
+                        const int xl = xs + c;
+                        if (xl < nw_tile) {
+                            const int lm = lmr[c], rm = rmr[c];
+                            if (lm == rm || x0 + xl == 0) p = xl + lm;
+                            else if (p < xl) p = xl + rm;
+                            if (p == xl + t - 1) selmask |= 1u << c;
+                        }
+                    }
+                }
+                carry = __shfl(p, (nw_tile - 1) / WV_C) + x0;     // the owner of the tile's last window
+                // emit wyhash(canonical k-mer) of the selected windows, in window order
+                const uint32_t cnt = (uint32_t)__popc(selmask);
+                const uint32_t incl = wave_incl_add(cnt);
+                uint32_t pos = n_sel + incl - cnt;
+                while (selmask) {
+                    const int c = __ffs((int)selmask) - 1;
+                    selmask &= selmask - 1;
+                    const uint32_t x = (uint32_t)(x0 + xs + c);
+                    const uint64_t f = extract_bases(sW, (x >> 4) - wbase, x & 15u, k);
+                    const uint64_t rc = revcomp64(f, k);
+                    if (pos < cap) sCand[pos] = wyhash_u64(f < rc ? f : rc);       // syncmer.cpp:144-145
+                    ++pos;
+                }
+                n_sel += __shfl(incl, 63);
+            }
+            if (n_sel > cap) {     // capacity bound (nwin / min(t, w-t+1) + 2) violated: internal invariant
+                if (lane == 0) atomicOr(&a.ctr->flags, FLAG_CAND_OVERFLOW);
+                n_sel = cap;
+            }
+            wave_lds_sync();
+            // ---- dedup: candidate i = lane + 64 q against every earlier one (ankerl set semantics, syncmer.cpp:157-165)
+            constexpr int QMAX = SYNC_WAVE_CAND / 64;
+            const uint32_t Q = (n_sel + 63u) >> 6;
+            uint64_t h[QMAX];
+            uint32_t firstmask = 0;
+            bool removed = false;
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q) {
+                h[q] = 0;
+                if ((uint32_t)q < Q) {                          // wave-uniform
+                    const uint32_t i = lane + 64u * (uint32_t)q;
+                    h[q] = sCand[min(i, (uint32_t)SYNC_WAVE_CAND - 1u)];
+                    bool dupf = false;
+                    const uint32_t jend = min(n_sel, 64u * (uint32_t)q + 63u);   // candidates before the last lane's
+                    for (uint32_t j0 = 0; j0 < jend; j0 += 8u) {
+                        uint64_t o[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) o[u] = sCand[min(j0 + (uint32_t)u, (uint32_t)SYNC_WAVE_CAND - 1u)];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) dupf |= (j0 + (uint32_t)u < i) && (o[u] == h[q]);
+                    }
+                    bool first = i < n_sel && !dupf;
+                    if (first && a.scaling_limit > 0.0 && !((double)wyhash_u64(h[q]) <= a.scaling_limit)) first = false;   // taxor_search.cpp:223-233
+                    if (first) firstmask |= 1u << q;
+                    removed |= (i < n_sel && !first);
+                }
+            }
+            uint32_t n_dist = 0;
+            if (!__any(removed ? 1 : 0)) {
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) {
+                    const uint32_t i = lane + 64u * (uint32_t)q;
+                    if ((uint32_t)q < Q && i < n_sel) outh[i] = h[q];
+                }
+                n_dist = n_sel;
+            } else {
+#pragma unroll
+                for (int q = 0; q < QMAX; ++q) {
+                    if ((uint32_t)q < Q) {
+                        const uint32_t f = (firstmask >> q) & 1u;
+                        const uint32_t incl = wave_incl_add(f);
+                        if (f) outh[n_dist + incl - 1u] = h[q];
+                        n_dist += __shfl(incl, 63);
+                    }
+                }
+            }
+            if (lane == 0) {
+                a.nh[r] = n_dist;                                                   // taxor_search.cpp:261
+                a.thr[r] = (uint64_t)((double)n_dist * a.ratio);                    // threshold.hpp:60,76-79
+            }
+            hashes_total += n_dist;
+        }
+    }
+    if (lane == 0 && hashes_total) atomicAdd(&a.ctr->n_hashes, hashes_total);
+}
+
+int syncmers_wave_grid(int device, int want_per_cu)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers_wave<11>, BLK, 0) != hipSuccess || per < 1) per = 2;
+    if (per > want_per_cu) per = want_per_cu;
+    return p.multiProcessorCount * per;
+}
+
+void launch_syncmers_wave(const SyncmerArgs &a, int grid, hipStream_t st)
+{
+    if (!a.n_reads) return;
+    hipLaunchKernelGGL(k_syncmers_wave<11>, dim3(grid), dim3(BLK), 0, st, a);
+}
+
+bool syncmers_wave_applies(int k, int s)
+{
+    static const bool off = [] { const char *e = getenv("TAXOR_SYNC_WAVE"); return e && atoi(e) == 0; }();
+    static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
+    return !off && !generic_only && k - s + 1 == 11 && s <= 13;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
 // k_minimisers -- hashing for indexes built WITHOUT --use-syncmer (taxor_search.cpp:210-212,239-260):
 // seqan3::views::minimiser_hash(ungapped{k}, window_size{w}, seed{adjust_seed(k)}).  Value of the k-mer at
 // position i = min(fwd ^ seed, revcomp ^ seed); a window is W = w-k+1 consecutive values (all of them when the read

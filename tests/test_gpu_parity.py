@@ -105,6 +105,35 @@ def test_syncmers_vs_oracle_ragged_and_tie_heavy(kst):
     idx.close()
 
 
+def test_syncmers_wave_kernel_edges():
+    """short reads go through the wave-per-read kernel (k_syncmers_wave: 512-window tiles, register-carried tie state,
+    all-pairs dedup): tile edges (nwin = 511, 512, 513, 1024, 1025), the candidate-capacity boundary where reads switch
+    back to the block kernel (~2.5 kb), duplicates and tie-heavy low-complexity sequence, mixed with long reads in one
+    sub-batch (the long ones form the prefix of the processing order) -- all against the sequential oracle"""
+    k, s, t = 22, 12, 5
+    rng = np.random.default_rng(2025)
+    rnd = lambda n: bytes(rng.choice(list(b"ACGT"), size=int(n)).astype(np.uint8))
+    reads = [rnd(n) for n in (k - 1, k, k + 1, 511 + k - 1, 512 + k - 1, 513 + k - 1, 1024 + k - 1, 1025 + k - 1, 1536 + k - 1,
+                              2000, 2500, 2540, 2550, 2560, 2570, 2580, 2600, 2700, 6000, 30000)]
+    unit = rnd(300)
+    reads += [unit * 3, unit * 8, unit[:150] + rnd(200) + unit[:150], b"A" * 900, b"AC" * 700, b"TTAGGG" * 400,
+              (b"ACGTTGCA" * 2 + b"G") * 120]
+    reads += [_lowcomplex(rng, int(n)) for n in rng.integers(k, 2560, size=60)]
+    reads += [rnd(n) for n in rng.integers(k, 2560, size=200)]
+    order = rng.permutation(len(reads))
+    reads = [reads[i] for i in order]
+    idx = _dummy_index(k, s, t)
+    for sub in (0, 13):                                    # one sub-batch / many small ones
+        sr = Searcher(idx, ratio=0.5, sub_batch_reads=sub)
+        hoff, hashes = sr.seq_to_syncmers(*_cat(reads))
+        for i, rd in enumerate(reads):
+            want = orc.seq_to_syncmers(rd, k, s, t)
+            got = hashes[int(hoff[i]):int(hoff[i + 1])]
+            assert got.tolist() == want.tolist(), (i, len(rd), got.size, want.size)
+        sr.close()
+    idx.close()
+
+
 def test_syncmers_long_reads_partitioned_and_global_dedup():
     """reads with more selected syncmers than one LDS table holds dedup in partitioned passes (with and without
     duplicates); beyond ~750 kb the per-block table in global memory takes over"""
