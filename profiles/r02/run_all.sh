@@ -37,6 +37,10 @@ python profiles/kmer_mode_bench.py 20 32 > $O/kmer_w32.txt 2>&1
 python profiles/phase_profile.py > $O/phase_10k.txt 2>&1
 python profiles/phase_profile.py --reads 1310720 --read-len 1000 > $O/phase_1k.txt 2>&1
 grep -h "^==\|^--\|^k=\|^algorithmic" $O/phase_10k.txt $O/phase_1k.txt $O/kmer_w20.txt $O/kmer_w32.txt
+TAXOR_NO_OVERLAP=1 run serial_10k
+TAXOR_NO_OVERLAP=1 run serial_unrel_len1k --reads 1310720 --read-len 1000 --batches 2 --family-size 1
+timeout 900 python tests/fuzz_parity.py 600 700000 > $O/fuzz_parity.txt 2>&1
+tail -2 $O/fuzz_parity.txt
 for f in $O/bench_*.json; do echo "$(basename $f): $(python3 -c "
 import json,sys
 for l in open('$f'):
