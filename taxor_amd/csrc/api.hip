@@ -996,10 +996,14 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         const uint64_t k = (uint64_t)s->idx->k;
         for (uint64_t r = 0; r < n_reads; ++r) {
             const uint64_t n = rlen[r] >= k ? rlen[r] - k + 1 : 0;
+            const double sf = (double)n / ((double)rlen[r] - (double)k + 1.0);                   // taxor_search.cpp:263
+            if (n >= (1u << 22)) {                // chromosome-sized "reads": not worth a table entry each
+                thr_h[r] = taxor_threshold_model(TAXOR_THR_KMER, n, (uint32_t)k, s->prm.error_rate, -1.0, sf);
+                continue;
+            }
             if (n >= s->thr_memo.size()) s->thr_memo.resize(n + 1, ~0ull);
             uint64_t &m = s->thr_memo[n];
             if (m == ~0ull) {
-                const double sf = (double)n / ((double)rlen[r] - (double)k + 1.0);               // taxor_search.cpp:263
                 m = taxor_threshold_model(TAXOR_THR_KMER, n, (uint32_t)k, s->prm.error_rate, -1.0, sf);
                 if (m == ~0ull) m = ~0ull - 1;   // keep the marker free (a threshold that large is unreachable either way)
             }
