@@ -367,3 +367,36 @@ def test_cli_expect_tsv_compares_per_read(tmp_path):
                         capture_output=True, text=True, timeout=300)
     assert cp.returncode == 3 and "118 reads identical, 1 differ, 1 only in this run" in cp.stdout and "FAIL" in cp.stdout, cp.stdout
     assert f"read {ids[hit]} differs" in cp.stdout
+
+
+def test_cli_several_index_files(tmp_path):
+    """--index-file a.hixf,b.hixf: every query file is searched against every index in turn and the results are appended
+    to one output (search_hixf, taxor_search.cpp:344-358: for query: for index); indexes built with another k-mer
+    selection scheme are refused (:118-141)"""
+    g1, go1, host1, sp1, idx1 = _setup(tmp_path, 41)
+    g2, go2, host2, sp2, idx2 = _setup(tmp_path, 42)
+    qa, qb = tmp_path / "qa.fa", tmp_path / "qb.fa"
+    sets = []
+    for path, (g, go), seed in ((qa, (g1, go1), 13), (qb, (g2, go2), 14)):
+        bases, offs, origin = synth.synth_reads(g, go, 70, 1300, error_rate=0.02, frac_random=0.2, seed=seed)
+        reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(70)]
+        ids = [f"{path.stem}_{i}" for i in range(70)]
+        with open(path, "wb") as f:
+            for rid, r in zip(ids, reads):
+                f.write(b">" + rid.encode() + b"\n" + r + b"\n")
+        sets.append((ids, reads))
+    out = tmp_path / "o.tsv"
+    cp = subprocess.run([TAXOR, "search", "--index-file", f"{idx1},{idx2}", "--query-file", f"{qa},{qb}", "--output-file", str(out),
+                         "--threads", "2", "--batch-reads", "32"], capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr
+    want = HEADER
+    for ids, reads in sets:                              # query-major, index-minor
+        want += _expected(host1, sp1, ids, reads) + _expected(host2, sp2, ids, reads)
+    assert open(out).read() == want
+    assert want.count("Organism") > 60                  # reads of qa hit index 1, reads of qb hit index 2
+    # another (k, s, t): refused before anything is searched
+    other = tmp_path / "k24.hixf"
+    store_hixf(other, host2, max(s["user_bin"] for s in sp2) + 1, sp2, k=24, s=12, t=6)
+    cp = subprocess.run([TAXOR, "search", "--index-file", f"{idx1},{other}", "--query-file", str(qa), "--output-file", str(out)],
+                        capture_output=True, text=True, timeout=120)
+    assert cp.returncode != 0 and "different kmer selection schemes" in cp.stderr
