@@ -13,6 +13,7 @@
 
 #include <zlib.h>
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -44,6 +45,32 @@ struct Batch {
     bool may_pin = false;
 };
 
+// ---- bzip2 input (seqan3's sequence_file_input reads .bz2 when built with bzip2, which the reference's CMake fetches).
+//      The image carries libbz2's shared object but not its header, so the three entry points of its stable stdio-like
+//      interface are bound at run time; a host without the library gets a clear error instead of a silent mis-parse.
+struct Bz2Api {
+    void *(*open)(const char *, const char *) = nullptr;
+    int (*read)(void *, void *, int) = nullptr;
+    void (*close)(void *) = nullptr;
+    static const Bz2Api &get()
+    {
+        static const Bz2Api api = [] {
+            Bz2Api a;
+            void *h = nullptr;
+            for (const char *name : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+            if (h) {
+                a.open = reinterpret_cast<void *(*)(const char *, const char *)>(dlsym(h, "BZ2_bzopen"));
+                a.read = reinterpret_cast<int (*)(void *, void *, int)>(dlsym(h, "BZ2_bzread"));
+                a.close = reinterpret_cast<void (*)(void *)>(dlsym(h, "BZ2_bzclose"));
+            }
+            return a;
+        }();
+        return api;
+    }
+    bool ok() const { return open && read && close; }
+};
+
 // ---- sequential reader over zlib.  Lines are located with memchr inside a large refill buffer; sequence lines are
 //      appended straight into the batch and quality lines are skipped without being copied.
 struct FastxReader {
@@ -55,6 +82,7 @@ struct FastxReader {
     int fd = -1;         // range mode: bytes [rpos, rend) of a plain file, read with pread
     uint64_t rpos = 0, rend = 0;
     GzMembers *members = nullptr;   // multi-member gzip inflated in parallel (gzmembers.h)
+    void *bz = nullptr;             // bzip2 stream (Bz2Api)
 
     void open_range(int fd_, uint64_t b, uint64_t e)
     {
@@ -68,12 +96,27 @@ struct FastxReader {
     }
     bool open(const std::string &path)
     {
+        buf.resize(8u << 20);
+        unsigned char magic[3] = {0, 0, 0};
+        if (FILE *probe = fopen(path.c_str(), "rb")) {
+            const size_t got = fread(magic, 1, 3, probe);
+            fclose(probe);
+            if (got == 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') {
+                const Bz2Api &api = Bz2Api::get();
+                if (!api.ok()) throw std::runtime_error("query file " + path + " is bzip2-compressed and libbz2 is not available on this host");
+                bz = api.open(path.c_str(), "rb");
+                return bz != nullptr;
+            }
+        }
         f = gzopen(path.c_str(), "rb");
         if (f) gzbuffer(f, 1 << 20);
-        buf.resize(8u << 20);
         return f != nullptr;
     }
-    ~FastxReader() { if (f) gzclose(f); }
+    ~FastxReader()
+    {
+        if (f) gzclose(f);
+        if (bz) Bz2Api::get().close(bz);
+    }
     bool refill()
     {
         if (eof) return false;
@@ -84,6 +127,9 @@ struct FastxReader {
             const uint64_t want = std::min<uint64_t>(buf.size(), rend - rpos);
             n = want ? (long)pread(fd, buf.data(), want, (off_t)rpos) : 0;
             if (n > 0) rpos += (uint64_t)n;
+        } else if (bz) {
+            n = Bz2Api::get().read(bz, buf.data(), (int)buf.size());
+            if (n < 0) throw std::runtime_error("bzip2 stream is corrupt");
         } else {
             n = gzread(f, buf.data(), (unsigned)buf.size());
         }
@@ -234,6 +280,7 @@ struct RangedFastx {
         const size_t n = (size_t)std::min<uint64_t>(size, 1u << 16);
         if (!read_at(0, n)) return false;
         if ((unsigned char)win[0] == 0x1f && (unsigned char)win[1] == 0x8b) return false;      // gzip
+        if (n >= 3 && win[0] == 'B' && win[1] == 'Z' && win[2] == 'h') return false;           // bzip2
         size_t i = 0;
         while (i < n && (win[i] == '\n' || win[i] == '\r')) ++i;
         if (i == n) return false;

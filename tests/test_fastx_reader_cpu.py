@@ -209,3 +209,22 @@ def test_single_member_gzip_with_false_member_headers(tmp_path):
     assert cp.returncode == 0, cp.stderr
     rows = [l.split(b"\t") for l in cp.stdout.split(b"\n") if l]
     assert [(r[0], int(r[1]), int(r[2], 16)) for r in rows] == [(i.encode("latin1"), len(s), fnv1a(s)) for i, s in recs]
+
+
+def test_bzip2_input(tmp_path):
+    """seqan3's sequence_file_input reads .bz2 (the reference's CMake fetches bzip2): same records as the plain file"""
+    import bz2
+    rng = np.random.default_rng(17)
+    recs = make_records(rng, 150, lo=0, hi=900)
+    plain = tmp_path / "r.fastq"
+    write_fastq(plain, recs, rng)
+    pz = tmp_path / "r.fastq.bz2"
+    pz.write_bytes(bz2.compress(plain.read_bytes()))
+    for m in (("--threads", "1"), ("--threads", "4", "--batch-reads", "20"), ("--sequential",)):
+        assert run_reads(pz, *m)[0] == expected(recs), m
+    fa = tmp_path / "r.fa"
+    write_fasta(fa, recs, rng, width=70)
+    fz = tmp_path / "r.fa.bz2"
+    fz.write_bytes(bz2.compress(fa.read_bytes()) + bz2.compress(b">second_stream\nACGTACGT\n"))      # two concatenated streams
+    got = run_reads(fz, "--threads", "2")[0]
+    assert got[:len(recs)] == expected(recs)
