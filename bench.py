@@ -342,7 +342,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         acc = dict(q_ms=0.0, q_bytes=0.0, q_touched=0.0, launches=0, bases=0, sync_ms=0.0, query_ms=0.0, fin_ms=0.0, total_ms=0.0,
-                   hashes=0, tuples=0, work=0, reads=0, alg=0)
+                   hashes=0, tuples=0, work=0, reads=0, alg=0, lvl_ms=[0.0] * 8, lvl_bytes=[0] * 8, lvl_rows=[0] * 8)
         for i in range(steps):
             sr = step(warmup + i, pool)
             st = sr.stats()
@@ -359,6 +359,10 @@ def main():
             acc["work"] += st["n_work_items"]
             acc["reads"] += st["n_reads"]
             acc["alg"] += st["algorithmic_bytes"]
+            for l in range(8):
+                acc["lvl_ms"][l] += st["level_ms"][l]
+                acc["lvl_bytes"][l] += st["level_requested_bytes"][l]
+                acc["lvl_rows"][l] += st["level_row_reads"][l]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -437,6 +441,13 @@ def main():
                 "vs_dense": round(acc["q_bytes"] / max(1.0, acc["q_touched"]), 4)}
         if traffic is not None:
             roof["traffic_over_requested"] = round(traffic / max(1.0, acc["q_touched"] / launches), 4)
+        # per HIXF level: wide rows are bound by bytes, rows of <= 128 B by the number of DRAM rows opened per second
+        roof["levels"] = [{"level": l, "ms_per_step": round(acc["lvl_ms"][l] / args.steps, 3),
+                           "requested_GBps": round(acc["lvl_bytes"][l] / (acc["lvl_ms"][l] * 1e-3) / 1e9, 1),
+                           "frac": round(acc["lvl_bytes"][l] / (acc["lvl_ms"][l] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                           "row_reads_G_per_s": round(acc["lvl_rows"][l] / (acc["lvl_ms"][l] * 1e-3) / 1e9, 2),
+                           "bytes_per_row_read": round(acc["lvl_bytes"][l] / max(1, acc["lvl_rows"][l]), 1)}
+                          for l in range(8) if acc["lvl_ms"][l] > 0]
 
         # ---- the contract formula on a kernel that does all the algorithmic work: pruning off -------------------
         if not args.no_unpruned and world == 1:
@@ -468,9 +479,12 @@ def main():
         # measured gather ceiling: random whole-row reads of the same IXFs by a kernel that does nothing else
         if not args.no_ceiling:
             ceiling = {}
-            for name, ixf in (("root", 0), ("child", 1 if idx.n_ixf > 1 else 0)):
-                gbps, row_bytes = idx.gather_ceiling(ixf, want_bytes=16 << 30, reps=3)
-                ceiling[name] = {"ixf": ixf, "row_bytes": row_bytes, "GBps": round(gbps, 1)}
+            gbps, row_bytes = idx.gather_ceiling(0, want_bytes=16 << 30, reps=3)
+            ceiling["root"] = {"ixf": 0, "row_bytes": row_bytes, "GBps": round(gbps, 1), "row_reads_G_per_s": round(gbps / row_bytes, 2)}
+            if idx.n_ixf > 1:          # all equally shaped children at once: one of them alone would sit in the caches
+                gbps, row_bytes, used = idx.gather_ceiling(1, want_bytes=16 << 30, reps=3, span=idx.n_ixf - 1)
+                ceiling["children"] = {"first_ixf": 1, "ixfs": used, "row_bytes": row_bytes, "GBps": round(gbps, 1),
+                                       "row_reads_G_per_s": round(gbps / row_bytes, 2)}
             roof["gather_ceiling"] = ceiling
 
         last = searchers[(args.warmup + args.steps - 1) % len(searchers)]

@@ -85,6 +85,10 @@ uint32_t taxor_gpu_index_depth(const taxor_gpu_index *idx);
  * one row) and nothing else, `reps` times; reports the requested-bytes rate and the bytes read per row. */
 int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint64_t want_bytes, int reps, double *gb_per_s,
                              uint64_t *row_bytes);
+/* the same over up to n_ixf consecutive, equally shaped IXFs starting at `ixf` (e.g. all children of a synthetic index:
+ * one 128-bin IXF of 68 MB sits in the caches, a thousand of them do not); *span_used = how many were covered */
+int taxor_gpu_gather_ceiling_span(taxor_gpu_index *idx, uint64_t ixf, uint64_t n_ixf, uint64_t want_bytes, int reps,
+                                  double *gb_per_s, uint64_t *row_bytes, uint64_t *span_used);
 /* Index construction helpers for synthetic / planted indexes (what a GPU builder would use):
  * fill one IXF with seeded pseudo-random fingerprints (behaves like non-matching bins, FPR 2^-8),
  * overwrite one bin column (rows = 3*seg_len bytes), read an IXF back (to hand the same bytes to a
@@ -208,6 +212,11 @@ typedef struct {
     float syncmer_ms;
     float finalize_ms;
     float total_ms;
+    /* k_query_level per HIXF level (level 7 collects everything deeper): HIP-event milliseconds, requested bytes, and
+     * fingerprint-row reads (levels of rows <= 128 B are bound by DRAM row activations, not by bytes) */
+    float level_ms[8];
+    uint64_t level_requested_bytes[8];
+    uint64_t level_row_reads[8];
 } taxor_gpu_run_stats;
 int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out);
 /* Measurement aid: a searcher created while TAXOR_PROFILE_PHASES=1 is set launches instrumented instantiations of the

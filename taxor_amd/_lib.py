@@ -45,7 +45,8 @@ class RunStats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_hashes", C.c_uint64),
                 ("n_tuples", C.c_uint64), ("n_work_items", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("query_bytes", C.c_uint64), ("query_touched_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
-                ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float)]
+                ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
+                ("level_ms", C.c_float * 8), ("level_requested_bytes", C.c_uint64 * 8), ("level_row_reads", C.c_uint64 * 8)]
 
 
 class Species(C.Structure):
@@ -82,6 +83,8 @@ SIGNATURES = {
     "taxor_gpu_index_ixf_seed": (C.c_uint64, [_P, C.c_uint64]),
     "taxor_gpu_index_data_bytes": (C.c_uint64, [_P]),
     "taxor_gpu_gather_ceiling": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "taxor_gpu_gather_ceiling_span": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                              C.POINTER(C.c_uint64)]),
     "taxor_gpu_index_leaf_runs": (C.c_uint64, [_P]),
     "taxor_gpu_index_depth": (C.c_uint32, [_P]),
     "taxor_gpu_index_fill_random": (C.c_int, [_P, C.c_uint64, C.c_uint64]),

@@ -148,7 +148,7 @@ struct taxor_gpu_searcher {
     // timing
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
-    std::vector<std::pair<size_t, int>> ev_spans; // (start event index, kind 0=syncmer 1=query 2=finalize)
+    std::vector<std::pair<size_t, int>> ev_spans; // (start event index, kind 0=syncmer 2=finalize 3=whole run, 16+l = query level l)
     taxor_gpu_run_stats stats{};
 };
 
@@ -398,8 +398,25 @@ extern "C" int taxor_gpu_index_fill_random(taxor_gpu_index *idx, uint64_t ixf, u
 extern "C" int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint64_t want_bytes, int reps, double *gb_per_s,
                                         uint64_t *row_bytes)
 {
-    if (!idx || ixf >= idx->h_ixf.size() || !gb_per_s) return fail(TAXOR_E_ARG, "gather_ceiling: bad argument");
+    return taxor_gpu_gather_ceiling_span(idx, ixf, 1, want_bytes, reps, gb_per_s, row_bytes, nullptr);
+}
+
+extern "C" int taxor_gpu_gather_ceiling_span(taxor_gpu_index *idx, uint64_t ixf, uint64_t n_ixf, uint64_t want_bytes, int reps,
+                                             double *gb_per_s, uint64_t *row_bytes, uint64_t *span_used)
+{
+    if (!idx || ixf >= idx->h_ixf.size() || !gb_per_s || !n_ixf) return fail(TAXOR_E_ARG, "gather_ceiling: bad argument");
     const IxfDesc &f = idx->h_ixf[ixf];
+    // the longest run of IXFs from `ixf` on that share its shape and lie equally spaced in the slab
+    uint64_t span = 1, spacing = 0;
+    if (n_ixf > 1 && ixf + 1 < idx->h_ixf.size()) {
+        spacing = (uint64_t)(idx->h_ixf[ixf + 1].data - f.data);
+        while (span < n_ixf && ixf + span < idx->h_ixf.size()) {
+            const IxfDesc &g = idx->h_ixf[ixf + span];
+            if (g.bins != f.bins || g.stride != f.stride || g.seg_len != f.seg_len || (uint64_t)(g.data - f.data) != span * spacing) break;
+            ++span;
+        }
+    }
+    if (span_used) *span_used = span;
     const uint32_t units = (f.bins + 15) / 16;
     if (units > 256) return fail(TAXOR_E_ARG, "gather_ceiling: rows wider than 4096 bins");
     if (reps < 1) reps = 1;
@@ -411,10 +428,10 @@ extern "C" int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
-    uint64_t bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 1, sink, nt, nullptr);   // warm-up
+    uint64_t bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 1, sink, nt, nullptr, (uint32_t)span, spacing);   // warm-up
     HIP_TRY(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps; ++r)
-        bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 2 + r, sink, nt, nullptr);
+        bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 2 + r, sink, nt, nullptr, (uint32_t)span, spacing);
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipGetLastError());
@@ -797,7 +814,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         // long read is ~30 us of work and chunks of those would leave blocks idle at the tail of the launch)
         q.cursor_chunk = chunk_env ? chunk_env : ((lvl >= 1 || s->mean_read_len < 3000) ? 4u : 1u);
         size_t slot;
-        if (ev_begin(s, 1, &slot)) return TAXOR_E_HIP;
+        if (ev_begin(s, 16 + (int)std::min(lvl, 7u), &slot)) return TAXOR_E_HIP;
         // four blocks per CU for short reads and for every level below the root (small items: half their time is spent
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
         static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
@@ -1117,11 +1134,16 @@ extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
             st.query_touched_bytes = s->h_ctr.touched_bytes;
             st.algorithmic_bytes = s->packed_in_bytes + st.query_bytes + 8 * st.n_reads + 12 * st.n_tuples;
             st.query_ms = st.syncmer_ms = st.finalize_ms = st.total_ms = 0.f;
+            for (int l = 0; l < 8; ++l) {
+                st.level_ms[l] = 0.f;
+                st.level_requested_bytes[l] = s->h_ctr.lvl_touched[l];
+                st.level_row_reads[l] = s->h_ctr.lvl_rows[l];
+            }
             for (auto &sp : s->ev_spans) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, s->ev[sp.first], s->ev[sp.first + 1]) != hipSuccess) continue;
                 if (sp.second == 0) st.syncmer_ms += ms;
-                else if (sp.second == 1) st.query_ms += ms;
+                else if (sp.second >= 16) { st.query_ms += ms; st.level_ms[sp.second - 16] += ms; }
                 else if (sp.second == 2) st.finalize_ms += ms;
                 else st.total_ms += ms;
             }

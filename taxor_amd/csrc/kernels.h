@@ -60,6 +60,11 @@ struct Counters {
     unsigned long long n_work;                     // work items processed
     unsigned long long touched_bytes;              // bytes the query kernel actually requested (after pruning)
     unsigned long long pad1[13];
+    // per HIXF level (levels >= 7 share the last entry): requested bytes and fingerprint-row reads (one per hash and row
+    // in the dense phase, one per hash, row and surviving unit in the sparse phase) -- a narrow row is bound by the
+    // number of DRAM rows opened, not by its bytes
+    unsigned long long lvl_touched[8];
+    unsigned long long lvl_rows[8];
 };
 static constexpr int MAX_LEVELS = 16;
 
@@ -153,7 +158,7 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
 // random whole-row reads of one IXF, nothing else; returns the bytes the launch requests
 uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,
-                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st);
+                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st, uint32_t n_ixf = 1, uint64_t spacing = 0);
 void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,
                            hipStream_t st);
 

@@ -1219,7 +1219,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
     // syncmer kernel of the next sub-batch shares the CU, age-based arbitration would starve these waves.
     __builtin_amdgcn_s_setprio(3);
     const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0;
-    unsigned long long st_bytes = 0, st_touched = 0, st_work = 0;
+    unsigned long long st_bytes = 0, st_touched = 0, st_work = 0, st_rows = 0;
 
     // Returning atomics on one word are served serially by one L2 channel, ~13 ns each.  A launch of small work items
     // (deeper levels, short reads) issues one per item on the work cursor and one per item on the hit / queue append
@@ -1316,7 +1316,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
             const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + 4.5f);
             dense_end = (thr >= (uint64_t)n + margin) ? 0u : min(n, (uint32_t)((uint64_t)n + margin - thr));
         }
-        uint64_t touched = 0;
+        uint64_t touched = 0, rows_read = 0;
 
         const bool staged = n <= (uint32_t)Q_CAP; // all probes of this read fit: stage them once for both phases
         if (staged)
@@ -1337,6 +1337,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         PMARK(1)                                                     // 1: clearing the tally, bin info + probe staging
         query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC, staged);
         touched += (uint64_t)dense_end * 3ull * stride;
+        rows_read += (uint64_t)dense_end * 3ull;
         __syncthreads();
         PMARK(2)                                                     // 2: dense phase (row gathers)
 
@@ -1369,6 +1370,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
             if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
                 query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC, staged);
                 touched += rem * 3ull * stride;
+                rows_read += rem * 3ull;
             } else if (n_alive > 0) {
                 const uint32_t ST = staged ? (uint32_t)rem : (uint32_t)Q_HT2;
                 for (uint32_t t0 = dense_end; t0 < n; t0 += ST) {
@@ -1425,6 +1427,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
                     }
                 }
                 touched += rem * (uint64_t)n_alive * 3ull * 64ull; // one 64-B sector per 16-B unit load
+                rows_read += rem * (uint64_t)n_alive * 3ull;
             }
         }
         __syncthreads();
@@ -1473,6 +1476,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         }
         st_bytes += (unsigned long long)n * 3ull * D.bins;
         st_touched += touched;
+        st_rows += rows_read;
         st_work += 1ull;
         ++item;
         PMARK(5)                                                     // 5: run tally, child pushes, hit records
@@ -1487,6 +1491,8 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         atomicAdd(&a.ctr->query_bytes, st_bytes);
         atomicAdd(&a.ctr->touched_bytes, st_touched);
         atomicAdd(&a.ctr->n_work, st_work);
+        atomicAdd(&a.ctr->lvl_touched[min(lvl, 7u)], st_touched);
+        atomicAdd(&a.ctr->lvl_rows[min(lvl, 7u)], st_rows);
     }
 }
 
@@ -1672,7 +1678,8 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t st)
 // ------------------------------------------------------------------------------------------------------
 template <bool NT>
 __global__ __launch_bounds__(BLK) void k_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t units,
-                                                        uint32_t passes, uint64_t seed, uint32_t *sink)
+                                                        uint32_t passes, uint64_t seed, uint32_t *sink, uint32_t n_ixf,
+                                                        uint64_t spacing)
 {
     const uint32_t per_pass = BLK / units;                  // rows one block reads per pass
     const uint32_t slot = threadIdx.x / units, u = threadIdx.x - slot * units;
@@ -1686,7 +1693,9 @@ __global__ __launch_bounds__(BLK) void k_gather_ceiling(const uint8_t *data, uin
         for (int j = 0; j < U; ++j) {
             const uint64_t h = murmur64(seed + d + (uint64_t)j * per_pass);
             const uint64_t row = (uint64_t)(((unsigned __int128)h * rows) >> 64);
-            v[j] = ld16<NT>(data + row * stride + (uint64_t)u * 16);
+            // n_ixf equally shaped IXFs `spacing` bytes apart (the children of a synthetic index): a random one of them
+            const uint64_t which = n_ixf > 1u ? (uint64_t)__umulhi((uint32_t)(h * 0x9E3779B97F4A7C15ull >> 32), n_ixf) : 0ull;
+            v[j] = ld16<NT>(data + which * spacing + row * stride + (uint64_t)u * 16);
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
@@ -1696,7 +1705,7 @@ __global__ __launch_bounds__(BLK) void k_gather_ceiling(const uint8_t *data, uin
 }
 
 uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,
-                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st)
+                               uint64_t seed, uint32_t *sink, bool nt, hipStream_t st, uint32_t n_ixf, uint64_t spacing)
 {
     const uint32_t units = (bins + 15) / 16;                // like the query kernel: only units that hold bins are read
     const uint32_t per_pass = BLK / units;
@@ -1704,8 +1713,8 @@ uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stri
     const uint64_t per_block = (uint64_t)passes * per_pass * units * 16;
     uint64_t grid = std::max<uint64_t>(1, want_bytes / per_block);
     if (grid > (1u << 30)) grid = 1u << 30;
-    if (nt) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
-    else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
+    if (nt) hipLaunchKernelGGL(k_gather_ceiling<true>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink, n_ixf, spacing);
+    else hipLaunchKernelGGL(k_gather_ceiling<false>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink, n_ixf, spacing);
     return grid * per_block;
 }
 

@@ -120,11 +120,13 @@ class GpuIndex:
     def depth(self):
         return int(_lib.lib().taxor_gpu_index_depth(self._h))
 
-    def gather_ceiling(self, ixf=0, want_bytes=32 << 30, reps=3):
-        """random whole-row reads of IXF `ixf`, nothing else -> (GB/s requested, bytes read per row)"""
-        g, rb = C.c_double(), C.c_uint64()
-        check(_lib.lib().taxor_gpu_gather_ceiling(self._h, ixf, int(want_bytes), int(reps), C.byref(g), C.byref(rb)))
-        return g.value, int(rb.value)
+    def gather_ceiling(self, ixf=0, want_bytes=32 << 30, reps=3, span=1):
+        """random whole-row reads of IXF `ixf` (or of up to `span` equally shaped IXFs from it on), nothing else
+        -> (GB/s requested, bytes read per row[, IXFs covered])"""
+        g, rb, used = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(_lib.lib().taxor_gpu_gather_ceiling_span(self._h, ixf, int(span), int(want_bytes), int(reps), C.byref(g), C.byref(rb),
+                                                       C.byref(used)))
+        return (g.value, int(rb.value)) if span == 1 else (g.value, int(rb.value), int(used.value))
 
     def fill_random(self, ixf, seed):
         check(_lib.lib().taxor_gpu_index_fill_random(self._h, ixf, seed))
@@ -244,7 +246,10 @@ class Searcher:
     def stats(self):
         st = _lib.RunStats()
         check(_lib.lib().taxor_gpu_batch_stats(self._h, C.byref(st)))
-        return {f: getattr(st, f) for f, _ in _lib.RunStats._fields_}
+        out = {f: getattr(st, f) for f, _ in _lib.RunStats._fields_}
+        for f in ("level_ms", "level_requested_bytes", "level_row_reads"):
+            out[f] = list(out[f])
+        return out
 
     def phase_profile(self):
         """per-phase cycle sums of k_syncmers [0..7] and k_query_level [8..15] since the last call (needs a searcher
