@@ -18,7 +18,7 @@ cat $O/trace_summary.txt
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/gtdb_kernel_stats.csv \;
 find $O/stats $O/pmc_fetch -type f -size +200k -delete
 cd $R
-B="--traffic none --no-cpu-baseline --no-dropin --no-ceiling"
+B="--traffic none --no-cpu-baseline --no-dropin"
 run() { name=$1; shift; python bench.py $B "$@" > $O/bench_$name.json 2> $O/bench_$name.err; }
 run fam_e02                       # default workload again (table row)
 run fam_e04 --read-error 0.04
@@ -39,8 +39,8 @@ python profiles/phase_profile.py --reads 1310720 --read-len 1000 > $O/phase_1k.t
 grep -h "^==\|^--\|^k=\|^algorithmic" $O/phase_10k.txt $O/phase_1k.txt $O/kmer_w20.txt $O/kmer_w32.txt
 TAXOR_NO_OVERLAP=1 run serial_10k
 TAXOR_NO_OVERLAP=1 run serial_unrel_len1k --reads 1310720 --read-len 1000 --batches 2 --family-size 1
-timeout 900 python tests/fuzz_parity.py 600 700000 > $O/fuzz_parity.txt 2>&1
-tail -2 $O/fuzz_parity.txt
+timeout 900 python tests/fuzz_parity.py 300 900000 > $O/fuzz_parity_b.txt 2>&1
+tail -2 $O/fuzz_parity_b.txt
 for f in $O/bench_*.json; do echo "$(basename $f): $(python3 -c "
 import json,sys
 for l in open('$f'):
