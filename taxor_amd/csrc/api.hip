@@ -76,6 +76,7 @@ struct taxor_gpu_index {
     std::vector<uint64_t> rows;
     uint64_t n_user_bins = 0, total_bins = 0, leaf_runs = 0;
     uint32_t depth = 0, max_stride = 0;
+    uint32_t lvl_max_stride[MAX_LEVELS] = {};   // widest row among the IXFs of each hierarchy level (root = level 0)
     int k = 0, s = 0, t = 0;
     uint32_t scaling = 1;
     int w_min = 0;           // > 0: index built without --use-syncmer, minimiser window size (== k: every k-mer)
@@ -108,6 +109,8 @@ struct taxor_gpu_searcher {
     Counters *d_ctr = nullptr;
     unsigned long long *d_prof = nullptr;   // TAXOR_PROFILE_PHASES=1: per-phase cycle sums of the two big kernels
     Counters h_ctr{};
+    int grid_query_small[MAX_LEVELS] = {};      // single-wave query blocks for levels of narrow IXFs under short reads (0 = not eligible)
+    size_t lds_query_small[MAX_LEVELS] = {};
     int grid_wave = 0, grid_wave_overlap = 0;   // k_syncmers_wave: full occupancy / beside a query kernel
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0, grid_query_short = 0;   // query blocks: 3 per CU, 4 for short reads
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
@@ -284,6 +287,8 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
             const uint32_t g = idx->h_ixf[fr.ixf].bin_base + (uint32_t)b;
             dfs[g] = key++;
             idx->depth = std::max(idx->depth, fr.depth);
+            if (fr.depth - 1 < (uint32_t)MAX_LEVELS)
+                idx->lvl_max_stride[fr.depth - 1] = std::max(idx->lvl_max_stride[fr.depth - 1], idx->h_ixf[fr.ixf].stride);
             if (binfo[g] & BINFO_MERGED) {
                 const uint64_t ch = binfo[g] & 0x3FFFFFFFu;
                 if (seen[ch]) {
@@ -539,6 +544,14 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     }
     s->grid_query = query_grid(idx->device, s->lds_query, 3);
     s->grid_query_short = query_grid(idx->device, s->lds_query, 4);
+    {
+        static const bool small_off = [] { const char *e = getenv("TAXOR_QUERY_SMALL"); return e && atoi(e) == 0; }();
+        for (uint32_t l = 0; l < idx->depth && l < (uint32_t)MAX_LEVELS && !small_off; ++l) {
+            if (idx->lvl_max_stride[l] == 0 || idx->lvl_max_stride[l] > 256) continue;      // <= 16 units per row
+            s->lds_query_small[l] = query_lds_bytes(idx->lvl_max_stride[l], true);
+            s->grid_query_small[l] = query_grid_small(idx->device, s->lds_query_small[l]);
+        }
+    }
     *out = s;
     return TAXOR_OK;
 }
@@ -819,7 +832,18 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
         static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4);
-        launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
+        // tiny items (a level of IXFs with <= 256 bins, reads short enough that their probes fit 256 LDS slots): the
+        // single-wave instantiation, sixteen blocks per CU; raw bulk_count calls (d_counts_out) stay on the general one
+        const bool small = !d_counts_out && only_ixf < 0 && lvl < (uint32_t)MAX_LEVELS && s->grid_query_small[lvl] > 0 &&
+                           s->mean_read_len < 2600 && !s->d_prof;
+        if (small) {
+            QueryArgs qs = q;
+            qs.max_stride = idx->lvl_max_stride[lvl];
+            qs.map_words = query_map_words(idx->lvl_max_stride[lvl]);
+            qs.cursor_chunk = 4;
+            launch_query_level(qs, s->grid_query_small[lvl], s->lds_query_small[lvl], s->st, true);
+        } else
+            launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
         if (ev_end(s, slot)) return TAXOR_E_HIP;
         s->stats.query_launches++;
     }

@@ -150,9 +150,11 @@ void launch_syncmers_wave(const SyncmerArgs &a, int grid, hipStream_t st);
 int syncmers_wave_grid(int device, int want_per_cu);
 bool syncmers_wave_applies(int k, int s);
 int syncmers_grid(int device);
-void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
+// small = the single-wave instantiation for launches of tiny items (IXFs of <= 256 bins under short reads)
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small = false);
 int query_grid(int device, size_t lds_bytes, int want_per_cu);
-size_t query_lds_bytes(uint32_t max_stride);
+int query_grid_small(int device, size_t lds_bytes);
+size_t query_lds_bytes(uint32_t max_stride, bool small = false);
 uint32_t query_map_words(uint32_t max_stride);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);

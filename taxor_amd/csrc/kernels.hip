@@ -1050,6 +1050,8 @@ static constexpr int Q_HT = 240;   // hashes per probe tile when one thread sees
 static constexpr int Q_HT2 = 480;  // probe tile when hashes are split over G >= 2 thread groups
 static constexpr int Q_OB = 64;    // child pushes / hit records buffered in LDS before they are appended globally
 static constexpr int Q_CAP = 1024; // LDS probe capacity: reads with n_h <= Q_CAP stage all their probes once per work item
+static constexpr int Q_CAP_SMALL = 256; // ... of the single-wave instantiation for tiny items
+static constexpr int Q_BLK_SMALL = 64;
 
 __device__ __forceinline__ uint32_t zero_bytes01(uint32_t y)
 {
@@ -1109,23 +1111,23 @@ __host__ __device__ inline size_t query_lds_map_words(uint32_t max_stride) { ret
 
 uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_words(max_stride); }
 
-size_t query_lds_bytes(uint32_t max_stride)
+size_t query_lds_bytes(uint32_t max_stride, bool small)
 {
-    return (size_t)Q_CAP * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 8;
+    return (size_t)(small ? Q_CAP_SMALL : Q_CAP) * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 8;
 }
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
 // its subset and counts byte matches; counters are flushed into the LDS counts at the end.
-template <bool NT, int U>
+template <bool NT, int U, int BS, int QC>
 __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64_t *__restrict__ hp, uint32_t h0,
                                                   uint32_t h1, uint4 *sProbe, uint32_t *sC, bool staged)
 {
     const uint32_t tid = threadIdx.x;
     const uint32_t units = D.units, stride = D.stride;
     // column passes: 256 units (4096 bins) per pass; almost always exactly one
-    for (uint32_t u0 = 0; u0 < units; u0 += BLK) {
-        const uint32_t upass = min(units - u0, (uint32_t)BLK);
-        const uint32_t G = BLK / upass;           // hashes processed concurrently by the block
+    for (uint32_t u0 = 0; u0 < units; u0 += BS) {
+        const uint32_t upass = min(units - u0, (uint32_t)BS);
+        const uint32_t G = BS / upass;           // hashes processed concurrently by the block
         const uint32_t g = tid / upass;
         const uint32_t u = u0 + (tid - g * upass);
         const bool active = g < G;
@@ -1133,13 +1135,13 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 
         // a tile bounds the per-thread increments of the packed byte counters (<= 240); when the probes are not
         // pre-staged it is also what fits the staging loop
-        const uint32_t HT = staged ? 240u * G : ((G == 1u) ? (uint32_t)Q_HT : (uint32_t)Q_HT2);
+        const uint32_t HT = staged ? 240u * G : min((G == 1u) ? (uint32_t)Q_HT : (uint32_t)Q_HT2, (uint32_t)QC);
         for (uint32_t t0 = h0; t0 < h1; t0 += HT) {
             const uint32_t nt = min(HT, h1 - t0);
             const uint4 *pr = sProbe + (staged ? t0 : 0u);
             if (!staged) {
                 __syncthreads();
-                for (uint32_t i = tid; i < nt; i += BLK) {
+                for (uint32_t i = tid; i < nt; i += BS) {
                     const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
                     sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                 }
@@ -1200,13 +1202,18 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
     }
 }
 
-template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) void k_query_level(const QueryArgs a)
+// BS threads per block; QC probes fit the LDS staging area.  (256, 1024) is the general instantiation; (64, 256) serves
+// launches of TINY items -- levels of narrow IXFs (<= 256 bins) under short reads -- where an item is a handful of memory
+// round trips and fixed cost: sixteen single-wave blocks per CU keep four times as many items in flight as four
+// four-wave blocks, and a single-wave block's barriers cost nothing.
+template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP>
+__global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
 {
     uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t plast = PROF ? __builtin_amdgcn_s_memtime() : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint4 *sProbe = reinterpret_cast<uint4 *>(smem);
-    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + Q_CAP * sizeof(uint4));       // [0] item, [1] n alive units
+    uint32_t *sScal = reinterpret_cast<uint32_t *>(smem + QC * sizeof(uint4));       // [0] item, [1] n alive units
     uint32_t *sUnits = sScal + 16;
     uint32_t *sMap = sUnits + Q_MAXU;
     uint32_t *sC = sMap + a.map_words;
@@ -1238,11 +1245,11 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         }
         __syncthreads();
         const uint32_t bq = sScal[4], bh = sScal[5];
-        for (uint32_t i = tid; i < nq; i += BLK) {
+        for (uint32_t i = tid; i < nq; i += BS) {
             if (bq + i < a.q_cap) a.q_out[bq + i] = sOutQ[i];
             else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
         }
-        for (uint32_t i = tid; i < nh; i += BLK) {
+        for (uint32_t i = tid; i < nh; i += BS) {
             if (bh + i < a.hit_cap) a.hits[bh + i] = sOutH[i];
             else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
         }
@@ -1287,17 +1294,17 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         // The per-bin info words are read twice per item (pruning check, tally): out of LDS, not out of L2 -- a global
         // load per phase is a round trip of its own, which is most of what a small item costs.  Rows of up to 1024 bins
         // take them through registers so that these loads and the hash loads of the probe staging below fly together.
-        const bool info_regs = nb_round <= 4u * BLK;
+        const bool info_regs = nb_round <= 4u * BS;
         uint32_t infoReg[4] = {0u, 0u, 0u, 0u};
         if (info_regs) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t b = tid + (uint32_t)j * BLK;
+                const uint32_t b = tid + (uint32_t)j * BS;
                 if (b < D.bins) infoReg[j] = bi[b];
             }
         }
-        for (uint32_t i = tid; i < stride; i += BLK) sC[i] = 0;
-        for (uint32_t i = tid; i < a.map_words; i += BLK) sMap[i] = 0;
+        for (uint32_t i = tid; i < stride; i += BS) sC[i] = 0;
+        for (uint32_t i = tid; i < a.map_words; i += BS) sMap[i] = 0;
         if (tid == 0) sScal[1] = 0;
 
         // ---- threshold-aware pruning ---------------------------------------------------------------------------
@@ -1318,24 +1325,24 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         }
         uint64_t touched = 0, rows_read = 0;
 
-        const bool staged = n <= (uint32_t)Q_CAP; // all probes of this read fit: stage them once for both phases
+        const bool staged = n <= (uint32_t)QC; // all probes of this read fit: stage them once for both phases
         if (staged)
-            for (uint32_t i = tid; i < n; i += BLK) {
+            for (uint32_t i = tid; i < n; i += BS) {
                 const ixf_probe p = ixf_probe_key(hp[i], D.seed, D.seg_len);
                 sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
         if (info_regs) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const uint32_t b = tid + (uint32_t)j * BLK;
+                const uint32_t b = tid + (uint32_t)j * BS;
                 if (b < nb_round) sInfo[b] = infoReg[j];
             }
         } else {
-            for (uint32_t b = tid; b < nb_round; b += BLK) sInfo[b] = b < D.bins ? bi[b] : 0u;
+            for (uint32_t b = tid; b < nb_round; b += BS) sInfo[b] = b < D.bins ? bi[b] : 0u;
         }
         __syncthreads();
         PMARK(1)                                                     // 1: clearing the tally, bin info + probe staging
-        query_dense_range<NT, U>(D, hp, 0, dense_end, sProbe, sC, staged);
+        query_dense_range<NT, U, BS, QC>(D, hp, 0, dense_end, sProbe, sC, staged);
         touched += (uint64_t)dense_end * 3ull * stride;
         rows_read += (uint64_t)dense_end * 3ull;
         __syncthreads();
@@ -1343,7 +1350,7 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
 
         if (dense_end < n) {
             const uint64_t rem = n - dense_end;
-            for (uint32_t b = tid; b < nb_round; b += BLK) {
+            for (uint32_t b = tid; b < nb_round; b += BS) {
                 if (b < D.bins) {
                     const uint32_t info = sInfo[b];
                     if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
@@ -1368,17 +1375,17 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
             PMARK(3)                                                 // 3: which runs can still reach the threshold
             const uint32_t n_alive = sScal[1];
             if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
-                query_dense_range<NT, U>(D, hp, dense_end, n, sProbe, sC, staged);
+                query_dense_range<NT, U, BS, QC>(D, hp, dense_end, n, sProbe, sC, staged);
                 touched += rem * 3ull * stride;
                 rows_read += rem * 3ull;
             } else if (n_alive > 0) {
-                const uint32_t ST = staged ? (uint32_t)rem : (uint32_t)Q_HT2;
+                const uint32_t ST = staged ? (uint32_t)rem : min((uint32_t)Q_HT2, (uint32_t)QC);
                 for (uint32_t t0 = dense_end; t0 < n; t0 += ST) {
                     const uint32_t nt = min(ST, n - t0);
                     const uint4 *pr = sProbe + (staged ? t0 : 0u);
                     if (!staged) {
                         __syncthreads();
-                        for (uint32_t i = tid; i < nt; i += BLK) {
+                        for (uint32_t i = tid; i < nt; i += BS) {
                             const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
                             sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                         }
@@ -1389,12 +1396,12 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
                     // loads in flight per lane); one at a time this phase is a chain of dependent latencies.
                     const uint32_t tasks = nt * n_alive;
                     constexpr int SU = 4;
-                    for (uint32_t task0 = tid; task0 < tasks; task0 += BLK * SU) {
+                    for (uint32_t task0 = tid; task0 < tasks; task0 += BS * SU) {
                         uint4 r0[SU], r1[SU], r2[SU];
                         uint32_t xs[SU], fp4[SU];
 #pragma unroll
                         for (int u = 0; u < SU; ++u) {
-                            const uint32_t task = task0 + (uint32_t)u * BLK;
+                            const uint32_t task = task0 + (uint32_t)u * BS;
                             xs[u] = 0xFFFFFFFFu;
                             r0[u] = r1[u] = r2[u] = make_uint4(0, 0, 0, 0);
                             fp4[u] = 0;
@@ -1434,10 +1441,10 @@ template <bool NT, int U, bool PROF = false> __global__ __launch_bounds__(BLK) v
         PMARK(4)                                                     // 4: sparse phase (surviving units only)
 
         if (a.counts_out)
-            for (uint32_t b = tid; b < D.bins; b += BLK) a.counts_out[b] = sC[b];
+            for (uint32_t b = tid; b < D.bins; b += BS) a.counts_out[b] = sC[b];
 
         // ---- tally: hierarchical_interleaved_xor_filter.hpp:313-338 --------------------------------------
-        for (uint32_t b = tid; b < nb_round; b += BLK) {
+        for (uint32_t b = tid; b < nb_round; b += BS) {
             bool push_child = false, push_hit = false;
             uint32_t sum = 0, info = 0;
             if (b < D.bins) {
@@ -1512,12 +1519,29 @@ int query_grid(int device, size_t lds_bytes, int want_per_cu)
     return p.multiProcessorCount * per;
 }
 
-void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
+// single-wave blocks for tiny items: as many per CU as registers and LDS allow (sixteen at 108 VGPRs)
+int query_grid_small(int device, size_t lds_bytes)
+{
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) return 4096;
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>, Q_BLK_SMALL, lds_bytes) != hipSuccess || per < 1)
+        per = 8;
+    if (per > 16) per = 16;
+    if (const char *e = getenv("TAXOR_QUERY_BPC_SMALL")) { const int v = atoi(e); if (v >= 1 && v <= 32) per = v; }
+    return p.multiProcessorCount * per;
+}
+
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small)
 {
     static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
     static const int unroll0 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
     static const int unroll1 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
     const int unroll = (a.level >= 1 && unroll1) ? unroll1 : unroll0;
+    if (small) {
+        hipLaunchKernelGGL((k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>), dim3(grid), dim3(Q_BLK_SMALL), lds_bytes, st, a);
+        return;
+    }
     if (a.prof) {
         hipLaunchKernelGGL((k_query_level<true, 2, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
         return;
