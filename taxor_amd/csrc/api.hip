@@ -547,7 +547,8 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     {
         static const bool small_off = [] { const char *e = getenv("TAXOR_QUERY_SMALL"); return e && atoi(e) == 0; }();
         for (uint32_t l = 0; l < idx->depth && l < (uint32_t)MAX_LEVELS && !small_off; ++l) {
-            if (idx->lvl_max_stride[l] == 0 || idx->lvl_max_stride[l] > 256) continue;      // <= 16 units per row
+            static const uint32_t max_stride_small = [] { const char *e = getenv("TAXOR_QUERY_SMALL_MAXSTRIDE"); return e ? (uint32_t)atoi(e) : 512u; }();
+            if (idx->lvl_max_stride[l] == 0 || idx->lvl_max_stride[l] > max_stride_small) continue;      // rows of up to 512 bins (1024-bin roots gain nothing: 34.4 vs 34.7 ms)
             s->lds_query_small[l] = query_lds_bytes(idx->lvl_max_stride[l], true);
             s->grid_query_small[l] = query_grid_small(idx->device, s->lds_query_small[l]);
         }
