@@ -32,6 +32,8 @@ run len3k --reads 436906 --read-len 3000 --batches 2
 run len30k --reads 43690 --read-len 30000 --batches 2
 run ont --len-mix ont --batches 2
 run unrel_len1k --reads 1310720 --read-len 1000 --batches 2 --family-size 1
+run refseq_len1k --workload refseq --reads 1310720 --read-len 1000 --batches 2
+run viral_len1k --workload viral --reads 1310720 --read-len 1000 --batches 2
 python profiles/kmer_mode_bench.py > $O/kmer_w20.txt 2>&1
 python profiles/kmer_mode_bench.py 20 32 > $O/kmer_w32.txt 2>&1
 python profiles/phase_profile.py > $O/phase_10k.txt 2>&1
@@ -39,8 +41,8 @@ python profiles/phase_profile.py --reads 1310720 --read-len 1000 > $O/phase_1k.t
 grep -h "^==\|^--\|^k=\|^algorithmic" $O/phase_10k.txt $O/phase_1k.txt $O/kmer_w20.txt $O/kmer_w32.txt
 TAXOR_NO_OVERLAP=1 run serial_10k
 TAXOR_NO_OVERLAP=1 run serial_unrel_len1k --reads 1310720 --read-len 1000 --batches 2 --family-size 1
-timeout 900 python tests/fuzz_parity.py 300 900000 > $O/fuzz_parity_b.txt 2>&1
-tail -2 $O/fuzz_parity_b.txt
+timeout 900 python tests/fuzz_parity.py 240 1500000 > $O/fuzz_parity_c.txt 2>&1
+tail -2 $O/fuzz_parity_c.txt
 for f in $O/bench_*.json; do echo "$(basename $f): $(python3 -c "
 import json,sys
 for l in open('$f'):

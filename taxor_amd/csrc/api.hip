@@ -833,7 +833,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
         static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4);
-        // tiny items (a level of IXFs with <= 256 bins, reads short enough that their probes fit 256 LDS slots): the
+        // tiny items (a level of IXFs with <= 512 bins, reads short enough that their probes fit 256 LDS slots): the
         // single-wave instantiation, sixteen blocks per CU; raw bulk_count calls (d_counts_out) stay on the general one
         const bool small = !d_counts_out && only_ixf < 0 && lvl < (uint32_t)MAX_LEVELS && s->grid_query_small[lvl] > 0 &&
                            s->mean_read_len < 2600 && !s->d_prof;

@@ -1203,7 +1203,7 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 }
 
 // BS threads per block; QC probes fit the LDS staging area.  (256, 1024) is the general instantiation; (64, 256) serves
-// launches of TINY items -- levels of narrow IXFs (<= 256 bins) under short reads -- where an item is a handful of memory
+// launches of TINY items -- levels of narrow IXFs (<= 512 bins) under short reads -- where an item is a handful of memory
 // round trips and fixed cost: sixteen single-wave blocks per CU keep four times as many items in flight as four
 // four-wave blocks, and a single-wave block's barriers cost nothing.
 template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP>

@@ -540,6 +540,35 @@ def test_mixed_read_lengths_longest_first_order():
     idx.close()
 
 
+def test_single_wave_query_blocks_short_reads_with_long_outliers():
+    """a batch whose MEAN read length is short (the levels of narrow IXFs -- here all of them: 66-bin root, 40-bin
+    children -- run the single-wave instantiation k_query_level<.., 64, 256>) but which contains reads with more hashes
+    than its 256 probe slots hold (unstaged tiles), reads that fill them exactly, threshold-0 reads and empty ones;
+    thresholds on both sides, several sub-batch sizes -- against the oracle"""
+    g, go, lay, host = _planted_setup(43, n_genomes=6, glen=40000, root_bins=66, child_bins=40, n_children=3)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    rng = np.random.default_rng(9)
+    reads = []
+    for L, n in ((700, 500), (1500, 150), (2940, 40), (3000, 20), (12000, 6), (35000, 3), (21, 4), (0, 2)):
+        if L < 22:
+            reads += [bytes(g[5:5 + L])] * n
+            continue
+        b, o, _ = synth.synth_reads(g, go, n, L, error_rate=0.02, frac_random=0.2, seed=int(rng.integers(1, 10**6)))
+        reads += [bytes(b[int(o[i]):int(o[i + 1])]) for i in range(n)]
+    perm = rng.permutation(len(reads))
+    reads = [reads[i] for i in perm]
+    B, O = _cat(reads)
+    assert O[-1] / len(reads) < 2600                       # the condition under which the library picks that instantiation
+    for err, sub in ((0.04, 0), (0.1, 97), (0.0, 1000)):
+        sr = Searcher(idx, error_rate=err, sub_batch_reads=sub)
+        res = sr.search_batch(B, O)
+        _compare(res, h.search_batch(B, O, err=err, threads=8), len(reads))
+        assert res.user_bin.size > 500
+        sr.close()
+    idx.close()
+
+
 def test_pruning_with_rows_wider_than_one_block_pass():
     """5000 bins = 313 units: the dense loop needs two column passes and the alive-unit bitmap spans ten words;
     pruning, sparse probing and the tally must still equal the oracle"""
