@@ -664,7 +664,8 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         uint64_t lim_reads = full_reads, lim_bases = s->prm.sub_batch_bases;
         if (ramp) {
             double f = 1.0 / (double)first_div;
-            for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= 1.25;
+            static const double growth = [] { const char *e = getenv("TAXOR_RAMP_GROWTH"); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1.25; }();
+            for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= growth;
             if (f < 1.0) {
                 lim_reads = std::max<uint64_t>((uint64_t)((double)lim_reads * f), 1);
                 lim_bases = std::max<uint64_t>((uint64_t)((double)lim_bases * f), 1);
@@ -993,6 +994,13 @@ int check_flags(taxor_gpu_searcher *s, bool *rerun)
 
 namespace {
 
+// streamed batches: the first sub-batch is 1/n of a full one (TAXOR_STREAM_FIRST_DIV, default 8)
+uint32_t stream_first_div(const taxor_gpu_searcher *s)
+{
+    static const uint32_t env = [] { const char *e = getenv("TAXOR_STREAM_FIRST_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
+    return env ? env : std::max(s->first_div, 8u);
+}
+
 // host-side layout + device copies of the per-read arrays (everything except the bases themselves)
 int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads, bool streamed)
 {
@@ -1004,7 +1012,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     std::vector<uint64_t> poff, hoff;
     std::vector<uint32_t> rlen, hcap, order;
     // streamed: the first sub-batch's PCIe copy has nothing to hide behind either, so it is a quarter the size
-    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? std::max(s->first_div, 8u) : s->first_div, streamed))
+    if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? stream_first_div(s) : s->first_div, streamed))
         return rc;
     s->n_reads = n_reads;
     s->h_rlen = rlen;
