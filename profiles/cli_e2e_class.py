@@ -26,7 +26,13 @@ args = bench.parse_args(["--workload", workload, "--reads", str(n_reads), "--bat
 wl, idx, lay, batches, info = bench.build_workload(args, 0, 0, 1)
 bases, offs = batches[0]
 read_len = info["read_len"]
-tmp = tempfile.mkdtemp(prefix="taxor_e2e_", dir="/tmp")
+import shutil  # noqa: E402
+need = idx.data_bytes * 1.05 + n_reads * (2 * read_len + 64)
+base = next((d for d in (os.environ.get("TAXOR_E2E_TMP"), "/tmp", "/dev/shm") if d and os.path.isdir(d) and shutil.disk_usage(d).free > need), None)
+if base is None:
+    raise SystemExit(f"no scratch directory with {need/1e9:.0f} GB free")
+tmp = tempfile.mkdtemp(prefix="taxor_e2e_", dir=base)
+print(f"scratch: {tmp}", flush=True)
 t0 = time.time()
 host = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=idx.ixf_seed(i), next_ixf=f["next_ixf"], fname_idx=f["fname_idx"],
              data=idx.download_ixf(i)) for i, f in enumerate(lay["ixfs"])]
