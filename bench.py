@@ -32,6 +32,7 @@ import glob
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -129,13 +130,18 @@ def live_traffic(args):
             d = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
             t0 = time.time()
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
             try:
-                cp = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420,
-                                    start_new_session=True)
+                _, err = proc.communicate(timeout=420)
             except subprocess.TimeoutExpired:
+                try:                       # the profiler AND the profiled child (its own session = its own process group)
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.communicate()
                 return None, f"rocprofv3 --pmc {counter} pass timed out"
-            if cp.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {cp.returncode}): {cp.stderr.decode(errors='replace')[-300:]}"
+            if proc.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, f"rocprofv3 --pmc {counter}: no counter_collection.csv"

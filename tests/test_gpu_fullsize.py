@@ -224,3 +224,20 @@ def test_refseq_class_ten_million_reads():
 def test_gtdb_class_ten_million_reads():
     """BASELINE.json configs[3]: GTDB-220-class k22/s12 index (113 GB, README.md:51) resident in one GPU's HBM, 10 M x 10 kb"""
     _full_size_class("gtdb", 105e9, 120e9)
+
+
+def test_refseq_class_hixf_file_through_the_cli(tmp_path):
+    """BASELINE configs[2] through the whole drop-in chain: the RefSeq-class index written as an 11 GB `.hixf` with the
+    library's writer, loaded and searched by the C++ `taxor search` CLI (parallel FASTQ parsing, streamed batches), its
+    TSV byte-identical to the library formatter over the Python searcher's tuples (profiles/cli_e2e_class.py)"""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.disk_usage(str(tmp_path)).free < 20e9:
+        pytest.skip("needs 20 GB of scratch space")
+    cp = subprocess.run([sys.executable, os.path.join(root, "profiles", "cli_e2e_class.py"), "refseq", "100000"], capture_output=True, text=True,
+                        timeout=900, env=dict(os.environ, TAXOR_E2E_TMP=str(tmp_path)))
+    assert cp.returncode == 0, cp.stdout[-2000:] + cp.stderr[-2000:]
+    assert "identical to formatter(searcher results): True" in cp.stdout
+    assert cp.stdout.count(" rc 0 ") == 3
