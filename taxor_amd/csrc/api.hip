@@ -131,7 +131,8 @@ struct taxor_gpu_searcher {
 
     // per-sub-batch scratch
     DBuf<uint64_t> d_cand[2], d_hashes[2];   // double-buffered across sub-batches
-    DBuf<uint2> d_q[2];
+    DBuf<uint2> d_q[2], d_qs;     // work queues of two consecutive levels; the next level's queue grouped by IXF
+    DBuf<uint32_t> d_qhist;
     DBuf<uint4> d_hits;
     DBuf<uint32_t> d_read_hits, d_cursor, d_roff, d_biglist, d_gtab;
     uint32_t q_cap = 0, hit_cap = 0, gtab_stride = 0;
@@ -578,7 +579,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
     if (s->st_sync2) (void)hipStreamDestroy(s->st_sync2);
     if (s->ev_wave) (void)hipEventDestroy(s->ev_wave);
-    s->d_q[0].release(); s->d_q[1].release(); s->d_hits.release();
+    s->d_q[0].release(); s->d_q[1].release(); s->d_qs.release(); s->d_qhist.release(); s->d_hits.release();
     s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release();
     s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
     for (auto ev : s->ev) (void)hipEventDestroy(ev);
@@ -772,7 +773,9 @@ int ensure_scratch(taxor_gpu_searcher *s)
     const uint64_t hmin = std::max<uint64_t>(16ull * R, idx->leaf_runs + 64);
     if (s->q_cap < qmin) s->q_cap = (uint32_t)std::min<uint64_t>(qmin, 0x7FFFFFFFu);
     if (s->hit_cap < hmin) s->hit_cap = (uint32_t)std::min<uint64_t>(hmin, 0x7FFFFFFFu);
-    if (s->d_q[0].reserve(s->q_cap) || s->d_q[1].reserve(s->q_cap)) return TAXOR_E_HIP;
+    if (s->d_q[0].reserve(s->q_cap) || s->d_q[1].reserve(s->q_cap) || s->d_qs.reserve(s->q_cap) ||
+        s->d_qhist.reserve(idx->h_ixf.size() + 1))
+        return TAXOR_E_HIP;
     if (s->d_hits.reserve(s->hit_cap)) return TAXOR_E_HIP;
     if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R))
         return TAXOR_E_HIP;
@@ -818,9 +821,16 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
     q.prof = s->d_prof;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
+    static const bool group_queue = [] { const char *e = getenv("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
         q.level = lvl;
         q.q_in = (lvl == 0 && only_ixf < 0) ? nullptr : s->d_q[lvl & 1].p;
+        if (lvl >= 1 && only_ixf < 0 && group_queue) {
+            // this level's items, pushed by the previous one in no particular order, grouped by IXF: blocks that run at
+            // the same time then read the same few child IXFs (cache-resident) instead of rows all over the slab
+            launch_queue_group_by_ixf(s->d_q[lvl & 1].p, s->d_ctr, lvl, s->q_cap, s->d_qhist.p, (uint32_t)idx->h_ixf.size(), s->d_qs.p, s->st);
+            q.q_in = s->d_qs.p;
+        }
         q.q_out = s->d_q[(lvl + 1) & 1].p;
         q.n_level0 = n_reads;
         q.order0 = d_order;

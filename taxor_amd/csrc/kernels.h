@@ -157,6 +157,9 @@ int query_grid_small(int device, size_t lds_bytes);
 size_t query_lds_bytes(uint32_t max_stride, bool small = false);
 uint32_t query_map_words(uint32_t max_stride);
 void launch_finalize(const FinalizeArgs &a, hipStream_t st);
+// counting sort of a level's work queue by IXF id (q -> out; hist = n_ixf words of scratch); the item count is read on the device
+void launch_queue_group_by_ixf(const uint2 *q, const Counters *ctr, uint32_t lvl, uint32_t q_cap, uint32_t *hist, uint32_t n_ixf,
+                               uint2 *out, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
 // random whole-row reads of one IXF, nothing else; returns the bytes the launch requests
 uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,

@@ -1534,12 +1534,18 @@ int query_grid_small(int device, size_t lds_bytes)
 
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small)
 {
-    static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
+    static const bool nt0 = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
     static const int unroll0 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
     static const int unroll1 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
     const int unroll = (a.level >= 1 && unroll1) ? unroll1 : unroll0;
+    // levels below the root: their items arrive grouped by IXF (launch_queue_group_by_ixf), so consecutive items re-read
+    // the rows of the same child -- plain loads let them stay in L2 / the memory-side cache; the root's rows are random
+    // in tens of gigabytes and stream (non-temporal)
+    static const int nt1 = [] { const char *e = getenv("TAXOR_QUERY_NT_L1"); return e ? atoi(e) : 0; }();
+    const bool nt = a.level >= 1 ? nt1 != 0 : nt0;
     if (small) {
-        hipLaunchKernelGGL((k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>), dim3(grid), dim3(Q_BLK_SMALL), lds_bytes, st, a);
+        if (nt) hipLaunchKernelGGL((k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>), dim3(grid), dim3(Q_BLK_SMALL), lds_bytes, st, a);
+        else hipLaunchKernelGGL((k_query_level<false, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>), dim3(grid), dim3(Q_BLK_SMALL), lds_bytes, st, a);
         return;
     }
     if (a.prof) {
@@ -1553,6 +1559,105 @@ void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStrea
         if (nt) hipLaunchKernelGGL((k_query_level<true, 4>), dim3(grid), dim3(BLK), lds_bytes, st, a);
         else hipLaunchKernelGGL((k_query_level<false, 4>), dim3(grid), dim3(BLK), lds_bytes, st, a);
     }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Work-queue ordering between levels.  The (read, IXF) items a level pushes arrive in no particular order; the next
+// level takes them in queue order, so grouping them by IXF makes the blocks that run at one time read the SAME few
+// child IXFs -- a child of tens of megabytes then stays in the memory-side cache while its items are processed (reads of
+// an abundant organism all descend into the same children), instead of every fingerprint row being a DRAM row
+// activation.  A counting sort by IXF id: histogram, scan, scatter.  The order inside a group does not matter -- hits
+// are ordered per read by DFS key at the end -- and results do not change.
+// ------------------------------------------------------------------------------------------------------
+// Block-aggregated: a block takes a contiguous chunk of the queue, counts its IXF ids in LDS and touches the global
+// counters once per (block, id) -- the items of a sub-batch concentrate on a few dozen child IXFs, and one global atomic per
+// ITEM on those few words costs more than the level it orders (1-kb reads: 12 ms per step).
+static constexpr uint32_t QG_LDS_IDS = 8192;    // IXF ids counted in LDS; larger ids (huge hierarchies) go to the global words directly
+
+__device__ __forceinline__ void queue_chunk(uint32_t n, uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t per = (n + gridDim.x - 1u) / gridDim.x;
+    lo = min(blockIdx.x * per, n);
+    hi = min(lo + per, n);
+}
+
+__global__ __launch_bounds__(BLK) void k_queue_hist(const uint2 *__restrict__ q, const Counters *__restrict__ ctr, uint32_t lvl,
+                                                    uint32_t q_cap, uint32_t *__restrict__ hist, uint32_t n_ixf)
+{
+    __shared__ uint32_t sH[QG_LDS_IDS];
+    const uint32_t n = min(ctr->q_n[lvl].v, q_cap), nl = min(n_ixf, QG_LDS_IDS);
+    uint32_t lo, hi;
+    queue_chunk(n, lo, hi);
+    if (lo >= hi) return;
+    for (uint32_t i = threadIdx.x; i < nl; i += BLK) sH[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLK) {
+        const uint32_t id = q[i].y;
+        if (id < nl) atomicAdd(&sH[id], 1u);
+        else atomicAdd(&hist[id], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nl; i += BLK)
+        if (sH[i]) atomicAdd(&hist[i], sH[i]);
+}
+
+__global__ __launch_bounds__(1024) void k_queue_scan(uint32_t *__restrict__ hist, uint32_t n_ixf)
+{
+    __shared__ uint32_t sW[16];
+    __shared__ uint32_t sCarry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) sCarry = 0;
+    for (uint32_t b0 = 0; b0 < n_ixf; b0 += 1024) {
+        __syncthreads();
+        const uint32_t i = b0 + tid;
+        const uint32_t v = i < n_ixf ? hist[i] : 0u;
+        const uint32_t incl = wave_incl_add(v);
+        if (lane_id() == 63) sW[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t off = sCarry, tot = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t x = sW[w];
+            if (w < (tid >> 6)) off += x;
+            tot += x;
+        }
+        if (i < n_ixf) hist[i] = off + incl - v;          // exclusive start of this IXF's group
+        __syncthreads();
+        if (tid == 0) sCarry += tot;
+    }
+}
+
+__global__ __launch_bounds__(BLK) void k_queue_scatter(const uint2 *__restrict__ q, const Counters *__restrict__ ctr, uint32_t lvl,
+                                                       uint32_t q_cap, uint32_t *__restrict__ hist, uint2 *__restrict__ out, uint32_t n_ixf)
+{
+    __shared__ uint32_t sH[QG_LDS_IDS];       // count of this block's chunk per id, then the block's next slot for that id
+    const uint32_t n = min(ctr->q_n[lvl].v, q_cap), nl = min(n_ixf, QG_LDS_IDS);
+    uint32_t lo, hi;
+    queue_chunk(n, lo, hi);
+    if (lo >= hi) return;
+    for (uint32_t i = threadIdx.x; i < nl; i += BLK) sH[i] = 0u;
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLK) {
+        const uint32_t id = q[i].y;
+        if (id < nl) atomicAdd(&sH[id], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nl; i += BLK)
+        if (sH[i]) sH[i] = atomicAdd(&hist[i], sH[i]);      // reserve this block's run inside the id's group
+    __syncthreads();
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += BLK) {
+        const uint2 it = q[i];
+        const uint32_t pos = it.y < nl ? atomicAdd(&sH[it.y], 1u) : atomicAdd(&hist[it.y], 1u);
+        out[pos] = it;
+    }
+}
+
+void launch_queue_group_by_ixf(const uint2 *q, const Counters *ctr, uint32_t lvl, uint32_t q_cap, uint32_t *hist, uint32_t n_ixf,
+                               uint2 *out, hipStream_t st)
+{
+    (void)hipMemsetAsync(hist, 0, (size_t)n_ixf * sizeof(uint32_t), st);
+    hipLaunchKernelGGL(k_queue_hist, dim3(256), dim3(BLK), 0, st, q, ctr, lvl, q_cap, hist, n_ixf);
+    hipLaunchKernelGGL(k_queue_scan, dim3(1), dim3(1024), 0, st, hist, n_ixf);
+    hipLaunchKernelGGL(k_queue_scatter, dim3(256), dim3(BLK), 0, st, q, ctr, lvl, q_cap, hist, out, n_ixf);
 }
 
 // ------------------------------------------------------------------------------------------------------
