@@ -439,7 +439,9 @@ def main():
                 "note": "achieved = bytes k_query_level requested (device-counted) / its HIP-event time on the searcher's "
                         "stream.  algorithmic_* = the reference's n_h*3*bins per visited IXF (SURVEY 8(d)); pruning asks for "
                         "fewer bytes with identical tuples, so vs_dense > 1 is saved work, not bandwidth.  `unpruned`: same "
-                        "steps with pruning off, where the contract formula (algorithmic bytes / time) is physical.",
+                        "steps with pruning off, where the contract formula (algorithmic bytes / time) is physical.  Below the "
+                        "root, items are grouped by IXF and re-read children partly out of L2 / the memory-side cache (levels[].frac "
+                        "can then exceed what HBM alone would deliver); traffic (PMC) counts L2 misses.",
                 "launches": acc["launches"], "avg_launch_ms": round(acc["q_ms"] / launches, 4),
                 "requested_bytes_per_launch": round(acc["q_touched"] / launches, 1),
                 "algorithmic_bytes_per_launch": round(acc["q_bytes"] / launches, 1),
@@ -447,6 +449,7 @@ def main():
                 "vs_dense": round(acc["q_bytes"] / max(1.0, acc["q_touched"]), 4)}
         if traffic is not None:
             roof["traffic_over_requested"] = round(traffic / max(1.0, acc["q_touched"] / launches), 4)
+
         # per HIXF level: wide rows are bound by bytes, rows of <= 128 B by the number of DRAM rows opened per second
         roof["levels"] = [{"level": l, "ms_per_step": round(acc["lvl_ms"][l] / args.steps, 3),
                            "requested_GBps": round(acc["lvl_bytes"][l] / (acc["lvl_ms"][l] * 1e-3) / 1e9, 1),
