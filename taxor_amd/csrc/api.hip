@@ -844,6 +844,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
         static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4);
+        const bool root_streams = idx->rows[0] * (uint64_t)idx->h_ixf[0].stride > (16ull << 30);   // root table beyond any cache
         // tiny items (a level of IXFs with <= 512 bins, reads short enough that their probes fit 256 LDS slots): the
         // single-wave instantiation, sixteen blocks per CU; raw bulk_count calls (d_counts_out) stay on the general one
         const bool small = !d_counts_out && only_ixf < 0 && lvl < (uint32_t)MAX_LEVELS && s->grid_query_small[lvl] > 0 &&
@@ -853,9 +854,9 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
             qs.max_stride = idx->lvl_max_stride[lvl];
             qs.map_words = query_map_words(idx->lvl_max_stride[lvl]);
             qs.cursor_chunk = 4;
-            launch_query_level(qs, s->grid_query_small[lvl], s->lds_query_small[lvl], s->st, true);
+            launch_query_level(qs, s->grid_query_small[lvl], s->lds_query_small[lvl], s->st, true, root_streams);
         } else
-            launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st);
+            launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st, false, root_streams);
         if (ev_end(s, slot)) return TAXOR_E_HIP;
         s->stats.query_launches++;
     }

@@ -151,7 +151,7 @@ int syncmers_wave_grid(int device, int want_per_cu);
 bool syncmers_wave_applies(int k, int s);
 int syncmers_grid(int device);
 // small = the single-wave instantiation for launches of tiny items (IXFs of <= 512 bins under short reads)
-void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small = false);
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small = false, bool root_streams = true);
 int query_grid(int device, size_t lds_bytes, int want_per_cu);
 int query_grid_small(int device, size_t lds_bytes);
 size_t query_lds_bytes(uint32_t max_stride, bool small = false);

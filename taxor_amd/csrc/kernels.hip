@@ -1532,9 +1532,13 @@ int query_grid_small(int device, size_t lds_bytes)
     return p.multiProcessorCount * per;
 }
 
-void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small)
+void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small, bool root_streams)
 {
-    static const bool nt0 = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
+    // the root's rows: non-temporal when its table is far larger than the caches (random rows in tens of gigabytes: no
+    // reuse to protect), plain when it is small enough for the 256 MB memory-side cache to matter (viral-class root,
+    // 150 MB: +8 %; RefSeq-class, 4 GB: +3 %; GTDB-class, 45 GB: -1 %)
+    static const int nt_env = [] { const char *e = getenv("TAXOR_QUERY_NT"); return e ? atoi(e) : -1; }();
+    const bool nt0 = nt_env >= 0 ? nt_env != 0 : root_streams;
     static const int unroll0 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
     static const int unroll1 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
     const int unroll = (a.level >= 1 && unroll1) ? unroll1 : unroll0;
