@@ -569,6 +569,63 @@ def test_single_wave_query_blocks_short_reads_with_long_outliers():
     idx.close()
 
 
+def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram():
+    """a hierarchy of 10 101 small IXFs (root -> 100 -> 10 000): the work queues of the deeper levels are grouped by IXF
+    id with a counting sort whose per-block histogram covers ids below 8192 in LDS and takes the rest through global
+    atomics -- genomes planted under IXFs on both sides of that boundary, against the oracle"""
+    rng = np.random.default_rng(77)
+    g, go = synth.random_genomes(6, 6000, seed=77)
+    planted = [np.unique(orc.seq_to_syncmers(bytes(g[int(go[i]):int(go[i + 1])]))) for i in range(6)]
+    next_ub = [0]
+
+    def new_ub():
+        next_ub[0] += 1
+        return next_ub[0] - 1
+
+    def new_ixf(bins):
+        return dict(bins=bins, stride=64 * ((bins + 63) // 64), keys={}, next_ixf=None, fname_idx=np.full(bins, -2, dtype=np.int64),
+                    child_of={}, max_elems=None)
+
+    ixfs = [new_ixf(100)]
+    mids = []
+    for b in range(100):
+        ixfs.append(new_ixf(100))
+        mids.append(len(ixfs) - 1)
+        ixfs[0]["fname_idx"][b] = -1
+        ixfs[0]["child_of"][b] = mids[-1]
+    leaves = {}
+    for m in mids:
+        for b in range(100):
+            ixfs.append(new_ixf(8))
+            leaves[(m, b)] = len(ixfs) - 1
+            ixfs[m]["fname_idx"][b] = -1
+            ixfs[m]["child_of"][b] = leaves[(m, b)]
+    assert len(ixfs) == 10101
+    spots = [(mids[0], 0, 3), (mids[40], 7, 0), (mids[79], 99, 5), (mids[81], 0, 1), (mids[99], 50, 7), (mids[99], 99, 2)]
+    ids = [leaves[(m, b)] for m, b, _ in spots]
+    assert min(ids) < 8192 < max(ids) and sum(i >= 8192 for i in ids) >= 3
+    planted_ub = []
+    for (m, b, leaf_bin), keys in zip(spots, planted):
+        ub = new_ub()
+        planted_ub.append(ub)
+        ixfs[leaves[(m, b)]]["keys"][leaf_bin] = keys
+        ixfs[leaves[(m, b)]]["fname_idx"][leaf_bin] = ub
+    lay = dict(ixfs=synth._finalize_layout(ixfs, new_ub, rng, "host"), n_user_bins=next_ub[0])
+    host = synth.materialize_host(lay)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    assert idx.depth == 3 and idx.n_ixf == 10101
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, origin = synth.synth_reads(g, go, 400, 1500, error_rate=0.02, frac_random=0.1, seed=5)
+    for sub in (0, 57):
+        sr = Searcher(idx, sub_batch_reads=sub)
+        res = sr.search_batch(bases, offs)
+        _compare(res, h.search_batch(bases, offs, threads=8), 400)
+        hit = sum(planted_ub[origin[i]] in [u for u, _ in res.tuples(i)] for i in range(400) if origin[i] >= 0)
+        assert hit > 0.85 * int((origin >= 0).sum())
+        sr.close()
+    idx.close()
+
+
 def test_pruning_with_rows_wider_than_one_block_pass():
     """5000 bins = 313 units: the dense loop needs two column passes and the alive-unit bitmap spans ten words;
     pruning, sparse probing and the tally must still equal the oracle"""
