@@ -559,26 +559,49 @@ int main(int argc, char **argv)
         return -1;
     }
     Config cfg;
-    for (; a < argc; ++a) {
-        const std::string k = argv[a];
+    // seqan3::argument_parser takes a long option's value either as the next argument or attached with '='
+    // ("--threads 4" / "--threads=4"); split the second form so that one loop handles both
+    std::vector<std::string> args;
+    for (int i = a; i < argc; ++i) {
+        const std::string tok = argv[i];
+        const size_t eq = tok.find('=');
+        if (tok.size() > 2 && tok[0] == '-' && tok[1] == '-' && eq != std::string::npos && eq > 2) {
+            args.push_back(tok.substr(0, eq));
+            args.push_back(tok.substr(eq + 1));
+        } else
+            args.push_back(tok);
+    }
+    for (size_t ai = 0; ai < args.size(); ++ai) {
+        const std::string k = args[ai];
         auto val = [&]() -> std::string {
-            if (a + 1 >= argc) die("Missing value for option " + k);
-            return argv[++a];
+            if (ai + 1 >= args.size()) die("Missing value for option " + k);
+            return args[++ai];
+        };
+        auto num = [&](const std::string &v, bool integer) -> double {   // seqan3 rejects "4x" / "abc" instead of reading a prefix
+            char *end = nullptr;
+            const double d = integer ? (double)strtoll(v.c_str(), &end, 10) : strtod(v.c_str(), &end);
+            if (v.empty() || !end || *end != '\0') die("Value parse failed for " + k + ": Argument " + v + " could not be parsed as type " + (integer ? "unsigned 64 bit integer." : "double."));
+            return d;
         };
         if (k == "--index-file") cfg.index_file = val();
         else if (k == "--query-file") cfg.query_file = val();
         else if (k == "--output-file") cfg.report_file = val();
         else if (k == "--threads") {
-            const long t = atol(val().c_str());
+            const long t = (long)num(val(), true);
             if (t < 1 || t > 32) die("Validation failed for option --threads: Value not in range [1,32].");   // :51-55
             cfg.threads = (unsigned)t;
         } else if (k == "--percentage") {
-            cfg.threshold = atof(val().c_str());
+            cfg.threshold = num(val(), false);
             if (cfg.threshold < 0.0 || cfg.threshold > 1.0) die("Validation failed for option --percentage: Value not in range [0,1]."); // :57-61
         } else if (k == "--error-rate") {
-            cfg.error_rate = atof(val().c_str());
+            cfg.error_rate = num(val(), false);
             if (cfg.error_rate < 0.0 || cfg.error_rate > 1.0) die("Validation failed for option --error-rate: Value not in range [0,1]."); // :63-67
-        } else if (k == "--gpu") cfg.gpus.assign(1, atoi(val().c_str()));
+        }
+        // hidden flags of the reference's parser (taxor_search.cpp:68-79): accepted, without effect there as here
+        else if (k == "--output-verbose-statistics" || k == "--debug") continue;
+        else if (k == "--version") { printf("taxor-search version: 0.2.0 (MI355X build)\n"); return 0; }               // :34
+        else if (k == "--") break;
+        else if (k == "--gpu") cfg.gpus.assign(1, atoi(val().c_str()));
         else if (k == "--gpus") {
             const int n = atoi(val().c_str());
             if (n < 1 || n > 64) die("Validation failed for option --gpus: Value not in range [1,64].");
@@ -591,7 +614,7 @@ int main(int argc, char **argv)
         }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--expect") cfg.expect_file = val();
-        else if (k == "-h" || k == "--help") { usage(); return 0; }
+        else if (k == "-h" || k == "--help" || k == "-hh" || k == "--advanced-help") { usage(); return 0; }
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
     if (cfg.index_file.empty()) die("Option --index-file is required but not set.");

@@ -77,6 +77,13 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
     want = HEADER + _expected(host, sp, ids, reads) + _expected(host, sp, ids2, reads2)
     assert open(out).read() == want
 
+    # the parser's other spelling (--opt=value) and the reference's hidden no-op flags (taxor_search.cpp:68-79)
+    out_eq = tmp_path / "out_eq.tsv"
+    cp = subprocess.run([TAXOR, "search", f"--index-file={idx_path}", f"--query-file={fq},{fa}", f"--output-file={out_eq}",
+                         "--threads=4", "--batch-reads=50", "--debug", "--output-verbose-statistics"], capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr
+    assert open(out_eq).read() == want
+
     # two (three) workers sharding the chunks -- here on the same device -- must give the identical file in input order
     for devs in ("0,0", "0,0,0"):
         out2 = tmp_path / "out_multi.tsv"
