@@ -112,6 +112,11 @@ def live_traffic(args):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not found"
+    # this process is itself being profiled (rocprofv3 -- python3 bench.py ...): nested counter passes would inherit the
+    # tool's environment and contend for the counters -- skip, and say so
+    if any("rocprofiler" in os.environ.get(v, "") or "rocprofv3" in os.environ.get(v, "")
+           for v in ("ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "ROCPROFILER_REGISTER_FORCE_LOAD")) or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return None, "skipped: this process runs under a rocprofiler tool already (use --traffic none when profiling bench.py)"
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "1", "--warmup", "0",
              "--workload", args.workload, "--family-size", str(args.family_size), "--read-error", str(args.read_error),
              "--error-rate", str(args.error_rate), "--batches", "1"]
@@ -176,7 +181,7 @@ def build_workload(args, local_rank, rank, world):
     genome_len = args.genome_len or wl["genome_len"]
     fam_size = max(1, min(args.family_size, n_genomes))
     k, s, t = 22, 12, 5
-    ncpu = os.cpu_count() or 8
+    ncpu = len(os.sched_getaffinity(0)) or 8       # this rank's cores (bound to its GPU's NUMA node in main())
 
     # ---- planted genomes and their syncmer hashes (hashed on the GPU; same seed on every rank) -------------
     t0 = time.time()
@@ -268,6 +273,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
+    # Bind this rank's host threads (and, by first touch, its staging buffers) to the NUMA node of its GPU before
+    # anything touches the GPU: eight ranks feeding eight GPUs from host memory otherwise stage across the socket
+    # fabric and share cores at random.  sysfs only, no numactl, no re-exec.
+    from taxor_amd import numa
+    full_affinity = os.sched_getaffinity(0)
+    numa_info = {"bound": False, "reason": "TAXOR_BENCH_NUMA=0"}
+    if os.environ.get("TAXOR_BENCH_NUMA", "1") != "0" and not args.pmc_child:
+        numa_info = numa.bind_to_gpu(0 if os.environ.get("TAXOR_BENCH_SAME_GPU") == "1" else local_rank)
+
     # live PMC passes run as child processes before anything here touches the GPU
     traffic, traffic_src = None, "not collected (--traffic none, a child run, or N > 1)"
     if args.traffic == "live" and not args.pmc_child and world == 1:
@@ -293,10 +307,27 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        # Fail loudly and early: a rendezvous or first-transfer failure must end the job with one readable line and a
+        # non-zero exit code, not a hang in the timed region or a silent change of transport (no fallback, no re-exec).
+        try:
+            import datetime
+            tmo = datetime.timedelta(seconds=float(os.environ.get("TAXOR_BENCH_RDZV_TIMEOUT", "600")))
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+            from taxor_amd import distributed as td_
+            dev_ = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
+            probe = td_.gather_csr(torch.tensor([0, 1], dtype=torch.int64, device=dev_), torch.tensor([rank], dtype=torch.int64, device=dev_),
+                                   torch.tensor([rank], dtype=torch.int32, device=dev_), torch.tensor([1], dtype=torch.int32, device=dev_), dst=0)
+            if rank == 0 and [int(x) for x in probe[1].cpu()] != list(range(world)):
+                raise RuntimeError(f"first point-to-point gather returned {probe[1].tolist()}")
+            if backend == "nccl":
+                torch.cuda.synchronize()
+        except Exception as e:
+            print(f"[bench] FATAL rank {rank}/{world}: {backend} ({'RCCL' if backend == 'nccl' else backend}) process group or first "
+                  f"point-to-point gather failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            os._exit(13)
 
     from taxor_amd import Searcher
 
@@ -401,24 +432,40 @@ def main():
 
     # N > 1: the drop-in call with HOST buffers on every rank at the same time -- the ranks share the host's memory
     # bandwidth and PCIe root complexes, which is where a sharded run is won or lost (the resident-batch `value` is not)
+    # The resident-batch `value` scales with N by construction; what decides >= 6x at N = 8 is the host side.  So rank 0
+    # first runs the host-fed measurement ALONE (the other ranks wait at a barrier: the N = 1 condition inside this very
+    # job), then every rank runs it at once; host_fed_scaling = sum of the concurrent per-rank rates / rank 0's solo rate.
     per_rank = None
     if world > 1 and not args.no_dropin and not args.pmc_child:
-        dist.barrier()
         small = argparse.Namespace(**vars(args))
         small.sustained_reads = max(1, args.sustained_reads // 4)
-        try:
-            single, sustained = dropin_measurements(small, idx, batches, read_len)
-        except Exception as e:       # an aid: its failure on one rank must not desynchronise the collective below
-            log(f"host-fed measurement failed: {type(e).__name__}: {e}")
-            single, sustained = {"value": 0.0}, None
-        mine = torch.tensor([single["value"], sustained["value"] if sustained else 0.0], dtype=torch.float64,
+
+        def host_fed():
+            try:
+                return dropin_measurements(small, idx, batches, read_len)
+            except Exception as e:   # an aid: its failure on one rank must not desynchronise the collectives below
+                log(f"host-fed measurement failed: {type(e).__name__}: {e}")
+                return {"value": 0.0}, None
+
+        dist.barrier()
+        solo = host_fed() if rank == 0 else None
+        dist.barrier()
+        single, sustained = host_fed()
+        mine = torch.tensor([single["value"], sustained["value"] if sustained else 0.0, float(numa_info.get("numa_node", -1)),
+                             float(numa_info.get("cpus", 0))], dtype=torch.float64,
                             device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
         if rank == 0:
+            solo_sus = solo[1]["value"] if solo and solo[1] else 0.0
+            ssum = float(sum(v[1] for v in allv))
             per_rank = {"single_call_Mbp_s": [round(float(v[0]), 1) for v in allv], "sustained_Mbp_s": [round(float(v[1]), 1) for v in allv],
-                        "sustained_sum_Mbp_s": round(float(sum(v[1] for v in allv)), 1),
-                        "note": "taxor_gpu_search_batch on host buffers, all ranks at once; per-rank rates, PCIe inside"}
+                        "sustained_sum_Mbp_s": round(ssum, 1),
+                        "solo_rank0": {"single_call_Mbp_s": round(float(solo[0]["value"]), 1) if solo else None, "sustained_Mbp_s": round(solo_sus, 1)},
+                        "host_fed_scaling": round(ssum / solo_sus, 3) if solo_sus > 0 else None,
+                        "numa_node": [int(v[2]) for v in allv], "bound_cpus": [int(v[3]) for v in allv],
+                        "note": "taxor_gpu_search_batch on host buffers (PCIe inside): rank 0 alone while the others wait, then all "
+                                "ranks at once; host_fed_scaling = sum of the concurrent per-rank sustained rates / rank 0's solo rate"}
 
     if args.pmc_child:                 # profiled child: the launches above are all the parent wanted
         for sr in searchers:
@@ -528,7 +575,12 @@ def main():
             out["pcie_inclusive"], out["sustained"] = dropin_measurements(args, idx, batches, read_len)
         if per_rank is not None:
             out["pcie_inclusive_per_rank"] = per_rank
+            out["sustained_sum_Mbp_s"] = per_rank["sustained_sum_Mbp_s"]
+            out["host_fed_scaling"] = per_rank["host_fed_scaling"]
+        out["host_binding"] = numa_info
         if world == 1 and not args.no_cpu_baseline:
+            os.sched_setaffinity(0, full_affinity)      # the CPU baseline is timed on the box's host cores, all sockets
+            ncpu = len(full_affinity)
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu)
         print(json.dumps(out), flush=True)
     for sr in searchers:

@@ -13,7 +13,7 @@ for bpc in 3 4 5 6; do
   TAXOR_QUERY_BPC=$bpc python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dropin > $O/bench_10k_bpc$bpc.json 2> $O/bench_10k_bpc$bpc.err
 done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1k -o t -- python3 $R/bench.py --steps 2 --warmup 1 --reads 1310720 --read-len 1000 --no-cpu-baseline --no-dropin > $O/bench_stats1k.json 2> $O/bench_stats1k.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1k -o t -- python3 $R/bench.py --traffic none --steps 2 --warmup 1 --reads 1310720 --read-len 1000 --no-cpu-baseline --no-dropin > $O/bench_stats1k.json 2> $O/bench_stats1k.err
 find $O/stats1k -name "*kernel_stats.csv" -exec head -12 {} \; > $O/stats1k_summary.txt
 find $O/stats1k -type f ! -name "*kernel_stats.csv" -delete
 for f in $O/bench_*.json; do echo "$f: $(python3 -c "

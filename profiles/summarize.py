@@ -57,6 +57,4 @@ if traffic.get("k_query_level"):
          "k_syncmers_bytes_per_launch": round(traffic.get("k_syncmers", 0.0), 1),
          "source": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + --pmc WRITE_SIZE, separate passes, "
                    + os.path.basename(out)}
-    with open(os.path.join(out, f"traffic_{wl}.json"), "w") as f:
-        json.dump(j, f, indent=1)
-    print("-- traffic:", json.dumps(j))
+    print("-- traffic:", json.dumps(j))        # informative only: bench.py measures its own traffic live (--traffic live)

@@ -5,7 +5,7 @@ WL=${1:-gtdb}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trace_overlap
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_overlap -o t -- python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_overlap -o t -- python3 $R/bench.py --workload $WL --steps 1 --warmup 0 --traffic none --no-cpu-baseline > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob,os
 R=os.environ.get("GRAFT_REPO_ROOT","/root/repo")

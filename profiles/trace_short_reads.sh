@@ -1,7 +1,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/trace1k
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace1k -o t -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-dropin --reads 1310720 --read-len 1000 > $R/gpurun_out/trace1k.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace1k -o t -- python3 $R/bench.py --steps 1 --warmup 0 --traffic none --no-cpu-baseline --no-dropin --reads 1310720 --read-len 1000 > $R/gpurun_out/trace1k.json 2>/dev/null
 python3 - <<'PY'
 import csv,glob,os,json
 R=os.environ.get("GRAFT_REPO_ROOT","/root/repo")

@@ -67,3 +67,29 @@ def test_three_ranks_weak_scaling_gathers_every_shard(tmp_path):
     assert int(r3["read_off"][-1]) == r3["user_bin"].size > t
     # weak scaling: three times the bases per step
     assert abs(j3["value"] * j3["ms_per_step"] / (j1["value"] * j1["ms_per_step"]) - 3.0) < 6e-2
+
+
+def test_eight_ranks_on_one_gpu(tmp_path):
+    """the driver's largest launch (N = 8) in miniature: eight ranks through torch.distributed.run, all on GPU 0; the gathered
+    CSR of the strong-scaling run equals the single-rank result, and the line carries the host-fed scaling figures"""
+    j1, r1 = _run(1, ["--scaling", "strong"], tmp_path / "n1.npz")
+    j8, r8 = _run(8, ["--scaling", "strong"], tmp_path / "n8.npz")
+    assert j8["n_gpus"] == 8
+    for key in ("read_off", "user_bin", "count", "n_hashes"):
+        assert np.array_equal(r1[key], r8[key]), key
+    pr = j8["pcie_inclusive_per_rank"]
+    assert len(pr["sustained_Mbp_s"]) == 8 and all(v > 0 for v in pr["sustained_Mbp_s"])
+    assert pr["solo_rank0"]["sustained_Mbp_s"] > 0
+    assert j8["sustained_sum_Mbp_s"] == pr["sustained_sum_Mbp_s"] and j8["host_fed_scaling"] == pr["host_fed_scaling"] > 0
+    assert "host_binding" in j8 and "host_binding" in j1
+
+
+def test_rendezvous_failure_is_loud(tmp_path):
+    """a rank whose process group cannot form ends with one FATAL line and a non-zero exit code (no hang, no fallback):
+    WORLD_SIZE says two ranks, only one is started, and the rendezvous times out"""
+    env = dict(os.environ, TAXOR_BENCH_BACKEND="gloo", TAXOR_BENCH_SAME_GPU="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="1", LOCAL_RANK="1", WORLD_SIZE="2", TAXOR_BENCH_RDZV_TIMEOUT="20")
+    cp = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "tiny", "--traffic", "none"], cwd=ROOT, env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 13, (cp.returncode, cp.stderr[-2000:])
+    assert "FATAL rank 1/2" in cp.stderr and not [l for l in cp.stdout.splitlines() if l.startswith("{")]
