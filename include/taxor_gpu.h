@@ -197,6 +197,45 @@ int taxor_gpu_batch_result_sizes(taxor_gpu_searcher *s, uint64_t *n_reads, uint6
 int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read_off, void *d_user_bin, void *d_count,
                                   void *d_n_hashes);
 
+/* ------------------------------------------------------------------------------------------------
+ * Several GPUs of one node, driven by ONE host process (taxor search --gpus N).  Reads are independent
+ * (taxor_search.cpp:214): the index is replicated, every device classifies its own batches, and the path has two
+ * exchange steps, both behind a communicator:
+ *   taxor_gpu_index_create_replicated : one PCIe upload into devices[0], ncclBroadcast of the fingerprint slab to
+ *                                       the others behind it (instead of N uploads of the same index);
+ *   taxor_gpu_gather_results          : after a round in which searcher i classified its own batch on devices[i],
+ *                                       the per-read results of all of them on devices[0] (grouped ncclSend /
+ *                                       ncclRecv, every peer on its own xGMI link), handed out as ONE CSR in device
+ *                                       order -- reads of searcher 0 first -- with offsets rebased.
+ * Replaces: the reference has one address space; its workers write into one result stream under a mutex
+ * (taxor_search.cpp:311, sync_out.hpp:24-29) and all read the one loaded index (taxor_search.cpp:323).
+ * Transports: TAXOR_COMM_RCCL (RCCL bound at run time; one rank per device, a device may not repeat) or
+ * TAXOR_COMM_HOST (same calls, every transfer staged through host memory over each device's own PCIe link).  A
+ * communicator never changes transport by itself: a failing RCCL call is an error return.
+ * Single-caller: create / replicate / gather are called from one host thread while no searcher of the communicator
+ * is running a batch (gather synchronises the searchers it is given).  Result pointers stay valid until the next
+ * gather on the communicator.
+ * ---------------------------------------------------------------------------------------------- */
+enum { TAXOR_COMM_RCCL = 0, TAXOR_COMM_HOST = 1 };
+typedef struct taxor_gpu_comm taxor_gpu_comm;
+int taxor_gpu_comm_create(const int *devices, uint32_t n_devices, int transport, taxor_gpu_comm **out);
+void taxor_gpu_comm_destroy(taxor_gpu_comm *c);
+/* out[n_devices]: out[i] is the replica on devices[i]; each is destroyed with taxor_gpu_index_destroy */
+int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_hixf_view *view, taxor_gpu_index **out);
+/* searchers[n_devices]: searcher i was created on out[i] / devices[i] and has a run in flight or finished */
+int taxor_gpu_gather_results(taxor_gpu_comm *c, taxor_gpu_searcher *const *searchers, taxor_gpu_results *out);
+typedef struct {
+    int32_t transport;
+    uint32_t n_devices;
+    uint64_t index_bytes;            /* fingerprint bytes of one replica                                  */
+    uint64_t index_upload_bytes;     /* bytes that crossed PCIe host -> device for the replicas           */
+    uint64_t index_broadcast_bytes;  /* bytes delivered device -> device by ncclBroadcast                 */
+    double index_seconds;            /* wall time of taxor_gpu_index_create_replicated                    */
+    uint64_t gathers, gather_bytes;  /* gather calls; result bytes that left a peer device                */
+    double gather_seconds;           /* wall time inside taxor_gpu_gather_results (sync of the runs included) */
+} taxor_gpu_comm_stats;
+int taxor_gpu_comm_info(const taxor_gpu_comm *c, taxor_gpu_comm_stats *out);
+
 /* Measurement of the last taxor_gpu_batch_run (valid after sync).  algorithmic_bytes follows SURVEY.md
  * section 8(d): sum over reads of ceil(L/4) + sum over visited IXFs n_h*3*bins + 8 + 12*tuples;
  * query_* are the dominant kernel (k_query_level) only: launches, HIP-event milliseconds on the searcher's

@@ -4,6 +4,6 @@ The product is libtaxor_gpu.so (hand-written HIP for gfx950 behind the C ABI in 
 C++ `taxor search` host (taxor_amd/csrc).  This package is the Python mirror of the host interface used by
 the tests and bench.py.  There is no CPU fallback: without the HIP library every compute call raises."""
 from . import _lib
-from .search import GpuIndex, Searcher, SearchResults, classify_filter, threshold, threshold_ratio  # noqa: F401
+from .search import Comm, GpuIndex, Searcher, SearchResults, classify_filter, threshold, threshold_ratio  # noqa: F401
 
-__all__ = ["GpuIndex", "Searcher", "SearchResults", "classify_filter", "threshold", "threshold_ratio", "_lib"]
+__all__ = ["Comm", "GpuIndex", "Searcher", "SearchResults", "classify_filter", "threshold", "threshold_ratio", "_lib"]

@@ -49,6 +49,15 @@ class RunStats(C.Structure):
                 ("level_ms", C.c_float * 8), ("level_requested_bytes", C.c_uint64 * 8), ("level_row_reads", C.c_uint64 * 8)]
 
 
+class CommStats(C.Structure):
+    _fields_ = [("transport", C.c_int32), ("n_devices", C.c_uint32), ("index_bytes", C.c_uint64), ("index_upload_bytes", C.c_uint64),
+                ("index_broadcast_bytes", C.c_uint64), ("index_seconds", C.c_double), ("gathers", C.c_uint64),
+                ("gather_bytes", C.c_uint64), ("gather_seconds", C.c_double)]
+
+
+COMM_RCCL, COMM_HOST = 0, 1
+
+
 class Species(C.Structure):
     _fields_ = [("organism_name", C.c_char_p), ("accession_id", C.c_char_p), ("taxid", C.c_char_p),
                 ("taxnames_string", C.c_char_p), ("taxid_string", C.c_char_p), ("user_bin", C.c_uint64),
@@ -108,6 +117,11 @@ SIGNATURES = {
     "taxor_gpu_batch_result_sizes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "taxor_gpu_batch_export_device": (C.c_int, [_P, _P, _P, _P, _P]),
     "taxor_gpu_batch_stats": (C.c_int, [_P, C.POINTER(RunStats)]),
+    "taxor_gpu_comm_create": (C.c_int, [C.POINTER(C.c_int), C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "taxor_gpu_comm_destroy": (None, [_P]),
+    "taxor_gpu_index_create_replicated": (C.c_int, [_P, C.POINTER(HixfView), C.POINTER(_P)]),
+    "taxor_gpu_gather_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(Results)]),
+    "taxor_gpu_comm_info": (C.c_int, [_P, C.POINTER(CommStats)]),
     "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),

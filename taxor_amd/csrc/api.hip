@@ -81,6 +81,9 @@ struct taxor_gpu_index {
     uint32_t scaling = 1;
     int w_min = 0;           // > 0: index built without --use-syncmer, minimiser window size (== k: every k-mer)
     std::vector<uint32_t> h_binfo, h_bin_base;   // host copies for the hierarchical builder (bin_base has n_ixf + 1 entries)
+    std::vector<int64_t> h_ubin;                 // host copies of the other per-bin tables: a replica on another device
+    std::vector<uint32_t> h_dfs;                 // (comm.hip) gets them from here, its fingerprint slab over RCCL
+    std::vector<uint64_t> slab_off;              // byte offset of every IXF inside the slab
 };
 
 struct SubBatch {
@@ -175,7 +178,9 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 // =========================================================================================================
 // index
 // =========================================================================================================
-extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
+// upload = false: everything but the fingerprint bytes (the slab is allocated, its rows are left as they are) -- for a
+// replica that receives them over RCCL, or through a pipelined upload (comm.hip)
+static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, taxor_gpu_index **out)
 {
     if (!v || !out || v->n_ixf == 0 || !v->ixf) return fail(TAXOR_E_ARG, "index_create: empty view");
     if (!v->use_syncmer) { // seqan3 minimiser_hash over window_size (taxor_search.cpp:210-212)
@@ -315,7 +320,7 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
     }
     for (uint64_t i = 0; i < n; ++i) {
         idx->h_ixf[i].data = idx->d_slab + slab_off[i];
-        if (v->ixf[i].data) {
+        if (upload && v->ixf[i].data) {
             e = hipMemcpy(idx->d_slab + slab_off[i], v->ixf[i].data, idx->rows[i] * v->ixf[i].stride, hipMemcpyHostToDevice);
             if (e != hipSuccess) {
                 taxor_gpu_index_destroy(idx);
@@ -335,8 +340,34 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
         taxor_gpu_index_destroy(idx);
         return fail(TAXOR_E_HIP, "index_create: table upload failed");
     }
+    idx->h_ubin = std::move(ubin);
+    idx->h_dfs = std::move(dfs);
+    idx->slab_off = std::move(slab_off);
     *out = idx;
     return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
+{
+    return index_create_impl(v, device, true, out);
+}
+
+// library-internal (comm.hip): an index on `device` with every table in place and an allocated but unwritten slab
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_create_empty(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
+{
+    return index_create_impl(v, device, false, out);
+}
+
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_slab(taxor_gpu_index *idx, uint8_t **slab, uint64_t *slab_bytes,
+                                                                      const uint64_t **ixf_off, uint64_t *n_ixf, int *device)
+{
+    if (!idx) return -1;
+    *slab = idx->d_slab;
+    *slab_bytes = idx->slab_bytes;
+    *ixf_off = idx->slab_off.data();
+    *n_ixf = idx->h_ixf.size();
+    *device = idx->device;
+    return 0;
 }
 
 extern "C" void taxor_gpu_index_destroy(taxor_gpu_index *idx)
@@ -1238,6 +1269,25 @@ extern "C" int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read
     if (d_count && nt) HIP_TRY(hipMemcpyAsync(d_count, s->d_out_cnt.p, nt * 4, hipMemcpyDeviceToDevice, s->st));
     if (d_n_hashes && nr) HIP_TRY(hipMemcpyAsync(d_n_hashes, s->d_nh.p, nr * 4, hipMemcpyDeviceToDevice, s->st));
     HIP_TRY(hipStreamSynchronize(s->st));
+    return TAXOR_OK;
+}
+
+// library-internal (comm.hip): the device-resident CSR of the last run, for the RCCL gather.  Synchronises the run.
+extern "C" __attribute__((visibility("hidden"))) int taxor_searcher_device_results(taxor_gpu_searcher *s, const uint64_t **d_read_off,
+                                                                                   const int64_t **d_user_bin, const uint32_t **d_count,
+                                                                                   const uint32_t **d_n_hashes, uint64_t *n_reads,
+                                                                                   uint64_t *n_tuples, int *device)
+{
+    if (!s) return fail(TAXOR_E_ARG, "device_results: null searcher");
+    if (!s->synced)
+        if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    *d_read_off = s->d_read_off.p;
+    *d_user_bin = s->d_out_ub.p;
+    *d_count = s->d_out_cnt.p;
+    *d_n_hashes = s->d_nh.p;
+    *n_reads = s->n_reads;
+    *n_tuples = s->h_ctr.tuple_total;
+    *device = s->idx->device;
     return TAXOR_OK;
 }
 

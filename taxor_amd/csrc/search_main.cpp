@@ -48,6 +48,15 @@ public:
         not_full_.notify_one();
         return true;
     }
+    bool try_pop(T &out) // false if nothing is queued right now
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
     void close()
     {
         std::lock_guard<std::mutex> lk(m_);
@@ -96,6 +105,8 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
+    std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
+                                // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
 };
 
 std::vector<std::string> str_split(const std::string &s, char delim)         // taxor_search.cpp:82-95
@@ -136,6 +147,8 @@ void usage()
             "  --gpu <id>               device ordinal (default 0)\n"
             "  --gpus <n>               use devices 0..n-1: the index is replicated, batches of reads are sharded\n"
             "  --gpu-list <a,b,..>      explicit device list (a device may be listed twice)\n"
+            "  --gather <rccl|host|none> several devices: index broadcast + per-round gather of the results on the first device over\n"
+            "                           RCCL/xGMI (default), the same staged through host memory, or independent workers\n"
             "  --batch-reads <n>        reads per GPU batch (default: about 128 MB of query file, 65536 reads for gzip)\n"
             "  --expect <tsv>           compare the output per read with a TSV the reference wrote for the same input (exit 3 if it differs)\n");
 }
@@ -614,6 +627,10 @@ int main(int argc, char **argv)
         }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--expect") cfg.expect_file = val();
+        else if (k == "--gather") {
+            cfg.gather = val();
+            if (cfg.gather != "rccl" && cfg.gather != "host" && cfg.gather != "none") die("Validation failed for option --gather: Value not in {rccl, host, none}.");
+        }
         else if (k == "-h" || k == "--help" || k == "-hh" || k == "--advanced-help") { usage(); return 0; }
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
@@ -651,7 +668,7 @@ int main(int argc, char **argv)
     if (!out) die("cannot open output file " + cfg.report_file);
     fputs("#QUERY_NAME\tACCESSION\tREFERENCE_NAME\tTAXID\tREF_LEN\tQUERY_LEN\tQHASH_COUNT\tQHASH_MATCH\tTAX_STR\tTAX_ID_STR\n", out);
 
-    double t_index = 0, t_reads = 0, t_compute = 0, t_pin = 0, t_search = 0;
+    double t_index = 0, t_reads = 0, t_compute = 0, t_pin = 0, t_search = 0, t_gather = 0;
     uint64_t n_batches = 0;
     uint64_t total_reads = 0, total_bases = 0;
     std::mutex stat_mu;
@@ -673,7 +690,28 @@ int main(int argc, char **argv)
         // replicated, batches are sharded); replicas are uploaded concurrently
         const size_t ng = cfg.gpus.size();
         std::vector<taxor_gpu_index *> gidx(ng, nullptr);
-        {
+        // Several devices (north star: "reads sharded across the GPUs, per-read results gathered over RCCL/xGMI"): one
+        // communicator; the index crosses PCIe once and is broadcast, rounds of ng batches are classified side by side and
+        // their results gathered on the first device (taxor_gpu.h, "Several GPUs of one node").  The transport is decided
+        // here, once, by rule -- never by a failure.
+        taxor_gpu_comm *comm = nullptr;
+        std::string gather = cfg.gather;
+        if (gather.empty()) {
+            bool distinct = true;
+            for (size_t i = 0; i < ng; ++i)
+                for (size_t j = i + 1; j < ng; ++j) distinct = distinct && cfg.gpus[i] != cfg.gpus[j];
+            gather = ng == 1 ? "none" : (distinct ? "rccl" : "host");
+        }
+        if (gather != "none") {
+            if (taxor_gpu_comm_create(cfg.gpus.data(), (uint32_t)ng, gather == "rccl" ? TAXOR_COMM_RCCL : TAXOR_COMM_HOST, &comm) != TAXOR_OK)
+                die(std::string(taxor_gpu_last_error()) + "\n(--gather host stages the same transfers through host memory)");
+            if (taxor_gpu_index_create_replicated(comm, view, gidx.data()) != TAXOR_OK) die(taxor_gpu_last_error());
+            taxor_gpu_comm_stats cs{};
+            taxor_gpu_comm_info(comm, &cs);
+            if (getenv("TAXOR_CLI_TRACE"))
+                fprintf(stderr, "[trace] index on %zu devices (%s): %.2f GB per replica, %.2f GB over PCIe, %.2f GB by ncclBroadcast, %.3f s\n", ng,
+                        gather.c_str(), cs.index_bytes / 1e9, cs.index_upload_bytes / 1e9, cs.index_broadcast_bytes / 1e9, cs.index_seconds);
+        } else {
             std::vector<std::thread> up;
             std::vector<std::string> errs(ng);
             for (size_t g = 0; g < ng; ++g)
@@ -790,6 +828,78 @@ int main(int argc, char **argv)
             }
         });
         std::vector<std::thread> workers;
+        if (comm)
+            workers.emplace_back([&] {
+                // one round = up to ng batches, batch j on device j, classified side by side; then ONE gather of the round's
+                // per-read results on the first device and one copy to the host.  Devices without a batch in a round run an
+                // empty one, so that every searcher has a finished run to gather.
+                std::vector<std::unique_ptr<Batch>> round;
+                std::unique_ptr<Batch> b;
+                const uint64_t zero_off[1] = {0};
+                for (;;) {
+                    round.clear();
+                    if (!q_in.pop(b)) break;
+                    if (b->end_of_file) { q_out.push(std::move(b)); continue; }
+                    round.push_back(std::move(b));
+                    std::unique_ptr<Batch> eof;           // an end-of-file marker ends the round and follows it
+                    while (round.size() < ng && q_in.try_pop(b)) {
+                        if (b->end_of_file) { eof = std::move(b); break; }
+                        round.push_back(std::move(b));
+                    }
+                    const double t1 = now();
+                    std::vector<std::thread> dev;
+                    std::vector<std::string> errs(ng);
+                    for (size_t g = 0; g < ng; ++g)
+                        dev.emplace_back([&, g] {
+                            if (g >= round.size()) {
+                                if (taxor_gpu_search_batch_begin(sr[g], nullptr, zero_off, 0) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                                return;
+                            }
+                            Batch &bt = *round[g];
+                            if (bt.may_pin && !bt.pinned && bt.bases.capacity() >= (1u << 20) &&
+                                taxor_gpu_host_register(&bt.bases[0], bt.bases.capacity()) == TAXOR_OK)
+                                bt.pinned = &bt.bases[0];
+                            int rc = taxor_gpu_search_batch_begin(sr[g], bt.bases.data(), bt.offsets.data(), bt.ids.size());
+                            if (rc == TAXOR_OK) rc = taxor_gpu_batch_sync(sr[g]);
+                            if (rc == TAXOR_E_ALPHABET && strip_space_and_digits(bt)) {
+                                rc = taxor_gpu_search_batch_begin(sr[g], bt.bases.data(), bt.offsets.data(), bt.ids.size());
+                                if (rc == TAXOR_OK) rc = taxor_gpu_batch_sync(sr[g]);
+                            }
+                            if (rc != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                        });
+                    for (auto &t : dev) t.join();
+                    for (const auto &e : errs)
+                        if (!e.empty()) die(e);
+                    const double t2 = now();
+                    taxor_gpu_results res{};
+                    if (taxor_gpu_gather_results(comm, sr.data(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                    const double t3 = now();
+                    uint64_t r0 = 0;
+                    for (auto &bt : round) {               // the gathered CSR is in device order = batch order of the round
+                        const uint64_t n = bt->ids.size(), t0_ = res.read_off[r0], t1_ = res.read_off[r0 + n];
+                        bt->read_off.resize(n + 1);
+                        for (uint64_t i = 0; i <= n; ++i) bt->read_off[i] = res.read_off[r0 + i] - t0_;
+                        bt->user_bin.assign(res.user_bin + t0_, res.user_bin + t1_);
+                        bt->count.assign(res.count + t0_, res.count + t1_);
+                        bt->n_hashes.assign(res.n_hashes + r0, res.n_hashes + r0 + n);
+                        r0 += n;
+                        std::lock_guard<std::mutex> lk(stat_mu);
+                        ++n_batches;
+                        total_reads += n;
+                        total_bases += bt->bases.size();
+                    }
+                    if (r0 != res.n_reads) die("internal: the gathered round does not hold the round's reads");
+                    {
+                        std::lock_guard<std::mutex> lk(stat_mu);
+                        t_search += t2 - t1;
+                        t_gather += t3 - t2;
+                        t_compute += now() - t1;
+                    }
+                    for (auto &bt : round) q_out.push(std::move(bt));
+                    if (eof) q_out.push(std::move(eof));
+                }
+            });
+        else
         for (size_t g = 0; g < ng; ++g)
             workers.emplace_back([&, g] {
                 std::unique_ptr<Batch> b;
@@ -829,10 +939,16 @@ int main(int argc, char **argv)
         writer.join();
         trace("writer done");
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
-        for (size_t g = 0; g < ng; ++g) {
-            taxor_gpu_searcher_destroy(sr[g]);
-            taxor_gpu_index_destroy(gidx[g]);
+        for (size_t g = 0; g < ng; ++g) taxor_gpu_searcher_destroy(sr[g]);
+        if (comm) {
+            taxor_gpu_comm_stats cs{};
+            taxor_gpu_comm_info(comm, &cs);
+            if (getenv("TAXOR_CLI_TRACE"))
+                fprintf(stderr, "[trace] %llu gathers (%s): %.1f MB from peer devices, %.3f s inside taxor_gpu_gather_results\n",
+                        (unsigned long long)cs.gathers, gather.c_str(), cs.gather_bytes / 1e6, cs.gather_seconds);
+            taxor_gpu_comm_destroy(comm);
         }
+        for (size_t g = 0; g < ng; ++g) taxor_gpu_index_destroy(gidx[g]);
         trace("GPU memory released");
         taxor_hixf_free(h);
         trace("host index released");
@@ -858,8 +974,8 @@ int main(int argc, char **argv)
     fclose(out);
     trace("output closed");
     if (getenv("TAXOR_CLI_TRACE"))
-        fprintf(stderr, "[trace] %llu batches: pin %.3f s, search_batch %.3f s, copy-out %.3f s\n", (unsigned long long)n_batches, t_pin,
-                t_search, t_compute - t_pin - t_search);
+        fprintf(stderr, "[trace] %llu batches: pin %.3f s, search_batch %.3f s, gather %.3f s, copy-out %.3f s\n", (unsigned long long)n_batches, t_pin,
+                t_search, t_gather, t_compute - t_pin - t_search - t_gather);
     printf("Index I/O\tReads I/O\tCompute\n%.2f\t%.2f\t%.2f\n", t_index, t_reads, t_compute);   // :328-336
     printf("%llu reads, %llu bases classified\n", (unsigned long long)total_reads, (unsigned long long)total_bases);
     {   // the reference's main() closes with the process's CPU time and peak resident set (main.cpp:37-49,79-84)

@@ -75,7 +75,16 @@ class GpuIndex:
     def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None):
         """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)}"""
         L = _lib.lib()
-        self._keep = []
+        view, keep = self._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size)
+        h = C.c_void_p()
+        check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
+        del keep                 # the library copied everything into HBM
+        self._adopt(h, ixfs, n_user_bins, k, s, t, device, use_syncmer, window_size)
+
+    @staticmethod
+    def _view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size):
+        """taxor_hixf_view over numpy arrays (+ the arrays that must stay alive while the library reads it)"""
+        keep = []
         arr = (_lib.IxfView * len(ixfs))()
         for i, f in enumerate(ixfs):
             nx = np.ascontiguousarray(f["next_ixf"], dtype=np.int64)
@@ -85,16 +94,17 @@ class GpuIndex:
             if d is not None:
                 d = np.ascontiguousarray(d, dtype=np.uint8)
                 assert d.size == 3 * f["seg_len"] * f["stride"], "IXF data size mismatch"
-            self._keep += [nx, fn, d]
+            keep += [nx, fn, d]
             arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"],
                                   d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data)
+        ws = int(window_size) if window_size is not None else k
+        keep.append(arr)
+        return _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, ws), keep
+
+    def _adopt(self, h, ixfs, n_user_bins, k, s, t, device, use_syncmer, window_size):
+        self._h = h
         self.use_syncmer = bool(use_syncmer)
         self.window_size = int(window_size) if window_size is not None else k
-        view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, self.window_size)
-        h = C.c_void_p()
-        check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
-        self._h = h
-        self._keep = []          # the library copied everything into HBM
         self.device = device
         self.k, self.s, self.t = k, s, t
         self.n_ixf = len(ixfs)
@@ -291,3 +301,50 @@ class Searcher:
         check(_lib.lib().taxor_gpu_bulk_contains(self._h, _p(h), h.size, int(thr), C.byref(res)))
         r = _results(res)
         return r.user_bin, r.count
+
+
+class Comm:
+    """Several GPUs of one node driven by this one process (the C++ host's `taxor search --gpus N` shape): the index is
+    replicated (one upload + ncclBroadcast), every device classifies its own batch, results are gathered on devices[0].
+    transport: "rccl" (RCCL over xGMI, one rank per device) or "host" (same calls staged through host memory)."""
+
+    def __init__(self, devices, transport="rccl"):
+        self.devices = [int(d) for d in devices]
+        self.transport = transport
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        check(_lib.lib().taxor_gpu_comm_create(arr, len(self.devices), _lib.COMM_RCCL if transport == "rccl" else _lib.COMM_HOST, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().taxor_gpu_comm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def replicate_index(self, ixfs, n_user_bins, k=22, s=12, t=5, use_syncmer=True, scaling=1, window_size=None):
+        """-> [GpuIndex on devices[0], GpuIndex on devices[1], ...]"""
+        view, keep = GpuIndex._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size)
+        out = (C.c_void_p * len(self.devices))()
+        check(_lib.lib().taxor_gpu_index_create_replicated(self._h, C.byref(view), out))
+        del keep
+        idx = []
+        for d, h in zip(self.devices, out):
+            g = GpuIndex.__new__(GpuIndex)
+            g._adopt(C.c_void_p(h), ixfs, n_user_bins, k, s, t, d, use_syncmer, window_size)
+            idx.append(g)
+        return idx
+
+    def gather(self, searchers) -> SearchResults:
+        """per-read results of one round (searcher i ran its batch on devices[i]) as one CSR in device order"""
+        assert len(searchers) == len(self.devices)
+        arr = (C.c_void_p * len(searchers))(*[s._h for s in searchers])
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_gather_results(self._h, arr, C.byref(res)))
+        return _results(res)
+
+    def info(self):
+        st = _lib.CommStats()
+        check(_lib.lib().taxor_gpu_comm_info(self._h, C.byref(st)))
+        return {f: getattr(st, f) for f, _ in _lib.CommStats._fields_}

@@ -92,6 +92,21 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
         assert cp.returncode == 0, cp.stderr
         assert open(out2).read() == want
 
+    # the communicator paths: rounds of batches + one gather per round (host transport: a device may repeat; RCCL: one rank)
+    for extra in (["--gpu-list", "0,0", "--gather", "host"], ["--gpu-list", "0,0,0"], ["--gpu", "0", "--gather", "rccl"],
+                  ["--gpu-list", "0,0", "--gather", "none"]):
+        out3 = tmp_path / "out_comm.tsv"
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--output-file",
+                             str(out3), "--batch-reads", "23", "--threads", "3"] + extra, capture_output=True, text=True, timeout=300,
+                            env=dict(os.environ, TAXOR_CLI_TRACE="1"))
+        assert cp.returncode == 0, cp.stderr
+        assert open(out3).read() == want, extra
+        if "none" not in extra:
+            assert "gathers (" in cp.stderr
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out), "--gpu-list", "0,0",
+                         "--gather", "rccl"], capture_output=True, text=True, timeout=300)
+    assert cp.returncode != 0 and "listed twice" in cp.stderr and "--gather host" in cp.stderr
+
     # --error-rate / --percentage change the threshold exactly like the reference's models
     for extra, kw in ((["--error-rate", "0.1"], dict(err=0.1)), (["--percentage", "0.3"], dict(percentage=0.3))):
         cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out)]

@@ -1,0 +1,107 @@
+"""The C-ABI communicator (taxor_gpu_comm_*, taxor_amd/csrc/comm.hip): index replication and the per-round gather of the
+per-read results.  One GPU is what the test box has, so RCCL runs as a communicator of one rank (ncclCommInitAll over one
+device: the broadcast and the gather degenerate to their device-0 halves, which is the code every larger run also goes
+through for rank 0) and the several-replica logic is exercised through the host transport, which accepts a device twice.
+Both transports must hand out byte-identical CSRs, equal to the concatenation of the searchers' own results."""
+import numpy as np
+import pytest
+
+from taxor_amd import Comm, GpuIndex, Searcher, synth
+from taxor_amd._lib import TaxorError
+
+pytestmark = pytest.mark.gpu
+
+
+def _index_and_batches(n_batches, seed=7):
+    g, go = synth.random_genomes(6, 20000, seed=seed)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64),
+                           fname_idx=np.arange(bins), data=np.zeros(3 * 16 * 64, np.uint8))], bins)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(6)]
+    lay = synth.make_layout(planted, root_bins=64, child_bins=32, n_children=3, seed=seed)
+    host = synth.materialize_host(lay)
+    batches = [synth.synth_reads(g, go, 150 + 37 * b, 1500, error_rate=0.02, frac_random=0.15, seed=seed + 10 + b)[:2] for b in range(n_batches)]
+    return host, lay["n_user_bins"], batches
+
+
+def _concat(results):
+    off, base = [np.zeros(1, np.uint64)], 0
+    for r in results:
+        off.append(r.read_off[1:] + np.uint64(base))
+        base += int(r.read_off[-1])
+    return (np.concatenate(off), np.concatenate([r.user_bin for r in results]), np.concatenate([r.count for r in results]),
+            np.concatenate([r.n_hashes for r in results]))
+
+
+def _same(res, want):
+    return (np.array_equal(res.read_off, want[0]) and np.array_equal(res.user_bin, want[1]) and np.array_equal(res.count, want[2])
+            and np.array_equal(res.n_hashes, want[3]))
+
+
+@pytest.mark.parametrize("transport", ["rccl", "host"])
+def test_single_rank_communicator(transport):
+    host, nub, batches = _index_and_batches(2)
+    ref_idx = GpuIndex(host, nub)
+    ref = Searcher(ref_idx)
+    want = [ref.search_batch(*b) for b in batches]
+    comm = Comm([0], transport)
+    (idx,) = comm.replicate_index(host, nub)
+    assert idx.data_bytes == ref_idx.data_bytes
+    for i in range(len(host)):       # the replica holds the same fingerprint bytes
+        assert np.array_equal(idx.download_ixf(i), ref_idx.download_ixf(i))
+    sr = Searcher(idx)
+    for b, w in zip(batches, want):
+        sr.search_batch_begin(*b)
+        got = comm.gather([sr])
+        assert _same(got, (w.read_off, w.user_bin, w.count, w.n_hashes))
+        assert got.user_bin.size > 0
+    info = comm.info()
+    assert info["n_devices"] == 1 and info["gathers"] == 2 and info["index_bytes"] == ref_idx.data_bytes
+    sr.close(); idx.close(); comm.close(); ref.close(); ref_idx.close()
+
+
+def test_host_transport_three_replicas_one_round():
+    """three replicas (the same device three times: only the host transport allows that), one batch each, an empty batch on the
+    third searcher in the second round"""
+    host, nub, batches = _index_and_batches(3)
+    comm = Comm([0, 0, 0], "host")
+    idxs = comm.replicate_index(host, nub)
+    srs = [Searcher(i) for i in idxs]
+    singles = [Searcher(idxs[0]).search_batch(*b) for b in batches]
+    for s, b in zip(srs, batches):
+        s.search_batch_begin(*b)
+    got = comm.gather(srs)
+    assert _same(got, _concat(singles))
+    # second round: devices 0 and 1 swap batches, device 2 has none
+    srs[0].search_batch_begin(*batches[1])
+    srs[1].search_batch_begin(*batches[0])
+    srs[2].search_batch_begin(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    got = comm.gather(srs)
+    assert _same(got, _concat([singles[1], singles[0]]))
+    assert comm.info()["index_upload_bytes"] == 3 * idxs[0].data_bytes
+    for s in srs:
+        s.close()
+    for i in idxs:
+        i.close()
+    comm.close()
+
+
+def test_rccl_refuses_a_repeated_device_and_unknown_devices():
+    with pytest.raises(TaxorError, match="listed twice"):
+        Comm([0, 0], "rccl")
+    with pytest.raises(TaxorError, match="does not exist"):
+        Comm([0, 99], "host")
+
+
+def test_gather_checks_the_searchers_device():
+    host, nub, batches = _index_and_batches(1)
+    comm = Comm([0], "host")
+    (idx,) = comm.replicate_index(host, nub)
+    sr = Searcher(idx)
+    with pytest.raises(TaxorError, match="no run in flight"):
+        comm.gather([sr])
+    sr.close(); idx.close(); comm.close()
