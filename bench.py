@@ -111,12 +111,12 @@ def parse_args(argv=None):
 def live_traffic(args):
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     # this process is itself being profiled (rocprofv3 -- python3 bench.py ...): nested counter passes would inherit the
     # tool's environment and contend for the counters -- skip, and say so
     if any("rocprofiler" in os.environ.get(v, "") or "rocprofv3" in os.environ.get(v, "")
            for v in ("ROCP_TOOL_LIBRARIES", "LD_PRELOAD", "ROCPROFILER_REGISTER_FORCE_LOAD")) or os.environ.get("ROCP_TOOL_LIBRARIES"):
-        return None, "skipped: this process runs under a rocprofiler tool already (use --traffic none when profiling bench.py)"
+        return None, "skipped: this process runs under a rocprofiler tool already (use --traffic none when profiling bench.py)", {}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "1", "--warmup", "0",
              "--workload", args.workload, "--family-size", str(args.family_size), "--read-error", str(args.read_error),
              "--error-rate", str(args.error_rate), "--batches", "1"]
@@ -130,43 +130,74 @@ def live_traffic(args):
     launches = None
     tmp = tempfile.mkdtemp(prefix="taxor_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+
+    def one_pass(counters):
+        """-> ({counter: summed value over the k_query_level dispatches}, n dispatches) or (None, reason)"""
+        d = os.path.join(tmp, "_".join(counters))
+        cmd = [exe, "--pmc", *counters, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+        try:
+            _, err = proc.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            try:                       # the profiler AND the profiled child (its own session = its own process group)
+                os.killpg(proc.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            proc.communicate()
+            return None, f"rocprofv3 --pmc {' '.join(counters)} pass timed out"
+        if proc.returncode != 0:
+            return None, f"rocprofv3 --pmc {' '.join(counters)} pass failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return None, f"rocprofv3 --pmc {' '.join(counters)}: no counter_collection.csv"
+        tot, ids = {}, set()
+        for f in files:
+            for r in csv.DictReader(open(f)):
+                if "k_query_level" in r.get("Kernel_Name", ""):
+                    tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                    ids.add(r.get("Dispatch_Id"))
+        if not ids or any(c not in tot for c in counters):
+            return None, f"rocprofv3 --pmc {' '.join(counters)}: no k_query_level dispatch (or a counter missing) in the trace"
+        return tot, len(ids)
+
     try:
-        for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--"] + child
-            t0 = time.time()
-            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
-            try:
-                _, err = proc.communicate(timeout=420)
-            except subprocess.TimeoutExpired:
-                try:                       # the profiler AND the profiled child (its own session = its own process group)
-                    os.killpg(proc.pid, signal.SIGKILL)
-                except OSError:
-                    pass
-                proc.communicate()
-                return None, f"rocprofv3 --pmc {counter} pass timed out"
-            if proc.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} pass failed (rc {proc.returncode}): {err.decode(errors='replace')[-300:]}"
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if not files:
-                return None, f"rocprofv3 --pmc {counter}: no counter_collection.csv"
-            tot, ids = 0.0, set()
-            for f in files:
-                for r in csv.DictReader(open(f)):
-                    if r.get("Counter_Name") == counter and "k_query_level" in r.get("Kernel_Name", ""):
-                        tot += float(r["Counter_Value"])
-                        ids.add(r.get("Dispatch_Id"))
-            if not ids:
-                return None, f"rocprofv3 --pmc {counter}: no k_query_level dispatch in the trace"
-            per_launch[counter] = tot * 1024.0 * corr / len(ids)     # KB -> bytes, gfx950 correction
-            launches = len(ids)
-            log(f"rocprofv3 --pmc {counter}: {len(ids)} k_query_level launches, {per_launch[counter]/1e9:.3f} GB per launch "
-                f"(corrected x{corr:g}), {time.time()-t0:.0f}s")
+        # READ bytes: the L2's memory-side read requests BY SIZE (32 / 64 / 128 B), so no correction factor is assumed.
+        # profiles/r03/fetch_calibration*.json (known request counts in this kernel's access shapes): every miss is ONE
+        # 128-B request -- a 1-KiB row is eight, a 64-B row is one, a lone 16-B load of the pruned phase is one -- and
+        # FETCH_SIZE tallies each request as 64 B, so FETCH_SIZE x 2 is the same number (the fallback if this rocprofv3
+        # lacks the by-size counters).
+        t0 = time.time()
+        by_size = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+        tot, n = one_pass(by_size)
+        detail = {}
+        if tot is not None:
+            n32, n64, n128 = tot["TCC_EA0_RDREQ_32B_sum"], tot["TCC_EA0_RDREQ_64B_sum"], tot["TCC_EA0_RDREQ_128B_sum"]
+            other = max(0.0, tot["TCC_EA0_RDREQ_sum"] - n32 - n64 - n128)         # requests of no listed size: tallied at 64 B like FETCH_SIZE does
+            per_launch["read"] = (32.0 * n32 + 64.0 * (n64 + other) + 128.0 * n128) / n
+            detail = {"read_requests_per_launch": round(tot["TCC_EA0_RDREQ_sum"] / n, 1), "requests_128B": round(n128 / n, 1),
+                      "requests_64B": round(n64 / n, 1), "requests_32B": round(n32 / n, 1)}
+            read_src = "TCC_EA0_RDREQ by request size (32/64/128 B) x size"
+        else:
+            log("traffic: by-size request counters unavailable (" + str(n) + "); falling back to FETCH_SIZE x 2")
+            tot, n = one_pass(["FETCH_SIZE"])
+            if tot is None:
+                return None, n, {}
+            per_launch["read"] = tot["FETCH_SIZE"] * 1024.0 * 2.0 / n
+            read_src = "FETCH_SIZE x 2 (every request is a 128-B line tallied at 64 B: profiles/r03/fetch_calibration.txt)"
+        launches = n
+        log(f"rocprofv3 read pass: {n} k_query_level launches, {per_launch['read']/1e9:.3f} GB read per launch, {time.time()-t0:.0f}s")
+        t0 = time.time()
+        tot, n = one_pass(["WRITE_SIZE"])
+        if tot is None:
+            return None, n, {}
+        per_launch["write"] = tot["WRITE_SIZE"] * 1024.0 / n
+        log(f"rocprofv3 write pass: {per_launch['write']/1e6:.3f} MB written per launch, {time.time()-t0:.0f}s")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return per_launch["FETCH_SIZE"] + per_launch["WRITE_SIZE"], \
-        f"live rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, separate passes over one step " \
-        f"({launches} launches) of this workload in this invocation"
+    detail.update({"read_bytes_per_launch": round(per_launch["read"], 1), "write_bytes_per_launch": round(per_launch["write"], 1)})
+    return per_launch["read"] + per_launch["write"], \
+        f"live rocprofv3 --pmc passes over one step ({launches} launches) of this workload in this invocation: reads = {read_src}; " \
+        f"writes = WRITE_SIZE", detail
 
 
 def build_workload(args, local_rank, rank, world):
@@ -283,12 +314,12 @@ def main():
         numa_info = numa.bind_to_gpu(0 if os.environ.get("TAXOR_BENCH_SAME_GPU") == "1" else local_rank)
 
     # live PMC passes run as child processes before anything here touches the GPU
-    traffic, traffic_src = None, "not collected (--traffic none, a child run, or N > 1)"
+    traffic, traffic_src, traffic_detail = None, "not collected (--traffic none, a child run, or N > 1)", {}
     if args.traffic == "live" and not args.pmc_child and world == 1:
         try:
-            traffic, traffic_src = live_traffic(args)
+            traffic, traffic_src, traffic_detail = live_traffic(args)
         except Exception as e:      # the profiler is an aid: its failure must not take the benchmark down
-            traffic, traffic_src = None, f"rocprofv3 pass raised {type(e).__name__}: {e}"
+            traffic, traffic_src, traffic_detail = None, f"rocprofv3 pass raised {type(e).__name__}: {e}", {}
         if traffic is None:
             log("traffic:", traffic_src)
 
@@ -379,7 +410,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         acc = dict(q_ms=0.0, q_bytes=0.0, q_touched=0.0, launches=0, bases=0, sync_ms=0.0, query_ms=0.0, fin_ms=0.0, total_ms=0.0,
-                   hashes=0, tuples=0, work=0, reads=0, alg=0, lvl_ms=[0.0] * 8, lvl_bytes=[0] * 8, lvl_rows=[0] * 8)
+                   hashes=0, tuples=0, work=0, reads=0, alg=0, lvl_ms=[0.0] * 8, lvl_bytes=[0] * 8, lvl_rows=[0] * 8, lvl_sparse=[0] * 8)
         for i in range(steps):
             sr = step(warmup + i, pool)
             st = sr.stats()
@@ -400,6 +431,7 @@ def main():
                 acc["lvl_ms"][l] += st["level_ms"][l]
                 acc["lvl_bytes"][l] += st["level_requested_bytes"][l]
                 acc["lvl_rows"][l] += st["level_row_reads"][l]
+                acc["lvl_sparse"][l] += st["level_sparse_loads"][l]
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -494,8 +526,35 @@ def main():
                 "algorithmic_bytes_per_launch": round(acc["q_bytes"] / launches, 1),
                 "algorithmic_GBps": round(algorithmic, 1),
                 "vs_dense": round(acc["q_bytes"] / max(1.0, acc["q_touched"]), 4)}
+        # The same launches billed three ways.  A dense-phase row read asks for the 16-B units that hold bins; a load of the
+        # pruned (sparse) phase is 16 useful bytes.  What the memory system moves for either is whole 128-B lines (measured:
+        # profiles/r03/fetch_calibration.txt -- one 128-B request per line, also for a 64-B row and for a lone 16-B load).
+        #   useful16 : dense bytes + 16 B per sparse load          (what the arithmetic consumes)
+        #   sector64 : dense bytes + 64 B per sparse load          (= requested_bytes_per_launch / achieved / frac, as in round 2)
+        #   line128  : 128-B lines touched by either               (what HBM has to deliver; `traffic` is judged against this)
+        sparse = sum(acc["lvl_sparse"])
+        dense_bytes = acc["q_touched"] - 64.0 * sparse
+        lvl_row_bytes = [((wl["root_bins"] if l == 0 else wl["child_bins"]) + 15) // 16 * 16 for l in range(8)]
+        line128 = 0.0
+        for l in range(8):
+            dense_rows = acc["lvl_rows"][l] - acc["lvl_sparse"][l]
+            line128 += 128.0 * (dense_rows * -(-lvl_row_bytes[l] // 128) + acc["lvl_sparse"][l])
+        roof["requested_accounting"] = {
+            "useful16_bytes_per_launch": round((dense_bytes + 16.0 * sparse) / launches, 1),
+            "sector64_bytes_per_launch": round(acc["q_touched"] / launches, 1),
+            "line128_bytes_per_launch": round(line128 / launches, 1),
+            "frac_useful16": round((dense_bytes + 16.0 * sparse) / q_s / 1e9 / HBM_PEAK_GBS, 4) if q_s > 0 else 0.0,
+            "frac_sector64": roof["frac"],
+            "frac_line128": round(line128 / q_s / 1e9 / HBM_PEAK_GBS, 4) if q_s > 0 else 0.0,
+            "sparse_loads_per_launch": round(sparse / launches, 1),
+            "note": "line128 is what the memory system must move (one 128-B request per line touched); a 16-B load of the pruned phase "
+                    "and a 64-B row each cost a whole line"}
         if traffic is not None:
             roof["traffic_over_requested"] = round(traffic / max(1.0, acc["q_touched"] / launches), 4)
+            roof["traffic_over_line128"] = round(traffic / max(1.0, line128 / launches), 4)
+            roof["traffic_GBps"] = round(traffic / (acc["q_ms"] / launches * 1e-3) / 1e9, 1)
+            roof["traffic_frac_of_peak"] = round(roof["traffic_GBps"] / HBM_PEAK_GBS, 4)
+            roof["traffic_detail"] = traffic_detail
 
         # per HIXF level: wide rows are bound by bytes, rows of <= 128 B by the number of DRAM rows opened per second
         roof["levels"] = [{"level": l, "ms_per_step": round(acc["lvl_ms"][l] / args.steps, 3),

@@ -89,6 +89,14 @@ int taxor_gpu_gather_ceiling(taxor_gpu_index *idx, uint64_t ixf, uint64_t want_b
  * one 128-bin IXF of 68 MB sits in the caches, a thousand of them do not); *span_used = how many were covered */
 int taxor_gpu_gather_ceiling_span(taxor_gpu_index *idx, uint64_t ixf, uint64_t n_ixf, uint64_t want_bytes, int reps,
                                   double *gb_per_s, uint64_t *row_bytes, uint64_t *span_used);
+/* Calibration aid for the traffic counter (rocprofv3 --pmc FETCH_SIZE is calibrated for wide coalesced reads only):
+ * launches with a KNOWN request count in the two access shapes of the query kernel, nothing else.  pattern 0 = whole rows
+ * at random row indices (dense phase), pattern 1 = one 16-B load per lane, every lane on a row of its own (sparse phase);
+ * nt = non-temporal loads.  One warm-up launch plus `reps` timed ones, all of the same size; reports the requested-bytes
+ * rate and, per launch, the requested bytes (pattern 0: rows x row bytes; pattern 1: loads x 16) and the request count
+ * (rows / loads). */
+int taxor_gpu_gather_pattern(taxor_gpu_index *idx, uint64_t ixf, int pattern, int nt, uint64_t want_bytes, int reps,
+                             double *gb_per_s, uint64_t *bytes_per_launch, uint64_t *requests_per_launch);
 /* Index construction helpers for synthetic / planted indexes (what a GPU builder would use):
  * fill one IXF with seeded pseudo-random fingerprints (behaves like non-matching bins, FPR 2^-8),
  * overwrite one bin column (rows = 3*seg_len bytes), read an IXF back (to hand the same bytes to a
@@ -256,6 +264,8 @@ typedef struct {
     float level_ms[8];
     uint64_t level_requested_bytes[8];
     uint64_t level_row_reads[8];
+    uint64_t level_sparse_loads[8];  /* of level_row_reads: 16-B loads of the pruned (sparse) phase, one fingerprint row each;
+                                        level_requested_bytes bills each as one 64-B sector */
 } taxor_gpu_run_stats;
 int taxor_gpu_batch_stats(taxor_gpu_searcher *s, taxor_gpu_run_stats *out);
 /* Measurement aid: a searcher created while TAXOR_PROFILE_PHASES=1 is set launches instrumented instantiations of the

@@ -46,7 +46,8 @@ class RunStats(C.Structure):
                 ("n_tuples", C.c_uint64), ("n_work_items", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
                 ("query_bytes", C.c_uint64), ("query_touched_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
                 ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
-                ("level_ms", C.c_float * 8), ("level_requested_bytes", C.c_uint64 * 8), ("level_row_reads", C.c_uint64 * 8)]
+                ("level_ms", C.c_float * 8), ("level_requested_bytes", C.c_uint64 * 8), ("level_row_reads", C.c_uint64 * 8),
+                ("level_sparse_loads", C.c_uint64 * 8)]
 
 
 class CommStats(C.Structure):
@@ -94,6 +95,8 @@ SIGNATURES = {
     "taxor_gpu_gather_ceiling": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "taxor_gpu_gather_ceiling_span": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
                                               C.POINTER(C.c_uint64)]),
+    "taxor_gpu_gather_pattern": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint64)]),
     "taxor_gpu_index_leaf_runs": (C.c_uint64, [_P]),
     "taxor_gpu_index_depth": (C.c_uint32, [_P]),
     "taxor_gpu_index_fill_random": (C.c_int, [_P, C.c_uint64, C.c_uint64]),

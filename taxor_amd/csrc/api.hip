@@ -482,6 +482,48 @@ extern "C" int taxor_gpu_gather_ceiling_span(taxor_gpu_index *idx, uint64_t ixf,
     return TAXOR_OK;
 }
 
+extern "C" int taxor_gpu_gather_pattern(taxor_gpu_index *idx, uint64_t ixf, int pattern, int nt, uint64_t want_bytes, int reps,
+                                        double *gb_per_s, uint64_t *bytes_per_launch, uint64_t *requests_per_launch)
+{
+    if (!idx || ixf >= idx->h_ixf.size() || !gb_per_s || (pattern != 0 && pattern != 1)) return fail(TAXOR_E_ARG, "gather_pattern: bad argument");
+    const IxfDesc &f = idx->h_ixf[ixf];
+    const uint32_t units = (f.bins + 15) / 16;
+    if (units > 256) return fail(TAXOR_E_ARG, "gather_pattern: rows wider than 4096 bins");
+    if (reps < 1) reps = 1;
+    HIP_TRY(hipSetDevice(idx->device));
+    uint32_t *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 4));
+    HIP_TRY(hipMemset(sink, 0, 4));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    uint64_t bytes = 0, reqs = 0;
+    auto launch = [&](uint64_t seed) {
+        if (pattern == 0) {
+            bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, seed, sink, nt != 0, nullptr);
+            reqs = bytes / ((uint64_t)units * 16);
+        } else {
+            reqs = launch_gather_sparse(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes / 16, seed, sink, nt != 0, nullptr);
+            bytes = reqs * 16;
+        }
+    };
+    launch(1);   // warm-up
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps; ++r) launch(2 + (uint64_t)r);
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    *gb_per_s = ms > 0.f ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    if (bytes_per_launch) *bytes_per_launch = bytes;
+    if (requests_per_launch) *requests_per_launch = reqs;
+    return TAXOR_OK;
+}
+
 extern "C" int taxor_gpu_index_upload_bin(taxor_gpu_index *idx, uint64_t ixf, uint64_t bin, const uint8_t *column,
                                           uint64_t rows)
 {
@@ -1213,6 +1255,7 @@ extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
                 st.level_ms[l] = 0.f;
                 st.level_requested_bytes[l] = s->h_ctr.lvl_touched[l];
                 st.level_row_reads[l] = s->h_ctr.lvl_rows[l];
+                st.level_sparse_loads[l] = s->h_ctr.lvl_sparse[l];
             }
             for (auto &sp : s->ev_spans) {
                 float ms = 0.f;

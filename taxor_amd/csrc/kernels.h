@@ -65,6 +65,7 @@ struct Counters {
     // number of DRAM rows opened, not by its bytes
     unsigned long long lvl_touched[8];
     unsigned long long lvl_rows[8];
+    unsigned long long lvl_sparse[8];   // of lvl_rows: 16-B loads of the sparse phase (one row each, billed as a 64-B sector in lvl_touched)
 };
 static constexpr int MAX_LEVELS = 16;
 
@@ -162,6 +163,10 @@ void launch_queue_group_by_ixf(const uint2 *q, const Counters *ctr, uint32_t lvl
                                uint2 *out, hipStream_t st);
 void launch_fill_random(uint8_t *data, uint64_t n_bytes, uint64_t seed, hipStream_t st);
 // random whole-row reads of one IXF, nothing else; returns the bytes the launch requests
+// one 16-B load per lane, every lane on a row (and unit) of its own: the access shape of the query kernel's sparse phase;
+// returns the number of loads the launch issues
+uint64_t launch_gather_sparse(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_loads, uint64_t seed,
+                              uint32_t *sink, bool nt, hipStream_t st);
 uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,
                                uint64_t seed, uint32_t *sink, bool nt, hipStream_t st, uint32_t n_ixf = 1, uint64_t spacing = 0);
 void launch_scatter_column(uint8_t *data, uint64_t stride, uint64_t bin, const uint8_t *col, uint64_t rows,

@@ -1226,7 +1226,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     // syncmer kernel of the next sub-batch shares the CU, age-based arbitration would starve these waves.
     __builtin_amdgcn_s_setprio(3);
     const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0;
-    unsigned long long st_bytes = 0, st_touched = 0, st_work = 0, st_rows = 0;
+    unsigned long long st_bytes = 0, st_touched = 0, st_work = 0, st_rows = 0, st_sparse = 0;
 
     // Returning atomics on one word are served serially by one L2 channel, ~13 ns each.  A launch of small work items
     // (deeper levels, short reads) issues one per item on the work cursor and one per item on the hit / queue append
@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + 4.5f);
             dense_end = (thr >= (uint64_t)n + margin) ? 0u : min(n, (uint32_t)((uint64_t)n + margin - thr));
         }
-        uint64_t touched = 0, rows_read = 0;
+        uint64_t touched = 0, rows_read = 0, sparse_loads = 0;
 
         const bool staged = n <= (uint32_t)QC; // all probes of this read fit: stage them once for both phases
         if (staged)
@@ -1435,6 +1435,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 }
                 touched += rem * (uint64_t)n_alive * 3ull * 64ull; // one 64-B sector per 16-B unit load
                 rows_read += rem * (uint64_t)n_alive * 3ull;
+                sparse_loads += rem * (uint64_t)n_alive * 3ull;
             }
         }
         __syncthreads();
@@ -1484,6 +1485,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         st_bytes += (unsigned long long)n * 3ull * D.bins;
         st_touched += touched;
         st_rows += rows_read;
+        st_sparse += sparse_loads;
         st_work += 1ull;
         ++item;
         PMARK(5)                                                     // 5: run tally, child pushes, hit records
@@ -1500,6 +1502,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         atomicAdd(&a.ctr->n_work, st_work);
         atomicAdd(&a.ctr->lvl_touched[min(lvl, 7u)], st_touched);
         atomicAdd(&a.ctr->lvl_rows[min(lvl, 7u)], st_rows);
+        if (st_sparse) atomicAdd(&a.ctr->lvl_sparse[min(lvl, 7u)], st_sparse);
     }
 }
 
@@ -1835,6 +1838,45 @@ __global__ __launch_bounds__(BLK) void k_gather_ceiling(const uint8_t *data, uin
         d += (uint64_t)U * per_pass;
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) atomicAdd(sink, 1u);   // keeps the loads alive
+}
+
+// The sparse phase's access shape with nothing else: every lane one 16-B load from a row and unit of its own (in the
+// query kernel: one (hash, alive unit) task per lane, three rows each).  Used to calibrate the traffic counter for that
+// shape and to know what the memory system gives it.
+template <bool NT>
+__global__ __launch_bounds__(BLK) void k_gather_sparse(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t units, uint32_t passes,
+                                                       uint64_t seed, uint32_t *sink)
+{
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    uint64_t d = ((uint64_t)blockIdx.x * BLK + threadIdx.x) * passes;
+    constexpr int U = 12;                                   // twelve loads in flight per lane, like four sparse tasks
+    for (uint32_t p = 0; p < passes; p += U) {
+        uint4 v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const uint64_t h = murmur64(seed + d + (uint64_t)j);
+            const uint64_t row = (uint64_t)(((unsigned __int128)h * rows) >> 64);
+            const uint32_t u = __umulhi((uint32_t)(h * 0x9E3779B97F4A7C15ull >> 32), units);
+            v[j] = ld16<NT>(data + row * stride + (uint64_t)u * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) { acc.x ^= v[j].x; acc.y ^= v[j].y; acc.z ^= v[j].z; acc.w ^= v[j].w; }
+        d += U;
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) atomicAdd(sink, 1u);
+}
+
+uint64_t launch_gather_sparse(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_loads, uint64_t seed,
+                              uint32_t *sink, bool nt, hipStream_t st)
+{
+    const uint32_t units = (bins + 15) / 16;
+    const uint32_t passes = 96;                             // a multiple of the unroll
+    const uint64_t per_block = (uint64_t)BLK * passes;
+    uint64_t grid = std::max<uint64_t>(1, want_loads / per_block);
+    if (grid > (1u << 30)) grid = 1u << 30;
+    if (nt) hipLaunchKernelGGL(k_gather_sparse<true>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
+    else hipLaunchKernelGGL(k_gather_sparse<false>, dim3((uint32_t)grid), dim3(BLK), 0, st, data, rows, stride, units, passes, seed, sink);
+    return grid * per_block;
 }
 
 uint64_t launch_gather_ceiling(const uint8_t *data, uint64_t rows, uint32_t stride, uint32_t bins, uint64_t want_bytes,

@@ -138,6 +138,14 @@ class GpuIndex:
                                                        C.byref(used)))
         return (g.value, int(rb.value)) if span == 1 else (g.value, int(rb.value), int(used.value))
 
+    def gather_pattern(self, ixf, pattern, nt, want_bytes=8 << 30, reps=3):
+        """known-size launches in the query kernel's access shapes (0 = whole rows, 1 = one 16-B load per row)
+        -> (GB/s requested, requested bytes per launch, requests per launch)"""
+        g, b, r = C.c_double(), C.c_uint64(), C.c_uint64()
+        check(_lib.lib().taxor_gpu_gather_pattern(self._h, ixf, int(pattern), 1 if nt else 0, int(want_bytes), int(reps), C.byref(g),
+                                                  C.byref(b), C.byref(r)))
+        return g.value, int(b.value), int(r.value)
+
     def fill_random(self, ixf, seed):
         check(_lib.lib().taxor_gpu_index_fill_random(self._h, ixf, seed))
 
@@ -257,7 +265,7 @@ class Searcher:
         st = _lib.RunStats()
         check(_lib.lib().taxor_gpu_batch_stats(self._h, C.byref(st)))
         out = {f: getattr(st, f) for f, _ in _lib.RunStats._fields_}
-        for f in ("level_ms", "level_requested_bytes", "level_row_reads"):
+        for f in ("level_ms", "level_requested_bytes", "level_row_reads", "level_sparse_loads"):
             out[f] = list(out[f])
         return out
 
