@@ -55,6 +55,16 @@ typedef struct {
     const int64_t *fname_idx; /* [bins], -1 = merged bin                                            */
 } taxor_ixf_view;
 
+/* Fingerprint bytes that are NOT in host memory (a .hixf on disk or in tmpfs): the library pulls them piece by piece,
+ * from several of its own threads at once, straight into page-locked staging buffers on their way to HBM -- the 113 GB
+ * of a GTDB index then never get host page tables of their own (mapping the file and letting the runtime copy from the
+ * mapping costs a page fault per 4 KiB on the way in and seconds of munmap on the way out).  read() copies `len` bytes of
+ * IXF `ixf`'s array, starting at byte `offset` of it, to dst; returns 0 on success; must be thread-safe. */
+typedef struct {
+    int (*read)(void *ctx, uint64_t ixf, uint64_t offset, uint64_t len, void *dst);
+    void *ctx;
+} taxor_ixf_source;
+
 typedef struct {
     uint64_t n_ixf;
     const taxor_ixf_view *ixf;
@@ -67,6 +77,9 @@ typedef struct {
                                                    (taxor_search.cpp:223-233,243-249), applied on the device */
     uint64_t window_size;                       /* :212; used when use_syncmer == 0: window_size == kmer_size selects
                                                    every canonical k-mer, larger windows select minimisers */
+    const taxor_ixf_source *source;             /* NULL: the fingerprint bytes are at ixf[i].data.  Otherwise index creation
+                                                   reads them through the source and ignores ixf[i].data (taxor_hixf_load
+                                                   sets it to a pread() reader of the file) */
 } taxor_hixf_view;
 
 typedef struct taxor_gpu_index taxor_gpu_index;
@@ -179,6 +192,18 @@ int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint6
  * enqueued. */
 int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads);
 int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out);
+
+/* The same call over reads that live in SEVERAL host buffers (the reference's chunk is a vector of records, each with
+ * its own sequence storage, taxor_search.cpp:319): one batch over the reads of all segments in segment order -- a host
+ * whose parser threads each fill their own buffer hands the GPU a batch of useful size without copying them together.
+ * Segment j holds n_reads reads, read i at bases[offsets[i] .. offsets[i+1]).  Everything must stay valid until
+ * taxor_gpu_search_batch_end, which hands out one CSR over all reads (segment 0's first). */
+typedef struct {
+    const char *bases;
+    const uint64_t *offsets;   /* [n_reads + 1] */
+    uint64_t n_reads;
+} taxor_read_segment;
+int taxor_gpu_search_segments_begin(taxor_gpu_searcher *s, const taxor_read_segment *segs, uint64_t n_segs);
 
 /* Optional: pin a host buffer that the caller passes to taxor_gpu_search_batch / taxor_gpu_batch_upload again and
  * again (a recycled staging buffer, like the reference's per-chunk `records` vector, taxor_search.cpp:319).  Copies

@@ -24,7 +24,11 @@ class IxfView(C.Structure):
 class HixfView(C.Structure):
     _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
                 ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),
-                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64)]
+                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64), ("source", C.c_void_p)]
+
+
+class ReadSegment(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64)]
 
 
 class SearchParams(C.Structure):
@@ -111,6 +115,7 @@ SIGNATURES = {
     "taxor_gpu_host_register": (C.c_int, [_P, C.c_uint64]),
     "taxor_gpu_host_unregister": (C.c_int, [_P]),
     "taxor_gpu_search_batch_begin": (C.c_int, [_P, _P, _P, C.c_uint64]),
+    "taxor_gpu_search_segments_begin": (C.c_int, [_P, C.POINTER(ReadSegment), C.c_uint64]),
     "taxor_gpu_search_batch_end": (C.c_int, [_P, C.POINTER(Results)]),
     "taxor_gpu_search_batch": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(Results)]),
     "taxor_gpu_batch_upload": (C.c_int, [_P, _P, _P, C.c_uint64]),

@@ -6,11 +6,14 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace taxor;
@@ -122,6 +125,8 @@ struct taxor_gpu_searcher {
     size_t lds_query = 0;
 
     // batch-resident input
+    struct HostSpan { uint64_t vbegin, len; const char *ptr; };   // streamed batch: where the bases of [vbegin, vbegin+len) of the
+    std::vector<HostSpan> host_spans;                              // (virtually concatenated) ASCII input live in host memory
     uint64_t n_reads = 0, n_bases = 0, mean_read_len = 1u << 20;
     DBuf<uint8_t> d_ascii;
     DBuf<uint64_t> d_aoff, d_poff, d_hoff;
@@ -178,6 +183,110 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 // =========================================================================================================
 // index
 // =========================================================================================================
+// ---------------------------------------------------------------------------------------------------------
+// Fingerprint bytes -> the slab.  Two routes:
+//   * host pointers (view->source == NULL): one hipMemcpy per IXF piece from the caller's memory, in slab order (the
+//     runtime's pageable path; page-locked staging of our own was measured slower for such memory in round 2);
+//   * a source (a .hixf on disk / tmpfs, taxor_hixf_load): `threads` workers, each with two page-locked staging
+//     buffers and a stream of its own, take pieces off a shared cursor: read() into one buffer while the other is in
+//     flight.  No host mapping of the data is ever touched, so there is nothing to fault in and nothing to unmap.
+// progress(ctx, b): every byte of the slab below offset b is final (pieces complete out of order; b is the contiguous
+// prefix).  Used by the communicator to broadcast behind the upload.
+// ---------------------------------------------------------------------------------------------------------
+static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*progress)(void *, uint64_t), void *pctx)
+{
+    struct Piece { uint64_t ixf, off, len, slab_end; };
+    static const uint64_t piece_bytes = [] { const char *e = getenv("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 32) << 20; }();
+    const uint64_t n = v->n_ixf;
+    std::vector<Piece> pieces;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t bytes = idx->rows[i] * idx->h_ixf[i].stride;
+        const uint64_t next = i + 1 < n ? idx->slab_off[i + 1] : idx->slab_bytes;
+        if (!v->source && !v->ixf[i].data) continue;                     // left to fill_random / upload_bin / the builder
+        const uint64_t step = v->source ? piece_bytes : (1ull << 30);
+        for (uint64_t o = 0; o < bytes; o += step) {
+            const uint64_t len = std::min(step, bytes - o);
+            pieces.push_back({i, o, len, o + len == bytes ? next : idx->slab_off[i] + o + len});
+        }
+    }
+    if (pieces.empty()) { if (progress) progress(pctx, idx->slab_bytes); return 0; }
+    if (!v->source) {
+        for (const Piece &p : pieces) {
+            const hipError_t e = hipMemcpy(idx->d_slab + idx->slab_off[p.ixf] + p.off, v->ixf[p.ixf].data + p.off, p.len, hipMemcpyHostToDevice);
+            if (e != hipSuccess) return fail(TAXOR_E_HIP, "index upload of IXF %llu failed: %s", (unsigned long long)p.ixf, hipGetErrorString(e));
+            if (progress) progress(pctx, p.slab_end);
+        }
+        if (progress) progress(pctx, idx->slab_bytes);
+        return 0;
+    }
+    static const int n_threads = [] { const char *e = getenv("TAXOR_UPLOAD_THREADS"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 64 ? t : 8; }();
+    const int T = (int)std::min<size_t>((size_t)n_threads, pieces.size());
+    std::atomic<size_t> cursor{0};
+    std::vector<std::atomic<uint8_t>> done(pieces.size());
+    for (auto &d : done) d.store(0);
+    std::atomic<int> failed{0};
+    std::mutex mu;                      // progress bookkeeping + the first error text
+    size_t prefix = 0;
+    std::string err;
+    auto mark = [&](size_t i) {
+        done[i].store(1);
+        std::lock_guard<std::mutex> lk(mu);
+        bool moved = false;
+        while (prefix < pieces.size() && done[prefix].load()) { ++prefix; moved = true; }
+        if (moved && progress) progress(pctx, prefix == pieces.size() ? idx->slab_bytes : pieces[prefix - 1].slab_end);
+    };
+    auto set_err = [&](const std::string &m) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (err.empty()) err = m;
+        failed.store(1);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&] {
+            hipStream_t st = nullptr;
+            void *buf[2] = {nullptr, nullptr};
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            size_t inflight[2] = {(size_t)-1, (size_t)-1};
+            hipError_t e = hipSetDevice(idx->device);
+            if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+                e = hipHostMalloc(&buf[b], piece_bytes, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming);
+            }
+            if (e != hipSuccess) set_err(std::string("index upload: staging buffers: ") + hipGetErrorString(e));
+            int b = 0;
+            while (!failed.load()) {
+                const size_t i = cursor.fetch_add(1);
+                if (i >= pieces.size()) break;
+                const Piece &p = pieces[i];
+                if (inflight[b] != (size_t)-1) {                 // this buffer's previous copy must have left it
+                    if ((e = hipEventSynchronize(ev[b])) != hipSuccess) { set_err(std::string("index upload: ") + hipGetErrorString(e)); break; }
+                    mark(inflight[b]);
+                    inflight[b] = (size_t)-1;
+                }
+                if (v->source->read(v->source->ctx, p.ixf, p.off, p.len, buf[b]) != 0) {
+                    set_err("index upload: reading IXF " + std::to_string(p.ixf) + " at byte " + std::to_string(p.off) + " from its source failed");
+                    break;
+                }
+                e = hipMemcpyAsync(idx->d_slab + idx->slab_off[p.ixf] + p.off, buf[b], p.len, hipMemcpyHostToDevice, st);
+                if (e == hipSuccess) e = hipEventRecord(ev[b], st);
+                if (e != hipSuccess) { set_err(std::string("index upload: ") + hipGetErrorString(e)); break; }
+                inflight[b] = i;
+                b ^= 1;
+            }
+            if (st) (void)hipStreamSynchronize(st);
+            for (int k = 0; k < 2; ++k) {
+                if (inflight[k] != (size_t)-1 && !failed.load()) mark(inflight[k]);
+                if (ev[k]) (void)hipEventDestroy(ev[k]);
+                if (buf[k]) (void)hipHostFree(buf[k]);
+            }
+            if (st) (void)hipStreamDestroy(st);
+        });
+    for (auto &t : th) t.join();
+    if (failed.load()) return fail(TAXOR_E_IO, "%s", err.c_str());
+    return 0;
+}
+
 // upload = false: everything but the fingerprint bytes (the slab is allocated, its rows are left as they are) -- for a
 // replica that receives them over RCCL, or through a pipelined upload (comm.hip)
 static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, taxor_gpu_index **out)
@@ -318,16 +427,13 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
         return fail(TAXOR_E_NOMEM, "index_create: hipMalloc of %llu bytes failed: %s", (unsigned long long)idx->slab_bytes,
                     hipGetErrorString(e));
     }
-    for (uint64_t i = 0; i < n; ++i) {
-        idx->h_ixf[i].data = idx->d_slab + slab_off[i];
-        if (upload && v->ixf[i].data) {
-            e = hipMemcpy(idx->d_slab + slab_off[i], v->ixf[i].data, idx->rows[i] * v->ixf[i].stride, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                taxor_gpu_index_destroy(idx);
-                return fail(TAXOR_E_HIP, "index_create: upload of IXF %llu failed: %s", (unsigned long long)i, hipGetErrorString(e));
-            }
+    for (uint64_t i = 0; i < n; ++i) idx->h_ixf[i].data = idx->d_slab + slab_off[i];
+    idx->slab_off = slab_off;
+    if (upload)
+        if (int rc = index_upload(idx, v, nullptr, nullptr)) {
+            taxor_gpu_index_destroy(idx);
+            return rc;
         }
-    }
     bool ok = hipMalloc((void **)&idx->d_ixf, n * sizeof(IxfDesc)) == hipSuccess &&
               hipMalloc((void **)&idx->d_binfo, tb * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&idx->d_ubin, tb * sizeof(int64_t)) == hipSuccess &&
@@ -342,7 +448,6 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
     }
     idx->h_ubin = std::move(ubin);
     idx->h_dfs = std::move(dfs);
-    idx->slab_off = std::move(slab_off);
     *out = idx;
     return TAXOR_OK;
 }
@@ -356,6 +461,15 @@ extern "C" int taxor_gpu_index_create(const taxor_hixf_view *v, int device, taxo
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_create_empty(const taxor_hixf_view *v, int device, taxor_gpu_index **out)
 {
     return index_create_impl(v, device, false, out);
+}
+
+// library-internal (comm.hip): the upload alone, into an index made by taxor_index_create_empty, reporting progress
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v,
+                                                                        void (*progress)(void *, uint64_t), void *ctx)
+{
+    if (!idx || !v || v->n_ixf != idx->h_ixf.size()) return fail(TAXOR_E_ARG, "index_upload: view does not match the index");
+    HIP_TRY(hipSetDevice(idx->device));
+    return index_upload(idx, v, progress, ctx);
 }
 
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_slab(taxor_gpu_index *idx, uint8_t **slab, uint64_t *slab_bytes,
@@ -1152,7 +1266,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
 
 // The whole pipeline for the uploaded (host_ascii == nullptr) or streaming (host_ascii = first base of the batch)
 // case.  Streams: st_copy (H2D + pack of sub-batch i+1), st_sync (syncmers of i+1), st (query + CSR of i).
-int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
+int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
 {
     if (int rc = ensure_scratch(s)) return rc;
     s->ev_used = 0;
@@ -1173,13 +1287,19 @@ int run_pipeline(taxor_gpu_searcher *s, const char *host_ascii)
     // candidate/hash scratch is double buffered, events carry the dependencies.  When streaming, the bases of
     // sub-batch i+1 cross PCIe (pageable copy: the host blocks in it, the GPU keeps working) and are packed on
     // a third stream meanwhile.
+    size_t span_i = 0;
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
         const int buf = (int)(i & 1);
         if (host_ascii) {
-            if (sb.a_end > sb.a_begin)
-                HIP_TRY(hipMemcpyAsync(s->d_ascii.p + sb.a_begin, host_ascii + sb.a_begin, sb.a_end - sb.a_begin,
-                                       hipMemcpyHostToDevice, s->st_copy));
+            // the sub-batch's bases, from wherever the caller keeps them: one buffer, or several segments in turn
+            for (; span_i < s->host_spans.size() && s->host_spans[span_i].vbegin + s->host_spans[span_i].len <= sb.a_begin; ++span_i) {}
+            for (size_t j = span_i; j < s->host_spans.size() && s->host_spans[j].vbegin < sb.a_end; ++j) {
+                const auto &sp = s->host_spans[j];
+                const uint64_t lo = std::max(sp.vbegin, sb.a_begin), hi = std::min(sp.vbegin + sp.len, sb.a_end);
+                if (hi > lo)
+                    HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, s->st_copy));
+            }
             // packing runs beside the query kernel of the previous sub-batch: keep it to two blocks per CU
             launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr,
                              s->st_copy, s->grid_sync_overlap);
@@ -1227,7 +1347,7 @@ extern "C" int taxor_gpu_batch_run(taxor_gpu_searcher *s)
 {
     if (!s) return fail(TAXOR_E_ARG, "batch_run: null searcher");
     HIP_TRY(hipSetDevice(s->idx->device));
-    return run_pipeline(s, nullptr);
+    return run_pipeline(s, false);
 }
 
 extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
@@ -1367,7 +1487,42 @@ extern "C" int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *b
     // (page-locking the caller's buffer for the duration of the call was measured and is slower: the registration
     // costs more than the pageable staging it saves -- 55 vs 50 ms for 1.3 GB; a caller that re-uses its buffer
     // registers it once with taxor_gpu_host_register, and then this call returns as soon as everything is enqueued)
-    return run_pipeline(s, n_reads ? bases + offsets[0] : nullptr);
+    s->host_spans.clear();
+    if (n_reads) s->host_spans.push_back({0, offsets[n_reads] - offsets[0], bases + offsets[0]});
+    return run_pipeline(s, n_reads != 0);
+}
+
+extern "C" int taxor_gpu_search_segments_begin(taxor_gpu_searcher *s, const taxor_read_segment *segs, uint64_t n_segs)
+{
+    if (!s || (n_segs && !segs)) return fail(TAXOR_E_ARG, "search_segments_begin: null argument");
+    // one batch over the reads of all segments, in segment order: the offsets are concatenated here (8 bytes per read),
+    // the bases stay where they are and cross PCIe sub-batch by sub-batch straight from their segments
+    uint64_t n_reads = 0;
+    for (uint64_t j = 0; j < n_segs; ++j) {
+        if (segs[j].n_reads && (!segs[j].offsets || !segs[j].bases)) return fail(TAXOR_E_ARG, "search_segments_begin: segment %llu is null", (unsigned long long)j);
+        n_reads += segs[j].n_reads;
+    }
+    std::vector<uint64_t> off(n_reads + 1);
+    std::vector<taxor_gpu_searcher::HostSpan> spans;
+    uint64_t r = 0, vb = 0;
+    off[0] = 0;
+    for (uint64_t j = 0; j < n_segs; ++j) {
+        const taxor_read_segment &g = segs[j];
+        if (!g.n_reads) continue;
+        const uint64_t a0 = g.offsets[0];
+        for (uint64_t i = 0; i < g.n_reads; ++i) {
+            if (g.offsets[i + 1] < g.offsets[i]) return fail(TAXOR_E_ARG, "search_segments_begin: offsets of segment %llu not monotone", (unsigned long long)j);
+            off[r + i + 1] = vb + (g.offsets[i + 1] - a0);
+        }
+        const uint64_t len = g.offsets[g.n_reads] - a0;
+        if (len) spans.push_back({vb, len, g.bases + a0});
+        r += g.n_reads;
+        vb += len;
+    }
+    static const char nothing = 0;
+    if (int rc = prepare_batch(s, &nothing, off.data(), n_reads, true)) return rc;
+    s->host_spans = std::move(spans);
+    return run_pipeline(s, n_reads != 0);
 }
 
 extern "C" int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_results *out) { return taxor_gpu_batch_fetch(s, out); }

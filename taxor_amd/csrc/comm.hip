@@ -35,6 +35,8 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_create_empty(const taxor_hixf_view *v, int device, taxor_gpu_index **out);
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_slab(taxor_gpu_index *idx, uint8_t **slab, uint64_t *slab_bytes,
                                                                       const uint64_t **ixf_off, uint64_t *n_ixf, int *device);
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v,
+                                                                        void (*progress)(void *, uint64_t), void *ctx);
 extern "C" __attribute__((visibility("hidden"))) int taxor_searcher_device_results(taxor_gpu_searcher *s, const uint64_t **d_read_off,
                                                                                    const int64_t **d_user_bin, const uint32_t **d_count,
                                                                                    const uint32_t **d_n_hashes, uint64_t *n_reads,
@@ -274,37 +276,24 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
         }
     std::vector<uint8_t *> slab(n, nullptr);
     uint64_t slab_bytes = 0, n_ixf = 0;
-    const uint64_t *ixf_off = nullptr;
     for (size_t i = 0; i < n; ++i) {
         int dev;
         uint64_t sb, ni;
         const uint64_t *off;
         if (taxor_index_slab(out[i], &slab[i], &sb, &off, &ni, &dev)) { destroy_all(); return cfail(TAXOR_E_INTERNAL, "index_create_replicated: slab"); }
-        if (i == 0) { slab_bytes = sb; ixf_off = off; n_ixf = ni; }
+        if (i == 0) { slab_bytes = sb; n_ixf = ni; }
         else if (sb != slab_bytes) { destroy_all(); return cfail(TAXOR_E_INTERNAL, "index_create_replicated: replicas differ in size"); }
     }
-    // Upload thread: IXF after IXF in slab order, in pieces, publishing a watermark (slab byte offset below which device 0
-    // holds final bytes).  IXFs without host data (view.data == NULL: filled on the device later) count as uploaded.
+    // Upload thread: the library's own upload into device 0 (pieces, possibly several threads; api.hip), which reports the
+    // slab offset below which device 0 holds final bytes -- the watermark the broadcast follows.
     static const uint64_t piece = [] { const char *e = getenv("TAXOR_COMM_PIECE_MB"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 1024) << 20; }();
     std::atomic<uint64_t> watermark{0};
     std::atomic<int> up_rc{0};
     std::string up_err;
-    uint64_t uploaded = 0;
     std::thread uploader([&] {
-        if (hipSetDevice(c->devices[0]) != hipSuccess) { up_rc = TAXOR_E_HIP; up_err = "hipSetDevice"; watermark = slab_bytes; return; }
-        for (uint64_t i = 0; i < n_ixf; ++i) {
-            const taxor_ixf_view &f = view->ixf[i];
-            const uint64_t bytes = 3 * f.seg_len * f.stride;
-            if (f.data)
-                for (uint64_t o = 0; o < bytes; o += piece) {
-                    const uint64_t len = std::min(piece, bytes - o);
-                    const hipError_t e = hipMemcpy(slab[0] + ixf_off[i] + o, f.data + o, len, hipMemcpyHostToDevice);
-                    if (e != hipSuccess) { up_rc = TAXOR_E_HIP; up_err = hipGetErrorString(e); watermark = slab_bytes; return; }
-                    uploaded += len;
-                    watermark = ixf_off[i] + o + len;
-                }
-            watermark = i + 1 < n_ixf ? ixf_off[i + 1] : slab_bytes;
-        }
+        const int rc = taxor_index_upload(out[0], view, [](void *ctx, uint64_t b) { static_cast<std::atomic<uint64_t> *>(ctx)->store(b); }, &watermark);
+        if (rc) { up_err = taxor_gpu_last_error(); up_rc = rc; }
+        watermark = slab_bytes;           // also on failure: the broadcast loop must end
     });
     // Broadcast behind it: whatever lies below the watermark and has not been sent, once it is worth a collective
     // (>= one piece) or the upload is complete.  One ncclBroadcast per device inside a group, root = rank 0.
@@ -332,6 +321,9 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
             if (e != hipSuccess) { rc = TAXOR_E_HIP; bc_err = std::string("index broadcast: ") + hipGetErrorString(e); break; }
         }
     if (up_rc.load()) { rc = up_rc.load(); bc_err = "index upload to device " + std::to_string(c->devices[0]) + ": " + up_err; }
+    uint64_t uploaded = 0;
+    for (uint64_t i = 0; i < n_ixf; ++i)
+        if (view->source || view->ixf[i].data) uploaded += 3 * view->ixf[i].seg_len * view->ixf[i].stride;
     if (rc) {
         destroy_all();
         return cfail(rc, "%s", bc_err.c_str());

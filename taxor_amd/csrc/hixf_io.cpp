@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -79,6 +80,9 @@ struct Writer {
 struct taxor_hixf {
     void *map = nullptr;
     size_t map_len = 0;
+    int fd = -1;                                           // the file, kept open for the pread() source below
+    std::vector<uint64_t> file_off;                        // file offset of every IXF's fingerprint array
+    taxor_ixf_source source{};                             // view.source: the bytes by pread(), never through the mapping
     std::vector<taxor_ixf_view> ixf;
     std::vector<std::vector<int64_t>> next_ixf, fname_idx; // copies (the file's i64 arrays may be unaligned)
     std::vector<std::vector<uint8_t>> data_copy;           // only for IXFs whose payload is not 16-B aligned
@@ -106,7 +110,7 @@ struct Mapped {
     size_t len = 0;
 };
 
-int map_file(const char *path, Mapped &m)
+int map_file(const char *path, Mapped &m, int *keep_fd = nullptr)
 {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return io_fail(TAXOR_E_IO, std::string("cannot open index file ") + path);
@@ -116,7 +120,8 @@ int map_file(const char *path, Mapped &m)
         return io_fail(TAXOR_E_IO, std::string("index file too small: ") + path);
     }
     void *p = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
+    if (keep_fd && p != MAP_FAILED) *keep_fd = fd;
+    else close(fd);
     if (p == MAP_FAILED) return io_fail(TAXOR_E_IO, std::string("mmap failed for ") + path);
     m.map = p;
     m.len = (size_t)sb.st_size;
@@ -284,15 +289,32 @@ void finish_meta(taxor_hixf *h, const std::vector<uint64_t> &sp_ub, const std::v
     h->view.n_user_bins = n_files;
 }
 
+// taxor_ixf_source::read of a loaded file: pread() at the array's file offset.  The mapping stays for whoever wants to
+// look at the bytes from the host (its pages are only faulted in if someone does); index creation comes through here.
+int hixf_pread(void *ctx, uint64_t ixf, uint64_t offset, uint64_t len, void *dst)
+{
+    const taxor_hixf *h = static_cast<const taxor_hixf *>(ctx);
+    if (ixf >= h->file_off.size() || h->fd < 0) return -1;
+    uint64_t done = 0;
+    while (done < len) {
+        const ssize_t n = pread(h->fd, static_cast<char *>(dst) + done, len - done, (off_t)(h->file_off[ixf] + offset + done));
+        if (n <= 0) return -1;
+        done += (uint64_t)n;
+    }
+    return 0;
+}
+
 // 0 ok; TAXOR_E_IO with *schema_problem=true when only the IXF records did not fit the schema
 int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bool *schema_problem)
 {
     if (schema_problem) *schema_problem = false;
     Mapped m;
-    if (int rc = map_file(path, m)) return rc;
+    int fd = -1;
+    if (int rc = map_file(path, m, &fd)) return rc;
     auto h = new taxor_hixf();
     h->map = m.map;
     h->map_len = m.len;
+    h->fd = fd;
     Cursor c{(const uint8_t *)m.map, (const uint8_t *)m.map + m.len};
     auto bail = [&](const std::string &why) {
         taxor_hixf_free(h);
@@ -311,6 +333,12 @@ int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bo
         return bail(e + " -- the IXF record layout of this file may differ from the schema used (taxor_hixf_probe)");
     }
     finish_meta(h, sp_ub, sp_len, first_fn, n_files);
+    h->file_off.resize(h->ixf.size());
+    for (size_t i = 0; i < h->ixf.size(); ++i) h->file_off[i] = (uint64_t)(h->ixf[i].data - (const uint8_t *)m.map);
+    h->source.read = hixf_pread;
+    h->source.ctx = h;
+    static const bool use_map = [] { const char *e = getenv("TAXOR_HIXF_UPLOAD_FROM_MAP"); return e && atoi(e) != 0; }();   // A/B knob: round-2 path
+    h->view.source = use_map ? nullptr : &h->source;
     *out = h;
     return TAXOR_OK;
 }
@@ -457,6 +485,7 @@ extern "C" void taxor_hixf_free(taxor_hixf *h)
 {
     if (!h) return;
     if (h->map) munmap(h->map, h->map_len);
+    if (h->fd >= 0) close(h->fd);
     delete h;
 }
 

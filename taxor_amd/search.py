@@ -239,6 +239,17 @@ class Searcher:
         self._inflight = (b, o)
         check(_lib.lib().taxor_gpu_search_batch_begin(self._h, _p(b), _p(o), o.size - 1))
 
+    def search_segments(self, segments) -> SearchResults:
+        """one batch over reads that live in several (bases, offsets) buffers, in the order given"""
+        keep = [self._batch(b, o) for b, o in segments]
+        arr = (_lib.ReadSegment * len(keep))()
+        for i, (b, o) in enumerate(keep):
+            arr[i] = _lib.ReadSegment(b.ctypes.data, o.ctypes.data, o.size - 1)
+        check(_lib.lib().taxor_gpu_search_segments_begin(self._h, arr, len(keep)))
+        res = _lib.Results()
+        check(_lib.lib().taxor_gpu_search_batch_end(self._h, C.byref(res)))
+        return _results(res)
+
     def search_batch_end(self) -> SearchResults:
         res = _lib.Results()
         check(_lib.lib().taxor_gpu_search_batch_end(self._h, C.byref(res)))

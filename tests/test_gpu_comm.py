@@ -105,3 +105,27 @@ def test_gather_checks_the_searchers_device():
     with pytest.raises(TaxorError, match="no run in flight"):
         comm.gather([sr])
     sr.close(); idx.close(); comm.close()
+
+
+def test_segments_are_one_batch():
+    """taxor_gpu_search_segments_begin: reads in several host buffers (one with a non-zero first offset, one empty) give the
+    CSR of the same reads concatenated into one buffer -- through the streamed sub-batch path, whose H2D copies then come
+    from several segments per sub-batch"""
+    host, nub, batches = _index_and_batches(4, seed=11)
+    idx = GpuIndex(host, nub)
+    sr = Searcher(idx, sub_batch_reads=64)           # several sub-batches, cut across segment borders
+    singles = [sr.search_batch(*b) for b in batches]
+    b2, o2 = batches[2]
+    shifted = (np.concatenate([np.frombuffer(b"ACGTACGTAC", np.uint8), b2]), o2 + np.uint64(10))     # offsets[0] != 0
+    empty = (np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    got = sr.search_segments([batches[0], empty, batches[1], shifted, batches[3]])
+    assert _same(got, _concat(singles))
+    allb = np.concatenate([b for b, _ in batches])
+    offs, base = [np.zeros(1, np.uint64)], 0
+    for b, o in batches:
+        offs.append(o[1:] + np.uint64(base))
+        base += b.size
+    one = sr.search_batch(allb, np.concatenate(offs))
+    assert _same(got, (one.read_off, one.user_bin, one.count, one.n_hashes))
+    assert _same(sr.search_segments([]), (np.zeros(1, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.uint32), np.zeros(0, np.uint32)))
+    sr.close(); idx.close()
