@@ -407,6 +407,13 @@ uint64_t taxor_format_read(const taxor_hixf *h, const char *id, uint64_t id_len,
                            uint32_t n_hashes, const int64_t *user_bin, const uint32_t *count, uint64_t n_tuples,
                            char *buf, uint64_t cap);
 
+/* the same for a whole chunk of reads (what a formatter thread of the host calls): read r has id ids[r] (id_len[r] bytes),
+ * read_len[r] bases, n_hashes[r] hashes and the tuples [read_off[r], read_off[r+1]) of user_bin / count.  Returns the bytes
+ * the text needs; nothing is written unless it fits cap. */
+uint64_t taxor_format_reads(const taxor_hixf *h, uint64_t n_reads, const char *const *ids, const uint64_t *id_len,
+                            const uint64_t *read_len, const uint32_t *n_hashes, const uint64_t *read_off,
+                            const int64_t *user_bin, const uint32_t *count, char *buf, uint64_t cap);
+
 /* ------------------------------------------------------------------------------------------------
  * Host-side scalars of the path (no GPU needed).
  * ---------------------------------------------------------------------------------------------- */

@@ -149,6 +149,7 @@ SIGNATURES = {
     "taxor_hixf_store": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta)]),
     "taxor_format_read": (C.c_uint64, [_P, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, _P, _P, C.c_uint64,
                                        _P, C.c_uint64]),
+    "taxor_format_reads": (C.c_uint64, [_P, C.c_uint64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint64]),
     "taxor_threshold_ratio": (C.c_double, [C.c_uint32, C.c_double, C.c_double]),
     "taxor_threshold": (C.c_uint64, [C.c_uint64, C.c_double]),
     "taxor_classify_filter": (None, [_P, C.c_uint64, _P]),

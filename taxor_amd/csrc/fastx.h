@@ -40,6 +40,7 @@ struct Batch {
     std::vector<uint64_t> read_off;
     std::vector<int64_t> user_bin;
     std::vector<uint32_t> count, n_hashes;
+    std::string text;   // the chunk's TSV lines (formatter threads), written by the writer in chunk order
     // bases.data() as pinned for DMA by the consumer (search_main.cpp); the producer keeps bases from reallocating
     void *pinned = nullptr;
     bool may_pin = false;

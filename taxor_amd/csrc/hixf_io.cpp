@@ -92,6 +92,10 @@ struct taxor_hixf {
     std::vector<const char *> filenames;
     taxor_hixf_meta meta{};
     std::map<uint64_t, uint64_t> user_bin_index;           // user_bin -> first species index (taxor_search.cpp:172-178)
+    // the per-species parts of a hit line (taxor_search.cpp:287-305), rendered once: "ACCESSION\tNAME\tTAXID\tREF_LEN\t" and
+    // "TAX_STR\tTAX_ID_STR\n"; and user bin -> species index as a flat table for the user bins the index can report
+    std::vector<std::string> line_head, line_tail;
+    std::vector<uint32_t> ub_species;
 };
 
 // taxor_gpu_last_error() lives in api.hip; IO errors are routed through a library-internal hook there
@@ -278,6 +282,16 @@ void finish_meta(taxor_hixf *h, const std::vector<uint64_t> &sp_ub, const std::v
         s.seq_len = sp_len[i];
         h->user_bin_index.emplace(s.user_bin, i); // emplace keeps the first (taxor_search.cpp:174)
     }
+    h->line_head.resize(n_species);
+    h->line_tail.resize(n_species);
+    for (uint64_t i = 0; i < n_species; ++i) {
+        const taxor_species &s = h->species[i];
+        h->line_head[i] = std::string(s.accession_id) + '\t' + s.organism_name + '\t' + s.taxid + '\t' + std::to_string(s.seq_len) + '\t';
+        h->line_tail[i] = std::string(s.taxnames_string) + '\t' + s.taxid_string + '\n';
+    }
+    h->ub_species.assign(n_files, 0u);                     // unknown user bin -> species[0], like std::map::operator[] (:289)
+    for (uint64_t i = n_species; i-- > 0;)                 // descending, so that the first species of a user bin wins (:174)
+        if (h->species[i].user_bin < n_files) h->ub_species[h->species[i].user_bin] = (uint32_t)i;
     h->filenames.resize(n_files);
     for (uint64_t i = 0; i < n_files; ++i) h->filenames[i] = h->strings[first_fn + i].c_str();
     h->meta.n_species = n_species;
@@ -575,50 +589,96 @@ extern "C" int taxor_hixf_store(const char *path, const taxor_hixf_view *v, cons
     return taxor_hixf_store_schema(path, v, m, &sc);
 }
 
+namespace {
+
+inline char *put_u64(char *p, uint64_t v)
+{
+    char tmp[20];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
+inline uint64_t species_of(const taxor_hixf *h, int64_t user_bin)
+{
+    if ((uint64_t)user_bin < h->ub_species.size()) return h->ub_species[(uint64_t)user_bin];
+    const auto it = h->user_bin_index.find((uint64_t)user_bin);
+    return it == h->user_bin_index.end() ? 0 : it->second;
+}
+
+// bytes the lines of one read need (exact)
+inline uint64_t read_text_size(const taxor_hixf *h, uint64_t id_len, uint64_t read_len, uint32_t n_hashes, const int64_t *user_bin,
+                               const uint32_t *count, uint64_t n_tuples)
+{
+    auto digits = [](uint64_t v) { uint64_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; };
+    if (n_tuples == 0) return id_len + 1 + 8 + digits(read_len) + 1;
+    if (h->meta.n_species == 0) return 0;
+    uint32_t max_count = 0;
+    for (uint64_t i = 0; i < n_tuples; ++i) max_count = std::max(max_count, count[i]);
+    const uint64_t fixed = id_len + 1 + digits(read_len) + 1 + digits(n_hashes) + 1;
+    uint64_t need = 0;
+    for (uint64_t i = 0; i < n_tuples; ++i) {
+        if (static_cast<double>(count[i]) < static_cast<double>(max_count) * 0.8) continue;
+        const uint64_t si = species_of(h, user_bin[i]);
+        need += fixed + h->line_head[si].size() + digits(count[i]) + 1 + h->line_tail[si].size();
+    }
+    return need;
+}
+
+// taxor_search.cpp:268-305; p has room for read_text_size() bytes
+inline char *write_read_text(const taxor_hixf *h, const char *id, uint64_t id_len, uint64_t read_len, uint32_t n_hashes,
+                             const int64_t *user_bin, const uint32_t *count, uint64_t n_tuples, char *p)
+{
+    if (n_tuples == 0) {                                                              // :268-273
+        std::memcpy(p, id, id_len); p += id_len;
+        std::memcpy(p, "\t-\t-\t-\t-\t", 9); p += 9;
+        p = put_u64(p, read_len);
+        *p++ = '\n';
+        return p;
+    }
+    if (h->meta.n_species == 0) return p;
+    uint32_t max_count = 0;                                                           // :275-280
+    for (uint64_t i = 0; i < n_tuples; ++i) max_count = std::max(max_count, count[i]);
+    for (uint64_t i = 0; i < n_tuples; ++i) {
+        if (static_cast<double>(count[i]) < static_cast<double>(max_count) * 0.8) continue; // :285
+        const uint64_t si = species_of(h, user_bin[i]);                               // :289
+        std::memcpy(p, id, id_len); p += id_len;
+        *p++ = '\t';
+        const std::string &hd = h->line_head[si];
+        std::memcpy(p, hd.data(), hd.size()); p += hd.size();
+        p = put_u64(p, read_len); *p++ = '\t';
+        p = put_u64(p, n_hashes); *p++ = '\t';
+        p = put_u64(p, count[i]); *p++ = '\t';
+        const std::string &tl = h->line_tail[si];
+        std::memcpy(p, tl.data(), tl.size()); p += tl.size();
+    }
+    return p;
+}
+
+} // namespace
+
 // taxor_search.cpp:268-305
 extern "C" uint64_t taxor_format_read(const taxor_hixf *h, const char *id, uint64_t id_len, uint64_t read_len,
                                       uint32_t n_hashes, const int64_t *user_bin, const uint32_t *count, uint64_t n_tuples,
                                       char *buf, uint64_t cap)
 {
-    const taxor_hixf_meta *meta = &h->meta;
-    std::string out;
-    const std::string sid(id, id_len);
-    if (n_tuples == 0) {                                                              // :268-273
-        out += sid + '\t';
-        out += "-\t-\t-\t-\t";
-        out += std::to_string(read_len) + "\n";
-    } else {
-        uint64_t max_count = 0;                                                       // :275-280
-        for (uint64_t i = 0; i < n_tuples; ++i)
-            if (count[i] > max_count) max_count = count[i];
-        for (uint64_t i = 0; i < n_tuples; ++i) {
-            if (static_cast<double>(count[i]) < static_cast<double>(max_count) * 0.8) continue; // :285
-            // user_bin_index[count.first]: std::map::operator[] default-inserts 0 for an unknown user bin (:289)
-            if (meta->n_species == 0) continue;
-            const auto it = h->user_bin_index.find((uint64_t)user_bin[i]);
-            const uint64_t si = it == h->user_bin_index.end() ? 0 : it->second;
-            const taxor_species &s = meta->species[si];
-            out += sid + '\t';
-            out += s.accession_id;
-            out += '\t';
-            out += s.organism_name;
-            out += '\t';
-            out += s.taxid;
-            out += '\t';
-            out += std::to_string(s.seq_len);
-            out += '\t';
-            out += std::to_string(read_len);
-            out += '\t';
-            out += std::to_string(n_hashes);
-            out += '\t';
-            out += std::to_string(count[i]);
-            out += '\t';
-            out += s.taxnames_string;
-            out += '\t';
-            out += s.taxid_string;
-            out += '\n';
-        }
-    }
-    if (out.size() <= cap && buf) std::memcpy(buf, out.data(), out.size());
-    return out.size();
+    const uint64_t need = read_text_size(h, id_len, read_len, n_hashes, user_bin, count, n_tuples);
+    if (need <= cap && buf) write_read_text(h, id, id_len, read_len, n_hashes, user_bin, count, n_tuples, buf);
+    return need;
+}
+
+extern "C" uint64_t taxor_format_reads(const taxor_hixf *h, uint64_t n_reads, const char *const *ids, const uint64_t *id_len,
+                                       const uint64_t *read_len, const uint32_t *n_hashes, const uint64_t *read_off,
+                                       const int64_t *user_bin, const uint32_t *count, char *buf, uint64_t cap)
+{
+    uint64_t need = 0;
+    for (uint64_t r = 0; r < n_reads; ++r)
+        need += read_text_size(h, id_len[r], read_len[r], n_hashes[r], user_bin + read_off[r], count + read_off[r], read_off[r + 1] - read_off[r]);
+    if (need > cap || !buf) return need;
+    char *p = buf;
+    for (uint64_t r = 0; r < n_reads; ++r)
+        p = write_read_text(h, ids[r], id_len[r], read_len[r], n_hashes[r], user_bin + read_off[r], count + read_off[r],
+                            read_off[r + 1] - read_off[r], p);
+    return (uint64_t)(p - buf);
 }

@@ -105,6 +105,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
+    uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
                                 // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
 };
@@ -149,7 +150,8 @@ void usage()
             "  --gpu-list <a,b,..>      explicit device list (a device may be listed twice)\n"
             "  --gather <rccl|host|none> several devices: index broadcast + per-round gather of the results on the first device over\n"
             "                           RCCL/xGMI (default), the same staged through host memory, or independent workers\n"
-            "  --batch-reads <n>        reads per GPU batch (default: about 128 MB of query file, 65536 reads for gzip)\n"
+            "  --batch-reads <n>        reads per parsed chunk (default: about 128 MB of query file, 65536 reads for gzip)\n"
+            "  --group-reads <n>        reads per GPU batch, made of whole chunks (default 131072; --batch-reads if that is given)\n"
             "  --expect <tsv>           compare the output per read with a TSV the reference wrote for the same input (exit 3 if it differs)\n");
 }
 
@@ -627,6 +629,7 @@ int main(int argc, char **argv)
         }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--expect") cfg.expect_file = val();
+        else if (k == "--group-reads") cfg.group_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--gather") {
             cfg.gather = val();
             if (cfg.gather != "rccl" && cfg.gather != "host" && cfg.gather != "none") die("Validation failed for option --gather: Value not in {rccl, host, none}.");
@@ -668,8 +671,8 @@ int main(int argc, char **argv)
     if (!out) die("cannot open output file " + cfg.report_file);
     fputs("#QUERY_NAME\tACCESSION\tREFERENCE_NAME\tTAXID\tREF_LEN\tQUERY_LEN\tQHASH_COUNT\tQHASH_MATCH\tTAX_STR\tTAX_ID_STR\n", out);
 
-    double t_index = 0, t_reads = 0, t_compute = 0, t_pin = 0, t_search = 0, t_gather = 0;
-    uint64_t n_batches = 0;
+    double t_index = 0, t_reads = 0, t_compute = 0, t_pin = 0, t_search = 0, t_gather = 0, t_search_wall = 0;
+    uint64_t n_batches = 0, n_gpu_batches = 0;
     uint64_t total_reads = 0, total_bases = 0;
     std::mutex stat_mu;
     // One index, all of `queries`: the index is loaded and uploaded once; query files are read concurrently (a gzip
@@ -686,44 +689,6 @@ int main(int argc, char **argv)
                             "  The arithmetic of seqan3's interleaved_xor_filter is not part of the reference sources; this build's reading of it has\n"
                             "  not been checked against this file.  Run `taxor verify --index-file %s --genome-file <a genome in the index>` first:\n"
                             "  a wrong reading still loads and classifies at the false-positive floor.\n", hixf_file.c_str(), hixf_file.c_str());
-        // one index replica + searcher per device (reads are independent, taxor_search.cpp:214: the index is
-        // replicated, batches are sharded); replicas are uploaded concurrently
-        const size_t ng = cfg.gpus.size();
-        std::vector<taxor_gpu_index *> gidx(ng, nullptr);
-        // Several devices (north star: "reads sharded across the GPUs, per-read results gathered over RCCL/xGMI"): one
-        // communicator; the index crosses PCIe once and is broadcast, rounds of ng batches are classified side by side and
-        // their results gathered on the first device (taxor_gpu.h, "Several GPUs of one node").  The transport is decided
-        // here, once, by rule -- never by a failure.
-        taxor_gpu_comm *comm = nullptr;
-        std::string gather = cfg.gather;
-        if (gather.empty()) {
-            bool distinct = true;
-            for (size_t i = 0; i < ng; ++i)
-                for (size_t j = i + 1; j < ng; ++j) distinct = distinct && cfg.gpus[i] != cfg.gpus[j];
-            gather = ng == 1 ? "none" : (distinct ? "rccl" : "host");
-        }
-        if (gather != "none") {
-            if (taxor_gpu_comm_create(cfg.gpus.data(), (uint32_t)ng, gather == "rccl" ? TAXOR_COMM_RCCL : TAXOR_COMM_HOST, &comm) != TAXOR_OK)
-                die(std::string(taxor_gpu_last_error()) + "\n(--gather host stages the same transfers through host memory)");
-            if (taxor_gpu_index_create_replicated(comm, view, gidx.data()) != TAXOR_OK) die(taxor_gpu_last_error());
-            taxor_gpu_comm_stats cs{};
-            taxor_gpu_comm_info(comm, &cs);
-            if (getenv("TAXOR_CLI_TRACE"))
-                fprintf(stderr, "[trace] index on %zu devices (%s): %.2f GB per replica, %.2f GB over PCIe, %.2f GB by ncclBroadcast, %.3f s\n", ng,
-                        gather.c_str(), cs.index_bytes / 1e9, cs.index_upload_bytes / 1e9, cs.index_broadcast_bytes / 1e9, cs.index_seconds);
-        } else {
-            std::vector<std::thread> up;
-            std::vector<std::string> errs(ng);
-            for (size_t g = 0; g < ng; ++g)
-                up.emplace_back([&, g] {
-                    if (taxor_gpu_index_create(view, cfg.gpus[g], &gidx[g]) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
-                });
-            for (auto &t : up) t.join();
-            for (const auto &e : errs)
-                if (!e.empty()) die(e);
-        }
-        t_index += now() - t0;
-        trace("index resident in HBM");
         // threshold model (threshold.hpp:22-47)
         taxor_gpu_search_params prm{};
         if (taxor_threshold_select(view, cfg.error_rate, cfg.threshold, &prm) != TAXOR_OK)
@@ -734,22 +699,28 @@ int main(int argc, char **argv)
         case TAXOR_THR_KMER: printf("use kmer-model\n"); break;
         default: printf("use frac minhash\n"); break;
         }
-        std::vector<taxor_gpu_searcher *> sr(ng, nullptr);
-        for (size_t g = 0; g < ng; ++g)
-            if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g]) != TAXOR_OK) die(taxor_gpu_last_error());
+        const size_t ng = cfg.gpus.size();
 
         // Overlapped stages (the reference joins its workers after every 1024 reads, do_parallel.hpp:31-32):
         //   reader threads    : FASTA/FASTQ(.gz) -> numbered chunks of records   (taxor_search.cpp:315-321);
         //                       plain files are parsed by up to --threads threads (fastx.h), several files at a time
-        //   one thread per GPU: chunk -> GPU (streamed upload, kernels, fetch)   (:325)
-        //   writer thread     : tuples -> 0.8*max filter -> TSV lines -> file, in file and chunk order (:266-311)
-        // Output stays in input order (the reference's order at --threads 1).
+        //   GPU workers       : chunks -> one GPU batch of useful size (as many queued chunks as make ~131072 reads, handed
+        //                       over as segments, no copy) -> streamed upload, kernels, fetch (:325); two per device, so
+        //                       that one batch's transfers run beside the other's kernels
+        //   formatter threads : tuples -> 0.8*max filter -> TSV text of a chunk (:266-306)
+        //   writer thread     : chunk texts -> file, in file and chunk order (:311)
+        // Output stays in input order (the reference's order at --threads 1).  The host stages start BEFORE the index goes to
+        // the devices: the first chunks are parsed while it uploads.
         const size_t nf = queries.size();
         const unsigned readers = (unsigned)std::max<size_t>(1, std::min<size_t>({nf, cfg.threads, 8}));
-        const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 16u) / readers);
-        BoundedQueue<std::unique_ptr<Batch>> q_in(ng + 1), q_out(2 * ng + 2);
+        const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 32u) / readers);
+        const unsigned formatters = std::max(1u, std::min(cfg.threads, 32u) / 4u);
+        static const unsigned workers_per_gpu = [] { const char *e = getenv("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
+        const uint64_t group_reads = cfg.group_reads ? cfg.group_reads : (cfg.batch_reads ? cfg.batch_reads : 131072);
+        const size_t group_max_chunks = 32;
+        BoundedQueue<std::unique_ptr<Batch>> q_in(32), q_fmt(8), q_out(8);
         BatchPool pool;
-        pool.cap = readers * parse_threads + 3 * ng + 3 + 2 * readers; // being parsed + q_in + on a GPU + q_out / writer + look-ahead
+        pool.cap = readers * parse_threads + 32 + ng * workers_per_gpu * group_max_chunks + 8 + formatters + 8 + 8 + 2 * readers;
         // a file that is not being written yet may run at most two chunks ahead, so that the file whose turn it is can
         // always get buffers
         std::mutex fmu;
@@ -782,13 +753,39 @@ int main(int argc, char **argv)
             q_in.close();
             trace("readers done");
         });
+        std::vector<std::thread> fmt_threads;
+        for (unsigned ft = 0; ft < formatters; ++ft)
+            fmt_threads.emplace_back([&] {
+                std::unique_ptr<Batch> b;
+                std::vector<const char *> idp;
+                std::vector<uint64_t> idl, rl;
+                while (q_fmt.pop(b)) {
+                    if (!b->end_of_file) {
+                        const size_t n = b->ids.size();
+                        idp.resize(n); idl.resize(n); rl.resize(n);
+                        for (size_t r = 0; r < n; ++r) {
+                            idp[r] = b->ids[r].data();
+                            idl[r] = b->ids[r].size();
+                            rl[r] = b->offsets[r + 1] - b->offsets[r];
+                        }
+                        b->text.resize(b->text.capacity());            // a recycled chunk's buffer usually fits: one pass
+                        uint64_t need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), b->n_hashes.data(), b->read_off.data(),
+                                                           b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
+                        if (need > b->text.size()) {
+                            b->text.resize(need + need / 8 + 4096);
+                            need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), b->n_hashes.data(), b->read_off.data(),
+                                                      b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
+                        }
+                        b->text.resize(need);
+                    }
+                    q_out.push(std::move(b));
+                }
+            });
         std::thread writer([&] {
             std::unique_ptr<Batch> b;
             std::map<std::pair<uint32_t, uint64_t>, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
             uint32_t cur_file = 0;
             uint64_t next_seq = 0;
-            std::string text;
-            std::vector<char> line(4096);
             while (q_out.pop(b)) {
                 const auto key = std::make_pair(b->file, b->seq);
                 pending.emplace(key, std::move(b));
@@ -804,20 +801,8 @@ int main(int argc, char **argv)
                         continue;
                     }
                     ++next_seq;
-                    text.clear();
-                    for (size_t r = 0; r < cur->ids.size(); ++r) {
-                        const uint64_t lo = cur->read_off[r], n = cur->read_off[r + 1] - lo;
-                        const uint64_t rl = cur->offsets[r + 1] - cur->offsets[r];
-                        uint64_t need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
-                                                          cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
-                        if (need > line.size()) {
-                            line.resize(need + 1024);
-                            need = taxor_format_read(h, cur->ids[r].data(), cur->ids[r].size(), rl, cur->n_hashes[r],
-                                                     cur->user_bin.data() + lo, cur->count.data() + lo, n, line.data(), line.size());
-                        }
-                        text.append(line.data(), need);
-                    }
-                    fwrite(text.data(), 1, text.size(), out);
+                    if (!cur->text.empty() && fwrite(cur->text.data(), 1, cur->text.size(), out) != cur->text.size())
+                        die("cannot write to " + cfg.report_file);
                     {
                         std::lock_guard<std::mutex> lk(fmu);
                         --ahead[cur->file];
@@ -827,6 +812,76 @@ int main(int argc, char **argv)
                 }
             }
         });
+
+        // ---- the index: one replica per device (reads are independent, taxor_search.cpp:214: the index is replicated,
+        // batches are sharded).  Several devices (north star: "reads sharded across the GPUs, per-read results gathered over
+        // RCCL/xGMI"): one communicator; the index crosses PCIe once and is broadcast, rounds of ng batches are classified
+        // side by side and their results gathered on the first device (taxor_gpu.h, "Several GPUs of one node").  The
+        // transport is decided here, once, by rule -- never by a failure.
+        std::vector<taxor_gpu_index *> gidx(ng, nullptr);
+        taxor_gpu_comm *comm = nullptr;
+        std::string gather = cfg.gather;
+        if (gather.empty()) {
+            bool distinct = true;
+            for (size_t i = 0; i < ng; ++i)
+                for (size_t j = i + 1; j < ng; ++j) distinct = distinct && cfg.gpus[i] != cfg.gpus[j];
+            gather = ng == 1 ? "none" : (distinct ? "rccl" : "host");
+        }
+        if (gather != "none") {
+            if (taxor_gpu_comm_create(cfg.gpus.data(), (uint32_t)ng, gather == "rccl" ? TAXOR_COMM_RCCL : TAXOR_COMM_HOST, &comm) != TAXOR_OK)
+                die(std::string(taxor_gpu_last_error()) + "\n(--gather host stages the same transfers through host memory)");
+            if (taxor_gpu_index_create_replicated(comm, view, gidx.data()) != TAXOR_OK) die(taxor_gpu_last_error());
+            taxor_gpu_comm_stats cs{};
+            taxor_gpu_comm_info(comm, &cs);
+            if (getenv("TAXOR_CLI_TRACE"))
+                fprintf(stderr, "[trace] index on %zu devices (%s): %.2f GB per replica, %.2f GB over PCIe, %.2f GB by ncclBroadcast, %.3f s\n", ng,
+                        gather.c_str(), cs.index_bytes / 1e9, cs.index_upload_bytes / 1e9, cs.index_broadcast_bytes / 1e9, cs.index_seconds);
+        } else {
+            std::vector<std::thread> up;
+            std::vector<std::string> errs(ng);
+            for (size_t g = 0; g < ng; ++g)
+                up.emplace_back([&, g] {
+                    if (taxor_gpu_index_create(view, cfg.gpus[g], &gidx[g]) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                });
+            for (auto &t : up) t.join();
+            for (const auto &e : errs)
+                if (!e.empty()) die(e);
+        }
+        t_index += now() - t0;
+        trace("index resident in HBM");
+        if (getenv("TAXOR_CLI_TRACE"))
+            fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
+                    now() - t0, taxor_gpu_index_data_bytes(gidx[0]) / 1e9 / (now() - t0));
+        const double t_search0 = now();
+        const unsigned wpg = comm ? 1u : workers_per_gpu;
+        std::vector<taxor_gpu_searcher *> sr(ng * wpg, nullptr);
+        for (size_t g = 0; g < ng; ++g)
+            for (unsigned w = 0; w < wpg; ++w)
+                if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g * wpg + w]) != TAXOR_OK) die(taxor_gpu_last_error());
+
+        auto pin = [](Batch &bt) {      // recycled with the chunk: pinned once, DMA source from then on
+            if (bt.may_pin && !bt.pinned && bt.bases.capacity() >= (1u << 20) &&
+                taxor_gpu_host_register(&bt.bases[0], bt.bases.capacity()) == TAXOR_OK)
+                bt.pinned = &bt.bases[0];
+        };
+        // the CSR of several chunks classified as one batch -> each chunk's own CSR
+        auto split_results = [&](std::vector<std::unique_ptr<Batch>> &chunks, const taxor_gpu_results &res) {
+            uint64_t r0 = 0;
+            for (auto &bt : chunks) {
+                const uint64_t n = bt->ids.size(), lo = res.read_off[r0], hi = res.read_off[r0 + n];
+                bt->read_off.resize(n + 1);
+                for (uint64_t i = 0; i <= n; ++i) bt->read_off[i] = res.read_off[r0 + i] - lo;
+                bt->user_bin.assign(res.user_bin + lo, res.user_bin + hi);
+                bt->count.assign(res.count + lo, res.count + hi);
+                bt->n_hashes.assign(res.n_hashes + r0, res.n_hashes + r0 + n);
+                r0 += n;
+                std::lock_guard<std::mutex> lk(stat_mu);
+                ++n_batches;
+                total_reads += n;
+                total_bases += bt->bases.size();
+            }
+            if (r0 != res.n_reads) die("internal: a batch's results do not cover its chunks");
+        };
         std::vector<std::thread> workers;
         if (comm)
             workers.emplace_back([&] {
@@ -839,7 +894,7 @@ int main(int argc, char **argv)
                 for (;;) {
                     round.clear();
                     if (!q_in.pop(b)) break;
-                    if (b->end_of_file) { q_out.push(std::move(b)); continue; }
+                    if (b->end_of_file) { q_fmt.push(std::move(b)); continue; }
                     round.push_back(std::move(b));
                     std::unique_ptr<Batch> eof;           // an end-of-file marker ends the round and follows it
                     while (round.size() < ng && q_in.try_pop(b)) {
@@ -856,9 +911,7 @@ int main(int argc, char **argv)
                                 return;
                             }
                             Batch &bt = *round[g];
-                            if (bt.may_pin && !bt.pinned && bt.bases.capacity() >= (1u << 20) &&
-                                taxor_gpu_host_register(&bt.bases[0], bt.bases.capacity()) == TAXOR_OK)
-                                bt.pinned = &bt.bases[0];
+                            pin(bt);
                             int rc = taxor_gpu_search_batch_begin(sr[g], bt.bases.data(), bt.offsets.data(), bt.ids.size());
                             if (rc == TAXOR_OK) rc = taxor_gpu_batch_sync(sr[g]);
                             if (rc == TAXOR_E_ALPHABET && strip_space_and_digits(bt)) {
@@ -874,72 +927,78 @@ int main(int argc, char **argv)
                     taxor_gpu_results res{};
                     if (taxor_gpu_gather_results(comm, sr.data(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
                     const double t3 = now();
-                    uint64_t r0 = 0;
-                    for (auto &bt : round) {               // the gathered CSR is in device order = batch order of the round
-                        const uint64_t n = bt->ids.size(), t0_ = res.read_off[r0], t1_ = res.read_off[r0 + n];
-                        bt->read_off.resize(n + 1);
-                        for (uint64_t i = 0; i <= n; ++i) bt->read_off[i] = res.read_off[r0 + i] - t0_;
-                        bt->user_bin.assign(res.user_bin + t0_, res.user_bin + t1_);
-                        bt->count.assign(res.count + t0_, res.count + t1_);
-                        bt->n_hashes.assign(res.n_hashes + r0, res.n_hashes + r0 + n);
-                        r0 += n;
-                        std::lock_guard<std::mutex> lk(stat_mu);
-                        ++n_batches;
-                        total_reads += n;
-                        total_bases += bt->bases.size();
-                    }
-                    if (r0 != res.n_reads) die("internal: the gathered round does not hold the round's reads");
+                    split_results(round, res);              // the gathered CSR is in device order = chunk order of the round
                     {
                         std::lock_guard<std::mutex> lk(stat_mu);
                         t_search += t2 - t1;
                         t_gather += t3 - t2;
                         t_compute += now() - t1;
                     }
-                    for (auto &bt : round) q_out.push(std::move(bt));
-                    if (eof) q_out.push(std::move(eof));
+                    for (auto &bt : round) q_fmt.push(std::move(bt));
+                    if (eof) q_fmt.push(std::move(eof));
                 }
             });
         else
-        for (size_t g = 0; g < ng; ++g)
-            workers.emplace_back([&, g] {
-                std::unique_ptr<Batch> b;
-                while (q_in.pop(b)) {
-                    if (b->end_of_file) { q_out.push(std::move(b)); continue; }
-                    const double t1 = now();
-                    if (b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
-                        taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
-                        b->pinned = &b->bases[0];       // recycled with the batch: pinned once, DMA source from then on
-                    const double t2 = now();
-                    taxor_gpu_results res{};
-                    int rc = taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res);
-                    if (rc == TAXOR_E_ALPHABET && strip_space_and_digits(*b))
-                        rc = taxor_gpu_search_batch(sr[g], b->bases.data(), b->offsets.data(), b->ids.size(), &res);
-                    if (rc != TAXOR_OK) die(taxor_gpu_last_error());
-                    const double t3 = now();
-                    b->read_off.assign(res.read_off, res.read_off + res.n_reads + 1);
-                    b->user_bin.assign(res.user_bin, res.user_bin + res.n_tuples);
-                    b->count.assign(res.count, res.count + res.n_tuples);
-                    b->n_hashes.assign(res.n_hashes, res.n_hashes + res.n_reads);
-                    {
-                        std::lock_guard<std::mutex> lk(stat_mu);
-                        t_pin += t2 - t1;
-                        t_search += t3 - t2;
-                        ++n_batches;
-                        t_compute += now() - t1;
-                        total_reads += b->ids.size();
-                        total_bases += b->bases.size();
+            for (size_t wi = 0; wi < ng * wpg; ++wi)
+                workers.emplace_back([&, wi] {
+                    std::vector<std::unique_ptr<Batch>> group, eofs;
+                    std::vector<taxor_read_segment> segs;
+                    std::unique_ptr<Batch> b;
+                    while (q_in.pop(b)) {
+                        if (b->end_of_file) { q_fmt.push(std::move(b)); continue; }
+                        // one GPU batch = the queued chunks that make up ~group_reads reads: the kernels want >= 10^5 reads in
+                        // flight, the parsers want chunks small enough to hand out to many threads
+                        group.clear();
+                        eofs.clear();
+                        uint64_t gr = b->ids.size(), gb = b->bases.size();
+                        group.push_back(std::move(b));
+                        while (gr < group_reads && gb < (3ull << 30) && group.size() < group_max_chunks && q_in.try_pop(b)) {
+                            if (b->end_of_file) { eofs.push_back(std::move(b)); continue; }
+                            gr += b->ids.size();
+                            gb += b->bases.size();
+                            group.push_back(std::move(b));
+                        }
+                        const double t1 = now();
+                        for (auto &bt : group) pin(*bt);
+                        const double t2 = now();
+                        taxor_gpu_results res{};
+                        auto run = [&]() -> int {
+                            segs.clear();
+                            for (auto &bt : group) segs.push_back({bt->bases.data(), bt->offsets.data(), bt->ids.size()});
+                            const int rc = taxor_gpu_search_segments_begin(sr[wi], segs.data(), segs.size());
+                            return rc != TAXOR_OK ? rc : taxor_gpu_search_batch_end(sr[wi], &res);
+                        };
+                        int rc = run();
+                        if (rc == TAXOR_E_ALPHABET) {
+                            bool any = false;
+                            for (auto &bt : group) any = strip_space_and_digits(*bt) || any;
+                            if (any) rc = run();
+                        }
+                        if (rc != TAXOR_OK) die(taxor_gpu_last_error());
+                        const double t3 = now();
+                        split_results(group, res);
+                        {
+                            std::lock_guard<std::mutex> lk(stat_mu);
+                            t_pin += t2 - t1;
+                            t_search += t3 - t2;
+                            ++n_gpu_batches;
+                            t_compute += now() - t1;
+                        }
+                        for (auto &bt : group) q_fmt.push(std::move(bt));
+                        for (auto &e : eofs) q_fmt.push(std::move(e));
                     }
-                    q_out.push(std::move(b));
-                }
-            });
+                });
         for (auto &t : workers) t.join();
         trace("GPU workers done");
+        t_search_wall += now() - t_search0;
+        q_fmt.close();
+        for (auto &t : fmt_threads) t.join();
         q_out.close();
         reader.join();
         writer.join();
         trace("writer done");
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
-        for (size_t g = 0; g < ng; ++g) taxor_gpu_searcher_destroy(sr[g]);
+        for (auto *x : sr) taxor_gpu_searcher_destroy(x);
         if (comm) {
             taxor_gpu_comm_stats cs{};
             taxor_gpu_comm_info(comm, &cs);
@@ -974,8 +1033,10 @@ int main(int argc, char **argv)
     fclose(out);
     trace("output closed");
     if (getenv("TAXOR_CLI_TRACE"))
-        fprintf(stderr, "[trace] %llu batches: pin %.3f s, search_batch %.3f s, gather %.3f s, copy-out %.3f s\n", (unsigned long long)n_batches, t_pin,
-                t_search, t_gather, t_compute - t_pin - t_search - t_gather);
+        fprintf(stderr, "[trace] %llu chunks in %llu GPU batches: pin %.3f s, search %.3f s, gather %.3f s, copy-out %.3f s (summed over workers); "
+                        "search phase %.3f s wall after the index was resident = %.1f Mbp/s\n", (unsigned long long)n_batches,
+                (unsigned long long)(n_gpu_batches ? n_gpu_batches : n_batches), t_pin, t_search, t_gather, t_compute - t_pin - t_search - t_gather, t_search_wall,
+                t_search_wall > 0 ? total_bases / t_search_wall / 1e6 : 0.0);
     printf("Index I/O\tReads I/O\tCompute\n%.2f\t%.2f\t%.2f\n", t_index, t_reads, t_compute);   // :328-336
     printf("%llu reads, %llu bases classified\n", (unsigned long long)total_reads, (unsigned long long)total_bases);
     {   // the reference's main() closes with the process's CPU time and peak resident set (main.cpp:37-49,79-84)

@@ -100,6 +100,24 @@ class HixfFile:
                                              ub.size, buf, len(buf))
         return buf.raw[:n].decode("utf-8", "replace")
 
+    def format_reads(self, ids, read_lens, n_hashes, read_off, user_bin, count):
+        """the text of a whole chunk of reads (taxor_format_reads)"""
+        n = len(ids)
+        enc = [i.encode() for i in ids]
+        idp = (C.c_char_p * n)(*enc)
+        idl = np.array([len(e) for e in enc], dtype=np.uint64)
+        rl = np.ascontiguousarray(read_lens, dtype=np.uint64)
+        nh = np.ascontiguousarray(n_hashes, dtype=np.uint32)
+        ro = np.ascontiguousarray(read_off, dtype=np.uint64)
+        ub = np.ascontiguousarray(user_bin, dtype=np.int64)
+        ct = np.ascontiguousarray(count, dtype=np.uint32)
+        args = (self._h, n, C.cast(idp, C.c_void_p), idl.ctypes.data, rl.ctypes.data, nh.ctypes.data, ro.ctypes.data, ub.ctypes.data, ct.ctypes.data)
+        need = _lib.lib().taxor_format_reads(*args, None, 0)
+        buf = C.create_string_buffer(int(need) + 1)
+        got = _lib.lib().taxor_format_reads(*args, buf, int(need))
+        assert got == need
+        return buf.raw[:need].decode("utf-8", "replace")
+
     def close(self):
         if getattr(self, "_h", None):
             self.ixfs = []

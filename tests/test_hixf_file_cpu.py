@@ -116,6 +116,12 @@ def test_format_read_matches_reference_text(tmp_path):
     for rid, rl, nh, tup in cases:
         got = h.format_read(rid, rl, nh, [u for u, _ in tup], [c for _, c in tup])
         assert got == expected_lines(sp, rid, rl, nh, tup), rid
+    # the chunk formatter (what the CLI's formatter threads call) writes the same text for all of them at once
+    off = np.cumsum([0] + [len(t) for _, _, _, t in cases])
+    text = h.format_reads([c[0] for c in cases], [c[1] for c in cases], [c[2] for c in cases], off,
+                          [u for c in cases for u, _ in c[3]], [k for c in cases for _, k in c[3]])
+    assert text == "".join(expected_lines(sp, rid, rl, nh, tup) for rid, rl, nh, tup in cases)
+    assert h.format_reads([], [], [], [0], [], []) == ""
     h.close()
 
 
