@@ -295,7 +295,7 @@ def build_workload(args, local_rank, rank, world):
         origins.append(origin)
     log(f"{len(batches)} distinct batches of {batches[0][1].size - 1} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
     return wl, idx, lay, batches, dict(n_reads=n_reads, read_len=read_len, n_genomes=n_genomes, genome_len=genome_len,
-                                       fam_size=fam_size, ncpu=ncpu, origins=origins)
+                                       fam_size=fam_size, ncpu=ncpu, origins=origins, genomes=g, genome_off=go)
 
 
 def main():

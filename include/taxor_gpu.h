@@ -396,6 +396,11 @@ int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *view, const
 /* load with the default schema; if the records do not fit it, probe the file and load with what was found */
 int taxor_hixf_load(const char *path, taxor_hixf **out);
 void taxor_hixf_free(taxor_hixf *h);
+/* Once the index is resident on the devices: give the pages of the file mapping that hold fingerprint bytes back to the
+ * system, in slices, from whatever thread the caller likes (the search can run meanwhile).  The metadata (species,
+ * filenames, bin tables) stays; view->ixf[i].data must not be read by the caller afterwards.  taxor_hixf_free is then
+ * cheap. */
+void taxor_hixf_release_data(taxor_hixf *h);
 const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h);
 const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h);
 int taxor_hixf_store(const char *path, const taxor_hixf_view *view, const taxor_hixf_meta *meta);

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""The whole drop-in chain at BASELINE configs[2] scale: a RefSeq-class `.hixf` (9.9 GB, family workload, built on the
-GPU, read back and written to disk with the library's writer), a FASTQ of 10-kb reads, the C++ `taxor search` CLI --
-index load + upload, parallel parsing, GPU search, TSV -- and a per-read comparison of its TSV with the library's own
-formatter over the Python searcher's results for the same reads.
-usage: python profiles/cli_e2e_class.py [workload=refseq] [n_reads=400000]"""
+"""The whole drop-in chain at BASELINE configs[2] / [3] scale: a RefSeq- or GTDB-class `.hixf` (family workload, built on the
+GPU, read back and written to disk with the library's writer), a FASTQ of 10-kb reads (10 M of them = 200 GB for the
+round-3 measurement), the C++ `taxor search` CLI -- index load + upload, parallel parsing, GPU search, TSV -- and a
+byte comparison of its TSV with the library's own formatter over the Python searcher's results for the same reads.
+usage: python profiles/cli_e2e_class.py [workload=refseq] [n_reads=400000]      (TAXOR_E2E_RUNS=32,32,8: --threads of the runs)"""
 import os
 import subprocess
 import sys
@@ -22,12 +22,39 @@ from taxor_amd.hixf_file import HixfFile, store_hixf  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "refseq"
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
-args = bench.parse_args(["--workload", workload, "--reads", str(n_reads), "--batches", "1"])
+args = bench.parse_args(["--workload", workload, "--reads", str(min(n_reads, 131072)), "--batches", "1"])
 wl, idx, lay, batches, info = bench.build_workload(args, 0, 0, 1)
 bases, offs = batches[0]
 read_len = info["read_len"]
 import shutil  # noqa: E402
 need = idx.data_bytes * 1.05 + n_reads * (2 * read_len + 64)
+
+
+def _mem_limit():
+    """what this process tree may use: the cgroup limit if there is one, else MemAvailable"""
+    lim = None
+    for pth in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(pth).read().strip()
+            if v.isdigit() and int(v) < (1 << 60):
+                lim = int(v)
+        except OSError:
+            pass
+    try:
+        avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+    except (OSError, StopIteration):
+        avail = None
+    return min(x for x in (lim, avail) if x is not None) if (lim or avail) else None
+
+
+# index file + FASTQ + two TSVs live in tmpfs (= RAM) beside a host copy of the index while it is written: bound the
+# footprint against what the box (or its cgroup) really has, instead of finding out by exhausting it
+footprint = max(2.1 * idx.data_bytes,                                   # host copy + file while the index is written
+                1.05 * idx.data_bytes + n_reads * (2 * read_len + 64) + 2 * n_reads * 1200 + 20e9)   # file + FASTQ + two TSVs + the CLI's buffers
+lim = _mem_limit()
+print(f"memory: footprint ~{footprint/1e9:.0f} GB, limit/available {lim/1e9 if lim else float('nan'):.0f} GB", flush=True)
+if lim is not None and footprint > 0.8 * lim:
+    raise SystemExit(f"refusing: ~{footprint/1e9:.0f} GB of host memory needed, {lim/1e9:.0f} GB available")
 base = next((d for d in (os.environ.get("TAXOR_E2E_TMP"), "/tmp", "/dev/shm") if d and os.path.isdir(d) and shutil.disk_usage(d).free > need), None)
 if base is None:
     raise SystemExit(f"no scratch directory with {need/1e9:.0f} GB free")
@@ -44,39 +71,97 @@ del host
 print(f"{workload}-class index read back from HBM and written: {os.path.getsize(idx_path)/1e9:.2f} GB, {time.time()-t0:.1f}s", flush=True)
 fq = os.path.join(tmp, "reads.fastq")
 t0 = time.time()
-qual = b"I" * read_len
-bb = bases.tobytes()
-with open(fq, "wb") as f:
-    for i in range(n_reads):
-        f.write(b"@read_%d\n" % i)
-        f.write(bb[i * read_len:(i + 1) * read_len])
-        f.write(b"\n+\n")
-        f.write(qual)
-        f.write(b"\n")
-print(f"fastq {os.path.getsize(fq)/1e9:.2f} GB written in {time.time()-t0:.1f}s", flush=True)
+# the reads, batch by batch (same generator and seeds as bench.py's distinct batches): searched through the library for the
+# expected text, and appended to the FASTQ.  Fixed-width ids make every record the same length, so a batch is one 2-D array.
+from taxor_amd import synth  # noqa: E402
 sr = Searcher(idx, error_rate=args.error_rate)
-res = sr.search_batch(bases, offs)
+hx = HixfFile(idx_path)
+per = 131072
+g, go = info.get("genomes"), info.get("genome_off")
+expected_sizes, n_tuples, n_lines, kept = [], 0, 0, []
+want_path = os.path.join(tmp, "want.tsv")
+with open(fq, "wb") as f, open(want_path, "w") as wf:
+    done = 0
+    b = 0
+    while done < n_reads:
+        n = min(per, n_reads - done)
+        if b == 0:
+            bb, oo = bases, offs
+            if oo.size - 1 > n:
+                bb, oo = bb[: int(oo[n])], oo[: n + 1]
+            n = oo.size - 1
+        else:
+            bb, oo, _ = synth.synth_reads(g, go, n, read_len, error_rate=args.read_error, frac_random=0.1, seed=synth.DEFAULT_SEED + 1000 * b,
+                                          threads=info["ncpu"])
+        if len(kept) < 8:
+            kept.append((np.ascontiguousarray(bb), np.ascontiguousarray(oo)))
+        r = sr.search_batch(bb, oo)
+        ids = [f"read_{done + i:09d}" for i in range(n)]
+        text = hx.format_reads(ids, np.full(n, read_len), r.n_hashes, r.read_off, r.user_bin, r.count)
+        wf.write(text)
+        expected_sizes.append(len(text))
+        n_tuples += int(r.user_bin.size)
+        n_lines += text.count("\n")
+        rec = np.empty((n, 1 + 14 + 1 + read_len + 3 + read_len + 1), dtype=np.uint8)
+        rec[:, 0] = ord("@")
+        rec[:, 1:6] = np.frombuffer(b"read_", np.uint8)
+        num = np.arange(done, done + n, dtype=np.int64)
+        rec[:, 6:15] = (num[:, None] // 10 ** np.arange(8, -1, -1)) % 10 + 48
+        rec[:, 15] = 10
+        rec[:, 16:16 + read_len] = bb.reshape(n, read_len)
+        rec[:, 16 + read_len:19 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
+        rec[:, 19 + read_len:19 + 2 * read_len] = ord("I")
+        rec[:, -1] = 10
+        rec.tofile(f)
+        done += n
+        b += 1
 sr.close()
+hx.close()
+# the library's own host-fed rate on these reads (bench.py's `sustained`: page-locked staging buffers, two searchers in
+# flight, results fetched every call) -- what the CLI's search phase is held against
+keep = kept[:8]
+sargs = bench.parse_args(["--workload", workload, "--sustained-reads", str(max(n_reads, 4 * per))])
+_, sustained = bench.dropin_measurements(sargs, idx, keep, read_len)
+print(f"library sustained (host-fed, two searchers, {sustained['reads']} reads): {sustained['value']:.0f} Mbp/s", flush=True)
+del keep, kept
 idx.close()                      # the CLI loads its own replica
+print(f"fastq {os.path.getsize(fq)/1e9:.2f} GB ({n_reads} reads) written and searched through the library in {time.time()-t0:.1f}s", flush=True)
 out = os.path.join(tmp, "out.tsv")
-for extra in (["--threads", "32"], ["--threads", "32"], ["--threads", "8"]):
+runs = os.environ.get("TAXOR_E2E_RUNS", "32,32,8").split(",")
+for thr in runs:
+    extra = ["--threads", thr]
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
                         capture_output=True, text=True, env=dict(os.environ, TAXOR_CLI_TRACE="1"))
     dt = time.time() - t0
     print(" ".join(extra), "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end (index load included)")
     print(cp.stdout.strip().replace("\n", " | "))
-    print("\n".join(l for l in cp.stderr.splitlines() if "trace" in l)[:1200], flush=True)
-# the CLI's text against the library formatter over the Python searcher's tuples, read by read
-hx = HixfFile(idx_path)
-want = []
-for i in range(n_reads):
-    lo, hi = int(res.read_off[i]), int(res.read_off[i + 1])
-    want.append(hx.format_read(f"read_{i}", read_len, int(res.n_hashes[i]), res.user_bin[lo:hi], res.count[lo:hi]))
-hx.close()
-got = open(out).read()
-hdr, body = got.split("\n", 1)
-same = body == "".join(want)
-print(f"TSV: {got.count(chr(10))} lines, {res.user_bin.size} tuples before the 0.8*max filter; identical to formatter(searcher results): {same}")
-subprocess.run(["rm", "-rf", tmp])
+    tr = [l for l in cp.stderr.splitlines() if "trace" in l]
+    print("\n".join(tr)[:2400], flush=True)
+    import re  # noqa: E402
+    stamp = {}
+    for l in tr:
+        m = re.match(r"\[trace\]\s+([0-9.]+) s  (.*)", l)
+        if m:
+            stamp[m.group(2)] = float(m.group(1))
+    m = re.search(r"search phase ([0-9.]+) s wall after the index was resident = ([0-9.]+) Mbp/s", cp.stderr)
+    if m and "writer done" in stamp and "output closed" in stamp:
+        print(f"RATE --threads {thr}: search phase {float(m.group(2)):.0f} Mbp/s = {float(m.group(2)) / sustained['value']:.3f} x library sustained; "
+              f"teardown (writer done -> output closed) {stamp['output closed'] - stamp['writer done']:.3f} s; process exit {dt - stamp['output closed']:.3f} s later", flush=True)
+# the CLI's text against the library formatter over the Python searcher's tuples, batch by batch
+same = True
+with open(out, "rb") as fo, open(want_path, "rb") as fw:
+    hdr = fo.readline()
+    while True:
+        x, y = fo.read(64 << 20), fw.read(64 << 20)
+        if x != y:
+            same = False
+            break
+        if not x:
+            break
+print(f"TSV: {n_lines} lines, {n_tuples} tuples before the 0.8*max filter; identical to formatter(searcher results): {same}")
+if os.environ.get("TAXOR_E2E_KEEP"):
+    print(f"kept: {tmp}", flush=True)
+else:
+    subprocess.run(["rm", "-rf", tmp])
 sys.exit(0 if same else 1)

@@ -144,6 +144,7 @@ SIGNATURES = {
     "taxor_hixf_load_schema": (C.c_int, [C.c_char_p, C.POINTER(IxfSchema), C.POINTER(_P)]),
     "taxor_hixf_store_schema": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta), C.POINTER(IxfSchema)]),
     "taxor_hixf_free": (None, [_P]),
+    "taxor_hixf_release_data": (None, [_P]),
     "taxor_hixf_get_view": (C.POINTER(HixfView), [_P]),
     "taxor_hixf_get_meta": (C.POINTER(HixfMeta), [_P]),
     "taxor_hixf_store": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta)]),

@@ -5,6 +5,8 @@
 #include "ixf_arith.h"
 #include "kernels.h"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -196,7 +198,7 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*progress)(void *, uint64_t), void *pctx)
 {
     struct Piece { uint64_t ixf, off, len, slab_end; };
-    static const uint64_t piece_bytes = [] { const char *e = getenv("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 32) << 20; }();
+    static const uint64_t piece_bytes = [] { const char *e = getenv("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 8) << 20; }();
     const uint64_t n = v->n_ixf;
     std::vector<Piece> pieces;
     for (uint64_t i = 0; i < n; ++i) {
@@ -210,12 +212,58 @@ static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*p
         }
     }
     if (pieces.empty()) { if (progress) progress(pctx, idx->slab_bytes); return 0; }
+    static const bool trace_up = getenv("TAXOR_TRACE_UPLOAD") != nullptr;
+    const auto up_t0 = std::chrono::steady_clock::now();
+    struct UpTrace {
+        bool on; std::chrono::steady_clock::time_point t0; const std::vector<Piece> &pc; bool src;
+        ~UpTrace()
+        {
+            if (!on) return;
+            uint64_t b = 0;
+            for (const Piece &p : pc) b += p.len;
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "[upload] %.2f GB in %.3f s = %.1f GB/s (%s)\n", b / 1e9, dt, b / 1e9 / dt, src ? "source reader, page-locked staging" : "host pointers, runtime pageable path");
+        }
+    } up_trace{trace_up, up_t0, pieces, v->source != nullptr};
     if (!v->source) {
+        // The runtime copies large pageable buffers by pinning the caller's pages in place and letting the DMA engines read
+        // them -- no CPU copy, but every page has to be present in this process's page tables first, and the runtime's
+        // copy thread takes those faults one 4-KiB page at a time.  For a mapped file of tens of gigabytes that is most of
+        // the time; a few helper threads populate the page tables ahead of the copy (MADV_POPULATE_READ, Linux >= 5.14;
+        // where the kernel does not know it the call fails and the copy faults the pages in as before).
+        static const int pf_threads = [] { const char *e = getenv("TAXOR_UPLOAD_PREFAULT"); const int t = e ? atoi(e) : -1; return t >= 0 && t <= 64 ? t : 8; }();
+        uint64_t total = 0;
+        for (const Piece &p : pieces) total += p.len;
+        std::atomic<size_t> pf_cursor{0};
+        std::atomic<bool> pf_stop{false};
+        std::vector<std::thread> pf;
+        struct Slice { const uint8_t *p; uint64_t len; };
+        std::vector<Slice> slices;
+        if (pf_threads > 0 && total >= (256ull << 20)) {
+            const uint64_t sl = 64ull << 20;
+            for (const Piece &p : pieces)
+                for (uint64_t o = 0; o < p.len; o += sl) slices.push_back({v->ixf[p.ixf].data + p.off + o, std::min(sl, p.len - o)});
+            for (int t = 0; t < pf_threads; ++t)
+                pf.emplace_back([&] {
+                    for (;;) {
+                        const size_t i = pf_cursor.fetch_add(1);
+                        if (i >= slices.size() || pf_stop.load()) break;
+                        const uintptr_t a = (uintptr_t)slices[i].p & ~(uintptr_t)4095, e = ((uintptr_t)slices[i].p + slices[i].len + 4095) & ~(uintptr_t)4095;
+#ifdef MADV_POPULATE_READ
+                        if (madvise((void *)a, e - a, MADV_POPULATE_READ) != 0) { pf_stop.store(true); break; }
+#else
+                        (void)a; (void)e; pf_stop.store(true); break;
+#endif
+                    }
+                });
+        }
+        auto join_pf = [&] { pf_stop.store(true); for (auto &t : pf) t.join(); };
         for (const Piece &p : pieces) {
             const hipError_t e = hipMemcpy(idx->d_slab + idx->slab_off[p.ixf] + p.off, v->ixf[p.ixf].data + p.off, p.len, hipMemcpyHostToDevice);
-            if (e != hipSuccess) return fail(TAXOR_E_HIP, "index upload of IXF %llu failed: %s", (unsigned long long)p.ixf, hipGetErrorString(e));
+            if (e != hipSuccess) { join_pf(); return fail(TAXOR_E_HIP, "index upload of IXF %llu failed: %s", (unsigned long long)p.ixf, hipGetErrorString(e)); }
             if (progress) progress(pctx, p.slab_end);
         }
+        join_pf();
         if (progress) progress(pctx, idx->slab_bytes);
         return 0;
     }

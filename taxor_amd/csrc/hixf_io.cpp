@@ -495,6 +495,21 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
     return rc2;
 }
 
+// Give the fingerprint pages of the mapping back, slice by slice (MADV_DONTNEED takes the address-space lock shared and
+// only for a slice at a time; one munmap of 113 GB of populated mapping holds it exclusively for seconds and stalls every
+// page fault and allocation of the process meanwhile).  After this the view's data pointers must not be read through
+// any more by the caller's own code -- index creation and the source reader do not need them.
+extern "C" void taxor_hixf_release_data(taxor_hixf *h)
+{
+    if (!h || !h->map) return;
+    const uintptr_t base = (uintptr_t)h->map;
+    for (size_t i = 0; i < h->ixf.size(); ++i) {
+        const uint64_t len = 3 * h->ixf[i].seg_len * h->ixf[i].stride;
+        uintptr_t a = (base + h->file_off[i] + 4095) & ~(uintptr_t)4095, e = (base + h->file_off[i] + len) & ~(uintptr_t)4095;
+        for (; a < e; a += (256ull << 20)) madvise((void *)a, std::min<uintptr_t>(256ull << 20, e - a), MADV_DONTNEED);
+    }
+}
+
 extern "C" void taxor_hixf_free(taxor_hixf *h)
 {
     if (!h) return;

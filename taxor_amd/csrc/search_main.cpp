@@ -105,6 +105,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
+    bool pin_in_parser = false; // set by `search` (a GPU process); the `reads` checker never touches the GPU
     uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
                                 // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
@@ -220,6 +221,11 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                             if (bt->pinned) { taxor_gpu_host_unregister(bt->pinned); bt->pinned = nullptr; }
                             bt->bases.clear();
                             bt->bases.reserve((need + need / 16 + (2u << 20)) & ~size_t((2u << 20) - 1));
+                            // page-lock it here, on the parser's time (the chunk is recycled: once per buffer), not on the GPU
+                            // worker's; a failure leaves it pageable
+                            if (cfg.pin_in_parser && bt->bases.capacity() >= (1u << 20) &&
+                                taxor_gpu_host_register(&bt->bases[0], bt->bases.capacity()) == TAXOR_OK)
+                                bt->pinned = &bt->bases[0];
                         }
                         bt->ids.clear();
                         bt->bases.clear();
@@ -638,6 +644,7 @@ int main(int argc, char **argv)
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
     if (cfg.index_file.empty()) die("Option --index-file is required but not set.");
+    cfg.pin_in_parser = getenv("TAXOR_CLI_PIN_IN_WORKER") == nullptr;
 
     // ---- sanity checks (taxor_search.cpp:97-151) --------------------------------------------------------------
     printf("checking input ... ");
@@ -852,6 +859,8 @@ int main(int argc, char **argv)
         if (getenv("TAXOR_CLI_TRACE"))
             fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
                     now() - t0, taxor_gpu_index_data_bytes(gidx[0]) / 1e9 / (now() - t0));
+        // the host mapping of the index is not needed any more: its pages go back on a helper thread, beside the search
+        std::thread releaser([h] { taxor_hixf_release_data(h); });
         const double t_search0 = now();
         const unsigned wpg = comm ? 1u : workers_per_gpu;
         std::vector<taxor_gpu_searcher *> sr(ng * wpg, nullptr);
@@ -1009,6 +1018,7 @@ int main(int argc, char **argv)
         }
         for (size_t g = 0; g < ng; ++g) taxor_gpu_index_destroy(gidx[g]);
         trace("GPU memory released");
+        releaser.join();
         taxor_hixf_free(h);
         trace("host index released");
         if (last) {
