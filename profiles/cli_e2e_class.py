@@ -49,7 +49,7 @@ def _mem_limit():
 
 # index file + FASTQ + two TSVs live in tmpfs (= RAM) beside a host copy of the index while it is written: bound the
 # footprint against what the box (or its cgroup) really has, instead of finding out by exhausting it
-footprint = max(2.1 * idx.data_bytes,                                   # host copy + file while the index is written
+footprint = max(1.5 * idx.data_bytes,                                   # file + the largest IXF on the host while the index is written
                 1.05 * idx.data_bytes + n_reads * (2 * read_len + 64) + 2 * n_reads * 1200 + 20e9)   # file + FASTQ + two TSVs + the CLI's buffers
 lim = _mem_limit()
 print(f"memory: footprint ~{footprint/1e9:.0f} GB, limit/available {lim/1e9 if lim else float('nan'):.0f} GB", flush=True)
@@ -61,12 +61,13 @@ if base is None:
 tmp = tempfile.mkdtemp(prefix="taxor_e2e_", dir=base)
 print(f"scratch: {tmp}", flush=True)
 t0 = time.time()
+# the file is written IXF by IXF straight out of HBM (one IXF on the host at a time: the root's 45 GB, not all 113 GB)
 host = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=idx.ixf_seed(i), next_ixf=f["next_ixf"], fname_idx=f["fname_idx"],
-             data=idx.download_ixf(i)) for i, f in enumerate(lay["ixfs"])]
+             data=None) for i, f in enumerate(lay["ixfs"])]
 species = [dict(organism_name=f"Organism {u}", accession_id=f"GCF_{u:09d}.1", taxid=str(1000 + u), taxnames_string=f"k__Bacteria;s__Organism {u}",
                 taxid_string=f"2;{1000 + u}", user_bin=u, seq_len=info["genome_len"]) for u in range(lay["n_user_bins"])]
 idx_path = os.path.join(tmp, f"{workload}.hixf")
-store_hixf(idx_path, host, lay["n_user_bins"], species)
+store_hixf(idx_path, host, lay["n_user_bins"], species, data_of=idx.download_ixf)
 del host
 print(f"{workload}-class index read back from HBM and written: {os.path.getsize(idx_path)/1e9:.2f} GB, {time.time()-t0:.1f}s", flush=True)
 fq = os.path.join(tmp, "reads.fastq")

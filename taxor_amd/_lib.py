@@ -21,6 +21,13 @@ class IxfView(C.Structure):
                 ("data", C.c_void_p), ("next_ixf", C.c_void_p), ("fname_idx", C.c_void_p)]
 
 
+IXF_READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
+class IxfSource(C.Structure):
+    _fields_ = [("read", IXF_READ_FN), ("ctx", C.c_void_p)]
+
+
 class HixfView(C.Structure):
     _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
                 ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),

@@ -560,7 +560,7 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
     std::vector<uint64_t> sv(ns);
     for (uint64_t i = 0; i < v->n_ixf; ++i) {
         const taxor_ixf_view &x = v->ixf[i];
-        if (!x.data) {
+        if (!x.data && !v->source) {
             fclose(f);
             return io_fail(TAXOR_E_ARG, "hixf_store: IXF without host data");
         }
@@ -577,7 +577,18 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
         for (uint32_t j = 0; j < sc->n_before; ++j) w.put<uint64_t>(sv[j]);
         const uint64_t len = 3 * x.seg_len * x.stride;
         w.put<uint64_t>(len);
-        w.bytes(x.data, len);
+        if (v->source) {                                             // bytes that are not in host memory as a whole (e.g. an
+            std::vector<uint8_t> piece((size_t)std::min<uint64_t>(len, 64ull << 20));   // index resident on a GPU): piece by piece
+            for (uint64_t o = 0; o < len && w.ok; o += piece.size()) {
+                const uint64_t n = std::min<uint64_t>(piece.size(), len - o);
+                if (v->source->read(v->source->ctx, i, o, n, piece.data()) != 0) {
+                    fclose(f);
+                    return io_fail(TAXOR_E_IO, "hixf_store: the source failed to deliver IXF " + std::to_string(i));
+                }
+                w.bytes(piece.data(), n);
+            }
+        } else
+            w.bytes(x.data, len);
         for (uint32_t j = 0; j < sc->n_after; ++j) w.put<uint64_t>(sv[sc->n_before + j]);
     }
     w.put<uint64_t>(v->n_ixf);

@@ -9,19 +9,39 @@ from ._lib import check
 
 
 def store_hixf(path, ixfs, n_user_bins, species, k=22, s=12, t=5, filenames=None, window_size=None, scaling=1,
-               schema=None, use_syncmer=True):
-    """ixfs: list of dicts {bins, stride, seg_len, seed, data, next_ixf, fname_idx} (host data required);
-    species: list of dicts {organism_name, accession_id, taxid, taxnames_string, taxid_string, user_bin, seq_len}"""
+               schema=None, use_syncmer=True, data_of=None):
+    """ixfs: list of dicts {bins, stride, seg_len, seed, data, next_ixf, fname_idx};
+    species: list of dicts {organism_name, accession_id, taxid, taxnames_string, taxid_string, user_bin, seq_len}.
+    data_of: optional callable ixf -> uint8 array of that IXF's fingerprint bytes, called once per IXF in order while the file
+    is written (the ixfs' own "data" are then ignored): an index that is resident on a GPU is written without a host copy of
+    all of it at once."""
     keep = []
     arr = (_lib.IxfView * len(ixfs))()
     for i, f in enumerate(ixfs):
-        d = np.ascontiguousarray(f["data"], dtype=np.uint8)
+        d = None if data_of is not None else np.ascontiguousarray(f["data"], dtype=np.uint8)
         nx = np.ascontiguousarray(f["next_ixf"], dtype=np.int64)
         fn = np.ascontiguousarray(f["fname_idx"], dtype=np.int64)
         keep += [d, nx, fn]
-        arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data, nx.ctypes.data, fn.ctypes.data)
+        arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data)
     ws = window_size if window_size is not None else k
     view = _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, ws)
+    if data_of is not None:
+        cache = {}
+
+        def _read(_ctx, ixf, off, n, dst):
+            try:
+                if cache.get("ixf") != ixf:
+                    cache.clear()
+                    cache["ixf"], cache["data"] = ixf, np.ascontiguousarray(data_of(int(ixf)), dtype=np.uint8)
+                C.memmove(dst, cache["data"].ctypes.data + off, n)
+                return 0
+            except Exception:        # a Python exception must not unwind through the C caller
+                return -1
+
+        cb = _lib.IXF_READ_FN(_read)
+        src = _lib.IxfSource(cb, None)
+        keep += [cb, src]
+        view.source = C.cast(C.pointer(src), C.c_void_p)
     sp = (_lib.Species * len(species))()
     for i, x in enumerate(species):
         sp[i] = _lib.Species(x["organism_name"].encode(), x["accession_id"].encode(), x["taxid"].encode(),
