@@ -161,6 +161,8 @@ double now()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+std::atomic<bool> g_index_resident{false};   // parsers page-lock new chunk buffers only once the index is on the devices
+
 // TAXOR_CLI_TRACE=1: wall-clock marks of the pipeline stages on stderr
 const double g_t0 = now();
 void trace(const char *what)
@@ -222,8 +224,10 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                             bt->bases.clear();
                             bt->bases.reserve((need + need / 16 + (2u << 20)) & ~size_t((2u << 20) - 1));
                             // page-lock it here, on the parser's time (the chunk is recycled: once per buffer), not on the GPU
-                            // worker's; a failure leaves it pageable
-                            if (cfg.pin_in_parser && bt->bases.capacity() >= (1u << 20) &&
+                            // worker's; a failure leaves it pageable.  Not while the index is still on its way to the devices:
+                            // registrations then queue behind the driver's 113 GB allocation and the parsers stand still
+                            // (buffers made that early are pinned by the GPU worker at first use)
+                            if (cfg.pin_in_parser && g_index_resident.load() && bt->bases.capacity() >= (1u << 20) &&
                                 taxor_gpu_host_register(&bt->bases[0], bt->bases.capacity()) == TAXOR_OK)
                                 bt->pinned = &bt->bases[0];
                         }
@@ -855,6 +859,7 @@ int main(int argc, char **argv)
                 if (!e.empty()) die(e);
         }
         t_index += now() - t0;
+        g_index_resident.store(true);
         trace("index resident in HBM");
         if (getenv("TAXOR_CLI_TRACE"))
             fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
@@ -998,6 +1003,7 @@ int main(int argc, char **argv)
                     }
                 });
         for (auto &t : workers) t.join();
+        g_index_resident.store(false);
         trace("GPU workers done");
         t_search_wall += now() - t_search0;
         q_fmt.close();

@@ -277,3 +277,38 @@ def test_tsv_is_what_taxor_profile_parses(tmp_path):
     # an id containing a tab shifts the columns in the reference's own output as well (it writes the id verbatim,
     # taxor_search.cpp:270,287): the formatter must not "repair" it
     assert "read_3\twith_tab\t" in text
+
+
+def test_store_from_a_source_writes_the_same_file(tmp_path):
+    """store_hixf(data_of=...): the fingerprint bytes come through a taxor_ixf_source, one IXF at a time (an index resident on a
+    GPU is written without a host copy of all of it) -- byte-identical to the file written from host arrays; and a loaded
+    file's own source (pread) delivers the same bytes as its mapping"""
+    import ctypes as C
+    import filecmp
+    from taxor_amd import _lib
+    lay, host, _ = small_layout()
+    sp = make_species(lay)
+    a, b = tmp_path / "a.hixf", tmp_path / "b.hixf"
+    store_hixf(a, host, lay["n_user_bins"], sp)
+    calls = []
+
+    def data_of(i):
+        calls.append(i)
+        return host[i]["data"]
+
+    store_hixf(b, [dict(f, data=None) for f in host], lay["n_user_bins"], sp, data_of=data_of)
+    assert filecmp.cmp(a, b, shallow=False) and calls == list(range(len(host)))
+    h = HixfFile(a)
+    v = _lib.lib().taxor_hixf_get_view(h._h).contents
+    assert v.source                                           # the loader offers a pread() reader of the file
+    src = C.cast(v.source, C.POINTER(_lib.IxfSource)).contents
+    for i, f in enumerate(h.ixfs):
+        n = f["data"].size
+        buf = np.empty(n, dtype=np.uint8)
+        assert src.read(src.ctx, i, 0, n, buf.ctypes.data) == 0 and np.array_equal(buf, f["data"])
+        if n > 100:
+            assert src.read(src.ctx, i, 37, 50, buf.ctypes.data) == 0 and np.array_equal(buf[:50], f["data"][37:87])
+    assert src.read(src.ctx, len(h.ixfs), 0, 1, buf.ctypes.data) != 0
+    _lib.lib().taxor_hixf_release_data(h._h)                  # gives the mapping's data pages back; the source still reads
+    assert src.read(src.ctx, 0, 0, 16, buf.ctypes.data) == 0 and np.array_equal(buf[:16], host[0]["data"][:16])
+    h.close()
