@@ -105,7 +105,6 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
-    bool pin_in_parser = false; // set by `search` (a GPU process); the `reads` checker never touches the GPU
     uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
                                 // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
@@ -160,8 +159,6 @@ double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-
-std::atomic<bool> g_index_resident{false};   // parsers page-lock new chunk buffers only once the index is on the devices
 
 // TAXOR_CLI_TRACE=1: wall-clock marks of the pipeline stages on stderr
 const double g_t0 = now();
@@ -223,13 +220,6 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                             if (bt->pinned) { taxor_gpu_host_unregister(bt->pinned); bt->pinned = nullptr; }
                             bt->bases.clear();
                             bt->bases.reserve((need + need / 16 + (2u << 20)) & ~size_t((2u << 20) - 1));
-                            // page-lock it here, on the parser's time (the chunk is recycled: once per buffer), not on the GPU
-                            // worker's; a failure leaves it pageable.  Not while the index is still on its way to the devices:
-                            // registrations then queue behind the driver's 113 GB allocation and the parsers stand still
-                            // (buffers made that early are pinned by the GPU worker at first use)
-                            if (cfg.pin_in_parser && g_index_resident.load() && bt->bases.capacity() >= (1u << 20) &&
-                                taxor_gpu_host_register(&bt->bases[0], bt->bases.capacity()) == TAXOR_OK)
-                                bt->pinned = &bt->bases[0];
                         }
                         bt->ids.clear();
                         bt->bases.clear();
@@ -648,7 +638,6 @@ int main(int argc, char **argv)
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
     if (cfg.index_file.empty()) die("Option --index-file is required but not set.");
-    cfg.pin_in_parser = getenv("TAXOR_CLI_PIN_IN_WORKER") == nullptr;
 
     // ---- sanity checks (taxor_search.cpp:97-151) --------------------------------------------------------------
     printf("checking input ... ");
@@ -729,9 +718,9 @@ int main(int argc, char **argv)
         static const unsigned workers_per_gpu = [] { const char *e = getenv("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
         const uint64_t group_reads = cfg.group_reads ? cfg.group_reads : (cfg.batch_reads ? cfg.batch_reads : 131072);
         const size_t group_max_chunks = 32;
-        BoundedQueue<std::unique_ptr<Batch>> q_in(32), q_fmt(8), q_out(8);
+        BoundedQueue<std::unique_ptr<Batch>> q_parsed(16), q_in(32), q_fmt(8), q_out(8);
         BatchPool pool;
-        pool.cap = readers * parse_threads + 32 + ng * workers_per_gpu * group_max_chunks + 8 + formatters + 8 + 8 + 2 * readers;
+        pool.cap = readers * parse_threads + 16 + 2 + 32 + ng * workers_per_gpu * group_max_chunks + 8 + formatters + 8 + 8 + 2 * readers;
         // a file that is not being written yet may run at most two chunks ahead, so that the file whose turn it is can
         // always get buffers
         std::mutex fmu;
@@ -755,12 +744,28 @@ int main(int argc, char **argv)
                             std::lock_guard<std::mutex> lk(fmu);
                             ++ahead[f];
                         }
-                        q_in.push(std::move(b));
+                        q_parsed.push(std::move(b));
                     }, (uint32_t)f, parse_threads, gate);
+                }
+            });
+        // Page-locking a chunk buffer (once per buffer: chunks are recycled) costs ~50-90 ms per GB inside the driver.  Neither
+        // the parsers nor the GPU workers pay it: a small stage of its own between them does, so that a registration queued
+        // behind the driver's 113 GB allocation stalls nobody who has other work.
+        std::vector<std::thread> pinners;
+        for (int pt = 0; pt < 2; ++pt)
+            pinners.emplace_back([&] {
+                std::unique_ptr<Batch> b;
+                while (q_parsed.pop(b)) {
+                    if (!b->end_of_file && b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
+                        taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
+                        b->pinned = &b->bases[0];       // recycled with the chunk: a DMA source from then on
+                    q_in.push(std::move(b));
                 }
             });
         std::thread reader([&] {
             for (auto &t : reader_threads) t.join();
+            q_parsed.close();
+            for (auto &t : pinners) t.join();
             q_in.close();
             trace("readers done");
         });
@@ -859,7 +864,6 @@ int main(int argc, char **argv)
                 if (!e.empty()) die(e);
         }
         t_index += now() - t0;
-        g_index_resident.store(true);
         trace("index resident in HBM");
         if (getenv("TAXOR_CLI_TRACE"))
             fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
@@ -1003,7 +1007,6 @@ int main(int argc, char **argv)
                     }
                 });
         for (auto &t : workers) t.join();
-        g_index_resident.store(false);
         trace("GPU workers done");
         t_search_wall += now() - t_search0;
         q_fmt.close();

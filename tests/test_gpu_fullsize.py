@@ -241,3 +241,29 @@ def test_refseq_class_hixf_file_through_the_cli(tmp_path):
     assert cp.returncode == 0, cp.stdout[-2000:] + cp.stderr[-2000:]
     assert "identical to formatter(searcher results): True" in cp.stdout
     assert cp.stdout.count(" rc 0 ") == 3
+
+
+def test_cli_search_phase_keeps_up_with_the_library(tmp_path):
+    """the drop-in CLI must not be slower than the library it wraps.  RefSeq-class `.hixf` (11 GB) and 1.3 M x
+    10 kb reads as FASTQ (26 GB) in tmpfs: once the index is resident, the CLI's search phase (parse -> GPU batches made of
+    parsed chunks -> TSV text -> file) runs at >= 0.8 x the library's own host-fed `sustained` rate on the same reads, and
+    after the last line is written the command is done within 0.3 s (no host mapping of the index to tear down).  The first
+    run reads tmpfs pages that were written a moment ago (every page is promoted on the LRU under 32 readers) and is not the
+    one judged."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 80e9 else str(tmp_path)
+    if shutil.disk_usage(scratch).free < 80e9:
+        pytest.skip("needs 80 GB of scratch space")
+    cp = subprocess.run([sys.executable, os.path.join(root, "profiles", "cli_e2e_class.py"), "refseq", "1310720"], capture_output=True, text=True,
+                        timeout=1200, env=dict(os.environ, TAXOR_E2E_TMP=scratch, TAXOR_E2E_RUNS="16,16,8,8"))
+    assert cp.returncode == 0, cp.stdout[-3000:] + cp.stderr[-2000:]
+    assert "identical to formatter(searcher results): True" in cp.stdout
+    rates = [(float(m.group(1)), float(m.group(2))) for m in re.finditer(r"RATE .*? = ([0-9.]+) x library sustained; teardown .*? ([0-9.]+) s;", cp.stdout)]
+    assert len(rates) == 4, cp.stdout[-3000:]
+    print(cp.stdout[-2500:])
+    assert max(r for r, _ in rates[1:]) >= 0.8, rates
+    assert max(t for _, t in rates) < 0.3, rates
