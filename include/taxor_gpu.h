@@ -77,6 +77,10 @@ typedef struct {
                                                    (taxor_search.cpp:223-233,243-249), applied on the device */
     uint64_t window_size;                       /* :212; used when use_syncmer == 0: window_size == kmer_size selects
                                                    every canonical k-mer, larger windows select minimisers */
+    uint32_t ixf_arith;                         /* 0 = this library's reading of seqan3::interleaved_xor_filter's un-vendored
+                                                   arithmetic (taxor_amd/csrc/ixf_arith.h); otherwise the code of another
+                                                   reading, taxor_ixf_arith_code(variant): chosen at run time, e.g. the one
+                                                   `taxor verify --variants` found a foreign file to follow */
     const taxor_ixf_source *source;             /* NULL: the fingerprint bytes are at ixf[i].data.  Otherwise index creation
                                                    reads them through the source and ignores ixf[i].data (taxor_hixf_load
                                                    sets it to a pread() reader of the file) */
@@ -336,6 +340,12 @@ typedef struct {
     uint8_t layout;     /* 0 data[row*stride + bin] (interleaved), 1 data[bin*rows + row] */
     uint8_t pad[2];
 } taxor_ixf_variant;
+/* The arithmetic part of a variant (key hash, seed entry, rotation step, range reduction, fingerprint fold) as the code
+ * an index carries (taxor_hixf_view::ixf_arith); 0 for this library's reading.  layout, seed, seg_len and stride are not
+ * part of it: the last three come from the file per IXF, and only the interleaved layout can be searched.  _decode fills
+ * the five arithmetic fields of *out and leaves the others alone. */
+uint32_t taxor_ixf_arith_code(const taxor_ixf_variant *v);
+void taxor_ixf_arith_decode(uint32_t code, taxor_ixf_variant *out);
 /* this library's reading for the given seed / segment length / stride */
 void taxor_ixf_variant_default(taxor_ixf_variant *out, uint64_t seed, uint64_t seg_len, uint64_t stride);
 int taxor_gpu_ixf_variant_scan(taxor_gpu_index *idx, uint64_t ixf, const taxor_ixf_variant *variants, uint32_t n_variants,
@@ -402,6 +412,9 @@ void taxor_hixf_free(taxor_hixf *h);
  * cheap. */
 void taxor_hixf_release_data(taxor_hixf *h);
 const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h);
+/* the file does not say which reading of the IXF arithmetic its writer followed: a loaded file starts at 0 (this library's);
+ * the caller sets what `taxor verify --variants` found (taxor_ixf_arith_code) before creating the index from the view */
+void taxor_hixf_set_arith(taxor_hixf *h, uint32_t arith);
 const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h);
 int taxor_hixf_store(const char *path, const taxor_hixf_view *view, const taxor_hixf_meta *meta);
 
@@ -445,6 +458,8 @@ uint64_t taxor_ixf_seg_len(uint64_t max_bin_elements);
 /* XOR-filter construction of one bin column (3*seg_len bytes) for `keys` under (seed, seg_len); returns 0,
  * or 1 if peeling failed for this seed (caller redraws the seed like construct_ixf.cpp:100-108). */
 int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint8_t *column);
+/* the same under another arithmetic code (taxor_ixf_arith_code) */
+int taxor_ixf_build_bin_arith(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint32_t arith, uint8_t *column);
 /* Seeded synthetic long reads: read i is drawn from genome g_i at a uniform start
  * (reverse-complemented with probability frac_reverse) with ONT-like errors at rate e (40/30/30
  * sub/ins/del), or uniformly random with probability frac_random.  Note: with the reference's

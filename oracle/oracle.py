@@ -83,7 +83,7 @@ def ref_lib(reference_root="/root/reference"):
 
 class _Ixf(C.Structure):
     _fields_ = [("bins", C.c_uint64), ("stride", C.c_uint64), ("seg_len", C.c_uint64),
-                ("seed", C.c_uint64), ("data", C.c_void_p)]
+                ("seed", C.c_uint64), ("data", C.c_void_p), ("arith", C.c_uint32)]
 
 
 class _Hixf(C.Structure):
@@ -212,7 +212,8 @@ class Hixf:
     next_ixf / fname_idx: list of np.int64 arrays (one per IXF, length bins)
     """
 
-    def __init__(self, ixfs, next_ixf, fname_idx):
+    def __init__(self, ixfs, next_ixf, fname_idx, arith=0):
+        """arith: 0 = the restated reading of the un-vendored IXF arithmetic; else the code of another reading (taxor_oracle.h)"""
         self.n = len(ixfs)
         self._keep = []
         arr = (_Ixf * self.n)()
@@ -220,7 +221,7 @@ class Hixf:
             d = np.ascontiguousarray(f["data"], dtype=np.uint8)
             assert d.size == 3 * f["seg_len"] * f["stride"], "IXF data size mismatch"
             self._keep.append(d)
-            arr[i] = _Ixf(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data)
+            arr[i] = _Ixf(f["bins"], f["stride"], f["seg_len"], f["seed"], d.ctypes.data, int(arith))
         self._ixf = arr
         self._nx = [np.ascontiguousarray(a, dtype=np.int64) for a in next_ixf]
         self._fn = [np.ascontiguousarray(a, dtype=np.int64) for a in fname_idx]

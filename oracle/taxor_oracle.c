@@ -380,8 +380,37 @@ uint64_t orc_ixf_seg_len(uint64_t max_bin_elements)
     return array_len / 3;                                                              /* :68 */
 }
 
+/* another reading of the un-vendored arithmetic (orc_ixf::arith != 0), decoded field by field */
+static void ixf_probe_arith(const orc_ixf *f, uint64_t key, uint64_t rows[3], uint8_t *fp)
+{
+    const unsigned a = f->arith, kh = a & 3u, sm = (a >> 2) & 3u, red = (a >> 4) & 3u, fpm = (a >> 6) & 3u, rot = ((a >> 8) & 0xFFu) ^ 21u;
+    uint64_t x = key, h;
+    if (sm == 0) x = key + f->seed;
+    else if (sm == 1) x = key ^ f->seed;
+    if (kh == 0) h = murmur64(x);
+    else if (kh == 1) h = x;
+    else if (kh == 2) h = orc_wyhash_u64(x);
+    else {
+        uint64_t z = x + UINT64_C(0x9E3779B97F4A7C15);
+        z = (z ^ (z >> 30)) * UINT64_C(0xBF58476D1CE4E5B9);
+        z = (z ^ (z >> 27)) * UINT64_C(0x94D049BB133111EB);
+        h = z ^ (z >> 31);
+    }
+    if (sm == 2) h += f->seed;
+    *fp = fpm == 0 ? (uint8_t)(h ^ (h >> 32)) : fpm == 1 ? (uint8_t)h : fpm == 2 ? (uint8_t)(h >> 56) : (uint8_t)(h >> 32);
+    for (int i = 0; i < 3; ++i) {
+        const uint64_t r = rotl64(h, rot * (unsigned)i);
+        uint64_t row;
+        if (red == 0) row = ((uint64_t)(uint32_t)r * f->seg_len) >> 32;
+        else if (red == 1) row = (uint64_t)(uint32_t)r % f->seg_len;
+        else row = (uint64_t)(((unsigned __int128)r * f->seg_len) >> 64);
+        rows[i] = row + (uint64_t)i * f->seg_len;
+    }
+}
+
 void orc_ixf_probe(const orc_ixf *f, uint64_t key, uint64_t rows[3], uint8_t *fp)
 {
+    if (f->arith) { ixf_probe_arith(f, key, rows, fp); return; }
     uint64_t hash = murmur64(key + f->seed);                                           /* hashutil.hpp:59-61 */
     *fp = (uint8_t)(hash ^ (hash >> 32));                                              /* xorfilter.hpp:60-62 */
     for (int i = 0; i < 3; ++i) {                                                      /* :42-45,340-347 */
@@ -416,11 +445,38 @@ typedef struct {
     uint64_t bytes;
 } resbuf;
 
+/* The reference constructs a fresh `bins`-sized counting vector per visited IXF per read (:307).  The port keeps one per
+ * recursion depth and thread and reuses it: same values, no allocator traffic -- at 256 threads the malloc/free pairs of
+ * the literal form serialise in the allocator and the all-cores baseline measured the allocator, not the path. */
+#define ORC_MAX_DEPTH 64
+static _Thread_local uint32_t *tl_counts[ORC_MAX_DEPTH];
+static _Thread_local size_t tl_counts_cap[ORC_MAX_DEPTH];
+
+static uint32_t *counts_at_depth(int depth, size_t bins)
+{
+    if (depth >= ORC_MAX_DEPTH) return (uint32_t *)malloc((bins ? bins : 1) * sizeof(uint32_t));
+    if (tl_counts_cap[depth] < bins || !tl_counts[depth]) {
+        free(tl_counts[depth]);
+        tl_counts_cap[depth] = bins ? bins : 1;
+        tl_counts[depth] = (uint32_t *)malloc(tl_counts_cap[depth] * sizeof(uint32_t));
+    }
+    return tl_counts[depth];
+}
+
+static void bulk_contains_rec(const orc_hixf *h, const uint64_t *hashes, size_t n, int64_t ixf_idx,
+                              size_t threshold, resbuf *rb, int depth);
+
 static void bulk_contains_impl(const orc_hixf *h, const uint64_t *hashes, size_t n, int64_t ixf_idx,
                                size_t threshold, resbuf *rb)
 {
+    bulk_contains_rec(h, hashes, n, ixf_idx, threshold, rb, 0);
+}
+
+static void bulk_contains_rec(const orc_hixf *h, const uint64_t *hashes, size_t n, int64_t ixf_idx,
+                              size_t threshold, resbuf *rb, int depth)
+{
     const orc_ixf *f = &h->ixf[ixf_idx];
-    uint32_t *result = (uint32_t *)malloc((f->bins ? f->bins : 1) * sizeof(uint32_t)); /* :307 */
+    uint32_t *result = counts_at_depth(depth, f->bins);                                /* :307 */
     orc_ixf_bulk_count(f, hashes, n, result);                                          /* :309 */
     rb->bytes += (uint64_t)n * 3u * f->bins;
     uint32_t sum = 0;                                                                  /* :310 */
@@ -430,7 +486,7 @@ static void bulk_contains_impl(const orc_hixf *h, const uint64_t *hashes, size_t
         int64_t cur = fname[bin];                                                      /* :317 */
         if (cur < 0) {                                                                 /* :319 merged bin */
             if ((size_t)sum >= threshold)                                              /* :321 */
-                bulk_contains_impl(h, hashes, n, h->next_ixf[ixf_idx][bin], threshold, rb);
+                bulk_contains_rec(h, hashes, n, h->next_ixf[ixf_idx][bin], threshold, rb, depth + 1);
             sum = 0u;
         } else if (bin + 1u == f->bins || cur != fname[bin + 1]) {                     /* :325-326 */
             if ((size_t)sum >= threshold) {                                            /* :328 */
@@ -443,7 +499,7 @@ static void bulk_contains_impl(const orc_hixf *h, const uint64_t *hashes, size_t
             sum = 0u;
         }
     }
-    free(result);
+    if (depth >= ORC_MAX_DEPTH) free(result);
 }
 
 size_t orc_bulk_contains(const orc_hixf *h, const uint64_t *hashes, size_t n, size_t threshold,

@@ -98,6 +98,12 @@ typedef struct {
     uint64_t seg_len;     /* rows per segment; rows = 3*seg_len                         */
     uint64_t seed;        /* per-IXF hash seed (construct_ixf.cpp:100-108 may redraw it) */
     const uint8_t *data;  /* rows*stride fingerprints, data[row*stride + bin]           */
+    uint32_t arith;       /* 0 = the reading below (xorfilter.hpp / hashutil.hpp).  The IXF arithmetic is un-vendored in the
+                             reference, so a published index may follow another reading; the checker is parametrised the same
+                             way as the product (taxor_amd/csrc/ixf_arith.h, its own code): bits 0-1 key hash (0 murmur64
+                             finaliser, 1 none, 2 wyhash mix, 3 splitmix64), 2-3 seed entry (0 h(key+seed), 1 h(key^seed),
+                             2 h(key)+seed, 3 unused), 4-5 range reduction (0 (u32)rot*seg>>32, 1 (u32)rot%seg, 2 mulhi64),
+                             6-7 fingerprint (0 (u8)(h^h>>32), 1 (u8)h, 2 (u8)(h>>56), 3 (u8)(h>>32)), 8-15 rotation step ^ 21 */
 } orc_ixf;
 
 /* seg_len for a filter built for `max_bin_elements` keys per bin: (32 + 1.23*n)/3 (xorfilter.hpp:67-68) */

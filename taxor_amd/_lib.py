@@ -31,7 +31,8 @@ class IxfSource(C.Structure):
 class HixfView(C.Structure):
     _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
                 ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),
-                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64), ("source", C.c_void_p)]
+                ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64), ("ixf_arith", C.c_uint32),
+                ("source", C.c_void_p)]
 
 
 class ReadSegment(C.Structure):
@@ -142,6 +143,9 @@ SIGNATURES = {
                                      C.POINTER(C.POINTER(C.c_uint64))]),
     "taxor_gpu_ixf_bulk_count": (C.c_int, [_P, C.c_uint64, _P, C.c_uint64, _P]),
     "taxor_gpu_bulk_contains": (C.c_int, [_P, _P, C.c_uint64, C.c_uint64, C.POINTER(Results)]),
+    "taxor_ixf_arith_code": (C.c_uint32, [C.POINTER(IxfVariant)]),
+    "taxor_ixf_arith_decode": (None, [C.c_uint32, C.POINTER(IxfVariant)]),
+    "taxor_ixf_build_bin_arith": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "taxor_ixf_variant_default": (None, [C.POINTER(IxfVariant), C.c_uint64, C.c_uint64, C.c_uint64]),
     "taxor_gpu_ixf_variant_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(IxfVariant), C.c_uint32, _P, _P, C.c_uint64, _P]),
     "taxor_ixf_variant_describe": (C.c_uint64, [C.POINTER(IxfVariant), C.c_char_p, C.c_uint64]),
@@ -152,6 +156,7 @@ SIGNATURES = {
     "taxor_hixf_store_schema": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta), C.POINTER(IxfSchema)]),
     "taxor_hixf_free": (None, [_P]),
     "taxor_hixf_release_data": (None, [_P]),
+    "taxor_hixf_set_arith": (None, [_P, C.c_uint32]),
     "taxor_hixf_get_view": (C.POINTER(HixfView), [_P]),
     "taxor_hixf_get_meta": (C.POINTER(HixfMeta), [_P]),
     "taxor_hixf_store": (C.c_int, [C.c_char_p, C.POINTER(HixfView), C.POINTER(HixfMeta)]),

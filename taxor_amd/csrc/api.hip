@@ -388,7 +388,7 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
         d.stride = (uint32_t)f.stride;
         d.units = (uint32_t)(f.stride / 16);
         d.bin_base = (uint32_t)tb;
-        d.pad = 0;
+        d.arith = v->ixf_arith;
         tb += f.bins;
         idx->max_stride = std::max(idx->max_stride, d.stride);
     }
@@ -573,6 +573,11 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_
     if (!idx || ixf >= idx->h_ixf.size()) return -1;
     idx->h_ixf[ixf].seed = seed;
     return hipMemcpy(&idx->d_ixf[ixf], &idx->h_ixf[ixf], sizeof(IxfDesc), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
+extern "C" __attribute__((visibility("hidden"))) uint32_t taxor_index_arith(const taxor_gpu_index *idx)
+{
+    return idx && !idx->h_ixf.empty() ? idx->h_ixf[0].arith : 0u;
 }
 
 extern "C" uint64_t taxor_gpu_index_data_bytes(const taxor_gpu_index *idx) { return idx ? idx->data_bytes : 0; }

@@ -46,6 +46,7 @@ struct BuildArgs {
     uint64_t n_keys;
     uint64_t seed;
     uint32_t seg_len;
+    uint32_t arith;            // arithmetic code of the index (ixf_arith.h), 0 = this library's reading
     uint64_t rows;             // 3 * seg_len
     uint32_t *cnt;             // [chunk_bins * rows]
     uint64_t *xr;              // [chunk_bins * rows]
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(BB) void k_build_count(const BuildArgs a)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < a.n_keys; i += (uint64_t)gridDim.x * BB) {
         const uint64_t key = a.keys[i];
-        const ixf_probe p = ixf_probe_key(key, a.seed, a.seg_len);
+        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
         const uint64_t base = (uint64_t)a.key_bin[i] * a.rows;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(BB) void k_build_round(const BuildArgs a, int cur)
         if (__hip_atomic_load(&a.cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
         const uint64_t bin = slot / a.rows;
         const uint32_t row = (uint32_t)(slot - bin * a.rows);
-        const ixf_probe p = ixf_probe_key(key, a.seed, a.seg_len);
+        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
         const uint64_t base = bin * a.rows;
         // ownership: smallest-index row of this key that is flagged in the snapshot
         uint32_t owner = 0xFFFFFFFFu;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(BB) void k_build_assign(const BuildArgs a, uint8_t 
         const uint64_t cb = slot / a.rows;
         const uint32_t row = (uint32_t)(slot - cb * a.rows);
         const uint64_t bin = bin_ids[cb];
-        const ixf_probe p = ixf_probe_key(key, a.seed, a.seg_len);
+        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -198,6 +199,7 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_
                                                                           uint64_t *stride, uint64_t *seg_len, uint64_t *bins,
                                                                           int *device);
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed);
+extern "C" __attribute__((visibility("hidden"))) uint32_t taxor_index_arith(const taxor_gpu_index *idx);
 
 namespace {
 
@@ -280,6 +282,7 @@ int build_ixf_device(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *d_all_k
             a.key_bin = d_key_bin;
             a.n_keys = nk;
             a.seed = seed;
+            a.arith = taxor_index_arith(idx);
             a.seg_len = (uint32_t)seg_len;
             a.rows = rows;
             a.cnt = d_cnt;

@@ -518,6 +518,11 @@ extern "C" void taxor_hixf_free(taxor_hixf *h)
     delete h;
 }
 
+extern "C" void taxor_hixf_set_arith(taxor_hixf *h, uint32_t arith)
+{
+    if (h) h->view.ixf_arith = arith;
+}
+
 extern "C" const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h) { return h ? &h->view : nullptr; }
 extern "C" const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h) { return h ? &h->meta : nullptr; }
 

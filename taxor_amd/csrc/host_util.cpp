@@ -171,6 +171,11 @@ uint64_t taxor_ixf_seg_len(uint64_t max_bin_elements) { return taxor::ixf_seg_le
 // kept per thread and only the touched rows are cleared, so sparse bins of a very tall IXF cost O(n).
 int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint8_t *column)
 {
+    return taxor_ixf_build_bin_arith(keys, n, seed, seg_len, 0, column);
+}
+
+int taxor_ixf_build_bin_arith(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_t seg_len, uint32_t arith, uint8_t *column)
+{
     const uint64_t rows = 3 * seg_len;
     std::memset(column, 0, rows);
     if (n == 0) return 0;
@@ -184,7 +189,7 @@ int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_
     std::vector<uint32_t> touched;
     touched.reserve(3 * n);
     for (uint64_t i = 0; i < n; ++i) {
-        const taxor::ixf_probe p = taxor::ixf_probe_key(keys[i], seed, (uint32_t)seg_len);
+        const taxor::ixf_probe p = taxor::ixf_probe_key_arith(keys[i], seed, (uint32_t)seg_len, arith);
         for (int j = 0; j < 3; ++j) {
             if (cnt[p.row[j]]++ == 0) touched.push_back(p.row[j]);
             xr[p.row[j]] ^= keys[i];
@@ -205,7 +210,7 @@ int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_
         const uint64_t key = xr[r];
         st_key.push_back(key);
         st_row.push_back(r);
-        const taxor::ixf_probe p = taxor::ixf_probe_key(key, seed, (uint32_t)seg_len);
+        const taxor::ixf_probe p = taxor::ixf_probe_key_arith(key, seed, (uint32_t)seg_len, arith);
         for (int j = 0; j < 3; ++j) {
             const uint32_t rr = p.row[j];
             cnt[rr]--;
@@ -219,7 +224,7 @@ int taxor_ixf_build_bin(const uint64_t *keys, uint64_t n, uint64_t seed, uint64_
     }
     if (st_key.size() != n) return 1; // not peelable under this seed (or duplicate keys)
     for (size_t i = st_key.size(); i-- > 0;) {
-        const taxor::ixf_probe p = taxor::ixf_probe_key(st_key[i], seed, (uint32_t)seg_len);
+        const taxor::ixf_probe p = taxor::ixf_probe_key_arith(st_key[i], seed, (uint32_t)seg_len, arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
         for (int j = 0; j < 3; ++j)
             if (p.row[j] != st_row[i]) v ^= column[p.row[j]];

@@ -66,6 +66,86 @@ TAXOR_HD ixf_probe ixf_probe_key(uint64_t key, uint64_t seed, uint32_t seg_len)
     return p;
 }
 
+// ---- other readings of the un-vendored arithmetic, selectable at run time ----------------------------------------
+// What a published .hixf follows can only be learnt from the file (`taxor verify --variants`, verify.hip); the day one
+// differs from the reading above, searching it must not need a rebuild.  An index therefore carries an arithmetic CODE
+// (IxfDesc::arith, taxor_hixf_view::ixf_arith); 0 = the reading above (the fast path everywhere), anything else is
+// decoded per key by ixf_probe_key_arith.  Probes are computed once per (hash, work item) while staging, outside the
+// gather loops, so the general path costs nothing where the time goes.
+//   bits 0-1 key_hash   0 murmur64 finaliser (hashutil.hpp:50-57), 1 none, 2 wyhash mix, 3 splitmix64 finaliser
+//   bits 2-3 seed_mode  0 h(key + seed) (hashutil.hpp:59-61), 1 h(key ^ seed), 2 h(key) + seed, 3 seed unused
+//   bits 4-5 reduce     0 ((u32)rot * seg_len) >> 32 (xorfilter.hpp:36-40), 1 (u32)rot % seg_len, 2 mulhi64(rot, seg_len)
+//   bits 6-7 fp_mode    0 (u8)(h ^ h>>32) (xorfilter.hpp:60-62), 1 (u8)h, 2 (u8)(h>>56), 3 (u8)(h>>32)
+//   bits 8-15 rot ^ 21  row i uses rotl64(h, rot * i); 21 in xorfilter.hpp:42-45
+TAXOR_HD uint32_t ixf_arith_pack(unsigned key_hash, unsigned seed_mode, unsigned rot, unsigned reduce, unsigned fp_mode)
+{
+    return (key_hash & 3u) | ((seed_mode & 3u) << 2) | ((reduce & 3u) << 4) | ((fp_mode & 3u) << 6) | (((rot ^ 21u) & 0xFFu) << 8);
+}
+
+TAXOR_HD uint64_t mulhi64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((__uint128_t)a * b) >> 64);
+#endif
+}
+
+// the key's 64-bit hash under an arithmetic code
+TAXOR_HD uint64_t ixf_key_hash_arith(uint64_t key, uint64_t seed, uint32_t arith)
+{
+    const unsigned kh = arith & 3u, sm = (arith >> 2) & 3u;
+    uint64_t x = key;
+    if (sm == 0) x = key + seed;
+    else if (sm == 1) x = key ^ seed;
+    uint64_t h;
+    switch (kh) {
+    case 0: h = murmur64(x); break;
+    case 1: h = x; break;
+    case 2: h = wyhash_u64(x); break;
+    default: {
+        uint64_t z = x + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        h = z ^ (z >> 31);
+    }
+    }
+    if (sm == 2) h += seed;
+    return h;
+}
+
+TAXOR_HD uint8_t ixf_fingerprint_arith(uint64_t h, uint32_t arith)
+{
+    switch ((arith >> 6) & 3u) {
+    case 0: return (uint8_t)(h ^ (h >> 32));
+    case 1: return (uint8_t)h;
+    case 2: return (uint8_t)(h >> 56);
+    default: return (uint8_t)(h >> 32);
+    }
+}
+
+// row of segment i (segment offset included)
+TAXOR_HD uint64_t ixf_row_arith(uint64_t h, int i, uint64_t seg_len, uint32_t arith)
+{
+    const unsigned rot = ((arith >> 8) & 0xFFu) ^ 21u, red = (arith >> 4) & 3u;
+    const uint64_t r = rotl64(h, rot * (unsigned)i);
+    uint64_t row;
+    if (red == 0) row = ((uint64_t)(uint32_t)r * seg_len) >> 32;
+    else if (red == 1) row = (uint64_t)(uint32_t)r % seg_len;
+    else row = mulhi64(r, seg_len);
+    return row + (uint64_t)i * seg_len;
+}
+
+TAXOR_HD ixf_probe ixf_probe_key_arith(uint64_t key, uint64_t seed, uint32_t seg_len, uint32_t arith)
+{
+    if (arith == 0) return ixf_probe_key(key, seed, seg_len);
+    const uint64_t h = ixf_key_hash_arith(key, seed, arith);
+    ixf_probe p;
+    p.fp4 = (uint32_t)ixf_fingerprint_arith(h, arith) * 0x01010101u;
+    for (int i = 0; i < 3; ++i) p.row[i] = (uint32_t)ixf_row_arith(h, i, seg_len, arith);
+    return p;
+}
+
 // rows per segment for a bin capacity of n keys: arrayLength = 32 + 1.23*n; blockLength = arrayLength/3
 inline uint64_t ixf_seg_len(uint64_t max_bin_elements) // xorfilter.hpp:67-68
 {

@@ -17,7 +17,7 @@ struct IxfDesc {
     uint32_t stride;   // bytes per row
     uint32_t units;    // stride / 16
     uint32_t bin_base; // first entry of this IXF in the per-bin tables
-    uint32_t pad;
+    uint32_t arith;    // arithmetic code of the index (ixf_arith.h); 0 = this library's reading
 };
 
 // per-bin tables, indexed by bin_base + bin:

@@ -1142,7 +1142,7 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
             if (!staged) {
                 __syncthreads();
                 for (uint32_t i = tid; i < nt; i += BS) {
-                    const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                    const ixf_probe p = ixf_probe_key_arith(hp[t0 + i], D.seed, D.seg_len, D.arith);
                     sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                 }
                 __syncthreads();
@@ -1328,7 +1328,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         const bool staged = n <= (uint32_t)QC; // all probes of this read fit: stage them once for both phases
         if (staged)
             for (uint32_t i = tid; i < n; i += BS) {
-                const ixf_probe p = ixf_probe_key(hp[i], D.seed, D.seg_len);
+                const ixf_probe p = ixf_probe_key_arith(hp[i], D.seed, D.seg_len, D.arith);
                 sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
         if (info_regs) {
@@ -1386,7 +1386,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                     if (!staged) {
                         __syncthreads();
                         for (uint32_t i = tid; i < nt; i += BS) {
-                            const ixf_probe p = ixf_probe_key(hp[t0 + i], D.seed, D.seg_len);
+                            const ixf_probe p = ixf_probe_key_arith(hp[t0 + i], D.seed, D.seg_len, D.arith);
                             sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                         }
                         __syncthreads();

@@ -105,6 +105,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
+    uint32_t ixf_arith = 0;     // --ixf-arithmetic: the reading of the un-vendored IXF arithmetic the index follows (0 = this library's)
     uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
                                 // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
@@ -152,6 +153,8 @@ void usage()
             "                           RCCL/xGMI (default), the same staged through host memory, or independent workers\n"
             "  --batch-reads <n>        reads per parsed chunk (default: about 128 MB of query file, 65536 reads for gzip)\n"
             "  --group-reads <n>        reads per GPU batch, made of whole chunks (default 131072; --batch-reads if that is given)\n"
+            "  --ixf-arithmetic <spec>  search an index whose fingerprints follow another reading of the IXF arithmetic than this\n"
+            "                           build's (the spec `taxor verify --variants` prints: kh=..,sm=..,rot=..,red=..,fp=..)\n"
             "  --expect <tsv>           compare the output per read with a TSV the reference wrote for the same input (exit 3 if it differs)\n");
 }
 
@@ -363,6 +366,35 @@ uint64_t compare_tsv(const std::string &ours, const std::string &expect)
     return bad;
 }
 
+// "kh=0,sm=1,rot=21,red=1,fp=1" -> arithmetic code (taxor_ixf_arith_code); fields left out keep this library's reading
+bool parse_arith_spec(const std::string &spec, uint32_t *code)
+{
+    taxor_ixf_variant v;
+    taxor_ixf_variant_default(&v, 0, 1, 64);
+    for (const auto &tok : str_split(spec, ',')) {
+        const size_t eq = tok.find('=');
+        if (eq == std::string::npos) return false;
+        const std::string key = tok.substr(0, eq);
+        char *end = nullptr;
+        const long x = strtol(tok.c_str() + eq + 1, &end, 10);
+        if (!end || *end != '\0' || x < 0) return false;
+        if (key == "kh" && x <= 3) v.key_hash = (uint8_t)x;
+        else if (key == "sm" && x <= 3) v.seed_mode = (uint8_t)x;
+        else if (key == "rot" && x >= 1 && x <= 63) v.rot = (uint8_t)x;
+        else if (key == "red" && x <= 2) v.reduce = (uint8_t)x;
+        else if (key == "fp" && x <= 3) v.fp_mode = (uint8_t)x;
+        else return false;
+    }
+    *code = taxor_ixf_arith_code(&v);
+    return true;
+}
+
+std::string arith_spec(const taxor_ixf_variant &v)
+{
+    return "kh=" + std::to_string(v.key_hash) + ",sm=" + std::to_string(v.seed_mode) + ",rot=" + std::to_string(v.rot) + ",red=" +
+           std::to_string(v.reduce) + ",fp=" + std::to_string(v.fp_mode);
+}
+
 uint64_t fnv1a(const char *p, size_t n)
 {
     uint64_t h = 1469598103934665603ull;
@@ -400,6 +432,7 @@ int main(int argc, char **argv)
         uint64_t n_reads = 2000, read_len = 5000;
         int device = 0;
         bool scan_variants = false;
+        uint32_t verify_arith = 0;
         for (int i = 2; i < argc; ++i) {
             if (strcmp(argv[i], "--variants") == 0) { scan_variants = true; continue; }
             if (strcmp(argv[i], "--index-file") == 0 && i + 1 < argc) index_file = argv[++i];
@@ -407,11 +440,15 @@ int main(int argc, char **argv)
             else if (strcmp(argv[i], "--reads") == 0 && i + 1 < argc) n_reads = strtoull(argv[++i], nullptr, 10);
             else if (strcmp(argv[i], "--read-len") == 0 && i + 1 < argc) read_len = strtoull(argv[++i], nullptr, 10);
             else if (strcmp(argv[i], "--gpu") == 0 && i + 1 < argc) device = atoi(argv[++i]);
+            else if (strcmp(argv[i], "--ixf-arithmetic") == 0 && i + 1 < argc) {
+                if (!parse_arith_spec(argv[++i], &verify_arith)) die("--ixf-arithmetic: expected kh=..,sm=..,rot=..,red=..,fp=..");
+            }
         }
         if (index_file.empty() || genome_file.empty() || !file_exists(index_file) || !file_exists(genome_file) || !n_reads || !read_len)
             die("usage: taxor verify --index-file <x.hixf> --genome-file <fasta of a genome contained in the index> [--reads n] [--read-len l]");
         taxor_hixf *h = nullptr;
         if (taxor_hixf_load(index_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
+        taxor_hixf_set_arith(h, verify_arith);
         const taxor_hixf_view *view = taxor_hixf_get_view(h);
         taxor_gpu_index *gi = nullptr;
         if (taxor_gpu_index_create(view, device, &gi) != TAXOR_OK) die(taxor_gpu_last_error());
@@ -515,7 +552,7 @@ int main(int argc, char **argv)
                    (unsigned long long)n_lists);
             char desc[512];
             taxor_ixf_variant mine;
-            taxor_ixf_variant_default(&mine, root.seed, root.seg_len, root.stride);
+            taxor_ixf_variant_default(&mine, root.seed, root.seg_len, root.stride);   // this library's own reading (code 0)
             for (size_t i = 0; i < std::min<size_t>(5, rank.size()); ++i) {
                 const taxor_ixf_variant &v = vs[rank[i].second];
                 taxor_ixf_variant_describe(&v, desc, sizeof desc);
@@ -525,7 +562,16 @@ int main(int argc, char **argv)
             if (!rank.empty() && rank[0].first >= 0.9f) {
                 const bool is_mine = memcmp(&vs[rank[0].second], &mine, sizeof mine) == 0;
                 printf("%s\n", is_mine ? "the file follows this library's reading of the IXF arithmetic"
-                                       : "the file follows ANOTHER reading of the IXF arithmetic (first line): change taxor_amd/csrc/ixf_arith.h accordingly");
+                                       : "the file follows ANOTHER reading of the IXF arithmetic (first line)");
+                if (!is_mine) {
+                    const taxor_ixf_variant &bv = vs[rank[0].second];
+                    if (bv.layout != 0)
+                        printf("that reading stores the fingerprints bin-major (data[bin*rows + row]): this build searches the interleaved layout only\n");
+                    else if (bv.stride != root.stride || bv.seg_len != root.seg_len || bv.seed != root.seed)
+                        printf("that reading also differs in seed / segment length / row stride from what the loader took from the file: `taxor probe` shows the record layout\n");
+                    else
+                        printf("search it with: taxor search --ixf-arithmetic %s ...\n", arith_spec(bv).c_str());
+                }
             } else {
                 printf("no variant answers: the key hash (wyhash / minimiser value) or the genome is not what the index holds\n");
             }
@@ -630,6 +676,10 @@ int main(int argc, char **argv)
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--expect") cfg.expect_file = val();
         else if (k == "--group-reads") cfg.group_reads = strtoull(val().c_str(), nullptr, 10);
+        else if (k == "--ixf-arithmetic") {
+            const std::string spec = val();
+            if (!parse_arith_spec(spec, &cfg.ixf_arith)) die("Validation failed for option --ixf-arithmetic: expected kh=<0-3>,sm=<0-3>,rot=<1-63>,red=<0-2>,fp=<0-3> (as printed by `taxor verify --variants`), got " + spec);
+        }
         else if (k == "--gather") {
             cfg.gather = val();
             if (cfg.gather != "rccl" && cfg.gather != "host" && cfg.gather != "none") die("Validation failed for option --gather: Value not in {rccl, host, none}.");
@@ -683,6 +733,16 @@ int main(int argc, char **argv)
         taxor_hixf *h = nullptr;
         if (taxor_hixf_load(hixf_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
         trace("index file loaded");
+        if (cfg.ixf_arith) {
+            taxor_hixf_set_arith(h, cfg.ixf_arith);
+            taxor_ixf_variant av{};
+            taxor_ixf_arith_decode(cfg.ixf_arith, &av);
+            char desc[512];
+            taxor_ixf_variant_describe(&av, desc, sizeof desc);
+            fprintf(stderr, "[TAXOR SEARCH WARNING] %s is searched under --ixf-arithmetic %s, not under this build's own reading of the\n"
+                            "  un-vendored IXF arithmetic: %s (seed, segment length and row stride per IXF from the file)\n", hixf_file.c_str(),
+                    arith_spec(av).c_str(), desc);
+        }
         const taxor_hixf_view *view = taxor_hixf_get_view(h);
         if (taxor_hixf_get_meta(h)->foreign_schema)
             fprintf(stderr, "[TAXOR SEARCH WARNING] %s was not written by this library (its IXF records follow another layout, read by probing).\n"

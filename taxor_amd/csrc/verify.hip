@@ -26,25 +26,11 @@ namespace {
 
 using namespace taxor;
 
-__device__ __forceinline__ uint64_t variant_hash(const taxor_ixf_variant &v, uint64_t key)
+// the scan decodes a variant through the same functions the search kernels use for a non-default arithmetic code
+// (ixf_arith.h): what scores ~1.0 here is exactly what `taxor search --ixf-arithmetic` will compute
+__host__ __device__ inline uint32_t variant_code(const taxor_ixf_variant &v)
 {
-    uint64_t x = key;
-    if (v.seed_mode == 0) x = key + v.seed;                       // hashutil.hpp:59-61: murmur64(key + seed)
-    else if (v.seed_mode == 1) x = key ^ v.seed;
-    uint64_t h;
-    switch (v.key_hash) {
-    case 0: h = murmur64(x); break;
-    case 1: h = x; break;                                         // no mixer
-    case 2: h = wyhash_u64(x); break;
-    default: {                                                    // splitmix64 finaliser
-        uint64_t z = x + 0x9E3779B97F4A7C15ull;
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        h = z ^ (z >> 31);
-    }
-    }
-    if (v.seed_mode == 2) h += v.seed;                            // seed added after the mixer
-    return h;
+    return ixf_arith_pack(v.key_hash, v.seed_mode, v.rot, v.reduce, v.fp_mode);
 }
 
 __global__ __launch_bounds__(256) void k_variant_scan(const uint8_t *__restrict__ data, uint64_t data_len, uint32_t bins,
@@ -63,24 +49,13 @@ __global__ __launch_bounds__(256) void k_variant_scan(const uint8_t *__restrict_
     for (uint32_t b = threadIdx.x; b < bins; b += 256) {
         uint32_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
-            const uint64_t h = variant_hash(v, hashes[h0 + i]);
-            uint8_t fp;
-            switch (v.fp_mode) {
-            case 0: fp = (uint8_t)(h ^ (h >> 32)); break;          // xorfilter.hpp:60-62
-            case 1: fp = (uint8_t)h; break;
-            case 2: fp = (uint8_t)(h >> 56); break;
-            default: fp = (uint8_t)(h >> 32); break;
-            }
-            uint8_t x = fp;
+            const uint32_t code = variant_code(v);
+            const uint64_t h = ixf_key_hash_arith(hashes[h0 + i], v.seed, code);
+            uint8_t x = ixf_fingerprint_arith(h, code);
             bool ok = true;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const uint64_t rot = rotl64(h, (unsigned)v.rot * (unsigned)j);
-                uint64_t r;
-                if (v.reduce == 0) r = ((uint64_t)(uint32_t)rot * v.seg_len) >> 32;           // xorfilter.hpp:36-40
-                else if (v.reduce == 1) r = (uint64_t)(uint32_t)rot % v.seg_len;
-                else r = __umul64hi(rot, v.seg_len);
-                r += (uint64_t)j * v.seg_len;
+                const uint64_t r = ixf_row_arith(h, j, v.seg_len, code);
                 const uint64_t addr = v.layout == 0 ? r * v.stride + b : (uint64_t)b * rows + r;
                 if (addr >= data_len) { ok = false; break; }
                 x ^= data[addr];
@@ -139,6 +114,18 @@ extern "C" int taxor_gpu_ixf_variant_scan(taxor_gpu_index *idx, uint64_t ixf, co
     (void)hipFree(d_out);
     if (e != hipSuccess) return vfail(TAXOR_E_HIP, std::string("ixf_variant_scan: ") + hipGetErrorString(e));
     return TAXOR_OK;
+}
+
+extern "C" uint32_t taxor_ixf_arith_code(const taxor_ixf_variant *v) { return v ? variant_code(*v) : 0u; }
+
+extern "C" void taxor_ixf_arith_decode(uint32_t code, taxor_ixf_variant *out)
+{
+    if (!out) return;
+    out->key_hash = (uint8_t)(code & 3u);
+    out->seed_mode = (uint8_t)((code >> 2) & 3u);
+    out->reduce = (uint8_t)((code >> 4) & 3u);
+    out->fp_mode = (uint8_t)((code >> 6) & 3u);
+    out->rot = (uint8_t)(((code >> 8) & 0xFFu) ^ 21u);
 }
 
 extern "C" void taxor_ixf_variant_default(taxor_ixf_variant *out, uint64_t seed, uint64_t seg_len, uint64_t stride)

@@ -40,6 +40,12 @@ def threshold_model(kind, count, kmer_size, error_rate=0.04, percentage=-1.0, sc
                                                 float(scaling_factor)))
 
 
+def arith_code(key_hash=0, seed_mode=0, rot=21, reduce=0, fp_mode=0):
+    """code of a reading of the un-vendored IXF arithmetic (taxor_ixf_variant's five arithmetic fields); 0 = the library's"""
+    v = _lib.IxfVariant(0, 1, 64, key_hash, seed_mode, rot, reduce, fp_mode, 0)
+    return int(_lib.lib().taxor_ixf_arith_code(C.byref(v)))
+
+
 def classify_filter(counts):
     c = np.ascontiguousarray(counts, dtype=np.uint32)
     keep = np.zeros(c.size, dtype=np.uint8)
@@ -72,10 +78,11 @@ def _results(res: _lib.Results) -> SearchResults:
 class GpuIndex:
     """A HIXF resident in one GPU's HBM."""
 
-    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None):
+    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None, arith=0):
         """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)}"""
         L = _lib.lib()
         view, keep = self._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size)
+        view.ixf_arith = int(arith)      # 0 = the library's reading of the IXF arithmetic; else arith_code(...)
         h = C.c_void_p()
         check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
         del keep                 # the library copied everything into HBM

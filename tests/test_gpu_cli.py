@@ -36,8 +36,8 @@ def _setup(tmp_path, seed):
     return g, go, host, sp, path
 
 
-def _expected(host, sp, ids, reads, err=0.04, percentage=-1.0):
-    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+def _expected(host, sp, ids, reads, err=0.04, percentage=-1.0, arith=0):
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
     norm = [orc.dna4_normalise(r) for r in reads]
     B = np.frombuffer(b"".join(norm), dtype=np.uint8)
     O = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
@@ -351,6 +351,38 @@ def test_cli_verify_variant_scan_names_a_foreign_arithmetic(tmp_path):
     first = [l for l in cp.stdout.splitlines() if l.startswith("  1.0000")][0]
     assert "murmur64 as h(key ^ seed)" in first and "(u32)rot % seg" in first and "fingerprint (u8)h," in first and "data[row*stride + bin]" in first, first
     assert f"seed {seed}" in first and "rotl(h, 21*i)" in first
+    # ... and the reading it names is a run-time choice, not a rebuild: `taxor search --ixf-arithmetic <spec>`
+    # classifies the foreign index, bit for bit like the oracle parametrised the same way; without it the index answers at the
+    # false-positive floor
+    spec = [l for l in cp.stdout.splitlines() if l.startswith("search it with:")][0].split("--ixf-arithmetic ")[1].split()[0]
+    assert spec == "kh=0,sm=1,rot=21,red=1,fp=1", spec
+    from taxor_amd.search import arith_code
+    code = arith_code(key_hash=0, seed_mode=1, rot=21, reduce=1, fp_mode=1)
+    assert code != 0
+    bases, offs, _ = synth.synth_reads(g, np.array([0, len(genome)], np.uint64), 150, 1500, error_rate=0.01, frac_random=0.2, seed=9)
+    reads = [bytes(bases[int(offs[i]):int(offs[i + 1])]) for i in range(150)]
+    ids = [f"r{i}" for i in range(150)]
+    rfa = tmp_path / "reads.fa"
+    with open(rfa, "wb") as f:
+        for rid, r in zip(ids, reads):
+            f.write(b">" + rid.encode() + b"\n" + r + b"\n")
+    out = tmp_path / "foreign.tsv"
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(foreign), "--query-file", str(rfa), "--output-file", str(out), "--ixf-arithmetic", spec],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0, cp.stderr
+    assert "[TAXOR SEARCH WARNING]" in cp.stderr and "--ixf-arithmetic kh=0,sm=1" in cp.stderr
+    want = HEADER + _expected(host, sp, ids, reads, arith=code)
+    got = open(out).read()
+    assert got == want
+    hit_lines = [l for l in got.splitlines()[1:] if l.split("\t")[1] != "-"]
+    assert len(hit_lines) > 80 and all(l.split("\t")[1] == "A7" for l in hit_lines)      # the genome sits in bin 7
+    cp = subprocess.run([TAXOR, "search", "--index-file", str(foreign), "--query-file", str(rfa), "--output-file", str(out)],
+                        capture_output=True, text=True, timeout=300)
+    assert cp.returncode == 0 and open(out).read() == HEADER + _expected(host, sp, ids, reads)       # this build's reading: no hits
+    assert not [l for l in open(out).read().splitlines()[1:] if l.split("\t")[1] != "-"]
+    cp = subprocess.run([TAXOR, "verify", "--index-file", str(foreign), "--genome-file", str(fa), "--reads", "60", "--read-len", "1500",
+                         "--ixf-arithmetic", spec], capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0 and "PASS" in cp.stdout, cp.stdout + cp.stderr
     # the library's own files: recognised as such
     g2, go2, host2, sp2, own = _setup(tmp_path, 37)
     fa2 = tmp_path / "g2.fa"
