@@ -206,3 +206,37 @@ def test_hierarchical_build_rejects_keys_on_merged_bins():
         idx.build_hixf({(0, 0): np.arange(5, dtype=np.uint64)})
     idx.build_hixf({(1, 1): np.arange(1, 40, dtype=np.uint64), (0, 2): np.arange(100, 130, dtype=np.uint64)})
     idx.close()
+
+
+@pytest.mark.parametrize("kh,sm,rot,red,fp", [(0, 1, 21, 1, 1), (2, 2, 16, 2, 2), (3, 0, 16, 0, 3), (1, 3, 21, 1, 0)])
+def test_arithmetic_code_through_builder_query_and_oracle(kh, sm, rot, red, fp):
+    """an index created with another reading of the un-vendored IXF arithmetic (taxor_hixf_view::ixf_arith): the GPU builder,
+    the query kernel (raw bulk_count, and bulk_contains with pruning on) and the oracle parametrised with the same code agree
+    bit for bit; the default reading does not find the keys"""
+    from taxor_amd.search import arith_code
+    code = arith_code(kh, sm, rot, red, fp)
+    rng = np.random.default_rng(code)
+    bins, max_elems = 130, 6000
+    stride = 192
+    seg = synth.seg_len_for(max_elems)
+    data = rng.integers(0, 256, size=3 * seg * stride, dtype=np.uint8)
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64), fname_idx=np.arange(bins), data=data)
+    idx = GpuIndex([ixf], bins, arith=code)
+    keys = {b: np.unique(rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)) for b, n in {0: 6000, 64: 2500, 129: 900}.items()}
+    seed, _ = idx.build_ixf(0, keys, seed0=777)
+    after = idx.download_ixf(0)
+    h = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]], arith=code)
+    h0 = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    sr = Searcher(idx, ratio=0.5)
+    for b, ks in keys.items():
+        cnt = sr.ixf_bulk_count(0, ks)
+        assert cnt[b] == ks.size
+        assert np.array_equal(cnt, h.ixf_bulk_count(0, ks))
+        assert h0.ixf_bulk_count(0, ks)[b] < ks.size * 0.05
+        mix = np.concatenate([ks[:700], rng.integers(0, 2**64 - 1, size=300, dtype=np.uint64)])
+        for thr in (1, 500, 690, 700, 712, 1000):
+            ub, ct = sr.bulk_contains(mix, thr)
+            wub, wct, _ = h.bulk_contains(mix, thr)
+            assert np.array_equal(ub, wub) and np.array_equal(ct, wct), (b, thr)
+    sr.close()
+    idx.close()
