@@ -110,8 +110,8 @@ struct taxor_gpu_searcher {
     hipStream_t st_sync = nullptr;  // syncmer kernel of the next sub-batch, overlapped with the query of this one
     hipStream_t st_sync2 = nullptr; // its short reads (k_syncmers_wave), concurrent with the long ones on st_sync
     hipEvent_t ev_wave = nullptr;
-    hipStream_t st_copy = nullptr;  // H2D of the next sub-batch's bases + packing (streamed search_batch)
-    std::vector<hipEvent_t> ev_sync_done, ev_query_done, ev_pack_done;
+    hipStream_t st_copy = nullptr;  // H2D of the sub-batches' bases, nothing else (streamed search_batch)
+    std::vector<hipEvent_t> ev_sync_done, ev_query_done, ev_pack_done, ev_copy_done;
     hipEvent_t ev_reset = nullptr;
     DBuf<uint32_t> d_sync_cursor;
     Counters *d_ctr = nullptr;
@@ -814,6 +814,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     for (auto ev : s->ev_sync_done) (void)hipEventDestroy(ev);
     for (auto ev : s->ev_query_done) (void)hipEventDestroy(ev);
     for (auto ev : s->ev_pack_done) (void)hipEventDestroy(ev);
+    for (auto ev : s->ev_copy_done) (void)hipEventDestroy(ev);
     if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
@@ -1005,6 +1006,9 @@ int ensure_scratch(taxor_gpu_searcher *s)
         s->ev_sync_done.push_back(a);
         s->ev_query_done.push_back(b);
         s->ev_pack_done.push_back(c);
+        hipEvent_t d;
+        HIP_TRY(hipEventCreateWithFlags(&d, hipEventDisableTiming));
+        s->ev_copy_done.push_back(d);
     }
     // Initial capacities: a read of a clade with many indexed relatives reports a tuple per relative and enters several
     // child IXFs (8 tuples / 3 children per read on the family workload), and an overflow costs a rerun of the whole
@@ -1318,7 +1322,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
 }
 
 // The whole pipeline for the uploaded (host_ascii == nullptr) or streaming (host_ascii = first base of the batch)
-// case.  Streams: st_copy (H2D + pack of sub-batch i+1), st_sync (syncmers of i+1), st (query + CSR of i).
+// case.  Streams: st_copy (H2D of the sub-batches' bases, back to back), st_sync (pack + syncmers of i+1), st (query + CSR of i).
 int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
 {
     if (int rc = ensure_scratch(s)) return rc;
@@ -1353,19 +1357,28 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
                 if (hi > lo)
                     HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, s->st_copy));
             }
-            // packing runs beside the query kernel of the previous sub-batch: keep it to two blocks per CU
-            launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr,
-                             s->st_copy, s->grid_sync_overlap);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(s->ev_pack_done[i], s->st_copy));
-            HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_pack_done[i], 0));
-            HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_pack_done[i], 0));
+            HIP_TRY(hipEventRecord(s->ev_copy_done[i], s->st_copy));
         }
         // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
         static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
         hipStream_t ss = no_overlap ? s->st : s->st_sync;
-        if (host_ascii && no_overlap) HIP_TRY(hipStreamWaitEvent(ss, s->ev_pack_done[i], 0));
         hipStream_t ss2 = no_overlap ? s->st : s->st_sync2;
+        if (host_ascii) {
+            // The copy stream carries copies only, so they run back to back at PCIe speed, far ahead of the kernels.  The
+            // pack kernel sits on the hashing stream in front of its sub-batch's syncmer kernel: with the copy long done,
+            // pack + syncmers of sub-batch i+1 both fit beside the ROOT level of query i (three query blocks per CU leave
+            // room for one more; the deeper levels run four per CU and leave none).  Round 2 had the pack kernel on the
+            // copy stream, between the copies: copy(i+1) could only start after pack(i) had found room, finished about when
+            // root(i) did, and pack(i+1) then waited for query i's deeper levels to drain -- every sub-batch's hashing ran
+            // exposed, 10 ms of a 60 ms call (profiles/r03/single_call_timeline_before.txt).
+            HIP_TRY(hipStreamWaitEvent(ss, s->ev_copy_done[i], 0));
+            launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr, ss, s->grid_sync_overlap);
+            HIP_TRY(hipGetLastError());
+            if (ss2 != ss) {
+                HIP_TRY(hipEventRecord(s->ev_pack_done[i], ss));
+                HIP_TRY(hipStreamWaitEvent(ss2, s->ev_pack_done[i], 0));
+            }
+        }
         if (i >= 2) HIP_TRY(hipStreamWaitEvent(ss, s->ev_query_done[i - 2], 0));
         if (i >= 2 && ss2 != ss) HIP_TRY(hipStreamWaitEvent(ss2, s->ev_query_done[i - 2], 0));
         if (int rc = launch_syncmers_sub(s, sb, i, buf, ss, i > 0 && !no_overlap, ss2)) return rc;
