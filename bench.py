@@ -41,6 +41,11 @@ import time
 
 import numpy as np
 
+# the HIP runtime maps streams onto this many hardware queues per device (default 4) and streams that share one run in
+# submission order; a searcher's copy / hashing / query streams must not (taxor_amd/csrc/api.hip, runtime_env_once).  Set
+# before torch brings the runtime up; a value the user exported wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

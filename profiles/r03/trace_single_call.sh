@@ -4,13 +4,17 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_single
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python3 $R/profiles/single_call.py --reps 1 > $O/single_call.txt 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/trace -o t -- python3 $R/profiles/single_call.py --reps 1 > $O/single_call.txt 2>&1
 grep -E "resident|single call|plain" $O/single_call.txt
 python3 - <<'PY'
 import csv, glob, os
 O=os.environ.get("GRAFT_REPO_ROOT","/root/repo")+"/gpurun_out/r03_single"
 f=glob.glob(O+"/trace/**/*kernel_trace.csv", recursive=True)[0]
 rows=[(int(r["Start_Timestamp"]),int(r["End_Timestamp"]),r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+for mf in glob.glob(O+"/trace/**/*memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(mf)):
+        if int(r["End_Timestamp"])-int(r["Start_Timestamp"])>20000:
+            rows.append((int(r["Start_Timestamp"]),int(r["End_Timestamp"]),"COPY "+r.get("Direction","")+" "+r.get("Name","")[:20]))
 rows.sort()
 def short(n):
     for k in ("k_query_level","k_syncmers_wave","k_syncmers","k_pack_dna4","k_queue_hist","k_queue_scan","k_queue_scatter","k_scan_offsets","k_scatter_hits","k_sort_small","k_sort_big","k_fill_random","k_build","k_gather"):

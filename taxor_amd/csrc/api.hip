@@ -166,8 +166,25 @@ struct taxor_gpu_searcher {
     taxor_gpu_run_stats stats{};
 };
 
+// The HIP runtime multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues per device (default 4), and two streams
+// that share a queue execute in submission order.  A searcher's pipeline lives on concurrency between its streams -- the
+// copy stream ahead of everything, pack + syncmers of sub-batch i+1 beside the query of sub-batch i -- and with the null
+// stream a single streamed searcher already has five: measured on the streamed single call, the copy stream shared the
+// query stream's queue, every copy waited for the previous sub-batch's query chain and every syncmer launch ran exposed
+// (60 -> 55 ms per 1.31 Gbp with 8 or 16 queues, profiles/r03/single_call_hw_queues.txt).  The runtime reads the variable
+// once, when it initialises: set it here, before this library's first HIP call, unless the user has chosen a value.  In a
+// process whose runtime is already up (another library used HIP first) this has no effect; export it there.
+static void runtime_env_once()
+{
+    static const bool done = [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); return true; }();
+    (void)done;
+}
+
+extern "C" __attribute__((visibility("hidden"))) void taxor_runtime_env_once() { runtime_env_once(); }
+
 extern "C" int taxor_gpu_host_register(void *ptr, uint64_t bytes)
 {
+    runtime_env_once();
     if (!ptr || !bytes) return fail(TAXOR_E_ARG, "taxor_gpu_host_register: null buffer");
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
     return TAXOR_OK;
@@ -339,6 +356,7 @@ static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*p
 // replica that receives them over RCCL, or through a pipelined upload (comm.hip)
 static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, taxor_gpu_index **out)
 {
+    runtime_env_once();
     if (!v || !out || v->n_ixf == 0 || !v->ixf) return fail(TAXOR_E_ARG, "index_create: empty view");
     if (!v->use_syncmer) { // seqan3 minimiser_hash over window_size (taxor_search.cpp:210-212)
         if (v->kmer_size < 1 || v->kmer_size > 32)

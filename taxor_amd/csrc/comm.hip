@@ -161,8 +161,11 @@ struct taxor_gpu_comm {
     taxor_gpu_comm_stats stats{};
 };
 
+extern "C" __attribute__((visibility("hidden"))) void taxor_runtime_env_once();
+
 extern "C" int taxor_gpu_comm_create(const int *devices, uint32_t n_devices, int transport, taxor_gpu_comm **out)
 {
+    taxor_runtime_env_once();
     if (!devices || !n_devices || !out) return cfail(TAXOR_E_ARG, "comm_create: no devices");
     if (transport != TAXOR_COMM_RCCL && transport != TAXOR_COMM_HOST) return cfail(TAXOR_E_ARG, "comm_create: unknown transport %d", transport);
     int have = 0;
