@@ -44,7 +44,7 @@ import numpy as np
 # the HIP runtime maps streams onto this many hardware queues per device (default 4) and streams that share one run in
 # submission order; a searcher's copy / hashing / query streams must not (taxor_amd/csrc/api.hip, runtime_env_once).  Set
 # before torch brings the runtime up; a value the user exported wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -636,6 +636,11 @@ def main():
                                   "note": "HIP-event sums per stream; syncmers of sub-batch i+1 overlap the query of sub-batch i"},
         }
         if world == 1 and not args.no_dropin:
+            # the resident searchers (and their streams) are not needed any more: a drop-in user's process holds the one or two
+            # searchers it feeds, and the figures below are measured like that
+            for sr in searchers:
+                sr.close()
+            searchers = []
             out["pcie_inclusive"], out["sustained"] = dropin_measurements(args, idx, batches, read_len)
         if per_rank is not None:
             out["pcie_inclusive_per_rank"] = per_rank

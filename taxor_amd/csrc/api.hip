@@ -171,12 +171,13 @@ struct taxor_gpu_searcher {
 // copy stream ahead of everything, pack + syncmers of sub-batch i+1 beside the query of sub-batch i -- and with the null
 // stream a single streamed searcher already has five: measured on the streamed single call, the copy stream shared the
 // query stream's queue, every copy waited for the previous sub-batch's query chain and every syncmer launch ran exposed
-// (60 -> 55 ms per 1.31 Gbp with 8 or 16 queues, profiles/r03/single_call_hw_queues.txt).  The runtime reads the variable
+// (60 -> 55 ms per 1.31 Gbp with 8 or 16 queues, profiles/r03/single_call_hw_queues.txt; with 32 or 64 the whole pipeline
+// loses a third -- more queues than the hardware has slots are time-sliced).  The runtime reads the variable
 // once, when it initialises: set it here, before this library's first HIP call, unless the user has chosen a value.  In a
 // process whose runtime is already up (another library used HIP first) this has no effect; export it there.
 static void runtime_env_once()
 {
-    static const bool done = [] { setenv("GPU_MAX_HW_QUEUES", "16", 0); return true; }();
+    static const bool done = [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); return true; }();   // 32 and more: measured harmful (queues time-sliced)
     (void)done;
 }
 
@@ -762,9 +763,7 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
     hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_wave, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
     if (e != hipSuccess) {
@@ -1341,9 +1340,28 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
 
 // The whole pipeline for the uploaded (host_ascii == nullptr) or streaming (host_ascii = first base of the batch)
 // case.  Streams: st_copy (H2D of the sub-batches' bases, back to back), st_sync (pack + syncmers of i+1), st (query + CSR of i).
+// streams a searcher does not always need are made at first use: every stream the process holds is one more candidate
+// to share a hardware queue with (runtime_env_once above)
+int ensure_stream(hipStream_t *st)
+{
+    if (!*st) HIP_TRY(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    return 0;
+}
+
+bool host_pointer_is_pinned(const void *p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory: unknown to the runtime
+    return a.type == hipMemoryTypeHost;
+}
+
 int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
 {
     if (int rc = ensure_scratch(s)) return rc;
+    bool need_wave = false;
+    for (const SubBatch &sb : s->subs) need_wave = need_wave || (s->idx->w_min == 0 && sb.n_long < sb.n);
+    if (need_wave && ensure_stream(&s->st_sync2)) return TAXOR_E_HIP;
+    if (host_ascii && ensure_stream(&s->st_copy)) return TAXOR_E_HIP;
     s->ev_used = 0;
     s->ev_spans.clear();
     s->stats = taxor_gpu_run_stats{};
@@ -1352,9 +1370,32 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     HIP_TRY(hipMemsetAsync(s->d_sync_cursor.p, 0, 2 * (s->subs.size() + 1) * sizeof(uint32_t), s->st));
     HIP_TRY(hipEventRecord(s->ev_reset, s->st));
     HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_reset, 0));
-    HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_reset, 0));
-    HIP_TRY(hipStreamWaitEvent(s->st_copy, s->ev_reset, 0));
+    if (s->st_sync2) HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
+    // the bases of sub-batch i, from wherever the caller keeps them: one buffer, or several segments in turn
+    size_t span_i = 0;
+    auto enqueue_copy = [&](size_t i) -> int {
+        const SubBatch &sb = s->subs[i];
+        for (; span_i < s->host_spans.size() && s->host_spans[span_i].vbegin + s->host_spans[span_i].len <= sb.a_begin; ++span_i) {}
+        for (size_t j = span_i; j < s->host_spans.size() && s->host_spans[j].vbegin < sb.a_end; ++j) {
+            const auto &sp = s->host_spans[j];
+            const uint64_t lo = std::max(sp.vbegin, sb.a_begin), hi = std::min(sp.vbegin + sp.len, sb.a_end);
+            if (hi > lo)
+                HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, s->st_copy));
+        }
+        HIP_TRY(hipEventRecord(s->ev_copy_done[i], s->st_copy));
+        return 0;
+    };
+    // Page-locked input: every copy of the batch is enqueued now, before the first kernel -- they then run back to back at
+    // PCIe speed far ahead of the kernels even when the runtime has put the copy stream on a hardware queue it shares
+    // with one of the kernel streams (in-order per queue: what is submitted first runs first).  Pageable input: each
+    // copy blocks the host until it is done, so it is issued just before its sub-batch's kernels (the GPU works on the
+    // previous sub-batch meanwhile).
+    bool copies_first = host_ascii;
+    for (const auto &sp : s->host_spans) copies_first = copies_first && host_pointer_is_pinned(sp.ptr);
+    if (copies_first)
+        for (size_t i = 0; i < s->subs.size(); ++i)
+            if (int rc = enqueue_copy(i)) return rc;
     if (s->subs.empty()) { // zero reads: CSR = [0]
         HIP_TRY(hipMemsetAsync(s->d_read_off.p, 0, sizeof(uint64_t), s->st));
     }
@@ -1362,33 +1403,19 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     // candidate/hash scratch is double buffered, events carry the dependencies.  When streaming, the bases of
     // sub-batch i+1 cross PCIe (pageable copy: the host blocks in it, the GPU keeps working) and are packed on
     // a third stream meanwhile.
-    size_t span_i = 0;
     for (size_t i = 0; i < s->subs.size(); ++i) {
         const SubBatch &sb = s->subs[i];
         const int buf = (int)(i & 1);
-        if (host_ascii) {
-            // the sub-batch's bases, from wherever the caller keeps them: one buffer, or several segments in turn
-            for (; span_i < s->host_spans.size() && s->host_spans[span_i].vbegin + s->host_spans[span_i].len <= sb.a_begin; ++span_i) {}
-            for (size_t j = span_i; j < s->host_spans.size() && s->host_spans[j].vbegin < sb.a_end; ++j) {
-                const auto &sp = s->host_spans[j];
-                const uint64_t lo = std::max(sp.vbegin, sb.a_begin), hi = std::min(sp.vbegin + sp.len, sb.a_end);
-                if (hi > lo)
-                    HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, s->st_copy));
-            }
-            HIP_TRY(hipEventRecord(s->ev_copy_done[i], s->st_copy));
-        }
+        if (host_ascii && !copies_first)
+            if (int rc = enqueue_copy(i)) return rc;
         // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
         static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
         hipStream_t ss = no_overlap ? s->st : s->st_sync;
-        hipStream_t ss2 = no_overlap ? s->st : s->st_sync2;
+        hipStream_t ss2 = (no_overlap || !s->st_sync2) ? ss : s->st_sync2;
         if (host_ascii) {
-            // The copy stream carries copies only, so they run back to back at PCIe speed, far ahead of the kernels.  The
-            // pack kernel sits on the hashing stream in front of its sub-batch's syncmer kernel: with the copy long done,
-            // pack + syncmers of sub-batch i+1 both fit beside the ROOT level of query i (three query blocks per CU leave
-            // room for one more; the deeper levels run four per CU and leave none).  Round 2 had the pack kernel on the
-            // copy stream, between the copies: copy(i+1) could only start after pack(i) had found room, finished about when
-            // root(i) did, and pack(i+1) then waited for query i's deeper levels to drain -- every sub-batch's hashing ran
-            // exposed, 10 ms of a 60 ms call (profiles/r03/single_call_timeline_before.txt).
+            // The copy stream carries copies only; the pack kernel sits on the hashing stream in front of its sub-batch's
+            // syncmer kernel: with the copy long done, pack + syncmers of sub-batch i+1 both run beside the query of
+            // sub-batch i.
             HIP_TRY(hipStreamWaitEvent(ss, s->ev_copy_done[i], 0));
             launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr, ss, s->grid_sync_overlap);
             HIP_TRY(hipGetLastError());
