@@ -1318,8 +1318,10 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         const uint64_t k = (uint64_t)s->idx->k;
         for (uint64_t r = 0; r < n_reads; ++r) {
             const uint64_t n = rlen[r] >= k ? rlen[r] - k + 1 : 0;
-            const double sf = (double)n / ((double)rlen[r] - (double)k + 1.0);                   // taxor_search.cpp:263
-            if (n >= (1u << 22)) {                // chromosome-sized "reads": not worth a table entry each
+            // taxor_search.cpp:263; the k-mer model does not read the factor (threshold.hpp:62-66), and for a read shorter
+            // than k (n = 0) the quotient is 0/0 or -0: keep that out of the memo, whose key is n alone
+            const double sf = n ? (double)n / ((double)rlen[r] - (double)k + 1.0) : 0.0;
+            if (n == 0 || n >= (1u << 22)) {      // no k-mer at all, or chromosome-sized "reads": not worth a table entry each
                 thr_h[r] = taxor_threshold_model(TAXOR_THR_KMER, n, (uint32_t)k, s->prm.error_rate, -1.0, sf);
                 continue;
             }

@@ -23,6 +23,7 @@
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -50,9 +51,12 @@ struct Batch {
 //      The image carries libbz2's shared object but not its header, so the three entry points of its stable stdio-like
 //      interface are bound at run time; a host without the library gets a clear error instead of a silent mis-parse.
 struct Bz2Api {
-    void *(*open)(const char *, const char *) = nullptr;
-    int (*read)(void *, void *, int) = nullptr;
-    void (*close)(void *) = nullptr;
+    // the library's low-level reading interface: a .bz2 may hold SEVERAL streams back to back (pbzip2 output,
+    // `cat a.bz2 b.bz2`), and the stdio-like BZ2_bzread stops for good after the first one
+    void *(*read_open)(int *, FILE *, int, int, void *, int) = nullptr;
+    int (*read)(int *, void *, void *, int) = nullptr;
+    void (*get_unused)(int *, void *, void **, int *) = nullptr;
+    void (*read_close)(int *, void *) = nullptr;
     static const Bz2Api &get()
     {
         static const Bz2Api api = [] {
@@ -61,15 +65,72 @@ struct Bz2Api {
             for (const char *name : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"})
                 if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
             if (h) {
-                a.open = reinterpret_cast<void *(*)(const char *, const char *)>(dlsym(h, "BZ2_bzopen"));
-                a.read = reinterpret_cast<int (*)(void *, void *, int)>(dlsym(h, "BZ2_bzread"));
-                a.close = reinterpret_cast<void (*)(void *)>(dlsym(h, "BZ2_bzclose"));
+                a.read_open = reinterpret_cast<decltype(a.read_open)>(dlsym(h, "BZ2_bzReadOpen"));
+                a.read = reinterpret_cast<decltype(a.read)>(dlsym(h, "BZ2_bzRead"));
+                a.get_unused = reinterpret_cast<decltype(a.get_unused)>(dlsym(h, "BZ2_bzReadGetUnused"));
+                a.read_close = reinterpret_cast<decltype(a.read_close)>(dlsym(h, "BZ2_bzReadClose"));
             }
             return a;
         }();
         return api;
     }
-    bool ok() const { return open && read && close; }
+    bool ok() const { return read_open && read && get_unused && read_close; }
+};
+
+// all streams of a .bz2 file, one after the other (the loop of the bzip2 manual, "Reading a multi-stream file")
+struct Bz2Reader {
+    FILE *fp = nullptr;
+    void *bz = nullptr;
+    char unused[5000];       // BZ_MAX_UNUSED
+    int n_unused = 0;
+    bool done = false;
+    bool open(const char *path)
+    {
+        fp = fopen(path, "rb");
+        return fp && next_stream();
+    }
+    bool next_stream()
+    {
+        int err = 0;
+        bz = Bz2Api::get().read_open(&err, fp, 0, 0, n_unused ? unused : nullptr, n_unused);
+        if (err != 0 || !bz) { bz = nullptr; return false; }
+        return true;
+    }
+    // bytes read, 0 at the end of the last stream, -1 on a corrupt stream
+    long read(char *dst, int n)
+    {
+        const Bz2Api &api = Bz2Api::get();
+        long got = 0;
+        while (got < n && !done) {
+            int err = 0;
+            const int r = api.read(&err, bz, dst + got, n - (int)got);
+            if (err != 0 && err != 4) return -1;            // neither BZ_OK nor BZ_STREAM_END
+            got += r > 0 ? r : 0;
+            if (err == 4) {                                  // end of one stream: is another one behind it?
+                void *u = nullptr;
+                int nu = 0, e2 = 0;
+                api.get_unused(&e2, bz, &u, &nu);
+                if (e2 != 0 || nu < 0 || nu > (int)sizeof unused) return -1;
+                if (nu) memmove(unused, u, (size_t)nu);
+                n_unused = nu;
+                api.read_close(&e2, bz);
+                bz = nullptr;
+                if (n_unused == 0) {
+                    const int c = fgetc(fp);
+                    if (c == EOF) { done = true; break; }
+                    ungetc(c, fp);
+                }
+                if (!next_stream()) return -1;
+            }
+        }
+        return got;
+    }
+    ~Bz2Reader()
+    {
+        int e = 0;
+        if (bz) Bz2Api::get().read_close(&e, bz);
+        if (fp) fclose(fp);
+    }
 };
 
 // ---- sequential reader over zlib.  Lines are located with memchr inside a large refill buffer; sequence lines are
@@ -83,10 +144,13 @@ struct FastxReader {
     int fd = -1;         // range mode: bytes [rpos, rend) of a plain file, read with pread
     uint64_t rpos = 0, rend = 0;
     GzMembers *members = nullptr;   // multi-member gzip inflated in parallel (gzmembers.h)
-    void *bz = nullptr;             // bzip2 stream (Bz2Api)
+    std::unique_ptr<Bz2Reader> bz;  // bzip2 input, all of its streams
 
-    void open_range(int fd_, uint64_t b, uint64_t e)
+    bool strict4 = false;           // range mode on FASTQ: records must be the four-line kind the ranges were cut for
+
+    void open_range(int fd_, uint64_t b, uint64_t e, bool fastq_ranges = false)
     {
+        strict4 = fastq_ranges;
         fd = fd_;
         rpos = b;
         rend = e;
@@ -105,8 +169,9 @@ struct FastxReader {
             if (got == 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') {
                 const Bz2Api &api = Bz2Api::get();
                 if (!api.ok()) throw std::runtime_error("query file " + path + " is bzip2-compressed and libbz2 is not available on this host");
-                bz = api.open(path.c_str(), "rb");
-                return bz != nullptr;
+                bz.reset(new Bz2Reader());
+                if (!bz->open(path.c_str())) { bz.reset(); return false; }
+                return true;
             }
         }
         f = gzopen(path.c_str(), "rb");
@@ -116,7 +181,6 @@ struct FastxReader {
     ~FastxReader()
     {
         if (f) gzclose(f);
-        if (bz) Bz2Api::get().close(bz);
     }
     bool refill()
     {
@@ -129,7 +193,7 @@ struct FastxReader {
             n = want ? (long)pread(fd, buf.data(), want, (off_t)rpos) : 0;
             if (n > 0) rpos += (uint64_t)n;
         } else if (bz) {
-            n = Bz2Api::get().read(bz, buf.data(), (int)buf.size());
+            n = bz->read(buf.data(), (int)std::min<size_t>(buf.size(), 1u << 30));
             if (n < 0) throw std::runtime_error("bzip2 stream is corrupt");
         } else {
             n = gzread(f, buf.data(), (unsigned)buf.size());
@@ -203,18 +267,32 @@ struct FastxReader {
             for (;;) {
                 if (pos == len && !refill()) throw std::runtime_error("truncated FASTQ record: " + id);
                 if (buf[pos] == '+') break;
+                // A byte range of the parallel reader was cut on the assumption of four-line records (resync below; the
+                // file's first records were): a record that wraps its sequence means the cuts of this file cannot be
+                // trusted -- stop, do not mis-parse
+                if (strict4) throw std::runtime_error("FASTQ record '" + id + "' wraps its sequence over several lines; the parallel range reader "
+                                                      "needs four-line records -- rerun with --sequential");
                 line_to(&bases);
             }
             line_to(nullptr);                                                                    // the '+' line
             const size_t want = bases.size() - seq_begin;
             size_t got = 0, n = 0;
-            do {                                                                                 // quality: skipped, never copied
-                if (!line_to(nullptr, &n)) {
-                    if (got < want) throw std::runtime_error("truncated FASTQ record: " + id);
-                    break;
-                }
+            while (got < want) {                                                                 // quality: skipped, never copied
+                if (!line_to(nullptr, &n)) throw std::runtime_error("truncated FASTQ record: " + id);
                 got += n;
-            } while (got < want);
+                if (strict4 && got != want) break;
+            }
+            if (want == 0) line_to(nullptr, &n);                                                 // an empty read still has its (empty) quality line
+            // the quality string is exactly as long as the sequence and the next record (if any) starts with '@': anything
+            // else means the record boundaries are not where this parser thinks they are
+            if (got != want) throw std::runtime_error("malformed FASTQ record '" + id + "': " + std::to_string(want) + " bases, " + std::to_string(got) +
+                                                      " quality characters" + (strict4 ? " (parallel range reader: rerun with --sequential if the file is valid)" : ""));
+            for (;;) {
+                if (pos == len && !refill()) break;                                              // end of input
+                if (buf[pos] == '\n' || buf[pos] == '\r') { ++pos; continue; }                   // blank lines between records
+                if (buf[pos] != '@') throw std::runtime_error("malformed FASTQ: the line after record '" + id + "' does not start with '@'");
+                break;
+            }
             return true;
         }
         throw std::runtime_error("query file is neither FASTA nor FASTQ");

@@ -151,7 +151,9 @@ private:
     }
 
     // `guess`: distance to the next candidate, i.e. the compressed size if both are real boundaries
-    void inflate_member(size_t p, size_t guess, Result &r) const
+    // capped: the limits that keep a SPECULATIVE candidate from running through the rest of the file; a member the chain
+    // has actually arrived at is real, however large, and is inflated without them
+    void inflate_member(size_t p, size_t guess, Result &r, bool capped = true) const
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
@@ -161,15 +163,16 @@ private:
         // a real member is at most kMaxMember compressed bytes long (open() checked the candidate gaps); a false
         // candidate that happens to parse as deflate data must not run through the rest of the file, and no member may
         // grow its output without bound
-        size_t avail = std::min(size_ - p, kMaxMember + (1u << 16));
+        size_t avail = capped ? std::min(size_ - p, kMaxMember + (1u << 16)) : size_ - p;
+        const size_t max_output = capped ? kMaxOutput : SIZE_MAX / 2;
         r.out.resize(std::max<size_t>(1u << 16, 4 * guess));
         size_t produced = 0;
         for (;;) {
             const uInt in_chunk = (uInt)std::min<size_t>(avail, 1u << 30);
             zs.avail_in = in_chunk;
             if (produced == r.out.size()) {
-                if (produced >= kMaxOutput) break;
-                r.out.resize(std::min(r.out.size() * 2, kMaxOutput));
+                if (produced >= max_output) break;
+                r.out.resize(std::min(r.out.size() * 2, max_output));
             }
             const uInt out_chunk = (uInt)std::min<size_t>(r.out.size() - produced, 1u << 30);
             zs.next_out = (Bytef *)&r.out[produced];
@@ -213,7 +216,19 @@ private:
         chain_idx_ = i;
         cv_work_.notify_all();
         cv_done_.wait(lk, [&] { return res_[i].state >= 2; });
-        if (res_[i].state != 2) throw std::runtime_error("gzip file: corrupt member");
+        if (res_[i].state != 2) {
+            // The chain has arrived here from a verified member's end, so this IS a member.  The speculative inflate may
+            // have given up only because of its size caps (a genuine member beyond 256 MB compressed that also contains a
+            // false header candidate passes open()'s gap test): inflate it again without them before calling it corrupt.
+            lk.unlock();
+            Result r;
+            inflate_member(cand_[i], (i + 1 < cand_.size() ? cand_[i + 1] : size_) - cand_[i], r, false);
+            lk.lock();
+            if (r.state != 2) throw std::runtime_error("gzip file: corrupt member");
+            res_[i].out.swap(r.out);
+            res_[i].end = r.end;
+            res_[i].state = 2;
+        }
         cur_ = i;
         cur_pos_ = 0;
         return true;

@@ -105,6 +105,7 @@ struct Config {                              // taxor_search_configuration.hpp:8
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
+    bool sequential = false;    // --sequential: one reader thread per file, no byte-range cutting (any legal FASTA/FASTQ)
     uint32_t ixf_arith = 0;     // --ixf-arithmetic: the reading of the un-vendored IXF arithmetic the index follows (0 = this library's)
     uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
@@ -152,6 +153,7 @@ void usage()
             "  --gather <rccl|host|none> several devices: index broadcast + per-round gather of the results on the first device over\n"
             "                           RCCL/xGMI (default), the same staged through host memory, or independent workers\n"
             "  --batch-reads <n>        reads per parsed chunk (default: about 128 MB of query file, 65536 reads for gzip)\n"
+            "  --sequential             read every query file front to back on one thread (FASTQ whose records wrap their lines)\n"
             "  --group-reads <n>        reads per GPU batch, made of whole chunks (default 131072; --batch-reads if that is given)\n"
             "  --ixf-arithmetic <spec>  search an index whose fingerprints follow another reading of the IXF arithmetic than this\n"
             "                           build's (the spec `taxor verify --variants` prints: kh=..,sm=..,rot=..,red=..,fp=..)\n"
@@ -227,7 +229,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                         bt->ids.clear();
                         bt->bases.clear();
                         bt->offsets.assign(1, 0);
-                        rd.open_range(rf.fd, b, e);
+                        rd.open_range(rf.fd, b, e, rf.kind == '@');
                         while (rd.next(id, bt->bases)) {
                             bt->ids.push_back(id);
                             bt->offsets.push_back(bt->bases.size());
@@ -675,6 +677,7 @@ int main(int argc, char **argv)
         }
         else if (k == "--batch-reads") cfg.batch_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--expect") cfg.expect_file = val();
+        else if (k == "--sequential") cfg.sequential = true;
         else if (k == "--group-reads") cfg.group_reads = strtoull(val().c_str(), nullptr, 10);
         else if (k == "--ixf-arithmetic") {
             const std::string spec = val();
@@ -799,7 +802,7 @@ int main(int argc, char **argv)
                         std::unique_lock<std::mutex> lk(fmu);
                         fcv.wait(lk, [&] { return f == current_file || ahead[f] < 2; });
                     };
-                    reader_time[rt] += produce_batches(queries[f], cfg, true, pool, [&, f](std::unique_ptr<Batch> b) {
+                    reader_time[rt] += produce_batches(queries[f], cfg, !cfg.sequential, pool, [&, f](std::unique_ptr<Batch> b) {
                         if (!b->end_of_file) {
                             std::lock_guard<std::mutex> lk(fmu);
                             ++ahead[f];

@@ -228,3 +228,58 @@ def test_bzip2_input(tmp_path):
     fz.write_bytes(bz2.compress(fa.read_bytes()) + bz2.compress(b">second_stream\nACGTACGT\n"))      # two concatenated streams
     got = run_reads(fz, "--threads", "2")[0]
     assert got[:len(recs)] == expected(recs)
+    # ... and the second stream is read too (pbzip2 output, `cat a.bz2 b.bz2`): nothing is dropped silently
+    assert got == expected(recs) + expected([("second_stream", b"ACGTACGT")])
+    many = tmp_path / "many.fastq.bz2"
+    cut = [0, 40, 41, 97, len(recs)]
+    parts = []
+    for a, b in zip(cut, cut[1:]):
+        q = tmp_path / "part.fastq"
+        write_fastq(q, recs[a:b], rng)
+        parts.append(bz2.compress(q.read_bytes()))
+    many.write_bytes(b"".join(parts))
+    assert run_reads(many, "--threads", "3")[0] == expected(recs)
+    broken = tmp_path / "broken.fastq.bz2"
+    broken.write_bytes(parts[0] + parts[1][: len(parts[1]) // 2])
+    cp = subprocess.run([EXE, "reads", "--query-file", str(broken)], capture_output=True)
+    assert cp.returncode != 0 and b"bzip2" in cp.stderr
+
+
+def test_fastq_that_starts_four_line_and_wraps_later_is_not_cut_wrongly(tmp_path):
+    """the range cutter is chosen from the file's first records.  A FASTQ whose later records wrap their lines must
+    not be mis-parsed in parallel mode: the range parser notices (a record's sequence spans several lines, or quality and
+    sequence lengths differ) and stops with a message that names --sequential, under which the file parses correctly."""
+    rng = np.random.default_rng(23)
+    recs = make_records(rng, 400, lo=150, hi=400)
+    p = tmp_path / "mixed.fastq"
+    with open(p, "wb") as f:
+        for j, (i, s) in enumerate(recs):
+            q = bytes(rng.choice(np.frombuffer(b"I5>#", np.uint8), size=len(s)))
+            if j < 120:
+                f.write(b"@" + i.encode() + b"\n" + s + b"\n+\n" + q + b"\n")
+            else:                                   # wrapped at 80 columns, sequence and quality alike
+                f.write(b"@" + i.encode() + b"\n" + b"\n".join(s[k:k + 80] for k in range(0, len(s), 80)) + b"\n+\n" +
+                        b"\n".join(q[k:k + 80] for k in range(0, len(q), 80)) + b"\n")
+    cp = subprocess.run([EXE, "reads", "--query-file", str(p), "--threads", "4", "--batch-reads", "40"], capture_output=True, text=True)
+    assert cp.returncode != 0 and "--sequential" in cp.stderr, cp.stderr
+    assert run_reads(p, "--sequential")[0] == expected(recs)
+
+
+def test_malformed_fastq_fails_loudly(tmp_path):
+    rng = np.random.default_rng(29)
+    recs = make_records(rng, 30, lo=50, hi=90)
+    good = tmp_path / "good.fastq"
+    write_fastq(good, recs, rng)
+    lines = good.read_bytes().split(b"\n")
+    short = list(lines)
+    short[4 * 7 + 3] = short[4 * 7 + 3][:-5]                  # record 7: quality five characters short
+    bad1 = tmp_path / "short_quality.fastq"
+    bad1.write_bytes(b"\n".join(short))
+    longq = list(lines)
+    longq[4 * 9 + 3] = longq[4 * 9 + 3] + b"III"              # record 9: quality three characters too long
+    bad2 = tmp_path / "long_quality.fastq"
+    bad2.write_bytes(b"\n".join(longq))
+    for bad in (bad1, bad2):
+        for mode in ((), ("--sequential",)):
+            cp = subprocess.run([EXE, "reads", "--query-file", str(bad), *mode], capture_output=True, text=True)
+            assert cp.returncode != 0 and ("malformed FASTQ" in cp.stderr or "truncated FASTQ" in cp.stderr), (bad, mode, cp.stderr)
