@@ -94,6 +94,10 @@ def parse_args(argv=None):
     ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate through")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
+    ap.add_argument("--mode", default="syncmer", choices=("syncmer", "kmer", "minimiser"),
+                    help="hashing of the index: syncmer = k22/s12 open syncmers (the BASELINE configs); kmer = an index built WITHOUT "
+                         "--use-syncmer, the reference's default build mode (every canonical 20-mer, k-mer threshold model); minimiser = "
+                         "the same with window 32 (FracMinHash model).  kmer / minimiser run on the viral-class footprint with 5-kb reads")
     ap.add_argument("--len-mix", default="", help="'ont': skewed read lengths 1-100 kb (same total bases) instead of a fixed length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
@@ -124,7 +128,7 @@ def live_traffic(args):
         return None, "skipped: this process runs under a rocprofiler tool already (use --traffic none when profiling bench.py)", {}
     child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "1", "--warmup", "0",
              "--workload", args.workload, "--family-size", str(args.family_size), "--read-error", str(args.read_error),
-             "--error-rate", str(args.error_rate), "--batches", "1"]
+             "--error-rate", str(args.error_rate), "--batches", "1", "--mode", args.mode]
     for flag, v in (("--reads", args.reads), ("--read-len", args.read_len), ("--genomes", args.genomes),
                     ("--genome-len", args.genome_len), ("--root-bins", args.root_bins)):
         if v:
@@ -208,6 +212,8 @@ def live_traffic(args):
 def build_workload(args, local_rank, rank, world):
     """planted genomes, index resident in HBM, and this rank's distinct read batches"""
     from taxor_amd import GpuIndex, Searcher, synth
+    if args.mode != "syncmer":
+        return build_workload_no_syncmer(args, local_rank, rank, world)
     wl = dict(WORKLOADS[args.workload])
     if args.root_bins:
         wl["root_bins"] = args.root_bins
@@ -301,6 +307,50 @@ def build_workload(args, local_rank, rank, world):
     log(f"{len(batches)} distinct batches of {batches[0][1].size - 1} reads x {read_len} bp generated ({ncpu} threads), {time.time()-t0:.1f}s")
     return wl, idx, lay, batches, dict(n_reads=n_reads, read_len=read_len, n_genomes=n_genomes, genome_len=genome_len,
                                        fam_size=fam_size, ncpu=ncpu, origins=origins, genomes=g, genome_off=go)
+
+
+def build_workload_no_syncmer(args, local_rank, rank, world):
+    """An index built without --use-syncmer (taxor build's default; taxor_search.cpp:210-212,239-260): every canonical k-mer
+    (window == k) or window minimisers, on the viral-class footprint (root 256 bins, children 64), 5-kb reads.  Every k-mer
+    of a read is a hash (4981 per 5-kb read against 435 syncmers), nothing is deduplicated, and the threshold is the
+    reference's k-mer / FracMinHash model, evaluated on the host."""
+    from taxor_amd import GpuIndex, Searcher, synth
+    from taxor_amd import distributed as td
+    k = 20
+    w = 20 if args.mode == "kmer" else 32
+    n_reads = args.reads or 32768
+    read_len = args.read_len or 5000
+    n_genomes = args.genomes or 32
+    genome_len = args.genome_len or 100000
+    ncpu = len(os.sched_getaffinity(0)) or 8
+    t0 = time.time()
+    g, go = synth.random_genomes(n_genomes, genome_len, seed=synth.DEFAULT_SEED)
+    bins = 64
+    dummy = GpuIndex([dict(bins=bins, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(bins, np.int64), fname_idx=np.arange(bins),
+                           data=np.zeros(3 * 16 * 64, np.uint8))], bins, k=k, s=0, t=0, use_syncmer=False, window_size=w, device=local_rank)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = [np.unique(hashes[int(hoff[i]):int(hoff[i + 1])]) for i in range(n_genomes)]
+    per_bin = max(len(p) for p in planted)
+    wl = dict(root_bins=args.root_bins or 256, child_bins=64, n_children=252)
+    lay = synth.make_layout(planted, root_bins=wl["root_bins"], child_bins=64, n_children=min(252, wl["root_bins"] - 4), root_max_elems=per_bin * 20,
+                            child_max_elems=per_bin + 64, seed=synth.DEFAULT_SEED, build="gpu")
+    idx = synth.device_index(lay, k=k, s=0, t=0, use_syncmer=False, window_size=w, device=local_rank)
+    log(f"index built without syncmers (k={k}, window={w}) in HBM: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs, {time.time()-t0:.1f}s")
+    lo, hi = td.shard_range(n_reads, rank, world) if (args.scaling == "strong" and world > 1) else (0, n_reads)
+    batches, origins = [], []
+    for b in range(max(1, args.batches)):
+        seed = synth.DEFAULT_SEED + 1000 * b + (rank if args.scaling == "weak" else 0)
+        bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1, seed=seed, threads=ncpu)
+        if args.scaling == "strong" and world > 1:
+            bases, offs = bases[int(offs[lo]):int(offs[hi])], offs[lo:hi + 1] - offs[lo]
+            origin = origin[lo:hi]
+        batches.append((np.ascontiguousarray(bases), np.ascontiguousarray(offs)))
+        origins.append(origin)
+    return wl, idx, lay, batches, dict(n_reads=n_reads, read_len=read_len, n_genomes=n_genomes, genome_len=genome_len, fam_size=1, ncpu=ncpu,
+                                       origins=origins, genomes=g, genome_off=go, k=k, s=0, t=0, window=w)
 
 
 def main():
@@ -618,8 +668,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-class HIXF k22/s12 {idx.data_bytes/1e9:.0f} GB in HBM, root {wl['root_bins']} bins, "
-                                   f"{shard_reads[0]} reads x {int(read_len)} bp/GPU/step, {fam}",
+            "config": {"workload": (f"{args.workload}-class HIXF k22/s12 {idx.data_bytes/1e9:.0f} GB in HBM, root {wl['root_bins']} bins, "
+                                    f"{shard_reads[0]} reads x {int(read_len)} bp/GPU/step, {fam}") if args.mode == "syncmer" else
+                                   (f"viral-class HIXF built WITHOUT --use-syncmer (k={info['k']}, window={info['window']}: "
+                                    f"{'every canonical k-mer, k-mer threshold model' if args.mode == 'kmer' else 'window minimisers, FracMinHash threshold model'}) "
+                                    f"{idx.data_bytes/1e9:.2f} GB in HBM, root {wl['root_bins']} bins, {shard_reads[0]} reads x {int(read_len)} bp/GPU/step"),
+                       "mode": args.mode,
                        "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "root_bins": wl["root_bins"],
                        "child_bins": wl["child_bins"], "depth": idx.depth, "reads_per_gpu": shard_reads[0], "read_len": read_len,
                        "distinct_batches": len(batches), "read_error": args.read_error, "search_error_rate": args.error_rate,
@@ -650,7 +704,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, full_affinity)      # the CPU baseline is timed on the box's host cores, all sockets
             ncpu = len(full_affinity)
-            out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu)
+            hash_kw = dict(k=info["k"], s=info["s"], t=info["t"], window=info["window"]) if args.mode != "syncmer" else {}
+            out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu, hash_kw)
         print(json.dumps(out), flush=True)
     for sr in searchers:
         sr.close()
@@ -714,9 +769,37 @@ def dropin_measurements(args, idx, batches, read_len):
     return single, sustained
 
 
-def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu):
+def _interleave_host_memory(on):
+    """MPOL_INTERLEAVE over all NUMA nodes for pages this thread touches from now on (off: back to the default policy).  The
+    oracle's copy of the index is first touched here, on one thread: without this the 45 GB root table lands on one socket
+    and, at all hardware threads, the other socket reads every fingerprint row remotely (the round-2 `all_cores` figure was
+    slower than 32 threads for that reason).  Returns the node count used, 0 if the policy could not be set."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL(None, use_errno=True)
+        if not on:
+            libc.syscall(238, 0, None, 0)                    # set_mempolicy(MPOL_DEFAULT)
+            return 0
+        nodes = set()
+        for part in open("/sys/devices/system/node/online").read().strip().split(","):
+            a, _, b = part.partition("-")
+            nodes.update(range(int(a), int(b or a) + 1))
+        if len(nodes) < 2:
+            return 0
+        words = max(nodes) // 64 + 1
+        mask = (ctypes.c_ulong * words)()
+        for n in nodes:
+            mask[n // 64] |= 1 << (n % 64)
+        rc = libc.syscall(238, 3, mask, ctypes.c_ulong(words * 64 + 1))      # set_mempolicy(MPOL_INTERLEAVE, mask, maxnode)
+        return len(nodes) if rc == 0 else 0
+    except Exception:
+        return 0
+
+
+def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
     """The CPU oracle (a port of the reference path) on a bounded sample of the same reads + index, same box."""
     from oracle import oracle as orc
+    hash_kw = hash_kw or {}
     bases, offs = batch
     threads = min(ncpu, 32)                      # the reference caps --threads at 32 (taxor_search.cpp:51-55)
     # host copy of the IXFs the sample can visit: the root plus every IXF holding a planted path; the rest get
@@ -726,19 +809,25 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu):
     for i, f in enumerate(lay["ixfs"]):
         if (f["columns"] or f.get("key_sets")) and i > 0:
             needed.add(i)
+    interleaved = _interleave_host_memory(True)
     try:
         host = []
         for i, f in enumerate(lay["ixfs"]):
             nbytes = 3 * f["seg_len"] * f["stride"]
-            data = idx.download_ixf(i) if i in needed else np.empty(nbytes, dtype=np.uint8)
+            data = np.empty(nbytes, dtype=np.uint8)
+            if i in needed:
+                data[::4096] = 0                    # first touch under the interleave policy, then the bytes out of HBM
+                idx.download_ixf(i, out=data)
             host.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], data=data))
         h = orc.Hixf(host, [f["next_ixf"] for f in lay["ixfs"]], [f["fname_idx"] for f in lay["ixfs"]])
     except MemoryError as e:
         return {"value": None, "unit": "Mbp/s", "cores": threads, "kind": "port", "sample": f"skipped: {e}"}
+    finally:
+        _interleave_host_memory(False)
 
     def run(n, th):
         t0 = time.perf_counter()
-        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=th)
+        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=th, **hash_kw)
         return time.perf_counter() - t0, o
 
     n = min(256 * threads // 8 + 64, len(offs) - 1)
@@ -765,7 +854,7 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu):
     except OSError:
         pass
     return {**extra, "value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
-            "cpu_model": model, "hardware_threads": ncpu,
+            "cpu_model": model, "hardware_threads": ncpu, "index_copy_interleaved_over_numa_nodes": interleaved,
             "sample": f"first {n} reads of the last timed batch ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
                       f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
 

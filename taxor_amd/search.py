@@ -194,9 +194,11 @@ class GpuIndex:
     def ixf_seed(self, ixf):
         return int(_lib.lib().taxor_gpu_index_ixf_seed(self._h, ixf))
 
-    def download_ixf(self, ixf):
+    def download_ixf(self, ixf, out=None):
         bins, stride, seg = self.shapes[ixf]
-        out = np.empty(3 * seg * stride, dtype=np.uint8)
+        if out is None:
+            out = np.empty(3 * seg * stride, dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size == 3 * seg * stride and out.flags.c_contiguous
         check(_lib.lib().taxor_gpu_index_download_ixf(self._h, ixf, _p(out), out.size))
         return out
 

@@ -93,3 +93,18 @@ def test_rendezvous_failure_is_loud(tmp_path):
                         capture_output=True, text=True, timeout=300)
     assert cp.returncode == 13, (cp.returncode, cp.stderr[-2000:])
     assert "FATAL rank 1/2" in cp.stderr and not [l for l in cp.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.parametrize("mode", ["kmer", "minimiser"])
+def test_bench_tracks_indexes_built_without_syncmers(mode, tmp_path):
+    """bench.py --mode kmer|minimiser: the reference's default build mode gets the same line -- value, roofline
+    object, unpruned pass, and the oracle re-check of the sample (bench.py exits with PARITY FAILURE otherwise)"""
+    cmd = [sys.executable, "bench.py", "--mode", mode, "--reads", "4096", "--read-len", "2000", "--genomes", "8", "--genome-len", "30000",
+           "--steps", "2", "--warmup", "1", "--batches", "2", "--traffic", "none", "--no-ceiling", "--sustained-reads", "8192", "--cpu-seconds", "2"]
+    cp = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    j = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][0])
+    assert j["config"]["mode"] == mode and "WITHOUT --use-syncmer" in j["config"]["workload"]
+    assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["unpruned"]["frac"] > 0
+    assert j["config"]["hashes_per_read"] > (1500 if mode == "kmer" else 100)
+    assert "bit-identical" in j["cpu_baseline"]["sample"]
