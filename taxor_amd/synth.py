@@ -47,9 +47,10 @@ def seg_len_for(max_bin_elements):
     return int(_lib.lib().taxor_ixf_seg_len(int(max_bin_elements)))
 
 
-def build_columns(bin_keys, seg_len, seed0):
+def build_columns(bin_keys, seg_len, seed0, arith=0):
     """XOR-filter columns for several bins of one IXF under a common seed; redraws the seed like the
-    reference's reseed loop (src/hixf/build/construct_ixf.cpp:100-108) until every bin peels."""
+    reference's reseed loop (src/hixf/build/construct_ixf.cpp:100-108) until every bin peels.
+    arith: code of the IXF arithmetic the columns follow (search.arith_code; 0 = the library's reading)."""
     L = _lib.lib()
     seed = int(seed0) & (2**64 - 1)
     rows = 3 * seg_len
@@ -59,7 +60,7 @@ def build_columns(bin_keys, seg_len, seed0):
         for b, keys in bin_keys.items():
             k = np.ascontiguousarray(keys, dtype=np.uint64)
             col = np.zeros(rows, dtype=np.uint8)
-            if L.taxor_ixf_build_bin(_p(k), k.size, seed, seg_len, _p(col)) != 0:
+            if L.taxor_ixf_build_bin_arith(_p(k), k.size, seed, seg_len, int(arith), _p(col)) != 0:
                 ok = False
                 break
             cols[b] = col
@@ -306,7 +307,7 @@ def make_family_layout(planted, family, root_bins=64, child_bins=64, n_children=
     return dict(ixfs=out, n_user_bins=next_ub[0], planted_user_bin=planted_ub, depth=depth, split_runs=n_split + 1)
 
 
-def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 130, 300), max_ixfs=12):
+def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 130, 300), max_ixfs=12, arith=0):
     """A random HIXF around the planted hash sets, for differential tests: random tree shape, bin counts that are not
     multiples of 16 or 64, planted and decoy split runs of random length at random positions (so that runs straddle
     16-bin units and 64-bin rows), merged bins anywhere, empty bins.  Same return format as make_layout."""
@@ -390,7 +391,7 @@ def random_layout(planted, rng, max_depth=4, bins_choices=(5, 17, 40, 64, 100, 1
         mx = max([len(k) for k in f["keys"].values()] + [1])
         seg = seg_len_for(int(mx * float(rng.uniform(1.0, 1.5))) + 1)
         nonempty = {bb: k for bb, k in f["keys"].items() if len(k)}
-        sd, cols = build_columns(nonempty, seg, int(rng.integers(1, 2**63)))
+        sd, cols = build_columns(nonempty, seg, int(rng.integers(1, 2**63)), arith)
         nx = np.full(f["bins"], i, dtype=np.int64)
         for bb, ch in f["child_of"].items():
             nx[bb] = ch

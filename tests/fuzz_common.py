@@ -46,15 +46,22 @@ def run_trial(seed, verbose=False):
         if scaling > 1:
             hs = np.array([h for h in hs.tolist() if float(orc.wyhash(h)) <= float(2**64 - 1) / float(scaling)], dtype=np.uint64)
         planted.append(hs)
+    # one trial in four: an index that follows ANOTHER reading of the un-vendored IXF arithmetic (built, searched and checked
+    # under the same arithmetic code; rotation steps that keep the three rows independent)
+    arith = 0
+    if rng.random() < 0.25:
+        from taxor_amd.search import arith_code
+        arith = arith_code(int(rng.integers(0, 4)), int(rng.integers(0, 4)), int(rng.choice([7, 13, 16, 21, 27])), int(rng.integers(0, 3)),
+                           int(rng.integers(0, 4)))
     heavy = rng.random() < 0.08      # wide rows (several block passes, > 32 alive units possible) and reads whose probes
     #                                  do not fit the LDS staging area
     if heavy:
-        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 3)), bins_choices=(64, 1000, 2049, 4096), max_ixfs=4)
+        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 3)), bins_choices=(64, 1000, 2049, 4096), max_ixfs=4, arith=arith)
     else:
-        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 5)))
+        lay = synth.random_layout(planted, rng, max_depth=int(rng.integers(1, 5)), arith=arith)
     host = synth.materialize_host(lay)
-    idx = GpuIndex(host, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling)
-    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    idx = GpuIndex(host, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith)
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
     n_syn = int(rng.integers(20, 200))
     bases, offs, origin = synth.synth_reads(g, go, n_syn, int(rng.integers(200, 4000)), error_rate=float(rng.choice([0.0, 0.01, 0.03, 0.08])),
                                             frac_random=0.1, seed=int(rng.integers(1, 2**31)))
@@ -75,11 +82,20 @@ def run_trial(seed, verbose=False):
     err = float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.2])) if syncmer else float(rng.choice([0.01, 0.04, 0.1, 0.3]))
     sub = int(rng.choice([0, 1, 7, 64]))
     cfg = dict(seed=seed, syncmer=syncmer, k=k, s=s, t=t, window=win, scaling=scaling, n_ixf=len(host), depth=lay["depth"],
-               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub)
+               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith)
     if verbose:
         print(cfg, flush=True)
     sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub)
-    res = sr.search_batch(B, O)
+    n_seg = int(rng.choice([0, 0, 1, 2, 5]))
+    if n_seg == 0 or len(reads) < n_seg:
+        res = sr.search_batch(B, O)
+    else:      # the same reads handed over in several host buffers (taxor_gpu_search_segments_begin), cut at random reads
+        cuts = [0] + sorted(int(x) for x in rng.integers(0, len(reads) + 1, size=n_seg - 1)) + [len(reads)]
+        segs = []
+        for a, b in zip(cuts, cuts[1:]):
+            pad = int(rng.integers(0, 3))               # a segment's offsets need not start at 0
+            segs.append((np.concatenate([np.full(pad, ord("A"), np.uint8), B[int(O[a]):int(O[b])]]), O[a:b + 1] - O[a] + np.uint64(pad)))
+        res = sr.search_segments(segs)
     nh, off, ub, cnt, _ = h.search_batch(Bn, O, k=k, s=s, t=t, err=err, percentage=pct, threads=4, scaling=scaling, window=win)
     ok = (np.array_equal(res.n_hashes, nh) and np.array_equal(res.read_off, off) and np.array_equal(res.user_bin, ub) and
           np.array_equal(res.count, cnt))
