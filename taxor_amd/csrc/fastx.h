@@ -231,6 +231,17 @@ struct FastxReader {
             }
         }
     }
+    // step over n bytes of input without looking at them; false if the input ends first
+    bool skip_bytes(size_t n)
+    {
+        while (n) {
+            if (pos == len && !refill()) return false;
+            const size_t take = std::min(n, len - pos);
+            pos += take;
+            n -= take;
+        }
+        return true;
+    }
     bool getline(std::string &line)
     {
         line.clear();
@@ -277,6 +288,18 @@ struct FastxReader {
             line_to(nullptr);                                                                    // the '+' line
             const size_t want = bases.size() - seq_begin;
             size_t got = 0, n = 0;
+            if (strict4 && want) {
+                // four-line records (range reader): the quality line is exactly as long as the sequence, so it is stepped
+                // over without looking at its bytes -- only its end is checked (half of a FASTQ file is quality characters)
+                if (!skip_bytes(want)) throw std::runtime_error("truncated FASTQ record: " + id);
+                got = want;
+                if (pos == len && !refill()) return true;                                        // file ends without a final newline
+                if (buf[pos] == '\r') { ++pos; if (pos == len && !refill()) return true; }
+                if (buf[pos] != '\n')     // a shorter quality line puts this position inside the next record, a longer one inside itself
+                    throw std::runtime_error("malformed FASTQ record '" + id + "': quality line and sequence (" + std::to_string(want) +
+                                             " bases) differ in length (parallel range reader: rerun with --sequential if the file is valid)");
+                ++pos;
+            }
             while (got < want) {                                                                 // quality: skipped, never copied
                 if (!line_to(nullptr, &n)) throw std::runtime_error("truncated FASTQ record: " + id);
                 got += n;
