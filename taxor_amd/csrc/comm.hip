@@ -309,8 +309,10 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
         if (wm - sent < piece && wm < slab_bytes) { std::this_thread::sleep_for(std::chrono::microseconds(200)); continue; }
         const uint64_t len = wm - sent;
         ncclResult_t r = R.GroupStart();
-        for (size_t i = 0; i < n && r == ncclSuccess; ++i)
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+            (void)hipSetDevice(c->devices[i]);           // one thread drives every rank of the group: make the rank's device current
             r = R.Broadcast(slab[i] + sent, slab[i] + sent, (size_t)len, ncclUint8, 0, c->comms[i], c->streams[i]);   // in place; the send buffer counts on the root only
+        }
         const ncclResult_t r2 = R.GroupEnd();
         if (r == ncclSuccess) r = r2;
         if (r != ncclSuccess) { rc = TAXOR_E_HIP; bc_err = std::string("ncclBroadcast of the index: ") + R.GetErrorString(r); break; }
@@ -407,10 +409,12 @@ extern "C" int taxor_gpu_gather_results(taxor_gpu_comm *c, taxor_gpu_searcher *c
             C_NCCL(R.GroupStart());
             ncclResult_t r = ncclSuccess;
             for (size_t i = 1; i < n && r == ncclSuccess; ++i) {
+                (void)hipSetDevice(c->devices[i]);       // the sends belong to rank i's device ...
                 if (nr[i] && r == ncclSuccess) r = R.Send(d_ro[i], nr[i] * 8, ncclUint8, 0, c->comms[i], c->streams[i]);
                 if (nr[i] && r == ncclSuccess) r = R.Send(d_nh[i], nr[i] * 4, ncclUint8, 0, c->comms[i], c->streams[i]);
                 if (nt[i] && r == ncclSuccess) r = R.Send(d_ub[i], nt[i] * 8, ncclUint8, 0, c->comms[i], c->streams[i]);
                 if (nt[i] && r == ncclSuccess) r = R.Send(d_ct[i], nt[i] * 4, ncclUint8, 0, c->comms[i], c->streams[i]);
+                (void)hipSetDevice(c->devices[0]);       // ... the matching receives to rank 0's
                 if (nr[i] && r == ncclSuccess) r = R.Recv(c->g_off_tmp.p + rbase[i], nr[i] * 8, ncclUint8, (int)i, c->comms[0], s0);
                 if (nr[i] && r == ncclSuccess) r = R.Recv(c->g_nh.p + rbase[i], nr[i] * 4, ncclUint8, (int)i, c->comms[0], s0);
                 if (nt[i] && r == ncclSuccess) r = R.Recv(c->g_ub.p + tbase[i], nt[i] * 8, ncclUint8, (int)i, c->comms[0], s0);
