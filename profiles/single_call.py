@@ -64,7 +64,7 @@ for label, pinned in (("pageable", False), ("page-locked", True)):
     for r in range(a.reps):
         bb, oo = batches[r % 2]
         t0 = time.perf_counter()
-        res = sr.search_batch(bb, oo)
+        res = sr.search_batch(bb, oo, copy=False)
         dt = time.perf_counter() - t0
         if dt < best:
             best, line = dt, stats_line(sr)

@@ -66,12 +66,15 @@ class SearchResults:
         return [(int(a), int(b)) for a, b in zip(self.user_bin[lo:hi], self.count[lo:hi])]
 
 
-def _results(res: _lib.Results) -> SearchResults:
+def _results(res: _lib.Results, copy=True) -> SearchResults:
+    """copy=False: views of the library's own result arrays, valid until the next call on that searcher (the C ABI's
+    convention; what a C++ host sees) -- for callers that time the library and not numpy's memcpy of 100 MB of tuples"""
     n, t = int(res.n_reads), int(res.n_tuples)
-    ro = np.ctypeslib.as_array(res.read_off, shape=(n + 1,)).copy()
-    ub = np.ctypeslib.as_array(res.user_bin, shape=(t,)).copy() if t else np.zeros(0, np.int64)
-    ct = np.ctypeslib.as_array(res.count, shape=(t,)).copy() if t else np.zeros(0, np.uint32)
-    nh = np.ctypeslib.as_array(res.n_hashes, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+    c = (lambda a: a.copy()) if copy else (lambda a: a)
+    ro = c(np.ctypeslib.as_array(res.read_off, shape=(n + 1,)))
+    ub = c(np.ctypeslib.as_array(res.user_bin, shape=(t,))) if t else np.zeros(0, np.int64)
+    ct = c(np.ctypeslib.as_array(res.count, shape=(t,))) if t else np.zeros(0, np.uint32)
+    nh = c(np.ctypeslib.as_array(res.n_hashes, shape=(n,))) if n else np.zeros(0, np.uint32)
     return SearchResults(ro, ub, ct, nh)
 
 
@@ -236,11 +239,11 @@ class Searcher:
         return b, o
 
     # --- the drop-in batch call ---------------------------------------------------------------------------
-    def search_batch(self, bases, offsets) -> SearchResults:
+    def search_batch(self, bases, offsets, copy=True) -> SearchResults:
         b, o = self._batch(bases, offsets)
         res = _lib.Results()
         check(_lib.lib().taxor_gpu_search_batch(self._h, _p(b), _p(o), o.size - 1, C.byref(res)))
-        return _results(res)
+        return _results(res, copy)
 
     def search_batch_begin(self, bases, offsets):
         """enqueue the drop-in call; keep the arrays alive until search_batch_end()"""
