@@ -907,6 +907,8 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         const uint64_t mean_len = std::max<uint64_t>(1, (offsets[n_reads] - offsets[0]) / n_reads);
         while (full_reads < 131072 && full_reads * mean_len < (1ull << 27)) full_reads *= 2;
     }
+    uint64_t lim_reads = 0, lim_bases = 0;
+    size_t lim_for = (size_t)-1;
     for (uint64_t r = 0; r < n_reads; ++r) {
         if (offsets[r + 1] < offsets[r]) return fail(TAXOR_E_ARG, "offsets not monotone at read %llu", (unsigned long long)r);
         const uint64_t len = offsets[r + 1] - offsets[r];
@@ -920,18 +922,22 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         // should be ready before sub-batch i is classified -- which allows a growth of ~1.27x per sub-batch at 48 GB/s
         // of PCIe against ~35 Gbp/s of classification, so the sizes ramp 1/first_div, x1.25, x1.25, ... up to the full
         // size instead of jumping there (a jump leaves the GPU idle for most of the second sub-batch's copy).
-        uint64_t lim_reads = full_reads, lim_bases = s->prm.sub_batch_bases;
-        if (ramp) {
-            double f = 1.0 / (double)first_div;
-            static const double growth = [] { const char *e = getenv("TAXOR_RAMP_GROWTH"); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1.25; }();
-            for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= growth;
-            if (f < 1.0) {
-                lim_reads = std::max<uint64_t>((uint64_t)((double)lim_reads * f), 1);
-                lim_bases = std::max<uint64_t>((uint64_t)((double)lim_bases * f), 1);
+        if (lim_for != s->subs.size()) {          // the limits depend on the sub-batch's number alone: once per sub-batch, not per read
+            lim_for = s->subs.size();
+            lim_reads = full_reads;
+            lim_bases = s->prm.sub_batch_bases;
+            if (ramp) {
+                double f = 1.0 / (double)first_div;
+                static const double growth = [] { const char *e = getenv("TAXOR_RAMP_GROWTH"); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1.25; }();
+                for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= growth;
+                if (f < 1.0) {
+                    lim_reads = std::max<uint64_t>((uint64_t)((double)lim_reads * f), 1);
+                    lim_bases = std::max<uint64_t>((uint64_t)((double)lim_bases * f), 1);
+                }
+            } else if (s->subs.empty()) {
+                lim_reads = std::max<uint64_t>(lim_reads / first_div, 1);
+                lim_bases = std::max<uint64_t>(lim_bases / first_div, 1);
             }
-        } else if (s->subs.empty()) {
-            lim_reads = std::max<uint64_t>(lim_reads / first_div, 1);
-            lim_bases = std::max<uint64_t>(lim_bases / first_div, 1);
         }
         if (r > sub_first && (r - sub_first >= lim_reads || sub_bases + len > lim_bases)) {
             s->subs.push_back({sub_first, (uint32_t)(r - sub_first), (uint32_t)(r - sub_first), sub_slots, offsets[sub_first] - offsets[0], offsets[r] - offsets[0]});
