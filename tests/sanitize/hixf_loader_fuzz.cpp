@@ -44,6 +44,28 @@ int main(int argc, char **argv) {
             // format a line with arbitrary user bins
             int64_t ub[2] = {0, (int64_t)v->n_user_bins - 1}; unsigned ct[2] = {5, 4}; char buf[8192];
             taxor_format_read(h, "r", 1, 100, 10, ub, ct, 2, buf, sizeof buf);
+            {   // the chunk formatter with user bins the index does not have (species lookup falls back), and a buffer that is too small
+                const char *ids[3] = {"read_a", "b", ""};
+                uint64_t idl[3] = {6, 1, 0}, rl[3] = {5000, 30, 0}, ro[4] = {0, 2, 2, 4};
+                uint32_t nh[3] = {400, 0, 7}, c4[4] = {9, 8, 0, 3};
+                int64_t u4[4] = {0, (int64_t)v->n_user_bins + 5, -1, (int64_t)v->n_user_bins - 1};
+                const uint64_t need = taxor_format_reads(h, 3, ids, idl, rl, nh, ro, u4, c4, nullptr, 0);
+                std::vector<char> big(need + 1);
+                if (taxor_format_reads(h, 3, ids, idl, rl, nh, ro, u4, c4, big.data(), need) != need) return 3;
+                if (need > 4 && taxor_format_reads(h, 3, ids, idl, rl, nh, ro, u4, c4, big.data(), need - 1) != need) return 3;
+            }
+            if (v->source) {   // the pread() reader the index upload uses: first and last bytes of every IXF, and a request past its end
+                for (size_t i = 0; i < v->n_ixf; ++i) {
+                    const taxor_ixf_view &x = v->ixf[i];
+                    const size_t sz = 3 * x.seg_len * x.stride;
+                    unsigned char two[2] = {0, 0};
+                    if (v->source->read(v->source->ctx, i, 0, 1, two) != 0 || v->source->read(v->source->ctx, i, sz - 1, 1, two + 1) != 0) return 4;
+                    if (two[0] != x.data[0] || two[1] != x.data[sz - 1]) return 4;
+                }
+                unsigned char one;
+                (void)v->source->read(v->source->ctx, v->n_ixf, 0, 1, &one);
+            }
+            taxor_hixf_release_data(h);
             taxor_ixf_schema sc; char rep[4096]; taxor_hixf_probe(argv[5], &sc, rep, sizeof rep);
             if (sum == 42) puts("");
             taxor_hixf_free(h); ++ok;

@@ -53,3 +53,31 @@ def test_multi_member_gzip_reader_under_sanitizers(tmp_path, flag):
     cp = subprocess.run([str(exe), str(p)], capture_output=True, text=True, timeout=600)
     assert cp.returncode == 0 and "open=1" in cp.stdout and "6000 records 1800000 bases" in cp.stdout, cp.stdout + cp.stderr[-2000:]
     assert "ERROR" not in cp.stderr and "WARNING: ThreadSanitizer" not in cp.stderr, cp.stderr[-2000:]
+
+
+def test_fastx_readers_under_asan_ubsan(tmp_path):
+    """the sequential and the ranged readers over plain / bzip2 (two streams) input, and over damaged FASTQ: clean reports, no
+    sanitizer finding"""
+    import bz2
+    exe = _build(tmp_path, "fastx_read", [os.path.join(SAN, "fastx_read.cpp")], ["-fsanitize=address,undefined", "-ldl"])
+    rng = np.random.default_rng(3)
+    recs = [(b"r%d x" % i, bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 700))))) for i in range(400)]
+    raw = b"".join(b"@" + i + b"\n" + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in recs)
+    total = sum(len(s) for _, s in recs)
+    plain = tmp_path / "a.fastq"
+    plain.write_bytes(raw)
+    half = raw.index(b"@r200 x")
+    bz = tmp_path / "a.fastq.bz2"
+    bz.write_bytes(bz2.compress(raw[:half]) + bz2.compress(raw[half:]))
+    for args in ([str(plain)], [str(plain), "ranged"], [str(bz)]):
+        cp = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0 and f"400 records {total} bases" in cp.stdout, cp.stdout + cp.stderr[-1500:]
+        assert "ERROR" not in cp.stderr and "runtime error" not in cp.stderr, cp.stderr[-1500:]
+    for k, cut in enumerate((len(raw) // 3, len(raw) // 2 + 7, len(raw) - 3)):
+        bad = tmp_path / f"bad{k}.fastq"
+        damaged = bytearray(raw[:cut] + raw[cut + 5:])          # five bytes missing somewhere
+        bad.write_bytes(bytes(damaged))
+        for args in ([str(bad)], [str(bad), "ranged"]):
+            cp = subprocess.run([str(exe), *args], capture_output=True, text=True, timeout=300)
+            assert cp.returncode == 0 and ("error:" in cp.stdout or "records" in cp.stdout), cp.stdout + cp.stderr[-1500:]
+            assert "ERROR" not in cp.stderr and "runtime error" not in cp.stderr, cp.stderr[-1500:]
