@@ -1349,93 +1349,124 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         PMARK(2)                                                     // 2: dense phase (row gathers)
 
         if (dense_end < n) {
-            const uint64_t rem = n - dense_end;
-            for (uint32_t b = tid; b < nb_round; b += BS) {
-                if (b < D.bins) {
-                    const uint32_t info = sInfo[b];
-                    if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
-                        int bb = (int)b;
-                        uint64_t sum = sC[bb];
-                        if (!(info & BINFO_MERGED))
-                            while (bb > 0 && (sInfo[bb - 1] >> 30) == 0u) sum += sC[--bb];
-                        const uint64_t len = (uint64_t)b - (uint64_t)bb + 1u;
-                        if (sum + rem * len >= thr) {
-                            for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
-                                const uint32_t bit = 1u << (x & 31u);
-                                if (!(atomicOr(&sMap[x >> 5], bit) & bit)) {
-                                    const uint32_t k = atomicAdd(&sScal[1], 1u);
-                                    if (k < (uint32_t)Q_MAXU) sUnits[k] = x;
+            // The remaining hashes probe only the 16-bin units that still matter, in up to three stages; between stages the
+            // set is re-evaluated with the counts so far.  A unit matters while it holds
+            //   * a LEAF run that can still reach the threshold (or has reached it): its count is reported (:328-331), so it
+            //     is counted to the last hash;
+            //   * a MERGED bin whose fate is open: only `sum >= thr` is ever used of it (:321) -- once it has reached the
+            //     threshold it needs no more counting (the child is entered either way), once it cannot reach it it is dead.
+            // A matching read's merged bins reach the threshold after ~thr / (fraction of its hashes that match) hashes,
+            // i.e. well before the last one, and every later stage also drops the random survivors of the stage before: each
+            // unit dropped saves a 128-B line per hash and row (what HBM moves for a 16-B load).
+            uint32_t done = dense_end;
+            uint32_t chunk = 0;
+            bool first_eval = true;
+            for (;;) {
+                const uint64_t rem = n - done;
+                if (!first_eval) {
+                    for (uint32_t i = tid; i < a.map_words; i += BS) sMap[i] = 0;
+                    if (tid == 0) sScal[1] = 0;
+                    __syncthreads();
+                }
+                for (uint32_t b = tid; b < nb_round; b += BS) {
+                    if (b < D.bins) {
+                        const uint32_t info = sInfo[b];
+                        if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
+                            int bb = (int)b;
+                            uint64_t sum = sC[bb];
+                            bool alive;
+                            if (info & BINFO_MERGED) {
+                                alive = sum < thr && sum + rem >= thr;
+                            } else {
+                                while (bb > 0 && (sInfo[bb - 1] >> 30) == 0u) sum += sC[--bb];
+                                const uint64_t len = (uint64_t)b - (uint64_t)bb + 1u;
+                                alive = sum + rem * len >= thr;
+                            }
+                            if (alive) {
+                                for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
+                                    const uint32_t bit = 1u << (x & 31u);
+                                    if (!(atomicOr(&sMap[x >> 5], bit) & bit)) {
+                                        const uint32_t k = atomicAdd(&sScal[1], 1u);
+                                        if (k < (uint32_t)Q_MAXU) sUnits[k] = x;
+                                    }
                                 }
                             }
                         }
                     }
                 }
-            }
-            __syncthreads();
-            PMARK(3)                                                 // 3: which runs can still reach the threshold
-            const uint32_t n_alive = sScal[1];
-            if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
-                query_dense_range<NT, U, BS, QC>(D, hp, dense_end, n, sProbe, sC, staged);
-                touched += rem * 3ull * stride;
-                rows_read += rem * 3ull;
-            } else if (n_alive > 0) {
-                const uint32_t ST = staged ? (uint32_t)rem : min((uint32_t)Q_HT2, (uint32_t)QC);
-                for (uint32_t t0 = dense_end; t0 < n; t0 += ST) {
-                    const uint32_t nt = min(ST, n - t0);
-                    const uint4 *pr = sProbe + (staged ? t0 : 0u);
-                    if (!staged) {
-                        __syncthreads();
-                        for (uint32_t i = tid; i < nt; i += BS) {
-                            const ixf_probe p = ixf_probe_key_arith(hp[t0 + i], D.seed, D.seg_len, D.arith);
-                            sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
-                        }
-                        __syncthreads();
+                __syncthreads();
+                if (first_eval) { PMARK(3) }                             // 3: which runs can still reach the threshold
+                const uint32_t n_alive = sScal[1];
+                if (n_alive == 0) break;
+                if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
+                    query_dense_range<NT, U, BS, QC>(D, hp, done, n, sProbe, sC, staged);
+                    touched += rem * 3ull * stride;
+                    rows_read += rem * 3ull;
+                    break;
+                }
+                if (first_eval) {
+                    // staged probes: thirds (halves for medium reads, one stage for short ones -- a stage costs a pass over
+                    // the bins and two barriers); otherwise a stage is what fits the probe staging area
+                    const uint32_t stages = rem >= 384u ? 3u : (rem >= 128u ? 2u : 1u);
+                    chunk = staged ? (uint32_t)((rem + stages - 1u) / stages) : min((uint32_t)Q_HT2, (uint32_t)QC);
+                    first_eval = false;
+                }
+                const uint32_t nt = min(chunk, n - done);
+                const uint4 *pr = sProbe + (staged ? done : 0u);
+                if (!staged) {
+                    for (uint32_t i = tid; i < nt; i += BS) {
+                        const ixf_probe p = ixf_probe_key_arith(hp[done + i], D.seed, D.seg_len, D.arith);
+                        sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
                     }
-                    // one task = (hash, alive unit): three 16-B loads from three different rows.  A thread has only a few
-                    // tasks (rem * n_alive / 256) and each is a full memory round trip, so four are issued together (twelve
-                    // loads in flight per lane); one at a time this phase is a chain of dependent latencies.
-                    const uint32_t tasks = nt * n_alive;
-                    constexpr int SU = 4;
-                    for (uint32_t task0 = tid; task0 < tasks; task0 += BS * SU) {
-                        uint4 r0[SU], r1[SU], r2[SU];
-                        uint32_t xs[SU], fp4[SU];
+                    __syncthreads();
+                }
+                // one task = (hash, alive unit): three 16-B loads from three different rows.  A thread has only a few
+                // tasks (nt * n_alive / 256) and each is a full memory round trip, so four are issued together (twelve
+                // loads in flight per lane); one at a time this phase is a chain of dependent latencies.
+                const uint32_t tasks = nt * n_alive;
+                constexpr int SU = 4;
+                for (uint32_t task0 = tid; task0 < tasks; task0 += BS * SU) {
+                    uint4 r0[SU], r1[SU], r2[SU];
+                    uint32_t xs[SU], fp4[SU];
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) {
-                            const uint32_t task = task0 + (uint32_t)u * BS;
-                            xs[u] = 0xFFFFFFFFu;
-                            r0[u] = r1[u] = r2[u] = make_uint4(0, 0, 0, 0);
-                            fp4[u] = 0;
-                            if (task < tasks) {
-                                const uint32_t i = task / n_alive, j = task - i * n_alive;
-                                xs[u] = sUnits[j];
-                                const uint4 p = pr[i];
-                                fp4[u] = p.w;
-                                const uint8_t *base = D.data + (size_t)xs[u] * 16u;
-                                r0[u] = ld16<NT>(base + (size_t)p.x * stride);
-                                r1[u] = ld16<NT>(base + (size_t)p.y * stride);
-                                r2[u] = ld16<NT>(base + (size_t)p.z * stride);
-                            }
+                    for (int u = 0; u < SU; ++u) {
+                        const uint32_t task = task0 + (uint32_t)u * BS;
+                        xs[u] = 0xFFFFFFFFu;
+                        r0[u] = r1[u] = r2[u] = make_uint4(0, 0, 0, 0);
+                        fp4[u] = 0;
+                        if (task < tasks) {
+                            const uint32_t i = task / n_alive, j = task - i * n_alive;
+                            xs[u] = sUnits[j];
+                            const uint4 p = pr[i];
+                            fp4[u] = p.w;
+                            const uint8_t *base = D.data + (size_t)xs[u] * 16u;
+                            r0[u] = ld16<NT>(base + (size_t)p.x * stride);
+                            r1[u] = ld16<NT>(base + (size_t)p.y * stride);
+                            r2[u] = ld16<NT>(base + (size_t)p.z * stride);
                         }
+                    }
 #pragma unroll
-                        for (int u = 0; u < SU; ++u) {
-                            if (xs[u] == 0xFFFFFFFFu) continue;
-                            const uint32_t z[4] = {zero_bytes01(r0[u].x ^ r1[u].x ^ r2[u].x ^ fp4[u]), zero_bytes01(r0[u].y ^ r1[u].y ^ r2[u].y ^ fp4[u]),
-                                                   zero_bytes01(r0[u].z ^ r1[u].z ^ r2[u].z ^ fp4[u]), zero_bytes01(r0[u].w ^ r1[u].w ^ r2[u].w ^ fp4[u])};
+                    for (int u = 0; u < SU; ++u) {
+                        if (xs[u] == 0xFFFFFFFFu) continue;
+                        const uint32_t z[4] = {zero_bytes01(r0[u].x ^ r1[u].x ^ r2[u].x ^ fp4[u]), zero_bytes01(r0[u].y ^ r1[u].y ^ r2[u].y ^ fp4[u]),
+                                               zero_bytes01(r0[u].z ^ r1[u].z ^ r2[u].z ^ fp4[u]), zero_bytes01(r0[u].w ^ r1[u].w ^ r2[u].w ^ fp4[u])};
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                uint32_t m = z[q];
-                                while (m) {
-                                    const int bit = __ffs((int)m) - 1; // 0, 8, 16 or 24
-                                    m &= m - 1u;
-                                    atomicAdd(&sC[xs[u] * 16u + 4u * (uint32_t)q + ((uint32_t)bit >> 3)], 1u);
-                                }
+                        for (int q = 0; q < 4; ++q) {
+                            uint32_t m = z[q];
+                            while (m) {
+                                const int bit = __ffs((int)m) - 1; // 0, 8, 16 or 24
+                                m &= m - 1u;
+                                atomicAdd(&sC[xs[u] * 16u + 4u * (uint32_t)q + ((uint32_t)bit >> 3)], 1u);
                             }
                         }
                     }
                 }
-                touched += rem * (uint64_t)n_alive * 3ull * 64ull; // one 64-B sector per 16-B unit load
-                rows_read += rem * (uint64_t)n_alive * 3ull;
-                sparse_loads += rem * (uint64_t)n_alive * 3ull;
+                touched += (uint64_t)nt * (uint64_t)n_alive * 3ull * 64ull; // one 64-B sector per 16-B unit load (sector64 accounting; HBM moves a 128-B line)
+                rows_read += (uint64_t)nt * (uint64_t)n_alive * 3ull;
+                sparse_loads += (uint64_t)nt * (uint64_t)n_alive * 3ull;
+                done += nt;
+                __syncthreads();                                         // the stage's counts are in the tally; sUnits / sProbe may be rewritten
+                if (done >= n) break;
             }
         }
         __syncthreads();
