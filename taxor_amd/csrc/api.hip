@@ -1087,6 +1087,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.max_stride = idx->max_stride;
     q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
     q.prof = s->d_prof;
+    static const uint32_t stages_env = [] { const char *e = getenv("TAXOR_QUERY_STAGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
+    q.sparse_stages = stages_env;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     static const bool group_queue = [] { const char *e = getenv("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {

@@ -1407,7 +1407,8 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 if (first_eval) {
                     // staged probes: thirds (halves for medium reads, one stage for short ones -- a stage costs a pass over
                     // the bins and two barriers); otherwise a stage is what fits the probe staging area
-                    const uint32_t stages = rem >= 384u ? 3u : (rem >= 128u ? 2u : 1u);
+                    const uint32_t want = a.sparse_stages ? a.sparse_stages : 3u;
+                    const uint32_t stages = rem >= 128u * want ? want : max(1u, (uint32_t)(rem / 128u));
                     chunk = staged ? (uint32_t)((rem + stages - 1u) / stages) : min((uint32_t)Q_HT2, (uint32_t)QC);
                     first_eval = false;
                 }
