@@ -966,38 +966,61 @@ int main(int argc, char **argv)
         std::vector<std::thread> workers;
         if (comm)
             workers.emplace_back([&] {
-                // one round = up to ng batches, batch j on device j, classified side by side; then ONE gather of the round's
-                // per-read results on the first device and one copy to the host.  Devices without a batch in a round run an
-                // empty one, so that every searcher has a finished run to gather.
-                std::vector<std::unique_ptr<Batch>> round;
+                // one round = up to ng GPU batches, batch g on device g, classified side by side; then ONE gather of the round's
+                // per-read results on the first device and one copy to the host.  A GPU batch is made of queued chunks like in
+                // the single-device workers below (~group_reads reads, handed over as segments); devices without a batch in a
+                // round run an empty one, so that every searcher has a finished run to gather.
+                std::vector<std::vector<std::unique_ptr<Batch>>> round(ng);
+                std::vector<std::unique_ptr<Batch>> eofs, flat;
                 std::unique_ptr<Batch> b;
                 const uint64_t zero_off[1] = {0};
-                for (;;) {
-                    round.clear();
-                    if (!q_in.pop(b)) break;
-                    if (b->end_of_file) { q_fmt.push(std::move(b)); continue; }
-                    round.push_back(std::move(b));
-                    std::unique_ptr<Batch> eof;           // an end-of-file marker ends the round and follows it
-                    while (round.size() < ng && q_in.try_pop(b)) {
-                        if (b->end_of_file) { eof = std::move(b); break; }
-                        round.push_back(std::move(b));
+                bool open = true;
+                while (open) {
+                    for (auto &g : round) g.clear();
+                    eofs.clear();
+                    size_t used = 0;
+                    // the first chunk of a round is waited for; after that only what is already queued is taken
+                    for (size_t g = 0; g < ng; ++g) {
+                        uint64_t gr = 0, gb = 0;
+                        while (gr < group_reads && gb < (3ull << 30) && round[g].size() < group_max_chunks) {
+                            bool got;
+                            if (used == 0 && round[g].empty() && eofs.empty()) { got = q_in.pop(b); if (!got) open = false; }
+                            else got = q_in.try_pop(b);
+                            if (!got) break;
+                            if (b->end_of_file) { eofs.push_back(std::move(b)); continue; }
+                            gr += b->ids.size();
+                            gb += b->bases.size();
+                            round[g].push_back(std::move(b));
+                            ++used;
+                        }
+                        if (round[g].empty()) break;
+                    }
+                    if (used == 0) {
+                        for (auto &e : eofs) q_fmt.push(std::move(e));
+                        continue;
                     }
                     const double t1 = now();
                     std::vector<std::thread> dev;
                     std::vector<std::string> errs(ng);
                     for (size_t g = 0; g < ng; ++g)
                         dev.emplace_back([&, g] {
-                            if (g >= round.size()) {
+                            if (round[g].empty()) {
                                 if (taxor_gpu_search_batch_begin(sr[g], nullptr, zero_off, 0) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
                                 return;
                             }
-                            Batch &bt = *round[g];
-                            pin(bt);
-                            int rc = taxor_gpu_search_batch_begin(sr[g], bt.bases.data(), bt.offsets.data(), bt.ids.size());
-                            if (rc == TAXOR_OK) rc = taxor_gpu_batch_sync(sr[g]);
-                            if (rc == TAXOR_E_ALPHABET && strip_space_and_digits(bt)) {
-                                rc = taxor_gpu_search_batch_begin(sr[g], bt.bases.data(), bt.offsets.data(), bt.ids.size());
-                                if (rc == TAXOR_OK) rc = taxor_gpu_batch_sync(sr[g]);
+                            std::vector<taxor_read_segment> segs;
+                            auto run = [&]() -> int {
+                                segs.clear();
+                                for (auto &bt : round[g]) segs.push_back({bt->bases.data(), bt->offsets.data(), bt->ids.size()});
+                                const int rc = taxor_gpu_search_segments_begin(sr[g], segs.data(), segs.size());
+                                return rc != TAXOR_OK ? rc : taxor_gpu_batch_sync(sr[g]);
+                            };
+                            for (auto &bt : round[g]) pin(*bt);
+                            int rc = run();
+                            if (rc == TAXOR_E_ALPHABET) {
+                                bool any = false;
+                                for (auto &bt : round[g]) any = strip_space_and_digits(*bt) || any;
+                                if (any) rc = run();
                             }
                             if (rc != TAXOR_OK) errs[g] = taxor_gpu_last_error();
                         });
@@ -1008,15 +1031,19 @@ int main(int argc, char **argv)
                     taxor_gpu_results res{};
                     if (taxor_gpu_gather_results(comm, sr.data(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
                     const double t3 = now();
-                    split_results(round, res);              // the gathered CSR is in device order = chunk order of the round
+                    flat.clear();                           // the gathered CSR is in device order, and in chunk order within a device
+                    for (auto &g : round)
+                        for (auto &bt : g) flat.push_back(std::move(bt));
+                    split_results(flat, res);
                     {
                         std::lock_guard<std::mutex> lk(stat_mu);
                         t_search += t2 - t1;
                         t_gather += t3 - t2;
                         t_compute += now() - t1;
+                        n_gpu_batches += std::min(used, ng);
                     }
-                    for (auto &bt : round) q_fmt.push(std::move(bt));
-                    if (eof) q_fmt.push(std::move(eof));
+                    for (auto &bt : flat) q_fmt.push(std::move(bt));
+                    for (auto &e : eofs) q_fmt.push(std::move(e));
                 }
             });
         else
