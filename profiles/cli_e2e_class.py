@@ -128,9 +128,10 @@ del keep, kept
 idx.close()                      # the CLI loads its own replica
 print(f"fastq {os.path.getsize(fq)/1e9:.2f} GB ({n_reads} reads) written and searched through the library in {time.time()-t0:.1f}s", flush=True)
 out = os.path.join(tmp, "out.tsv")
-runs = os.environ.get("TAXOR_E2E_RUNS", "32,32,8").split(",")
+_r = os.environ.get("TAXOR_E2E_RUNS", "32,32,8")
+runs = _r.split(";") if ";" in _r else _r.split(",")       # "16;16:--gpu-list:0,0" when a run's extra arguments contain commas
 for thr in runs:
-    extra = ["--threads", thr]
+    extra = ["--threads", thr.split(":")[0]] + thr.split(":")[1:]       # "16:--gpu-list:0,0" = extra arguments after the thread count
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
                         capture_output=True, text=True, env=dict(os.environ, TAXOR_CLI_TRACE="1"))
@@ -140,6 +141,7 @@ for thr in runs:
     tr = [l for l in cp.stderr.splitlines() if "trace" in l]
     print("\n".join(tr)[:2400], flush=True)
     import re  # noqa: E402
+    thr = " ".join(extra[1:])
     stamp = {}
     for l in tr:
         m = re.match(r"\[trace\]\s+([0-9.]+) s  (.*)", l)

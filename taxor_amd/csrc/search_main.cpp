@@ -934,7 +934,7 @@ int main(int argc, char **argv)
         // the host mapping of the index is not needed any more: its pages go back on a helper thread, beside the search
         std::thread releaser([h] { taxor_hixf_release_data(h); });
         const double t_search0 = now();
-        const unsigned wpg = comm ? 1u : workers_per_gpu;
+        const unsigned wpg = workers_per_gpu;       // with a communicator: that many searcher SETS (one searcher per device each), rounds alternate between them
         std::vector<taxor_gpu_searcher *> sr(ng * wpg, nullptr);
         for (size_t g = 0; g < ng; ++g)
             for (unsigned w = 0; w < wpg; ++w)
@@ -964,8 +964,13 @@ int main(int argc, char **argv)
             if (r0 != res.n_reads) die("internal: a batch's results do not cover its chunks");
         };
         std::vector<std::thread> workers;
+        std::mutex comm_mu;     // a communicator is single-caller, and its result arrays live until its next gather
         if (comm)
-            workers.emplace_back([&] {
+          for (unsigned set = 0; set < wpg; ++set)
+            workers.emplace_back([&, set] {
+                // searcher of device g in this worker's set (sr is laid out device-major: sr[g * wpg + set])
+                std::vector<taxor_gpu_searcher *> mine(ng);
+                for (size_t g = 0; g < ng; ++g) mine[g] = sr[g * wpg + set];
                 // one round = up to ng GPU batches, batch g on device g, classified side by side; then ONE gather of the round's
                 // per-read results on the first device and one copy to the host.  A GPU batch is made of queued chunks like in
                 // the single-device workers below (~group_reads reads, handed over as segments); devices without a batch in a
@@ -1005,15 +1010,15 @@ int main(int argc, char **argv)
                     for (size_t g = 0; g < ng; ++g)
                         dev.emplace_back([&, g] {
                             if (round[g].empty()) {
-                                if (taxor_gpu_search_batch_begin(sr[g], nullptr, zero_off, 0) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
+                                if (taxor_gpu_search_batch_begin(mine[g], nullptr, zero_off, 0) != TAXOR_OK) errs[g] = taxor_gpu_last_error();
                                 return;
                             }
                             std::vector<taxor_read_segment> segs;
                             auto run = [&]() -> int {
                                 segs.clear();
                                 for (auto &bt : round[g]) segs.push_back({bt->bases.data(), bt->offsets.data(), bt->ids.size()});
-                                const int rc = taxor_gpu_search_segments_begin(sr[g], segs.data(), segs.size());
-                                return rc != TAXOR_OK ? rc : taxor_gpu_batch_sync(sr[g]);
+                                const int rc = taxor_gpu_search_segments_begin(mine[g], segs.data(), segs.size());
+                                return rc != TAXOR_OK ? rc : taxor_gpu_batch_sync(mine[g]);
                             };
                             for (auto &bt : round[g]) pin(*bt);
                             int rc = run();
@@ -1028,13 +1033,17 @@ int main(int argc, char **argv)
                     for (const auto &e : errs)
                         if (!e.empty()) die(e);
                     const double t2 = now();
-                    taxor_gpu_results res{};
-                    if (taxor_gpu_gather_results(comm, sr.data(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
-                    const double t3 = now();
                     flat.clear();                           // the gathered CSR is in device order, and in chunk order within a device
                     for (auto &g : round)
                         for (auto &bt : g) flat.push_back(std::move(bt));
-                    split_results(flat, res);
+                    double t3;
+                    {
+                        std::lock_guard<std::mutex> lk(comm_mu);      // the other set's round keeps the devices busy meanwhile
+                        taxor_gpu_results res{};
+                        if (taxor_gpu_gather_results(comm, mine.data(), &res) != TAXOR_OK) die(taxor_gpu_last_error());
+                        t3 = now();
+                        split_results(flat, res);
+                    }
                     {
                         std::lock_guard<std::mutex> lk(stat_mu);
                         t_search += t2 - t1;
