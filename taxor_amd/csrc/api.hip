@@ -103,6 +103,8 @@ struct taxor_gpu_searcher {
     taxor_gpu_index *idx = nullptr;
     taxor_gpu_search_params prm{};
     std::vector<uint32_t> h_rlen, h_nh_sub;   // k-mer / FracMinHash threshold models are evaluated on the host
+    std::vector<uint64_t> lay_poff, lay_hoff, lay_aoff;   // host side of the per-read layout arrays of the current batch (h_rlen is one of them)
+    std::vector<uint32_t> lay_hcap, lay_order;
     std::vector<uint64_t> h_thr_sub;
     bool thr_precomputed = false;             // k-mer model: the count is L-k+1, so the thresholds went up with the batch
     std::vector<uint64_t> thr_memo;           // k-mer model: threshold by k-mer count (index 0 unused marker = ~0)
@@ -915,7 +917,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
         if (len >= (1ull << 31)) return fail(TAXOR_E_ARG, "read %llu longer than 2^31 bases", (unsigned long long)r);
         const uint64_t nwin = len >= (uint64_t)idx->k ? len - idx->k + 1 : 0;
         // 128-B aligned regions: no line shared between reads.  Minimiser mode emits at most one value per window.
-        const uint64_t cap = round_up((idx->w_min > 0 ? nwin : nwin / gap) + 2, 16);
+        const uint64_t cap = round_up((idx->w_min > 0 ? nwin : (uint64_t)((uint32_t)nwin / (uint32_t)gap)) + 2, 16);   // len < 2^31: a 32-bit divide
         // the first sub-batch's syncmer kernel has nothing to hide behind: keep it a quarter the size
         // Resident batch: only the first sub-batch may be smaller (first_div).  Streamed batch: sub-batch i+1 is ready
         // when its bases have crossed PCIe (serially, behind all earlier ones) and its syncmer kernel has run, and it
@@ -1289,13 +1291,14 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     if (n_reads >= (1ull << 32)) return fail(TAXOR_E_ARG, "batch_upload: more than 2^32 reads in one batch");
     HIP_TRY(hipSetDevice(s->idx->device));
     s->ran = s->synced = false;
-    std::vector<uint64_t> poff, hoff;
-    std::vector<uint32_t> rlen, hcap, order;
+    // the per-read layout arrays live in the searcher: a batch of a million short reads is 45 MB of them, and fresh vectors
+    // per call cost more in page faults than the loop that fills them
+    std::vector<uint64_t> &poff = s->lay_poff, &hoff = s->lay_hoff, &aoff = s->lay_aoff;
+    std::vector<uint32_t> &rlen = s->h_rlen, &hcap = s->lay_hcap, &order = s->lay_order;
     // streamed: the first sub-batch's PCIe copy has nothing to hide behind either, so it is a quarter the size
     if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? stream_first_div(s) : s->first_div, streamed))
         return rc;
     s->n_reads = n_reads;
-    s->h_rlen = rlen;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     s->n_bases = nb;
     s->mean_read_len = n_reads ? nb / n_reads : (1u << 20);
@@ -1304,7 +1307,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         s->d_nh.reserve(n_reads + 1) || s->d_thr.reserve(n_reads + 1) || s->d_order.reserve(n_reads + 1) ||
         s->d_packed.reserve(s->packed_word_count))
         return TAXOR_E_HIP;
-    std::vector<uint64_t> aoff(n_reads + 1);
+    aoff.resize(n_reads + 1);
     for (uint64_t r = 0; r <= n_reads; ++r) aoff[r] = offsets[r] - a0;
     HIP_TRY(hipMemsetAsync(s->d_ctr, 0, sizeof(Counters), s->st));
     HIP_TRY(hipMemcpyAsync(s->d_aoff.p, aoff.data(), (n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
