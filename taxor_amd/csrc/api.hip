@@ -903,11 +903,15 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
     uint64_t words = 0, sub_slots = 0, sub_bases = 0;
     uint32_t sub_first = 0;
     // a sub-batch of 32768 reads of 1 kb is 33 Mbases: three query launches and four finalize kernels per millisecond
-    // of work.  With the size left to the library, short reads get up to 131072 per sub-batch (~128 Mbases).
+    // of work.  With the size left to the library, shorter reads get more of them per sub-batch, up to 524288 and as long as
+    // the sub-batch stays within sub_batch_bases (2^29): the fixed cost per level and sub-batch is paid less often and a
+    // level's work items, grouped by IXF, re-read their children out of the caches more often (1-kb reads, 131072 -> 524288
+    // per sub-batch: GTDB-class 22.0 -> 23.1 Gbp/s, RefSeq-class 30.0 -> 33.7; profiles/r03/sub_reads_1kb.txt).  10-kb reads
+    // keep 32768.
     uint64_t full_reads = s->prm.sub_batch_reads;
     if (s->auto_sub_reads && n_reads) {
         const uint64_t mean_len = std::max<uint64_t>(1, (offsets[n_reads] - offsets[0]) / n_reads);
-        while (full_reads < 131072 && full_reads * mean_len < (1ull << 27)) full_reads *= 2;
+        while (full_reads < 524288 && 2 * full_reads * mean_len <= s->prm.sub_batch_bases) full_reads *= 2;
     }
     uint64_t lim_reads = 0, lim_bases = 0;
     size_t lim_for = (size_t)-1;

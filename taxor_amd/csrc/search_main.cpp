@@ -987,7 +987,8 @@ int main(int argc, char **argv)
                     // the first chunk of a round is waited for; after that only what is already queued is taken
                     for (size_t g = 0; g < ng; ++g) {
                         uint64_t gr = 0, gb = 0;
-                        while (gr < group_reads && gb < (3ull << 30) && round[g].size() < group_max_chunks) {
+                        while ((gr < group_reads || (!cfg.batch_reads && !cfg.group_reads && gb < (1ull << 29) && gr < (1u << 20))) &&
+                               gb < (3ull << 30) && round[g].size() < group_max_chunks) {
                             bool got;
                             if (used == 0 && round[g].empty() && eofs.empty()) { got = q_in.pop(b); if (!got) open = false; }
                             else got = q_in.try_pop(b);
@@ -1069,7 +1070,10 @@ int main(int argc, char **argv)
                         eofs.clear();
                         uint64_t gr = b->ids.size(), gb = b->bases.size();
                         group.push_back(std::move(b));
-                        while (gr < group_reads && gb < (3ull << 30) && group.size() < group_max_chunks && q_in.try_pop(b)) {
+                        // (short reads: more of them, until the batch holds 2^29 bases -- the library's sub-batches then reach
+                        // their full size)
+                        while ((gr < group_reads || (!cfg.batch_reads && !cfg.group_reads && gb < (1ull << 29) && gr < (1u << 20))) &&
+                               gb < (3ull << 30) && group.size() < group_max_chunks && q_in.try_pop(b)) {
                             if (b->end_of_file) { eofs.push_back(std::move(b)); continue; }
                             gr += b->ids.size();
                             gb += b->bases.size();
