@@ -103,15 +103,17 @@ with open(fq, "wb") as f, open(want_path, "w") as wf:
         expected_sizes.append(len(text))
         n_tuples += int(r.user_bin.size)
         n_lines += text.count("\n")
-        rec = np.empty((n, 1 + 14 + 1 + read_len + 3 + read_len + 1), dtype=np.uint8)
-        rec[:, 0] = ord("@")
+        fasta = os.environ.get("TAXOR_E2E_FORMAT", "fastq") == "fasta"
+        rec = np.empty((n, 1 + 14 + 1 + read_len + 1 if fasta else 1 + 14 + 1 + read_len + 3 + read_len + 1), dtype=np.uint8)
+        rec[:, 0] = ord(">") if fasta else ord("@")
         rec[:, 1:6] = np.frombuffer(b"read_", np.uint8)
         num = np.arange(done, done + n, dtype=np.int64)
         rec[:, 6:15] = (num[:, None] // 10 ** np.arange(8, -1, -1)) % 10 + 48
         rec[:, 15] = 10
         rec[:, 16:16 + read_len] = bb.reshape(n, read_len)
-        rec[:, 16 + read_len:19 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
-        rec[:, 19 + read_len:19 + 2 * read_len] = ord("I")
+        if not fasta:
+            rec[:, 16 + read_len:19 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
+            rec[:, 19 + read_len:19 + 2 * read_len] = ord("I")
         rec[:, -1] = 10
         rec.tofile(f)
         done += n
