@@ -18,13 +18,20 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                  pruning requests fewer bytes with identical results, so the algorithmic rate is reported
                  separately (algorithmic_GBps, vs_dense) and `unpruned` holds the same steps with pruning switched
                  off, where requested == algorithmic and the contract formula is physical.
-                 traffic = HBM bytes per launch from two live rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950
-                 correction, WRITE_SIZE) over one step of the same workload, run as child processes before this
+                 traffic = memory-side bytes per launch from two live rocprofv3 --pmc passes over one step of the same
+                 workload (reads: the L2's read requests BY SIZE x their size -- every miss of this kernel is one 128-B
+                 request, profiles/r03/fetch_calibration.txt; writes: WRITE_SIZE), run as child processes before this
                  process touches the GPU; null when rocprofv3 is unavailable (never a constant from a file).
+                 requested_accounting bills the same launches three ways: useful16 / sector64 (= achieved, frac) / line128
+                 (the 128-B lines HBM has to move; traffic is judged against this one).
   cpu_baseline : the CPU oracle (oracle/, a port of the reference path) timed on this box's host cores on a
                  bounded sample of the same reads and index; also used to re-check parity on that sample.
   sustained    : >= 10 M reads fed from HOST buffers through taxor_gpu_search_batch_begin/_end (PCIe inside),
                  rotating through the same distinct batches; never reported as `value`.
+  N > 1        : pcie_inclusive_per_rank -- rank 0's host-fed rate alone, then every rank's at once, and
+                 host_fed_scaling = their sum / rank 0's solo rate (the resident `value` scales by construction);
+                 host_binding = the NUMA node each rank bound itself to before its first HIP call.
+  --mode kmer|minimiser : the same line for an index built without --use-syncmer (viral-class footprint).
 """
 import argparse
 import csv
