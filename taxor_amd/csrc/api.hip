@@ -146,7 +146,7 @@ struct taxor_gpu_searcher {
     DBuf<uint2> d_q[2], d_qs;     // work queues of two consecutive levels; the next level's queue grouped by IXF
     DBuf<uint32_t> d_qhist;
     DBuf<uint4> d_hits;
-    DBuf<uint32_t> d_read_hits, d_cursor, d_roff, d_biglist, d_gtab;
+    DBuf<uint32_t> d_read_hits, d_cursor, d_roff, d_biglist, d_gtab, d_scan;
     uint32_t q_cap = 0, hit_cap = 0, gtab_stride = 0;
 
     // batch-resident output
@@ -840,7 +840,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     if (s->st_sync2) (void)hipStreamDestroy(s->st_sync2);
     if (s->ev_wave) (void)hipEventDestroy(s->ev_wave);
     s->d_q[0].release(); s->d_q[1].release(); s->d_qs.release(); s->d_qhist.release(); s->d_hits.release();
-    s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release();
+    s->d_read_hits.release(); s->d_cursor.release(); s->d_roff.release(); s->d_biglist.release(); s->d_gtab.release(); s->d_scan.release();
     s->d_read_off.release(); s->d_out_ub.release(); s->d_out_cnt.release(); s->d_out_key.release();
     for (auto ev : s->ev) (void)hipEventDestroy(ev);
     if (s->d_ctr) (void)hipFree(s->d_ctr);
@@ -1050,7 +1050,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
         s->d_qhist.reserve(idx->h_ixf.size() + 1))
         return TAXOR_E_HIP;
     if (s->d_hits.reserve(s->hit_cap)) return TAXOR_E_HIP;
-    if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R))
+    if (s->d_read_hits.reserve(R) || s->d_cursor.reserve(R) || s->d_roff.reserve(R + 1) || s->d_biglist.reserve(R) || s->d_scan.reserve(R / 4096 + 8))
         return TAXOR_E_HIP;
     // dedup scratch in global memory, only for reads that could select more syncmers than the LDS passes cover
     if (syncmer_mode && s->max_read_slots > SYNC_LDS_DEDUP_MAX) {
@@ -1143,6 +1143,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     f.cursor = s->d_cursor.p;
     f.roff = s->d_roff.p;
     f.biglist = s->d_biglist.p;
+    f.block_sums = s->d_scan.p;
     f.dfs_key = idx->d_dfs_key;
     f.ubin = idx->d_ubin;
     f.read_off = d_read_off;

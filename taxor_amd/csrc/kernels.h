@@ -130,6 +130,7 @@ struct FinalizeArgs {
     uint32_t *cursor;          // zeroed scratch, per read
     uint32_t *roff;            // exclusive scan of read_hits (sub-batch local)
     uint32_t *biglist;
+    uint32_t *block_sums;      // scratch of the offset scan: ceil(n_reads / 4096) + 2 words
     const uint32_t *dfs_key;
     const int64_t *ubin;
     uint64_t *read_off;        // batch CSR, at the sub-batch's first read
