@@ -408,6 +408,10 @@ uint64_t fnv1a(const char *p, size_t n)
 
 int main(int argc, char **argv)
 {
+    // while the process is still single-threaded: the HIP runtime's hardware-queue count (taxor_amd/csrc/api.hip,
+    // runtime_env_once -- the library would set it at its first call, by which time this host has threads that read the
+    // environment)
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int a = 1;
     if (argc > 1 && strcmp(argv[1], "probe") == 0) {                       // hixf-probe: report a file's IXF record layout
         const char *path = nullptr;
