@@ -1095,6 +1095,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.prof = s->d_prof;
     static const uint32_t stages_env = [] { const char *e = getenv("TAXOR_QUERY_STAGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
     q.sparse_stages = stages_env;
+    static const float margin_env = [] { const char *e = getenv("TAXOR_QUERY_MARGIN"); const double v = e ? atof(e) : 0.0; return v > 0.0 && v < 64.0 ? (float)v : 0.f; }();
+    q.prune_margin = margin_env;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     static const bool group_queue = [] { const char *e = getenv("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {

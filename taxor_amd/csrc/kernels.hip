@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             // for reads of any length (a fixed margin either wastes dense traffic on short reads or lets every bin
             // of a 100-kb read survive).  The margin only trades dense against sparse work, never exactness.
             const float mu = thr < (uint64_t)n ? (float)((uint64_t)n - thr) * (1.0f / 256.0f) : 0.0f;
-            const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + 4.5f);
+            const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + (a.prune_margin > 0.f ? a.prune_margin : 4.5f));
             dense_end = (thr >= (uint64_t)n + margin) ? 0u : min(n, (uint32_t)((uint64_t)n + margin - thr));
         }
         uint64_t touched = 0, rows_read = 0, sparse_loads = 0;
