@@ -120,7 +120,7 @@ struct QueryArgs {
     uint32_t max_stride;      // widest row of the index: sizes the per-bin LDS arrays
     uint32_t prune;           // 1 = threshold-aware pruning of dead bin runs (off for raw bulk_count)
     uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
-    float prune_margin;       // constant term of the pruning margin mu + 4 sqrt(mu) + c (0 = 4.5)
+    float prune_margin;       // constant term of the pruning margin mu + 4 sqrt(mu) + c (0 = 3.5)
     uint32_t sparse_stages;   // stages of the pruned phase for long hash lists (0 = 3); between stages the alive set is re-evaluated
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };

@@ -1316,11 +1316,13 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         uint32_t dense_end = n;
         if (a.prune && thr > 0) {
             // margin above the minimum n - thr + 1: a random bin collects ~Poisson((n-thr)/256) matches in the dense
-            // phase; mean + 4 sigma + 4 keeps the expected number of falsely surviving units per item below ~0.1
+            // phase; mean + 4 sigma + 3.5 keeps the expected number of falsely surviving units per item below ~0.1 (a
+            // constant of 4.5 until round 3: 3.5 is 2 % faster on 1-kb reads, whose margin is mostly this constant, and
+            // within noise on 10-kb reads; 1.5 lets too many random units survive -- profiles/r03/margin.txt)
             // for reads of any length (a fixed margin either wastes dense traffic on short reads or lets every bin
             // of a 100-kb read survive).  The margin only trades dense against sparse work, never exactness.
             const float mu = thr < (uint64_t)n ? (float)((uint64_t)n - thr) * (1.0f / 256.0f) : 0.0f;
-            const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + (a.prune_margin > 0.f ? a.prune_margin : 4.5f));
+            const uint32_t margin = (uint32_t)(mu + 4.0f * sqrtf(mu) + (a.prune_margin > 0.f ? a.prune_margin : 3.5f));
             dense_end = (thr >= (uint64_t)n + margin) ? 0u : min(n, (uint32_t)((uint64_t)n + margin - thr));
         }
         uint64_t touched = 0, rows_read = 0, sparse_loads = 0;
