@@ -1096,6 +1096,7 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
 //   [.., +max_stride*4)                per-bin counts
 //   [.., +max_stride*4)                per-bin info words (binfo) of the current IXF
 static constexpr int Q_MAXU = 32;   // more alive units than this -> finish the item densely
+static constexpr int Q_MAXC = 64;   // candidate units remembered for the tally; more -> the tally walks every bin
 static constexpr int Q_CHUNK_MAX = 8; // work items taken per cursor atomic, at most
 
 // what a block needs to know about a work item, fetched for a whole cursor chunk at once (one lane per item) so that
@@ -1113,7 +1114,8 @@ uint32_t query_map_words(uint32_t max_stride) { return (uint32_t)query_lds_map_w
 
 size_t query_lds_bytes(uint32_t max_stride, bool small)
 {
-    return (size_t)(small ? Q_CAP_SMALL : Q_CAP) * 16 + 64 + (size_t)Q_MAXU * 4 + query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 8;
+    return (size_t)(small ? Q_CAP_SMALL : Q_CAP) * 16 + 64 + (size_t)Q_MAXU * 4 + 2 * query_lds_map_words(max_stride) * 4 + (size_t)max_stride * 8 +
+           (size_t)Q_MAXC * 4;
 }
 
 // dense pass over hashes [h0, h1): every thread (u, g) reads its 16-B unit of the three rows of every hash of
@@ -1218,6 +1220,8 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     uint32_t *sMap = sUnits + Q_MAXU;
     uint32_t *sC = sMap + a.map_words;
     uint32_t *sInfo = sC + a.max_stride;
+    uint32_t *sCandMap = sInfo + a.max_stride;    // units holding a run that could still pass when the dense phase ended
+    uint32_t *sCandUnits = sCandMap + a.map_words;
     __shared__ ItemMeta sItems[Q_CHUNK_MAX];
 
     const uint32_t tid = threadIdx.x;
@@ -1259,6 +1263,8 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
 
     const uint32_t chunk = min(max(a.cursor_chunk, 1u), (uint32_t)Q_CHUNK_MAX);
     uint32_t item = 0, item_end = 0, item0 = 0;
+    uint32_t info_of = 0xFFFFFFFFu;     // bin_base of the IXF whose info words sit in sInfo (block-uniform): at the root every
+                                        // item is IXF 0, below it the items arrive grouped by IXF -- no need to fetch them again
     for (;;) {
         __syncthreads();
         if (item == item_end) {
@@ -1294,9 +1300,10 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         // The per-bin info words are read twice per item (pruning check, tally): out of LDS, not out of L2 -- a global
         // load per phase is a round trip of its own, which is most of what a small item costs.  Rows of up to 1024 bins
         // take them through registers so that these loads and the hash loads of the probe staging below fly together.
+        const bool info_cached = info_of == D.bin_base;
         const bool info_regs = nb_round <= 4u * BS;
         uint32_t infoReg[4] = {0u, 0u, 0u, 0u};
-        if (info_regs) {
+        if (info_regs && !info_cached) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t b = tid + (uint32_t)j * BS;
@@ -1304,8 +1311,8 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             }
         }
         for (uint32_t i = tid; i < stride; i += BS) sC[i] = 0;
-        for (uint32_t i = tid; i < a.map_words; i += BS) sMap[i] = 0;
-        if (tid == 0) sScal[1] = 0;
+        for (uint32_t i = tid; i < a.map_words; i += BS) { sMap[i] = 0; sCandMap[i] = 0; }
+        if (tid == 0) { sScal[1] = 0; sScal[6] = 0; }
 
         // ---- threshold-aware pruning ---------------------------------------------------------------------------
         // After `dense_end` hashes a run of `len` technical bins whose partial sum satisfies
@@ -1333,7 +1340,9 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 const ixf_probe p = ixf_probe_key_arith(hp[i], D.seed, D.seg_len, D.arith);
                 sProbe[i] = make_uint4(p.row[0], p.row[1], p.row[2], p.fp4);
             }
-        if (info_regs) {
+        if (info_cached) {
+            // sInfo already holds this IXF's words
+        } else if (info_regs) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t b = tid + (uint32_t)j * BS;
@@ -1342,6 +1351,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         } else {
             for (uint32_t b = tid; b < nb_round; b += BS) sInfo[b] = b < D.bins ? bi[b] : 0u;
         }
+        info_of = D.bins ? D.bin_base : 0xFFFFFFFFu;
         __syncthreads();
         PMARK(1)                                                     // 1: clearing the tally, bin info + probe staging
         query_dense_range<NT, U, BS, QC>(D, hp, 0, dense_end, sProbe, sC, staged);
@@ -1350,6 +1360,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         __syncthreads();
         PMARK(2)                                                     // 2: dense phase (row gathers)
 
+        bool cand_valid = false;
         if (dense_end < n) {
             // The remaining hashes probe only the 16-bin units that still matter, in up to three stages; between stages the
             // set is re-evaluated with the counts so far.  A unit matters while it holds
@@ -1363,6 +1374,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             uint32_t done = dense_end;
             uint32_t chunk = 0;
             bool first_eval = true;
+            cand_valid = !a.counts_out;
             for (;;) {
                 const uint64_t rem = n - done;
                 if (!first_eval) {
@@ -1376,13 +1388,23 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                         if (info & BINFO_END) { // merged bins are runs of length one and carry BINFO_END too
                             int bb = (int)b;
                             uint64_t sum = sC[bb];
-                            bool alive;
+                            bool alive, cand;
                             if (info & BINFO_MERGED) {
-                                alive = sum < thr && sum + rem >= thr;
+                                cand = sum + rem >= thr;
+                                alive = cand && sum < thr;
                             } else {
                                 while (bb > 0 && (sInfo[bb - 1] >> 30) == 0u) sum += sC[--bb];
                                 const uint64_t len = (uint64_t)b - (uint64_t)bb + 1u;
-                                alive = sum + rem * len >= thr;
+                                alive = cand = sum + rem * len >= thr;
+                            }
+                            if (first_eval && cand) {      // whatever passes at the end was a candidate now: the tally walks only these units
+                                for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
+                                    const uint32_t bit = 1u << (x & 31u);
+                                    if (!(atomicOr(&sCandMap[x >> 5], bit) & bit)) {
+                                        const uint32_t k = atomicAdd(&sScal[6], 1u);
+                                        if (k < (uint32_t)Q_MAXC) sCandUnits[k] = x;
+                                    }
+                                }
                             }
                             if (alive) {
                                 for (uint32_t x = (uint32_t)bb >> 4; x <= (b >> 4); ++x) {
@@ -1479,9 +1501,17 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             for (uint32_t b = tid; b < D.bins; b += BS) a.counts_out[b] = sC[b];
 
         // ---- tally: hierarchical_interleaved_xor_filter.hpp:313-338 --------------------------------------
-        for (uint32_t b = tid; b < nb_round; b += BS) {
+        // A run that passes had `sum + rem * len >= thr` when the dense phase ended, so when pruning ran the walk covers just
+        // the units recorded then (a handful) instead of every bin of the row: for a small item this pass over the bins
+        // is a tenth of its time.  The loop bounds stay wave-uniform (wave_append ballots).
+        const uint32_t n_cand = sScal[6];
+        const bool cand_tally = cand_valid && n_cand <= (uint32_t)Q_MAXC;
+        const uint32_t t_end = cand_tally ? ((n_cand * 16u + 63u) & ~63u) : nb_round;
+        for (uint32_t t = tid; t < t_end; t += BS) {
             bool push_child = false, push_hit = false;
             uint32_t sum = 0, info = 0;
+            uint32_t b = t;
+            if (cand_tally) b = t < n_cand * 16u ? sCandUnits[t >> 4] * 16u + (t & 15u) : 0xFFFFFFFFu;
             if (b < D.bins) {
                 info = sInfo[b];
                 if (info & BINFO_MERGED) {
