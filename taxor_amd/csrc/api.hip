@@ -1097,6 +1097,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.sparse_stages = stages_env;
     static const float margin_env = [] { const char *e = getenv("TAXOR_QUERY_MARGIN"); const double v = e ? atof(e) : 0.0; return v > 0.0 && v < 64.0 ? (float)v : 0.f; }();
     q.prune_margin = margin_env;
+    static const uint32_t tally_env = [] { const char *e = getenv("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
+    q.tally_mode = tally_env;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     static const bool group_queue = [] { const char *e = getenv("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {

@@ -122,6 +122,7 @@ struct QueryArgs {
     uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
     float prune_margin;       // constant term of the pruning margin mu + 4 sqrt(mu) + c (0 = 3.5)
     uint32_t sparse_stages;   // stages of the pruned phase for long hash lists (0 = 3); between stages the alive set is re-evaluated
+    uint32_t tally_mode;      // measurement aid (TAXOR_QUERY_TALLY): bit 0 = tally walks every bin, bit 1 = bin info fetched per item
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };
 

@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         // The per-bin info words are read twice per item (pruning check, tally): out of LDS, not out of L2 -- a global
         // load per phase is a round trip of its own, which is most of what a small item costs.  Rows of up to 1024 bins
         // take them through registers so that these loads and the hash loads of the probe staging below fly together.
-        const bool info_cached = info_of == D.bin_base;
+        const bool info_cached = info_of == D.bin_base && !(a.tally_mode & 2u);
         const bool info_regs = nb_round <= 4u * BS;
         uint32_t infoReg[4] = {0u, 0u, 0u, 0u};
         if (info_regs && !info_cached) {
@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             uint32_t done = dense_end;
             uint32_t chunk = 0;
             bool first_eval = true;
-            cand_valid = !a.counts_out;
+            cand_valid = !a.counts_out && !(a.tally_mode & 1u);
             for (;;) {
                 const uint64_t rem = n - done;
                 if (!first_eval) {
