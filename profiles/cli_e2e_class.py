@@ -22,7 +22,9 @@ from taxor_amd.hixf_file import HixfFile, store_hixf  # noqa: E402
 
 workload = sys.argv[1] if len(sys.argv) > 1 else "refseq"
 n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 400000
-args = bench.parse_args(["--workload", workload, "--reads", str(min(n_reads, 131072)), "--batches", "1"])
+_rl = int(os.environ.get("TAXOR_E2E_READ_LEN", "0"))       # 0: the class's own read length (10 kb; viral 5 kb)
+per = 131072 if not _rl else max(131072, 131072 * 10000 // _rl)      # reads per generated batch: ~1.3 Gbp like bench.py's batches
+args = bench.parse_args(["--workload", workload, "--reads", str(min(n_reads, per)), "--batches", "1"] + (["--read-len", str(_rl)] if _rl else []))
 wl, idx, lay, batches, info = bench.build_workload(args, 0, 0, 1)
 bases, offs = batches[0]
 read_len = info["read_len"]
@@ -77,7 +79,6 @@ t0 = time.time()
 from taxor_amd import synth  # noqa: E402
 sr = Searcher(idx, error_rate=args.error_rate)
 hx = HixfFile(idx_path)
-per = 131072
 g, go = info.get("genomes"), info.get("genome_off")
 expected_sizes, n_tuples, n_lines, kept = [], 0, 0, []
 want_path = os.path.join(tmp, "want.tsv")
@@ -123,7 +124,7 @@ hx.close()
 # the library's own host-fed rate on these reads (bench.py's `sustained`: page-locked staging buffers, two searchers in
 # flight, results fetched every call) -- what the CLI's search phase is held against
 keep = kept[:8]
-sargs = bench.parse_args(["--workload", workload, "--sustained-reads", str(max(n_reads, 4 * per))])
+sargs = bench.parse_args(["--workload", workload, "--sustained-reads", str(max(n_reads, 4 * per))] + (["--read-len", str(_rl)] if _rl else []))
 _, sustained = bench.dropin_measurements(sargs, idx, keep, read_len)
 print(f"library sustained (host-fed, two searchers, {sustained['reads']} reads): {sustained['value']:.0f} Mbp/s", flush=True)
 del keep, kept

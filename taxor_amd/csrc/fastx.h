@@ -30,11 +30,26 @@
 namespace fastx {
 
 // one chunk of records on its way through the pipeline: reader -> GPU -> formatter/writer
+// the record ids of a chunk, back to back in one string: a chunk of short reads holds 10^5 of them, and a string object
+// each is a heap allocation per record as soon as the id is longer than 15 characters (every real sequencer's is)
+struct IdList {
+    std::string data;
+    std::vector<uint64_t> off{0};
+    size_t size() const { return off.size() - 1; }
+    bool empty() const { return off.size() == 1; }
+    void clear() { data.clear(); off.assign(1, 0); }
+    void reserve(size_t n, size_t bytes) { off.reserve(n + 1); data.reserve(bytes); }
+    void push_back(const std::string &id) { data.append(id); off.push_back(data.size()); }
+    const char *ptr(size_t i) const { return data.data() + off[i]; }
+    size_t len(size_t i) const { return (size_t)(off[i + 1] - off[i]); }
+    std::string str(size_t i) const { return std::string(ptr(i), len(i)); }
+};
+
 struct Batch {
     uint64_t seq = 0;   // position of this chunk in its query file
     uint32_t file = 0;  // position of the query file in --query-file
     bool end_of_file = false;   // marker that follows the last chunk of a file (seq = number of chunks), carries no records
-    std::vector<std::string> ids;
+    IdList ids;
     std::string bases;
     std::vector<uint64_t> offsets;
     // results copied out of the searcher (its buffers are reused by the next batch)
@@ -248,9 +263,9 @@ struct FastxReader {
         return line_to(&line);
     }
     // appends the record's sequence to `bases`; returns false at end of file
+    std::string line;    // the header line of the record being read (a member: its buffer is reused from record to record)
     bool next(std::string &id, std::string &bases)
     {
-        std::string line;
         if (pending.empty()) {
             do {
                 if (!getline(line)) return false;

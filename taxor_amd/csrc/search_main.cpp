@@ -213,6 +213,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                 fastx::FastxReader rd;
                 std::string id;
                 uint64_t b, e, seq;
+                size_t prev_records = 0, prev_id_bytes = 0;
                 for (;;) {
                     if (gate) gate();
                     auto bt = pool.get();                   // buffer first: ranges are then taken in the order they can be filled
@@ -229,11 +230,20 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                         bt->ids.clear();
                         bt->bases.clear();
                         bt->offsets.assign(1, 0);
+                        {   // a fresh chunk buffer: size the per-record arrays once, from what the previous range of this thread
+                            // held (growing a vector of 10^5 entries by doubling is a dozen reallocations, each an mmap/munmap
+                            // and a TLB shootdown across every thread of the process)
+                            const size_t guess = prev_records + prev_records / 8 + 1024;
+                            if (bt->offsets.capacity() < guess) bt->offsets.reserve(guess + 1);
+                            if (bt->ids.off.capacity() < guess || bt->ids.data.capacity() < prev_id_bytes) bt->ids.reserve(guess, prev_id_bytes + prev_id_bytes / 8 + 4096);
+                        }
                         rd.open_range(rf.fd, b, e, rf.kind == '@');
                         while (rd.next(id, bt->bases)) {
                             bt->ids.push_back(id);
                             bt->offsets.push_back(bt->bases.size());
                         }
+                        prev_records = bt->ids.size();
+                        prev_id_bytes = bt->ids.data.size();
                     } catch (const std::exception &ex) { die(ex.what()); }
                     push(std::move(bt));
                 }
@@ -612,7 +622,7 @@ int main(int argc, char **argv)
             const Batch &b = *kv.second;
             for (size_t r = 0; r < b.ids.size(); ++r) {
                 const uint64_t lo = b.offsets[r], len = b.offsets[r + 1] - lo;
-                printf("%s\t%llu\t%016llx\n", b.ids[r].c_str(), (unsigned long long)len, (unsigned long long)fnv1a(b.bases.data() + lo, len));
+                printf("%s\t%llu\t%016llx\n", b.ids.str(r).c_str(), (unsigned long long)len, (unsigned long long)fnv1a(b.bases.data() + lo, len));
                 ++n;
                 nb += len;
             }
@@ -842,16 +852,22 @@ int main(int argc, char **argv)
                 std::unique_ptr<Batch> b;
                 std::vector<const char *> idp;
                 std::vector<uint64_t> idl, rl;
+                size_t line_bytes_guess = 192;             // bytes of text per tuple, learnt from the chunks this thread formatted
                 while (q_fmt.pop(b)) {
                     if (!b->end_of_file) {
                         const size_t n = b->ids.size();
                         idp.resize(n); idl.resize(n); rl.resize(n);
                         for (size_t r = 0; r < n; ++r) {
-                            idp[r] = b->ids[r].data();
-                            idl[r] = b->ids[r].size();
+                            idp[r] = b->ids.ptr(r);
+                            idl[r] = b->ids.len(r);
                             rl[r] = b->offsets[r + 1] - b->offsets[r];
                         }
-                        b->text.resize(b->text.capacity());            // a recycled chunk's buffer usually fits: one pass
+                        {   // a recycled chunk's buffer usually fits; a fresh one is sized from the tuple count (formatting twice
+                            // because the first pass only measured costs as much as the pass that writes)
+                            const size_t guess = (size_t)b->user_bin.size() * line_bytes_guess + n * 96 + b->ids.data.size() * 2 + 4096;
+                            if (b->text.capacity() < guess) b->text.reserve(guess + guess / 8);
+                        }
+                        b->text.resize(b->text.capacity());
                         uint64_t need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), b->n_hashes.data(), b->read_off.data(),
                                                            b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
                         if (need > b->text.size()) {
@@ -860,6 +876,7 @@ int main(int argc, char **argv)
                                                       b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
                         }
                         b->text.resize(need);
+                        if (!b->user_bin.empty()) line_bytes_guess = std::max<size_t>(64, (size_t)(need / b->user_bin.size()) + 16);
                     }
                     q_out.push(std::move(b));
                 }
@@ -884,6 +901,9 @@ int main(int argc, char **argv)
                         continue;
                     }
                     ++next_seq;
+                    // One stream, one thread: 7-8 GB/s into a RAM-backed file, which bounds SHORT reads (a 1-kb read of the family
+                    // workload is six lines, 870 bytes of text per 1000 bases: ~9 Gbp/s; 20 Gbp/s with --output-file /dev/null).
+                    // Placing the blocks into the mapped file from several threads was tried and is no faster.
                     if (!cur->text.empty() && fwrite(cur->text.data(), 1, cur->text.size(), out) != cur->text.size())
                         die("cannot write to " + cfg.report_file);
                     {

@@ -454,3 +454,4 @@ def test_cli_several_index_files(tmp_path):
     cp = subprocess.run([TAXOR, "search", "--index-file", f"{idx1},{other}", "--query-file", str(qa), "--output-file", str(out)],
                         capture_output=True, text=True, timeout=120)
     assert cp.returncode != 0 and "different kmer selection schemes" in cp.stderr
+
