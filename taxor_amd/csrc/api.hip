@@ -1116,7 +1116,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_QUERY_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
         // levels below the root: small items, four per cursor atomic; the root level too when the reads are short (a
         // long read is ~30 us of work and chunks of those would leave blocks idle at the tail of the launch)
-        q.cursor_chunk = chunk_env ? chunk_env : ((lvl >= 1 || s->mean_read_len < 3000) ? 4u : 1u);
+        // (1-kb reads at the root, 2 / 4 / 8 per atomic: 23.69 / 23.85 / 23.98 Gbp/s -- profiles/r03/chunk_ab.txt)
+        q.cursor_chunk = chunk_env ? chunk_env : (lvl >= 1 ? 4u : (s->mean_read_len < 1500 ? 8u : (s->mean_read_len < 3000 ? 4u : 1u)));
         size_t slot;
         if (ev_begin(s, 16 + (int)std::min(lvl, 7u), &slot)) return TAXOR_E_HIP;
         // four blocks per CU for short reads and for every level below the root (small items: half their time is spent
@@ -1132,7 +1133,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
             QueryArgs qs = q;
             qs.max_stride = idx->lvl_max_stride[lvl];
             qs.map_words = query_map_words(idx->lvl_max_stride[lvl]);
-            qs.cursor_chunk = 4;
+            qs.cursor_chunk = chunk_env ? chunk_env : 4;
             launch_query_level(qs, s->grid_query_small[lvl], s->lds_query_small[lvl], s->st, true, root_streams);
         } else
             launch_query_level(q, wide_grid ? s->grid_query_short : s->grid_query, s->lds_query, s->st, false, root_streams);

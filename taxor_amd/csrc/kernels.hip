@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void probe_accumulate(uint4 &acc8, const uint4 &x, co
 //   [.., +max_stride*4)                per-bin info words (binfo) of the current IXF
 static constexpr int Q_MAXU = 32;   // more alive units than this -> finish the item densely
 static constexpr int Q_MAXC = 64;   // candidate units remembered for the tally; more -> the tally walks every bin
-static constexpr int Q_CHUNK_MAX = 8; // work items taken per cursor atomic, at most
+static constexpr int Q_CHUNK_MAX = 16; // work items taken per cursor atomic, at most
 
 // what a block needs to know about a work item, fetched for a whole cursor chunk at once (one lane per item) so that
 // the dependent loads  cursor -> (read, IXF) -> descriptor / hash count / threshold / hash offset  are paid once per
