@@ -52,6 +52,10 @@ import numpy as np
 # submission order; a searcher's copy / hashing / query streams must not (taxor_amd/csrc/api.hip, runtime_env_once).  Set
 # before torch brings the runtime up; a value the user exported wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# several ranks on one node: this pool's host driver shares device memory between processes through dmabuf only, and
+# RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid argument` under the legacy mode (exported on the
+# boxes already; set here too so that a hand-built environment does not lose it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
