@@ -680,7 +680,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": (f"{args.workload}-class HIXF k22/s12 {idx.data_bytes/1e9:.0f} GB in HBM, root {wl['root_bins']} bins, "
-                                    f"{shard_reads[0]} reads x {int(read_len)} bp/GPU/step, {fam}") if args.mode == "syncmer" else
+                                    + (f"{shard_reads[0]} reads x {int(read_len)} bp/GPU/step, {fam}" if not args.len_mix else
+                                       f"{shard_reads[0]} reads of 1-100 kb (ONT-like mix: 1/3/10/30/100 kb carrying 10/20/40/20/10 % of the bases, "
+                                       f"mean {shard_bases[0] // max(1, shard_reads[0])} bp)/GPU/step, {fam}")) if args.mode == "syncmer" else
                                    (f"viral-class HIXF built WITHOUT --use-syncmer (k={info['k']}, window={info['window']}: "
                                     f"{'every canonical k-mer, k-mer threshold model' if args.mode == 'kmer' else 'window minimisers, FracMinHash threshold model'}) "
                                     f"{idx.data_bytes/1e9:.2f} GB in HBM, root {wl['root_bins']} bins, {shard_reads[0]} reads x {int(read_len)} bp/GPU/step"),

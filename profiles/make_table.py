@@ -28,7 +28,9 @@ for name, label in ROWS:
     wl = c.get("workload", "")
     import re
     m = re.search(r"(\d+) reads x (\d+) bp", wl)
-    if m:
+    if name == "ont":
+        reads = f"{c['reads_per_gpu']} reads, mean {round(j['value'] * j['ms_per_step'] * 1e3 / c['reads_per_gpu'] / 100) / 10:.1f} kb"
+    elif m:
         n, L = int(m.group(1)), int(m.group(2))
         reads = f"{n} × {L // 1000} kb" if L % 1000 == 0 else f"{n} × {L} bp"
     else:
