@@ -1306,8 +1306,12 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     std::vector<uint64_t> &poff = s->lay_poff, &hoff = s->lay_hoff, &aoff = s->lay_aoff;
     std::vector<uint32_t> &rlen = s->h_rlen, &hcap = s->lay_hcap, &order = s->lay_order;
     // streamed: the first sub-batch's PCIe copy has nothing to hide behind either, so it is a quarter the size
+    static const bool trace = getenv("TAXOR_TRACE_BATCH") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? stream_first_div(s) : s->first_div, streamed))
         return rc;
+    const double t_layout = ms_since(t0);
     s->n_reads = n_reads;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     s->n_bases = nb;
@@ -1357,8 +1361,14 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
         HIP_TRY(hipMemcpyAsync(s->d_thr.p, thr_h.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, s->st));
         s->thr_precomputed = true;
     }
+    const double t_enq = ms_since(t0);
     HIP_TRY(hipStreamSynchronize(s->st)); // the pageable host vectors above may now die
-    return ensure_scratch(s);
+    const double t_sync = ms_since(t0);
+    const int rc = ensure_scratch(s);
+    if (trace)
+        fprintf(stderr, "[prepare_batch] %llu reads: layout %.2f ms, device buffers + per-read arrays enqueued at %.2f, on the device at %.2f, scratch ready at %.2f\n",
+                (unsigned long long)n_reads, t_layout, t_enq, t_sync, ms_since(t0));
+    return rc;
 }
 
 // The whole pipeline for the uploaded (host_ascii == nullptr) or streaming (host_ascii = first base of the batch)
