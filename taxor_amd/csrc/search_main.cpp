@@ -100,7 +100,7 @@ struct BatchPool {
 struct Config {                              // taxor_search_configuration.hpp:8-20
     std::string index_file, query_file, report_file;
     double threshold = -1.0, error_rate = 0.04;
-    unsigned threads = 1;
+    unsigned threads = 0;       // 0 = not given: as many host threads as feed one GPU (see main); the reference's default is ONE worker
     std::vector<int> gpus{0};   // devices that classify batches in parallel, each with its own index replica
     uint64_t batch_reads = 0, batch_bases = 1ull << 30;   // 0 reads: 65536 per batch (sequential reader) or ~128 MB of
                                                            // file per batch (plain file, parsed in parallel)
@@ -144,7 +144,9 @@ void usage()
             "  --index-file <f[,f..]>   taxor index file(s) containing HIXF index and reference information (required)\n"
             "  --query-file <f[,f..]>   file(s) containing sequences to query against the index\n"
             "  --output-file <f>        file name for the resulting output\n"
-            "  --threads <1..32>        host threads parsing the query file (plain FASTA/FASTQ; gzip is one stream)\n"
+            "  --threads <1..32>        host threads parsing the query file (plain FASTA/FASTQ; gzip is one stream) and rendering\n"
+            "                           the report; default 4-16 by the size of the machine (the reference's default of 1 is its\n"
+            "                           classifying thread; here one host thread cannot feed the GPU)\n"
             "  --percentage <0..1>      if set, this threshold is used instead of the syncmer model\n"
             "  --error-rate <0..1>      expected error rate of the reads (default 0.04)\n"
             "  --gpu <id>               device ordinal (default 0)\n"
@@ -606,6 +608,7 @@ int main(int argc, char **argv)
             else if (strcmp(argv[i], "--batch-reads") == 0 && i + 1 < argc) cfg.batch_reads = strtoull(argv[++i], nullptr, 10);
             else if (strcmp(argv[i], "--sequential") == 0) allow_ranges = false;
         }
+        if (cfg.threads == 0) cfg.threads = 1;
         if (cfg.query_file.empty() || !file_exists(cfg.query_file)) die("usage: taxor reads --query-file <fasta|fastq[.gz]> [--threads n] [--batch-reads n] [--sequential]");
         std::mutex mu;
         std::map<uint64_t, std::unique_ptr<Batch>> got;
@@ -705,6 +708,14 @@ int main(int argc, char **argv)
         else die("Unknown option " + k + ". In case this is meant to be a non-option/argument/parameter, please specify the start of non-options with '--'.");
     }
     if (cfg.index_file.empty()) die("Option --index-file is required but not set.");
+    if (cfg.threads == 0) {
+        // --threads not given.  The reference's default is one worker thread (taxor_search_configuration.hpp:17) -- there the
+        // thread that classifies; here host threads only parse the query file and render text for the GPU, and one of them
+        // delivers 1-3 Gbp/s to a device that classifies 25.  Default: a sixteenth of the machine, between 4 and 16.  A
+        // --threads the user gives is obeyed as it is.
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        cfg.threads = std::min(16u, std::max(4u, hw / 16u));
+    }
 
     // ---- sanity checks (taxor_search.cpp:97-151) --------------------------------------------------------------
     printf("checking input ... ");
