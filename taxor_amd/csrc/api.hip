@@ -160,6 +160,7 @@ struct taxor_gpu_searcher {
     std::vector<uint64_t> h_read_off, h_hash_off, h_hashes;
     std::vector<int64_t> h_ub;
     std::vector<uint32_t> h_cnt, h_nh;
+    void *h_small = nullptr;       // page-locked landing area for the results of SMALL batches (see taxor_gpu_batch_fetch)
 
     // timing
     std::vector<hipEvent_t> ev;
@@ -835,6 +836,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     for (auto ev : s->ev_pack_done) (void)hipEventDestroy(ev);
     for (auto ev : s->ev_copy_done) (void)hipEventDestroy(ev);
     if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
+    if (s->h_small) (void)hipHostFree(s->h_small);
     if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
     if (s->st_sync) (void)hipStreamDestroy(s->st_sync);
     if (s->st_sync2) (void)hipStreamDestroy(s->st_sync2);
@@ -1394,7 +1396,12 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     bool need_wave = false;
     for (const SubBatch &sb : s->subs) need_wave = need_wave || (s->idx->w_min == 0 && sb.n_long < sb.n);
     if (need_wave && ensure_stream(&s->st_sync2)) return TAXOR_E_HIP;
-    if (host_ascii && ensure_stream(&s->st_copy)) return TAXOR_E_HIP;
+    // pageable input: each copy blocks the host anyway, so the copy stream buys nothing -- the bases go in on the hashing
+    // stream, in front of their sub-batch's pack kernel (no event hop between two streams: ~50 us of a call of 1024 reads)
+    bool pinned_input = host_ascii;
+    for (const auto &sp : s->host_spans) pinned_input = pinned_input && host_pointer_is_pinned(sp.ptr);
+    const bool inline_copy = host_ascii && !pinned_input && s->subs.size() == 1;
+    if (host_ascii && !inline_copy && ensure_stream(&s->st_copy)) return TAXOR_E_HIP;
     s->ev_used = 0;
     s->ev_spans.clear();
     s->stats = taxor_gpu_run_stats{};
@@ -1405,18 +1412,21 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     HIP_TRY(hipStreamWaitEvent(s->st_sync, s->ev_reset, 0));
     if (s->st_sync2) HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
+    // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
+    static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
     // the bases of sub-batch i, from wherever the caller keeps them: one buffer, or several segments in turn
     size_t span_i = 0;
     auto enqueue_copy = [&](size_t i) -> int {
         const SubBatch &sb = s->subs[i];
+        hipStream_t cs = inline_copy ? (no_overlap ? s->st : s->st_sync) : s->st_copy;       // inline: the stream the pack kernel runs on
         for (; span_i < s->host_spans.size() && s->host_spans[span_i].vbegin + s->host_spans[span_i].len <= sb.a_begin; ++span_i) {}
         for (size_t j = span_i; j < s->host_spans.size() && s->host_spans[j].vbegin < sb.a_end; ++j) {
             const auto &sp = s->host_spans[j];
             const uint64_t lo = std::max(sp.vbegin, sb.a_begin), hi = std::min(sp.vbegin + sp.len, sb.a_end);
             if (hi > lo)
-                HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, s->st_copy));
+                HIP_TRY(hipMemcpyAsync(s->d_ascii.p + lo, sp.ptr + (lo - sp.vbegin), hi - lo, hipMemcpyHostToDevice, cs));
         }
-        HIP_TRY(hipEventRecord(s->ev_copy_done[i], s->st_copy));
+        if (!inline_copy) HIP_TRY(hipEventRecord(s->ev_copy_done[i], cs));
         return 0;
     };
     // Page-locked input: every copy of the batch is enqueued now, before the first kernel -- they then run back to back at
@@ -1424,8 +1434,7 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     // with one of the kernel streams (in-order per queue: what is submitted first runs first).  Pageable input: each
     // copy blocks the host until it is done, so it is issued just before its sub-batch's kernels (the GPU works on the
     // previous sub-batch meanwhile).
-    bool copies_first = host_ascii;
-    for (const auto &sp : s->host_spans) copies_first = copies_first && host_pointer_is_pinned(sp.ptr);
+    const bool copies_first = pinned_input;
     if (copies_first)
         for (size_t i = 0; i < s->subs.size(); ++i)
             if (int rc = enqueue_copy(i)) return rc;
@@ -1441,15 +1450,13 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
         const int buf = (int)(i & 1);
         if (host_ascii && !copies_first)
             if (int rc = enqueue_copy(i)) return rc;
-        // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
-        static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
         hipStream_t ss = no_overlap ? s->st : s->st_sync;
         hipStream_t ss2 = (no_overlap || !s->st_sync2) ? ss : s->st_sync2;
         if (host_ascii) {
             // The copy stream carries copies only; the pack kernel sits on the hashing stream in front of its sub-batch's
             // syncmer kernel: with the copy long done, pack + syncmers of sub-batch i+1 both run beside the query of
             // sub-batch i.
-            HIP_TRY(hipStreamWaitEvent(ss, s->ev_copy_done[i], 0));
+            if (!inline_copy) HIP_TRY(hipStreamWaitEvent(ss, s->ev_copy_done[i], 0));
             launch_pack_dna4(s->d_ascii.p, s->d_aoff.p + sb.first, s->d_poff.p + sb.first, s->d_packed.p, sb.n, s->d_ctr, ss, s->grid_sync_overlap);
             HIP_TRY(hipGetLastError());
             if (ss2 != ss) {
@@ -1608,13 +1615,33 @@ extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *o
     s->h_ub.resize(nt);
     s->h_cnt.resize(nt);
     s->h_nh.resize(nr);
-    HIP_TRY(hipMemcpyAsync(s->h_read_off.data(), s->d_read_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s->st));
-    if (nt) {
-        HIP_TRY(hipMemcpyAsync(s->h_ub.data(), s->d_out_ub.p, nt * 8, hipMemcpyDeviceToHost, s->st));
-        HIP_TRY(hipMemcpyAsync(s->h_cnt.data(), s->d_out_cnt.p, nt * 4, hipMemcpyDeviceToHost, s->st));
+    // A copy into pageable memory is a host round trip of its own (~35 us): four of them are a tenth of a call of 1024 reads,
+    // the reference's chunk size (taxor_search.cpp:315).  Small results land in a page-locked area first -- four copies in
+    // flight, one wait -- and are moved to the result arrays by the host.
+    constexpr uint64_t kSmall = 2ull << 20;
+    const uint64_t b_off = (nr + 1) * 8, b_ub = nt * 8, b_cnt = nt * 4, b_nh = nr * 4;
+    if (b_off + b_ub + b_cnt + b_nh + 64 <= kSmall && (s->h_small || hipHostMalloc(&s->h_small, kSmall, hipHostMallocDefault) == hipSuccess)) {
+        char *p0 = (char *)s->h_small, *p1 = p0 + b_off, *p2 = p1 + b_ub, *p3 = p2 + ((b_cnt + 7) & ~7ull);
+        HIP_TRY(hipMemcpyAsync(p0, s->d_read_off.p, b_off, hipMemcpyDeviceToHost, s->st));
+        if (nt) {
+            HIP_TRY(hipMemcpyAsync(p1, s->d_out_ub.p, b_ub, hipMemcpyDeviceToHost, s->st));
+            HIP_TRY(hipMemcpyAsync(p2, s->d_out_cnt.p, b_cnt, hipMemcpyDeviceToHost, s->st));
+        }
+        if (nr) HIP_TRY(hipMemcpyAsync(p3, s->d_nh.p, b_nh, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(hipStreamSynchronize(s->st));
+        memcpy(s->h_read_off.data(), p0, b_off);
+        if (nt) { memcpy(s->h_ub.data(), p1, b_ub); memcpy(s->h_cnt.data(), p2, b_cnt); }
+        if (nr) memcpy(s->h_nh.data(), p3, b_nh);
+    } else {
+        (void)hipGetLastError();
+        HIP_TRY(hipMemcpyAsync(s->h_read_off.data(), s->d_read_off.p, (nr + 1) * 8, hipMemcpyDeviceToHost, s->st));
+        if (nt) {
+            HIP_TRY(hipMemcpyAsync(s->h_ub.data(), s->d_out_ub.p, nt * 8, hipMemcpyDeviceToHost, s->st));
+            HIP_TRY(hipMemcpyAsync(s->h_cnt.data(), s->d_out_cnt.p, nt * 4, hipMemcpyDeviceToHost, s->st));
+        }
+        if (nr) HIP_TRY(hipMemcpyAsync(s->h_nh.data(), s->d_nh.p, nr * 4, hipMemcpyDeviceToHost, s->st));
+        HIP_TRY(hipStreamSynchronize(s->st));
     }
-    if (nr) HIP_TRY(hipMemcpyAsync(s->h_nh.data(), s->d_nh.p, nr * 4, hipMemcpyDeviceToHost, s->st));
-    HIP_TRY(hipStreamSynchronize(s->st));
     out->n_reads = nr;
     out->n_tuples = nt;
     out->read_off = s->h_read_off.data();
