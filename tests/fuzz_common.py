@@ -1,6 +1,8 @@
 """One randomized differential trial: random genomes, a random HIXF around them (taxor_amd.synth.random_layout), random
 reads and search parameters; the HIP path (through the C ABI) must equal the CPU oracle tuple for tuple.
 Used by tests/test_gpu_fuzz.py (fixed seeds) and tests/fuzz_parity.py (as long as you like)."""
+import os
+
 import numpy as np
 
 from oracle import oracle as orc
@@ -25,6 +27,9 @@ def _rand_read(rng, g, go, kind):
 
 def run_trial(seed, verbose=False):
     rng = np.random.default_rng(seed)
+    # the trials' batches are small: below 4096 reads the library skips the grouping of the work queues by IXF (read per call),
+    # so half of the trials force it on -- drawn from a generator of its own, the trial's other draws stay what they were
+    os.environ["TAXOR_QUERY_GROUP_MIN"] = "0" if np.random.default_rng(seed ^ 0x5EED).random() < 0.5 else "4096"
     syncmer = rng.random() < 0.7
     if syncmer:
         k, s = [(22, 12), (16, 8), (20, 10), (28, 14), (30, 12), (22, 16), (24, 9)][int(rng.integers(0, 7))]

@@ -569,10 +569,11 @@ def test_single_wave_query_blocks_short_reads_with_long_outliers():
     idx.close()
 
 
-def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram():
+def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram(monkeypatch):
     """a hierarchy of 10 101 small IXFs (root -> 100 -> 10 000): the work queues of the deeper levels are grouped by IXF
     id with a counting sort whose per-block histogram covers ids below 8192 in LDS and takes the rest through global
     atomics -- genomes planted under IXFs on both sides of that boundary, against the oracle"""
+    monkeypatch.setenv("TAXOR_QUERY_GROUP_MIN", "0")     # sub-batches below 4096 reads are not grouped by default; this test is about the grouping
     rng = np.random.default_rng(77)
     g, go = synth.random_genomes(6, 6000, seed=77)
     planted = [np.unique(orc.seq_to_syncmers(bytes(g[int(go[i]):int(go[i + 1])]))) for i in range(6)]
