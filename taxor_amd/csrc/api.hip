@@ -1132,7 +1132,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
         static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         // (and for a root level whose items all fit ONE round of the wide grid but not of the narrow one -- the reference's
-        // chunk of 1024 reads on 256 CUs: 768 resident blocks take two rounds of ~150-us items, 1024 take one)
+        // chunk of 1024 reads on 256 CUs; two searchers in flight gain ~10 %, one nothing)
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4) ||
                                (lvl == 0 && n_reads > (uint64_t)s->grid_query && n_reads <= (uint64_t)s->grid_query_short);
         const bool root_streams = idx->rows[0] * (uint64_t)idx->h_ixf[0].stride > (16ull << 30);   // root table beyond any cache
