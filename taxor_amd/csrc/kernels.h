@@ -54,6 +54,7 @@ struct Counters {
     PaddedU32 n_hits;
     PaddedU32 q_n[16];                // work items per level
     PaddedU32 q_cursor[16];           // dynamic work cursor per level
+    PaddedU32 q_xcur[16][8];          // levels below the root, queue grouped by IXF: one cursor per eighth of the queue (QueryArgs::xcd_slices)
     alignas(128) unsigned long long tuple_total;   // tuples emitted so far in this batch run
     unsigned long long n_hashes;                   // distinct hashes so far
     alignas(128) unsigned long long query_bytes;   // sum n_h*3*bins over work items
@@ -122,6 +123,8 @@ struct QueryArgs {
     uint32_t cursor_chunk;    // work items taken per cursor atomic (0 = 1)
     float prune_margin;       // constant term of the pruning margin mu + 4 sqrt(mu) + c (0 = 3.5)
     uint32_t sparse_stages;   // stages of the pruned phase for long hash lists (0 = 3); between stages the alive set is re-evaluated
+    uint32_t xcd_slices;      // 8 = the (IXF-grouped) queue is cut into eight slices and block b starts in slice b % 8 -- the XCD the
+                              // dispatcher places it on -- so an IXF's items meet in one XCD's L2 instead of all eight; 0 = one cursor
     uint32_t tally_mode;      // measurement aid (TAXOR_QUERY_TALLY): bit 0 = tally walks every bin, bit 1 = bin info fetched per item
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };

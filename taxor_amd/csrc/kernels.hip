@@ -1269,11 +1269,35 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         __syncthreads();
         if (item == item_end) {
             flush_out(false);
-            if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, chunk);
-            __syncthreads();
-            item = item0 = sScal[0];
-            item_end = min(item + chunk, n_items);
-            if (item >= n_items) break;
+            if (a.xcd_slices) {
+                // Eight slices of the grouped queue, eight cursors.  A block starts in the slice of its XCD (the dispatcher is
+                // observed to place block b on XCD b % 8; a wrong guess is slower, not wrong) and moves on to the next slice when
+                // its own is exhausted, so the launch ends balanced.  The items of one IXF are neighbours in the queue: they are
+                // now read through ONE L2 (4 MiB per XCD) instead of being fetched into all eight.
+                if (tid == 0) {
+                    const uint32_t per = (n_items + 7u) >> 3;
+                    uint32_t got = n_items, got_end = n_items;
+                    for (uint32_t k = 0; k < 8u; ++k) {
+                        const uint32_t sl = (blockIdx.x + k) & 7u;
+                        const uint32_t lo = min(sl * per, n_items), hi = min(lo + per, n_items);
+                        if (lo >= hi) continue;
+                        const uint32_t i = atomicAdd(&a.ctr->q_xcur[min(lvl, 15u)][sl].v, chunk);
+                        if (i < hi - lo) { got = lo + i; got_end = hi; break; }
+                    }
+                    sScal[0] = got;
+                    sScal[7] = got_end;
+                }
+                __syncthreads();
+                item = item0 = sScal[0];
+                item_end = min(item + chunk, sScal[7]);
+                if (item >= n_items) break;
+            } else {
+                if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[lvl].v, chunk);
+                __syncthreads();
+                item = item0 = sScal[0];
+                item_end = min(item + chunk, n_items);
+                if (item >= n_items) break;
+            }
             if (tid < item_end - item) {                             // one lane per item of the chunk
                 uint32_t r_, v_;
                 if (a.q_in) { const uint2 it = a.q_in[item + tid]; r_ = it.x; v_ = it.y; }
