@@ -1114,8 +1114,9 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         const uint32_t group_min = gm ? (uint32_t)atoi(gm) : 4096u;
         q.xcd_slices = 0;
         if (lvl >= 1 && only_ixf < 0 && group_queue && n_reads >= group_min) {
-            static const bool xcd_env = [] { const char *e = getenv("TAXOR_QUERY_XCD"); return !e || atoi(e) != 0; }();
-            q.xcd_slices = xcd_env ? 8u : 0u;
+            static const uint32_t xcd_env = [] { const char *e = getenv("TAXOR_QUERY_XCD"); const int v = e ? atoi(e) : 8;
+                                                 return (v == 1 || v == 8) ? 8u : (v == 2 || v == 4) ? (uint32_t)v : 0u; }();   // 0 = one cursor; 2 / 4 = XCD pairs / quads share a slice
+            q.xcd_slices = xcd_env;
             // this level's items, pushed by the previous one in no particular order, grouped by IXF: blocks that run at
             // the same time then read the same few child IXFs (cache-resident) instead of rows all over the slab
             launch_queue_group_by_ixf(s->d_q[lvl & 1].p, s->d_ctr, lvl, s->q_cap, s->d_qhist.p, (uint32_t)idx->h_ixf.size(), s->d_qs.p, s->st);

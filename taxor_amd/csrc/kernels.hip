@@ -1275,10 +1275,11 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 // its own is exhausted, so the launch ends balanced.  The items of one IXF are neighbours in the queue: they are
                 // now read through ONE L2 (4 MiB per XCD) instead of being fetched into all eight.
                 if (tid == 0) {
-                    const uint32_t per = (n_items + 7u) >> 3;
+                    const uint32_t S = a.xcd_slices;                       // 8, or fewer (power of two): neighbouring XCDs share a slice
+                    const uint32_t per = (n_items + S - 1u) / S;
                     uint32_t got = n_items, got_end = n_items;
-                    for (uint32_t k = 0; k < 8u; ++k) {
-                        const uint32_t sl = (blockIdx.x + k) & 7u;
+                    for (uint32_t k = 0; k < S; ++k) {
+                        const uint32_t sl = (((blockIdx.x & 7u) * S >> 3) + k) & (S - 1u);
                         const uint32_t lo = min(sl * per, n_items), hi = min(lo + per, n_items);
                         if (lo >= hi) continue;
                         const uint32_t i = atomicAdd(&a.ctr->q_xcur[min(lvl, 15u)][sl].v, chunk);
