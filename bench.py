@@ -27,7 +27,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   cpu_baseline : the CPU oracle (oracle/, a port of the reference path) timed on this box's host cores on a
                  bounded sample of the same reads and index; also used to re-check parity on that sample.
   sustained    : >= 10 M reads fed from HOST buffers through taxor_gpu_search_batch_begin/_end (PCIe inside),
-                 rotating through the same distinct batches; never reported as `value`.
+                 rotating through the same distinct batches.  Top level: value_host_fed (= sustained.value, or the sum over
+                 ranks at N > 1).  `value` itself stays the contract's figure -- K timed steps over HBM-resident batches (the
+                 task statement: a PCIe-inclusive rate "is never `value`") -- and the two sit side by side in every line.
+  value_e04    : the same index with reads at 4 % error (BASELINE.md section 3's workload; the default is 0.02, see
+                 --read-error), resident and host-fed, detail under "read_error_0.04".
+  roofline.contract_frac / moved_frac : SURVEY 8(d)'s formula on the kernel that does all of that work (= unpruned.frac) and
+                 the bytes the memory side moved (= traffic_frac_of_peak), beside `frac` (requested bytes of the pruned kernel).
+  TAXOR_BENCH_FORCE_DIST=1 : every N > 1 branch with one rank (RCCL process group, probe gather, collectives) -- tests.
   N > 1        : pcie_inclusive_per_rank -- rank 0's host-fed rate alone, then every rank's at once, and
                  host_fed_scaling = their sum / rank 0's solo rate (the resident `value` scales by construction);
                  host_binding = the NUMA node each rank bound itself to before its first HIP call.
@@ -114,6 +121,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
     ap.add_argument("--no-unpruned", action="store_true", help="skip the pruning-off pass")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the gather-ceiling microkernel")
+    ap.add_argument("--no-e04", action="store_true", help="skip the extra leg at read error 0.04 (BASELINE.md section 3's workload)")
     ap.add_argument("--sustained-reads", type=int, default=10_000_000, help="host-fed reads of the `sustained` figure (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--traffic", default="live", choices=("live", "none"),
@@ -369,6 +377,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # TAXOR_BENCH_FORCE_DIST=1: take every `world > 1` branch with WORLD_SIZE = 1 -- process group on RCCL with a device id,
+    # the probe gather on device tensors, all_gather / all_reduce / barrier, the per-step result gather, the solo-then-
+    # concurrent host-fed block, destroy_process_group -- so that ONE GPU executes the code the 8-GPU launch runs
+    # (tests/test_gpu_bench_multirank.py).  The line it prints must agree with the plain N = 1 run.
+    force_dist = os.environ.get("TAXOR_BENCH_FORCE_DIST") == "1"
+    dist_on = world > 1 or force_dist
 
     # Bind this rank's host threads (and, by first touch, its staging buffers) to the NUMA node of its GPU before
     # anything touches the GPU: eight ranks feeding eight GPUs from host memory otherwise stage across the socket
@@ -402,8 +416,15 @@ def main():
     if os.environ.get("TAXOR_BENCH_SAME_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:      # forced single-rank group launched without torch.distributed.run
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         # Fail loudly and early: a rendezvous or first-transfer failure must end the job with one readable line and a
         # non-zero exit code, not a hang in the timed region or a silent change of transport (no fallback, no re-exec).
         try:
@@ -447,7 +468,7 @@ def main():
 
     def gather_results(sr):
         """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
-        if world == 1:
+        if not dist_on:
             return
         nr, nt = sr.result_sizes()
         dev = torch.device("cuda", local_rank)
@@ -471,7 +492,7 @@ def main():
     def timed(pool, steps, warmup):
         for i in range(warmup):
             step(i, pool)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -499,10 +520,10 @@ def main():
                 acc["lvl_rows"][l] += st["level_row_reads"][l]
                 acc["lvl_sparse"][l] += st["level_sparse_loads"][l]
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if dist_on:
             tt = torch.tensor([elapsed, float(acc["bases"])], dtype=torch.float64,
                               device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
             dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
@@ -513,14 +534,14 @@ def main():
         return elapsed, acc
 
     elapsed, acc = timed(searchers, args.steps, args.warmup)
-    if world > 1 and rank == 0:
+    if dist_on and rank == 0:
         g_off, g_ub, g_cnt, g_nh = gathered["last"]
         assert g_off.numel() == g_nh.numel() + 1 and int(g_off[-1]) == g_ub.numel() == g_cnt.numel()
         want = n_reads if args.scaling == "strong" else n_reads * world
         assert g_nh.numel() == want, (g_nh.numel(), want)
     value = acc["all_bases"] / elapsed / 1e6
     if args.dump_results and rank == 0:
-        if world > 1:
+        if dist_on:
             d_off, d_ub, d_cnt, d_nh = (x.cpu().numpy() for x in gathered["last"])
         else:
             r_ = searchers[(args.warmup + args.steps - 1) % len(searchers)].fetch()
@@ -534,7 +555,7 @@ def main():
     # first runs the host-fed measurement ALONE (the other ranks wait at a barrier: the N = 1 condition inside this very
     # job), then every rank runs it at once; host_fed_scaling = sum of the concurrent per-rank rates / rank 0's solo rate.
     per_rank = None
-    if world > 1 and not args.no_dropin and not args.pmc_child:
+    if dist_on and not args.no_dropin and not args.pmc_child:
         small = argparse.Namespace(**vars(args))
         small.sustained_reads = max(1, args.sustained_reads // 4)
 
@@ -632,15 +653,11 @@ def main():
 
         # ---- the contract formula on a kernel that does all the algorithmic work: pruning off -------------------
         if not args.no_unpruned and world == 1:
-            os.environ["TAXOR_QUERY_PRUNE"] = "0"
-            try:
-                pool = []
-                for bases, offs in batches[:2]:
-                    s2 = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
-                    s2.upload(bases, offs)
-                    pool.append(s2)
-            finally:
-                del os.environ["TAXOR_QUERY_PRUNE"]
+            pool = []
+            for bases, offs in batches[:2]:
+                s2 = Searcher(idx, error_rate=args.error_rate, time_kernels=True, prune=False)
+                s2.upload(bases, offs)
+                pool.append(s2)
             e2, a2 = timed(pool, max(2, min(args.steps, 4)), 1)
             q2 = a2["q_ms"] * 1e-3
             assert a2["q_touched"] == a2["q_bytes"]
@@ -648,7 +665,7 @@ def main():
                                 "avg_launch_ms": round(a2["q_ms"] / max(1, a2["launches"]), 4),
                                 "algorithmic_bytes_per_launch": round(a2["q_bytes"] / max(1, a2["launches"]), 1),
                                 "value_Mbp_s": round(a2["all_bases"] / e2 / 1e6, 2),
-                                "note": "TAXOR_QUERY_PRUNE=0: every hash against every bin of every visited IXF, like the reference"}
+                                "note": "taxor_gpu_search_params.flags = TAXOR_SEARCH_NO_PRUNE: every hash against every bin of every visited IXF, like the reference"}
             ra, rb = pool[0].fetch(), searchers[0].fetch()      # both hold batch 0: pruning must not change a single tuple
             same = (np.array_equal(ra.read_off, rb.read_off) and np.array_equal(ra.user_bin, rb.user_bin)
                     and np.array_equal(ra.count, rb.count) and np.array_equal(ra.n_hashes, rb.n_hashes))
@@ -656,6 +673,42 @@ def main():
                 raise SystemExit("PARITY FAILURE: pruning changed the results")
             for s2 in pool:
                 s2.close()
+
+        # the three readings of the roofline side by side at top level, so that they cannot be confused:
+        #   frac          requested bytes (sector64 accounting) of the pruned kernel / its time / peak  -- what the kernel asks for
+        #   contract_frac SURVEY 8(d)'s formula, n_h*3*bins per visited IXF / time / peak, on the kernel that does ALL of
+        #                 that work (pruning off): the contract's number
+        #   moved_frac    bytes the memory side actually moved (PMC request counters) / time / peak
+        roof["contract_frac"] = roof.get("unpruned", {}).get("frac")
+        roof["moved_frac"] = roof.get("traffic_frac_of_peak")
+
+        # ---- BASELINE.md section 3's read error (0.04) beside the default 0.02 (why 0.02: --read-error's help text) ---------
+        e04 = None
+        if world == 1 and not args.no_e04 and args.mode == "syncmer" and not args.len_mix and abs(args.read_error - 0.04) > 1e-9:
+            from taxor_amd import synth as synth_
+            t0_ = time.time()
+            pool, b04 = [], []
+            for b in range(2):
+                bb, oo, _ = synth_.synth_reads(info["genomes"], info["genome_off"], n_reads, read_len, error_rate=0.04, frac_random=0.1,
+                                               seed=synth_.DEFAULT_SEED + 77000 + b, threads=ncpu)
+                bb, oo = np.ascontiguousarray(bb), np.ascontiguousarray(oo)
+                b04.append((bb, oo))
+                s2 = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+                s2.upload(bb, oo)
+                s2.run()
+                s2.sync()
+                pool.append(s2)
+            e4, a4 = timed(pool, max(2, min(args.steps, 6)), 2)
+            q4 = a4["q_ms"] * 1e-3
+            e04 = {"read_error": 0.04, "value": round(a4["all_bases"] / e4 / 1e6, 2), "unit": "Mbp/s",
+                   "frac": round(a4["q_touched"] / q4 / 1e9 / HBM_PEAK_GBS, 4) if q4 > 0 else None,
+                   "tuples_per_read": round(a4["tuples"] / max(1, a4["reads"]), 3), "work_items_per_read": round(a4["work"] / max(1, a4["reads"]), 3),
+                   "note": "the same index and searcher settings, reads with 4 % errors (BASELINE.md section 3): few of them keep enough "
+                           "22-mers to pass the 0.508 the reference's model demands, so most stop at the root -- the easier case"}
+            for s2 in pool:
+                s2.close()
+            e04["_batches"] = b04          # host-fed below, once the resident searchers (and their streams) are gone
+            log(f"read error 0.04 leg: {e04['value']:.0f} Mbp/s resident, {time.time()-t0_:.1f}s")
 
         # measured gather ceiling: random whole-row reads of the same IXFs by a kernel that does nothing else
         if not args.no_ceiling:
@@ -702,17 +755,36 @@ def main():
                                   "finalize": round(acc["fin_ms"] / args.steps, 3), "total": round(acc["total_ms"] / args.steps, 3),
                                   "note": "HIP-event sums per stream; syncmers of sub-batch i+1 overlap the query of sub-batch i"},
         }
-        if world == 1 and not args.no_dropin:
+        if world == 1 and not dist_on and not args.no_dropin:
             # the resident searchers (and their streams) are not needed any more: a drop-in user's process holds the one or two
             # searchers it feeds, and the figures below are measured like that
             for sr in searchers:
                 sr.close()
             searchers = []
             out["pcie_inclusive"], out["sustained"] = dropin_measurements(args, idx, batches, read_len)
+            if out["sustained"]:
+                out["value_host_fed"] = out["sustained"]["value"]
+            if e04 is not None and args.sustained_reads > 0:
+                a04 = argparse.Namespace(**vars(args))
+                a04.sustained_reads = max(1, min(args.sustained_reads, 2_000_000))
+                _, sus04 = dropin_measurements(a04, idx, e04["_batches"], read_len, single=False)
+                e04["value_host_fed"] = sus04["value"]
+                e04["host_fed_reads"] = sus04["reads"]
         if per_rank is not None:
             out["pcie_inclusive_per_rank"] = per_rank
             out["sustained_sum_Mbp_s"] = per_rank["sustained_sum_Mbp_s"]
             out["host_fed_scaling"] = per_rank["host_fed_scaling"]
+            out["value_host_fed"] = per_rank["sustained_sum_Mbp_s"]
+        if "value_host_fed" in out:
+            out["value_note"] = ("`value` is the contract's figure: K timed steps over batches already resident in HBM (2-bit packed).  "
+                                 "`value_host_fed` is the drop-in figure -- >= --sustained-reads reads fed from host buffers through "
+                                 "taxor_gpu_search_batch (PCIe, on-device packing and the D2H copy of the results inside), whole job")
+        if e04 is not None:
+            e04.pop("_batches", None)
+            out["value_e04"] = e04["value"]
+            if "value_host_fed" in e04:
+                out["value_e04_host_fed"] = e04["value_host_fed"]
+            out["read_error_0.04"] = e04
         out["host_binding"] = numa_info
         if world == 1 and not args.no_cpu_baseline:
             os.sched_setaffinity(0, full_affinity)      # the CPU baseline is timed on the box's host cores, all sockets
@@ -723,12 +795,12 @@ def main():
     for sr in searchers:
         sr.close()
     idx.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def dropin_measurements(args, idx, batches, read_len):
+def dropin_measurements(args, idx, batches, read_len, single=True):
     """The drop-in boundary with HOST buffers: (a) one taxor_gpu_search_batch call on pageable memory; (b) the sustained
     rate over >= --sustained-reads reads, rotating through the distinct batches from page-locked staging buffers with two
     searchers in flight (what the CLI's GPU workers do), results fetched to the host every call."""
@@ -737,16 +809,19 @@ def dropin_measurements(args, idx, batches, read_len):
     sr = Searcher(idx, error_rate=args.error_rate)
     bases, offs = batches[0]
     sr.search_batch(bases, offs)
-    samples = []
-    for _ in range(3):     # the blocking copies out of pageable memory vary from call to call (26-41 ms for the same 1.3 GB): median of three
-        t0 = time.perf_counter()
-        sr.search_batch(bases, offs, copy=False)   # the C call, results in the library's host arrays (what a C++ host gets)
-        samples.append(time.perf_counter() - t0)
-    dt = sorted(samples)[1]
-    single = {"seconds": round(dt, 4), "value": round(float(offs[-1]) / dt / 1e6, 2), "unit": "Mbp/s",
-              "samples_s": [round(x, 4) for x in samples],
-              "note": "one taxor_gpu_search_batch on host buffers (median of three calls): ASCII bases from pageable memory, streamed "
-                      "H2D + on-device pack overlapped with compute, results fetched to host; per GPU"}
+    if single:
+        samples = []
+        for _ in range(3):     # the blocking copies out of pageable memory vary from call to call (26-41 ms for the same 1.3 GB): median of three
+            t0 = time.perf_counter()
+            sr.search_batch(bases, offs, copy=False)   # the C call, results in the library's host arrays (what a C++ host gets)
+            samples.append(time.perf_counter() - t0)
+        dt = sorted(samples)[1]
+        single = {"seconds": round(dt, 4), "value": round(float(offs[-1]) / dt / 1e6, 2), "unit": "Mbp/s",
+                  "samples_s": [round(x, 4) for x in samples],
+                  "note": "one taxor_gpu_search_batch on host buffers (median of three calls): ASCII bases from pageable memory, streamed "
+                          "H2D + on-device pack overlapped with compute, results fetched to host; per GPU"}
+    else:
+        single = None
     sustained = None
     if args.sustained_reads > 0:
         L = _lib.lib()

@@ -156,7 +156,19 @@ typedef struct {
     uint32_t time_kernels;    /* 1 = bracket the dominant kernel with HIP events               */
     uint32_t model;           /* TAXOR_THR_*; PERCENTAGE and SYNCMER use `ratio`               */
     double error_rate;        /* --error-rate, used by the KMER and FRACMINHASH models         */
+    uint32_t flags;           /* TAXOR_SEARCH_* below; 0 = the defaults.  None changes a result      */
 } taxor_gpu_search_params;
+
+/* taxor_gpu_search_params::flags.  Choices a caller (a test, a benchmark) makes per searcher; the library reads nothing of
+ * the kind from the environment unless TAXOR_TUNING=1 is set (taxor_amd/csrc/tuning.h). */
+enum {
+    TAXOR_SEARCH_NO_PRUNE = 1u,      /* count every hash against every bin of every visited IXF, the reference's formulation
+                                        (hierarchical_interleaved_xor_filter.hpp:307-309) -- the default stops counting bin runs
+                                        that provably cannot reach the threshold; tuples are identical either way */
+    TAXOR_SEARCH_GROUP_ALWAYS = 2u,  /* group each level's work items by IXF whatever the sub-batch size (default: from 4096 reads) */
+    TAXOR_SEARCH_NO_SMALL_PATH = 4u, /* calls of a few thousand reads take the level-synchronous pipeline of large batches */
+    TAXOR_SEARCH_SPLIT_ALWAYS = 8u   /* root work items are split over column ranges (several blocks per read) whatever the batch size */
+};
 
 typedef struct taxor_gpu_searcher taxor_gpu_searcher;
 
@@ -246,12 +258,15 @@ int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read_off, void 
  *                                       order -- reads of searcher 0 first -- with offsets rebased.
  * Replaces: the reference has one address space; its workers write into one result stream under a mutex
  * (taxor_search.cpp:311, sync_out.hpp:24-29) and all read the one loaded index (taxor_search.cpp:323).
- * Transports: TAXOR_COMM_RCCL (RCCL bound at run time; one rank per device, a device may not repeat) or
+ * Transports: TAXOR_COMM_RCCL (RCCL bound at run time; one rank per device, a device may not repeat; creation sends known
+ * bytes through a broadcast and a grouped send/recv between all ranks and fails if they arrive wrong) or
  * TAXOR_COMM_HOST (same calls, every transfer staged through host memory over each device's own PCIe link).  A
  * communicator never changes transport by itself: a failing RCCL call is an error return.
- * Single-caller: create / replicate / gather are called from one host thread while no searcher of the communicator
- * is running a batch (gather synchronises the searchers it is given).  Result pointers stay valid until the next
- * gather on the communicator.
+ * Single-caller: create / replicate / gather of one communicator are called from one host thread at a time.  A gather
+ * waits for the runs of the searchers it is given (they may still be in flight when it is called) and touches nothing
+ * else: OTHER searchers on the same devices -- a second set working on the next round, which is how `taxor search --gpus N`
+ * overlaps one round's gather with the next round's kernels -- may keep running batches meanwhile.  Result pointers stay
+ * valid until the next gather on the communicator.
  * ---------------------------------------------------------------------------------------------- */
 enum { TAXOR_COMM_RCCL = 0, TAXOR_COMM_HOST = 1 };
 typedef struct taxor_gpu_comm taxor_gpu_comm;
@@ -270,8 +285,16 @@ typedef struct {
     double index_seconds;            /* wall time of taxor_gpu_index_create_replicated                    */
     uint64_t gathers, gather_bytes;  /* gather calls; result bytes that left a peer device                */
     double gather_seconds;           /* wall time inside taxor_gpu_gather_results (sync of the runs included) */
+    uint64_t index_broadcast_calls;  /* grouped ncclBroadcast rounds issued behind the upload (RCCL transport)  */
+    uint64_t self_exchange_bytes;    /* result bytes rank 0 sent to itself through ncclSend/ncclRecv (test hook below) */
+    int32_t rccl_version;            /* ncclGetVersion of the RCCL bound at run time, 0 = none loaded           */
+    uint64_t selftest_bytes;         /* known bytes verified through ncclBroadcast + ncclSend/ncclRecv at creation (RCCL) */
 } taxor_gpu_comm_stats;
 int taxor_gpu_comm_info(const taxor_gpu_comm *c, taxor_gpu_comm_stats *out);
+/* Test hook for boxes with ONE GPU: with on != 0, rank 0's own part of every gather travels through the grouped
+ * ncclSend / ncclRecv (to itself) like a peer's instead of a device-to-device copy, so a communicator of one rank executes
+ * the exchange code of a larger run line by line.  Results are unchanged.  RCCL transport only. */
+int taxor_gpu_comm_set_self_exchange(taxor_gpu_comm *c, int on);
 
 /* Measurement of the last taxor_gpu_batch_run (valid after sync).  algorithmic_bytes follows SURVEY.md
  * section 8(d): sum over reads of ceil(L/4) + sum over visited IXFs n_h*3*bins + 8 + 12*tuples;

@@ -54,7 +54,7 @@ configs = ([], [], ["--threads", "16"], ["--gpu-list", "0,0"], ["--threads", "1"
 for extra in configs:
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq,
-                         "--output-file", out] + (["--threads", "32"] if "--threads" not in extra else []) + extra, capture_output=True, text=True, env=dict(os.environ, TAXOR_CLI_TRACE="1"))
+                         "--output-file", out] + (["--threads", "32"] if "--threads" not in extra else []) + extra, capture_output=True, text=True, env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1"))
     dt = time.time() - t0
     print(" ".join(extra) or "(default batch)", "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end")
     print(cp.stdout.strip().replace("\n", " | "))

@@ -6,6 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["TAXOR_TUNING"] = "1"          # the library reads its measurement knobs only behind this gate
 os.environ["TAXOR_PROFILE_PHASES"] = "1"
 import torch  # noqa: F401,E402  (its HIP runtime first)
 

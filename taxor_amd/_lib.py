@@ -41,7 +41,10 @@ class ReadSegment(C.Structure):
 
 class SearchParams(C.Structure):
     _fields_ = [("ratio", C.c_double), ("sub_batch_reads", C.c_uint32), ("sub_batch_bases", C.c_uint64),
-                ("time_kernels", C.c_uint32), ("model", C.c_uint32), ("error_rate", C.c_double)]
+                ("time_kernels", C.c_uint32), ("model", C.c_uint32), ("error_rate", C.c_double), ("flags", C.c_uint32)]
+
+
+SEARCH_NO_PRUNE, SEARCH_GROUP_ALWAYS, SEARCH_NO_SMALL_PATH, SEARCH_SPLIT_ALWAYS = 1, 2, 4, 8
 
 
 THR_PERCENTAGE, THR_SYNCMER, THR_KMER, THR_FRACMINHASH = 0, 1, 2, 3
@@ -65,7 +68,8 @@ class RunStats(C.Structure):
 class CommStats(C.Structure):
     _fields_ = [("transport", C.c_int32), ("n_devices", C.c_uint32), ("index_bytes", C.c_uint64), ("index_upload_bytes", C.c_uint64),
                 ("index_broadcast_bytes", C.c_uint64), ("index_seconds", C.c_double), ("gathers", C.c_uint64),
-                ("gather_bytes", C.c_uint64), ("gather_seconds", C.c_double)]
+                ("gather_bytes", C.c_uint64), ("gather_seconds", C.c_double), ("index_broadcast_calls", C.c_uint64),
+                ("self_exchange_bytes", C.c_uint64), ("rccl_version", C.c_int32), ("selftest_bytes", C.c_uint64)]
 
 
 COMM_RCCL, COMM_HOST = 0, 1
@@ -138,6 +142,7 @@ SIGNATURES = {
     "taxor_gpu_index_create_replicated": (C.c_int, [_P, C.POINTER(HixfView), C.POINTER(_P)]),
     "taxor_gpu_gather_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(Results)]),
     "taxor_gpu_comm_info": (C.c_int, [_P, C.POINTER(CommStats)]),
+    "taxor_gpu_comm_set_self_exchange": (C.c_int, [_P, C.c_int]),
     "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),

@@ -4,6 +4,7 @@
 #include "../../include/taxor_gpu.h"
 #include "ixf_arith.h"
 #include "kernels.h"
+#include "tuning.h"
 
 #include <sys/mman.h>
 
@@ -125,7 +126,8 @@ struct taxor_gpu_searcher {
     int grid_sync = 0, grid_sync_overlap = 0, grid_query = 0, grid_query_short = 0;   // query blocks: 3 per CU, 4 for short reads
     uint32_t first_div = 1; // first sub-batch = 1/first_div of the others (its syncmer kernel is not hidden)
     bool auto_sub_reads = true; // sub_batch_reads was left to the library: short reads get more of them per sub-batch
-    bool prune = true;   // TAXOR_QUERY_PRUNE=0 disables the threshold-aware pruning (A/B measurements)
+    bool prune = true;   // taxor_gpu_search_params::flags & TAXOR_SEARCH_NO_PRUNE disables the threshold-aware pruning (A/B measurements)
+    bool group_always = false;   // TAXOR_SEARCH_GROUP_ALWAYS: the queue grouping also for sub-batches of a few thousand reads
     size_t lds_query = 0;
 
     // batch-resident input
@@ -220,7 +222,7 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*progress)(void *, uint64_t), void *pctx)
 {
     struct Piece { uint64_t ixf, off, len, slab_end; };
-    static const uint64_t piece_bytes = [] { const char *e = getenv("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 8) << 20; }();
+    static const uint64_t piece_bytes = [] { const char *e = tune_env("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 8) << 20; }();
     const uint64_t n = v->n_ixf;
     std::vector<Piece> pieces;
     for (uint64_t i = 0; i < n; ++i) {
@@ -234,7 +236,7 @@ static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*p
         }
     }
     if (pieces.empty()) { if (progress) progress(pctx, idx->slab_bytes); return 0; }
-    static const bool trace_up = getenv("TAXOR_TRACE_UPLOAD") != nullptr;
+    static const bool trace_up = tune_env("TAXOR_TRACE_UPLOAD") != nullptr;
     const auto up_t0 = std::chrono::steady_clock::now();
     struct UpTrace {
         bool on; std::chrono::steady_clock::time_point t0; const std::vector<Piece> &pc; bool src;
@@ -253,7 +255,7 @@ static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*p
         // copy thread takes those faults one 4-KiB page at a time.  For a mapped file of tens of gigabytes that is most of
         // the time; a few helper threads populate the page tables ahead of the copy (MADV_POPULATE_READ, Linux >= 5.14;
         // where the kernel does not know it the call fails and the copy faults the pages in as before).
-        static const int pf_threads = [] { const char *e = getenv("TAXOR_UPLOAD_PREFAULT"); const int t = e ? atoi(e) : -1; return t >= 0 && t <= 64 ? t : 8; }();
+        static const int pf_threads = [] { const char *e = tune_env("TAXOR_UPLOAD_PREFAULT"); const int t = e ? atoi(e) : -1; return t >= 0 && t <= 64 ? t : 8; }();
         uint64_t total = 0;
         for (const Piece &p : pieces) total += p.len;
         std::atomic<size_t> pf_cursor{0};
@@ -289,7 +291,7 @@ static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*p
         if (progress) progress(pctx, idx->slab_bytes);
         return 0;
     }
-    static const int n_threads = [] { const char *e = getenv("TAXOR_UPLOAD_THREADS"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 64 ? t : 8; }();
+    static const int n_threads = [] { const char *e = tune_env("TAXOR_UPLOAD_THREADS"); const int t = e ? atoi(e) : 0; return t >= 1 && t <= 64 ? t : 8; }();
     const int T = (int)std::min<size_t>((size_t)n_threads, pieces.size());
     std::atomic<size_t> cursor{0};
     std::vector<std::atomic<uint8_t>> done(pieces.size());
@@ -654,7 +656,7 @@ extern "C" int taxor_gpu_gather_ceiling_span(taxor_gpu_index *idx, uint64_t ixf,
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    static const bool nt = [] { const char *e = getenv("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
+    static const bool nt = [] { const char *e = tune_env("TAXOR_QUERY_NT"); return !e || atoi(e) != 0; }();
     uint64_t bytes = launch_gather_ceiling(f.data, idx->rows[ixf], (uint32_t)f.stride, f.bins, want_bytes, 1, sink, nt, nullptr, (uint32_t)span, spacing);   // warm-up
     HIP_TRY(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps; ++r)
@@ -780,36 +782,38 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
         return fail(TAXOR_E_ARG, "searcher_create: an IXF with %u-byte rows does not fit the LDS tally", idx->max_stride);
     }
     s->grid_sync = syncmers_grid(idx->device);
-    if (const char *e = getenv("TAXOR_PROFILE_PHASES")) {
+    if (const char *e = tune_env("TAXOR_PROFILE_PHASES")) {
         if (atoi(e) != 0 && (hipMalloc((void **)&s->d_prof, 16 * sizeof(unsigned long long)) != hipSuccess ||
                              hipMemset(s->d_prof, 0, 16 * sizeof(unsigned long long)) != hipSuccess)) {
             taxor_gpu_searcher_destroy(s);
             return fail(TAXOR_E_HIP, "searcher_create: profile buffer");
         }
     }
-    if (const char *e = getenv("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
-    if (const char *e = getenv("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
-    if (const char *e = getenv("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) { s->prm.sub_batch_reads = (uint32_t)v; s->auto_sub_reads = false; } }
+    s->prune = !(prm->flags & TAXOR_SEARCH_NO_PRUNE);
+    s->group_always = (prm->flags & TAXOR_SEARCH_GROUP_ALWAYS) != 0;
+    if (const char *e = tune_env("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
+    if (const char *e = tune_env("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
+    if (const char *e = tune_env("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) { s->prm.sub_batch_reads = (uint32_t)v; s->auto_sub_reads = false; } }
     {   // syncmer launches that run beside a query kernel keep to two blocks per CU: at full occupancy (three) the
         // query kernel stalls for as long as the syncmer kernel runs (measured); with one or two it is not slowed
         hipDeviceProp_t p;
         int per = 2;
-        if (const char *e = getenv("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+        if (const char *e = tune_env("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
         s->grid_sync_overlap = hipGetDeviceProperties(&p, idx->device) == hipSuccess ? p.multiProcessorCount * per : s->grid_sync;
         if (s->grid_sync_overlap > s->grid_sync) s->grid_sync_overlap = s->grid_sync;
     }
     s->grid_wave = syncmers_wave_grid(idx->device, 8);
     {
         int per = 2;
-        if (const char *e = getenv("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+        if (const char *e = tune_env("TAXOR_SYNC_BPC_OVERLAP")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
         s->grid_wave_overlap = syncmers_wave_grid(idx->device, per);
     }
     s->grid_query = query_grid(idx->device, s->lds_query, 3);
     s->grid_query_short = query_grid(idx->device, s->lds_query, 4);
     {
-        static const bool small_off = [] { const char *e = getenv("TAXOR_QUERY_SMALL"); return e && atoi(e) == 0; }();
+        static const bool small_off = [] { const char *e = tune_env("TAXOR_QUERY_SMALL"); return e && atoi(e) == 0; }();
         for (uint32_t l = 0; l < idx->depth && l < (uint32_t)MAX_LEVELS && !small_off; ++l) {
-            static const uint32_t max_stride_small = [] { const char *e = getenv("TAXOR_QUERY_SMALL_MAXSTRIDE"); return e ? (uint32_t)atoi(e) : 512u; }();
+            static const uint32_t max_stride_small = [] { const char *e = tune_env("TAXOR_QUERY_SMALL_MAXSTRIDE"); return e ? (uint32_t)atoi(e) : 512u; }();
             if (idx->lvl_max_stride[l] == 0 || idx->lvl_max_stride[l] > max_stride_small) continue;      // rows of up to 512 bins (1024-bin roots gain nothing: 34.4 vs 34.7 ms)
             s->lds_query_small[l] = query_lds_bytes(idx->lvl_max_stride[l], true);
             s->grid_query_small[l] = query_grid_small(idx->device, s->lds_query_small[l]);
@@ -938,7 +942,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
             lim_bases = s->prm.sub_batch_bases;
             if (ramp) {
                 double f = 1.0 / (double)first_div;
-                static const double growth = [] { const char *e = getenv("TAXOR_RAMP_GROWTH"); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1.25; }();
+                static const double growth = [] { const char *e = tune_env("TAXOR_RAMP_GROWTH"); const double v = e ? atof(e) : 0.0; return v > 1.0 ? v : 1.25; }();
                 for (size_t i = 0; i < s->subs.size() && f < 1.0; ++i) f *= growth;
                 if (f < 1.0) {
                     lim_reads = std::max<uint64_t>((uint64_t)((double)lim_reads * f), 1);
@@ -974,7 +978,7 @@ int layout_batch(taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_read
     // processing order inside each sub-batch: longest reads first (stable), so the dynamic work cursors hand out
     // the expensive items early and no long read is left alone at the tail of a launch
     order.resize(n_reads);
-    static const bool no_order = getenv("TAXOR_NO_ORDER") != nullptr; // A/B knob for measurements
+    static const bool no_order = tune_env("TAXOR_NO_ORDER") != nullptr; // A/B knob for measurements
     std::vector<uint32_t> tmp;
     const bool wave_ok = idx->w_min == 0 && syncmers_wave_applies(idx->k, idx->s);
     auto split_long_short = [&](SubBatch &sb) {   // the order is longest first: the short reads are a suffix of it
@@ -1097,24 +1101,24 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.max_stride = idx->max_stride;
     q.prune = (d_counts_out == nullptr && s->prune) ? 1u : 0u;
     q.prof = s->d_prof;
-    static const uint32_t stages_env = [] { const char *e = getenv("TAXOR_QUERY_STAGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
+    static const uint32_t stages_env = [] { const char *e = tune_env("TAXOR_QUERY_STAGES"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
     q.sparse_stages = stages_env;
-    static const float margin_env = [] { const char *e = getenv("TAXOR_QUERY_MARGIN"); const double v = e ? atof(e) : 0.0; return v > 0.0 && v < 64.0 ? (float)v : 0.f; }();
+    static const float margin_env = [] { const char *e = tune_env("TAXOR_QUERY_MARGIN"); const double v = e ? atof(e) : 0.0; return v > 0.0 && v < 64.0 ? (float)v : 0.f; }();
     q.prune_margin = margin_env;
-    static const uint32_t tally_env = [] { const char *e = getenv("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
+    static const uint32_t tally_env = [] { const char *e = tune_env("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
     q.tally_mode = tally_env;
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
-    static const bool group_queue = [] { const char *e = getenv("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
+    static const bool group_queue = [] { const char *e = tune_env("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
         q.level = lvl;
         q.q_in = (lvl == 0 && only_ixf < 0) ? nullptr : s->d_q[lvl & 1].p;
         // (not for small sub-batches -- a few thousand items have no cache locality to win, and the grouping's five small
         // launches per level are 5 % of a call of 1024 reads)
-        const char *gm = getenv("TAXOR_QUERY_GROUP_MIN");        // read per call: the parity test of the grouping itself sets it to 0
-        const uint32_t group_min = gm ? (uint32_t)atoi(gm) : 4096u;
+        const char *gm = tune_env("TAXOR_QUERY_GROUP_MIN");        // read per call: the parity test of the grouping itself sets it to 0
+        const uint32_t group_min = gm ? (uint32_t)atoi(gm) : (s->group_always ? 0u : 4096u);
         q.xcd_slices = 0;
         if (lvl >= 1 && only_ixf < 0 && group_queue && n_reads >= group_min) {
-            static const uint32_t xcd_env = [] { const char *e = getenv("TAXOR_QUERY_XCD"); const int v = e ? atoi(e) : 8;
+            static const uint32_t xcd_env = [] { const char *e = tune_env("TAXOR_QUERY_XCD"); const int v = e ? atoi(e) : 8;
                                                  return (v == 1 || v == 8) ? 8u : (v == 2 || v == 4) ? (uint32_t)v : 0u; }();   // 0 = one cursor; 2 / 4 = XCD pairs / quads share a slice
             q.xcd_slices = xcd_env;
             // this level's items, pushed by the previous one in no particular order, grouped by IXF: blocks that run at
@@ -1125,7 +1129,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.q_out = s->d_q[(lvl + 1) & 1].p;
         q.n_level0 = n_reads;
         q.order0 = d_order;
-        static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_QUERY_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t chunk_env = [] { const char *e = tune_env("TAXOR_QUERY_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
         // levels below the root: small items, four per cursor atomic; the root level too when the reads are short (a
         // long read is ~30 us of work and chunks of those would leave blocks idle at the tail of the launch)
         // (1-kb reads at the root, 2 / 4 / 8 per atomic: 23.69 / 23.85 / 23.98 Gbp/s -- profiles/r03/chunk_ab.txt)
@@ -1134,7 +1138,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         if (ev_begin(s, 16 + (int)std::min(lvl, 7u), &slot)) return TAXOR_E_HIP;
         // four blocks per CU for short reads and for every level below the root (small items: half their time is spent
         // outside the gather loop, and by then the next sub-batch's syncmer kernel has left the CUs), three otherwise
-        static const int bpc_l1 = [] { const char *e = getenv("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
+        static const int bpc_l1 = [] { const char *e = tune_env("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         // (and for a root level whose items all fit ONE round of the wide grid but not of the narrow one -- the reference's
         // chunk of 1024 reads on 256 CUs; two searchers in flight gain ~10 %, one nothing)
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4) ||
@@ -1219,7 +1223,7 @@ int launch_syncmers_sub(taxor_gpu_searcher *s, const SubBatch &sb, size_t sub_i,
     a.ctr = s->d_ctr;
     a.n_reads = sb.n;
     {   // short reads: eight per cursor atomic (metadata + first words prefetched); long reads one (load balance at the tail)
-        static const uint32_t chunk_env = [] { const char *e = getenv("TAXOR_SYNC_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
+        static const uint32_t chunk_env = [] { const char *e = tune_env("TAXOR_SYNC_CHUNK"); return e ? (uint32_t)atoi(e) : 0u; }();
         a.chunk = chunk_env ? chunk_env : (s->mean_read_len < 2500 ? 8u : (s->mean_read_len < 6000 ? 4u : 1u));
     }
     a.k = idx->k;
@@ -1304,7 +1308,7 @@ namespace {
 // streamed batches: the first sub-batch is 1/n of a full one (TAXOR_STREAM_FIRST_DIV, default 8)
 uint32_t stream_first_div(const taxor_gpu_searcher *s)
 {
-    static const uint32_t env = [] { const char *e = getenv("TAXOR_STREAM_FIRST_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
+    static const uint32_t env = [] { const char *e = tune_env("TAXOR_STREAM_FIRST_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (uint32_t)v : 0u; }();
     return env ? env : std::max(s->first_div, 8u);
 }
 
@@ -1321,7 +1325,7 @@ int prepare_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offs
     std::vector<uint64_t> &poff = s->lay_poff, &hoff = s->lay_hoff, &aoff = s->lay_aoff;
     std::vector<uint32_t> &rlen = s->h_rlen, &hcap = s->lay_hcap, &order = s->lay_order;
     // streamed: the first sub-batch's PCIe copy has nothing to hide behind either, so it is a quarter the size
-    static const bool trace = getenv("TAXOR_TRACE_BATCH") != nullptr;
+    static const bool trace = tune_env("TAXOR_TRACE_BATCH") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     if (int rc = layout_batch(s, offsets, n_reads, poff, rlen, hoff, hcap, order, streamed ? stream_first_div(s) : s->first_div, streamed))
@@ -1447,7 +1451,7 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
     if (s->st_sync2) HIP_TRY(hipStreamWaitEvent(s->st_sync2, s->ev_reset, 0));
     if (ev_begin(s, 3, &tot_slot)) return TAXOR_E_HIP;
     // TAXOR_NO_OVERLAP=1 (measurement knob): hashing on the query's own stream, at full occupancy, nothing concurrent
-    static const bool no_overlap = [] { const char *e = getenv("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
+    static const bool no_overlap = [] { const char *e = tune_env("TAXOR_NO_OVERLAP"); return e && atoi(e) != 0; }();
     // the bases of sub-batch i, from wherever the caller keeps them: one buffer, or several segments in turn
     size_t span_i = 0;
     auto enqueue_copy = [&](size_t i) -> int {
@@ -1735,7 +1739,7 @@ extern "C" int taxor_gpu_search_batch_end(taxor_gpu_searcher *s, taxor_gpu_resul
 extern "C" int taxor_gpu_search_batch(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads,
                                       taxor_gpu_results *out)
 {
-    static const bool trace = getenv("TAXOR_TRACE_BATCH") != nullptr;   // phase times of this call on stderr
+    static const bool trace = tune_env("TAXOR_TRACE_BATCH") != nullptr;   // phase times of this call on stderr
     const auto t0 = std::chrono::steady_clock::now();
     auto ms_since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
     if (int rc = taxor_gpu_search_batch_begin(s, bases, offsets, n_reads)) return rc;

@@ -15,9 +15,10 @@
 // it is selectable for machines without a working RCCL and is what the parity tests compare the RCCL transport with.
 // A failure is an error return with a message -- a communicator never silently changes transport.
 #include "../../include/taxor_gpu.h"
+#include "tuning.h"
+using taxor::tune_env;
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
@@ -41,6 +42,19 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_searcher_device_resul
                                                                                    const int64_t **d_user_bin, const uint32_t **d_count,
                                                                                    const uint32_t **d_n_hashes, uint64_t *n_reads,
                                                                                    uint64_t *n_tuples, int *device);
+
+// The handful of RCCL declarations this file needs, stated here instead of including <rccl/rccl.h>: the library is bound with
+// dlopen, so a ROCm installation without the RCCL development header still builds libtaxor_gpu.so (TAXOR_COMM_HOST serves
+// there), and nothing is compiled against one copy's header and then run against another's.  These are the stable parts of
+// the NCCL 2 API (opaque communicator handle, result code with 0 = success, ncclUint8 = 1); the copy found at run time is
+// asked for its version and anything but major version 2 is refused (rccl() below).
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;          // an enum in the header; 0 = ncclSuccess
+typedef int ncclDataType_t;        // an enum in the header
+}
+static constexpr ncclResult_t ncclSuccess = 0;
+static constexpr ncclDataType_t ncclUint8 = 1;
 
 namespace {
 
@@ -73,6 +87,8 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    int version = 0;
     bool ok = false;
 };
 
@@ -105,6 +121,17 @@ Rccl &rccl()
         x.Recv = reinterpret_cast<decltype(x.Recv)>(sym("ncclRecv"));
         x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(sym("ncclGetVersion"));
+        if (x.error.empty()) {
+            // NCCL_VERSION(X,Y,Z): X*1000 + Y*100 + Z up to 2.8, X*10000 + Y*100 + Z from 2.9 on
+            if (x.GetVersion(&x.version) != ncclSuccess) x.error = "ncclGetVersion failed";
+            else {
+                const int major = x.version >= 10000 ? x.version / 10000 : x.version / 1000;
+                if (major != 2)
+                    x.error = "the RCCL found (" + x.origin + ") reports version code " + std::to_string(x.version) +
+                              ": this library speaks the NCCL 2 API only";
+            }
+        }
         x.ok = x.error.empty();
         return x;
     }();
@@ -159,9 +186,86 @@ struct taxor_gpu_comm {
     std::vector<int64_t> h_ub;
     std::vector<uint32_t> h_cnt, h_nh;
     taxor_gpu_comm_stats stats{};
+    bool self_exchange = false;           // test hook (taxor_gpu_comm_set_self_exchange): rank 0's own part of a gather travels
+                                          // through ncclSend/ncclRecv to itself instead of a device-to-device copy
 };
 
 extern "C" __attribute__((visibility("hidden"))) void taxor_runtime_env_once();
+
+// Known bytes through both exchange primitives of a fresh RCCL communicator, verified on the host: an in-place ncclBroadcast
+// from rank 0 must arrive on every device, and a grouped ncclSend / ncclRecv from EVERY rank (rank 0 included: to itself) must
+// land in rank 0's buffer at the sender's slot.  256 KiB per rank, a few milliseconds; run once per communicator so that a
+// multi-GPU job whose xGMI / IPC path is broken on this machine ends here with a message instead of producing a report
+// from bytes nobody checked (the transport is never changed silently: the error names --gather host).
+static int comm_selftest(taxor_gpu_comm *c)
+{
+    Rccl &R = rccl();
+    const size_t n = c->devices.size();
+    constexpr size_t W = 1u << 16;                                       // 32-bit words per rank
+    auto pat = [](uint32_t tag, size_t i) { return (tag + 1u) * 0x9E3779B1u ^ (uint32_t)i * 0x85EBCA77u; };
+    std::vector<uint32_t *> bc(n, nullptr), tx(n, nullptr);
+    uint32_t *rx = nullptr;
+    std::vector<uint32_t> h(W);
+    int rc = TAXOR_OK;
+    std::string msg;
+    auto bad = [&](const std::string &m) { if (rc == TAXOR_OK) { rc = TAXOR_E_HIP; msg = m; } };
+    auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess) bad(std::string("RCCL self-test: ") + what + ": " + hipGetErrorString(e)); return e == hipSuccess; };
+    for (size_t i = 0; i < n && rc == TAXOR_OK; ++i) {
+        if (!hip_ok(hipSetDevice(c->devices[i]), "hipSetDevice")) break;
+        if (!hip_ok(hipMalloc((void **)&bc[i], W * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&tx[i], W * 4), "hipMalloc")) break;
+        for (size_t k = 0; k < W; ++k) h[k] = pat((uint32_t)i, k);
+        if (!hip_ok(hipMemcpy(tx[i], h.data(), W * 4, hipMemcpyHostToDevice), "hipMemcpy")) break;
+        if (i == 0) {
+            for (size_t k = 0; k < W; ++k) h[k] = pat(1000u, k);
+            if (!hip_ok(hipMemcpy(bc[0], h.data(), W * 4, hipMemcpyHostToDevice), "hipMemcpy")) break;
+            if (!hip_ok(hipMalloc((void **)&rx, n * W * 4), "hipMalloc") || !hip_ok(hipMemset(rx, 0, n * W * 4), "hipMemset")) break;
+        } else if (!hip_ok(hipMemset(bc[i], 0, W * 4), "hipMemset")) break;
+    }
+    if (rc == TAXOR_OK) {
+        ncclResult_t r = R.GroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+            (void)hipSetDevice(c->devices[i]);
+            r = R.Broadcast(bc[i], bc[i], W * 4, ncclUint8, 0, c->comms[i], c->streams[i]);
+        }
+        const ncclResult_t r2 = R.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) bad(std::string("RCCL self-test: ncclBroadcast failed: ") + R.GetErrorString(r));
+    }
+    if (rc == TAXOR_OK) {
+        ncclResult_t r = R.GroupStart();
+        for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
+            (void)hipSetDevice(c->devices[i]);
+            r = R.Send(tx[i], W * 4, ncclUint8, 0, c->comms[i], c->streams[i]);
+            (void)hipSetDevice(c->devices[0]);
+            if (r == ncclSuccess) r = R.Recv(rx + i * W, W * 4, ncclUint8, (int)i, c->comms[0], c->streams[0]);
+        }
+        const ncclResult_t r2 = R.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) bad(std::string("RCCL self-test: grouped ncclSend/ncclRecv failed: ") + R.GetErrorString(r));
+    }
+    for (size_t i = 0; i < n && rc == TAXOR_OK; ++i)
+        if (hip_ok(hipSetDevice(c->devices[i]), "hipSetDevice")) hip_ok(hipStreamSynchronize(c->streams[i]), "stream synchronisation after the collectives");
+    for (size_t i = 0; i < n && rc == TAXOR_OK; ++i) {
+        if (!hip_ok(hipSetDevice(c->devices[i]), "hipSetDevice") || !hip_ok(hipMemcpy(h.data(), bc[i], W * 4, hipMemcpyDeviceToHost), "hipMemcpy")) break;
+        for (size_t k = 0; k < W; ++k)
+            if (h[k] != pat(1000u, k)) { bad("RCCL self-test: the broadcast from device " + std::to_string(c->devices[0]) + " delivered wrong bytes to device " + std::to_string(c->devices[i])); break; }
+    }
+    for (size_t i = 0; i < n && rc == TAXOR_OK; ++i) {
+        if (!hip_ok(hipSetDevice(c->devices[0]), "hipSetDevice") || !hip_ok(hipMemcpy(h.data(), rx + i * W, W * 4, hipMemcpyDeviceToHost), "hipMemcpy")) break;
+        for (size_t k = 0; k < W; ++k)
+            if (h[k] != pat((uint32_t)i, k)) { bad("RCCL self-test: ncclSend from device " + std::to_string(c->devices[i]) + " arrived wrong on device " + std::to_string(c->devices[0])); break; }
+    }
+    for (size_t i = 0; i < n; ++i) {
+        (void)hipSetDevice(c->devices[i]);
+        if (bc[i]) (void)hipFree(bc[i]);
+        if (tx[i]) (void)hipFree(tx[i]);
+    }
+    (void)hipSetDevice(c->devices[0]);
+    if (rx) (void)hipFree(rx);
+    if (rc != TAXOR_OK) return cfail(rc, "%s (the host transport, --gather host, stages the same transfers through host memory)", msg.c_str());
+    c->stats.selftest_bytes = (uint64_t)n * W * 4 * 2;
+    return TAXOR_OK;
+}
 
 extern "C" int taxor_gpu_comm_create(const int *devices, uint32_t n_devices, int transport, taxor_gpu_comm **out)
 {
@@ -203,6 +307,11 @@ extern "C" int taxor_gpu_comm_create(const int *devices, uint32_t n_devices, int
             taxor_gpu_comm_destroy(c);
             return cfail(TAXOR_E_HIP, "comm_create: ncclCommInitAll over %u devices failed: %s", n_devices, R.GetErrorString(r));
         }
+        if (int rc = comm_selftest(c)) {
+            const std::string msg = taxor_gpu_last_error();
+            taxor_gpu_comm_destroy(c);
+            return cfail(rc, "comm_create: %s", msg.c_str());
+        }
     }
     *out = c;
     return TAXOR_OK;
@@ -224,10 +333,19 @@ extern "C" void taxor_gpu_comm_destroy(taxor_gpu_comm *c)
     delete c;
 }
 
+extern "C" int taxor_gpu_comm_set_self_exchange(taxor_gpu_comm *c, int on)
+{
+    if (!c) return cfail(TAXOR_E_ARG, "comm_set_self_exchange: null communicator");
+    if (on && c->transport != TAXOR_COMM_RCCL) return cfail(TAXOR_E_ARG, "comm_set_self_exchange: only the RCCL transport has a send/recv path");
+    c->self_exchange = on != 0;
+    return TAXOR_OK;
+}
+
 extern "C" int taxor_gpu_comm_info(const taxor_gpu_comm *c, taxor_gpu_comm_stats *out)
 {
     if (!c || !out) return cfail(TAXOR_E_ARG, "comm_info: null argument");
     *out = c->stats;
+    out->rccl_version = c->transport == TAXOR_COMM_RCCL ? rccl().version : 0;
     out->transport = c->transport;
     out->n_devices = (uint32_t)c->devices.size();
     return TAXOR_OK;
@@ -245,7 +363,10 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
         for (size_t i = 0; i < n; ++i) { if (out[i]) taxor_gpu_index_destroy(out[i]); out[i] = nullptr; }
     };
     const auto t0 = std::chrono::steady_clock::now();
-    if (c->transport == TAXOR_COMM_HOST || n == 1) {
+    // (An RCCL communicator of ONE rank takes the RCCL path below too: create-empty, the upload thread with its watermark, the
+    // broadcast loop behind it -- an in-place ncclBroadcast on one rank moves nothing, but every line a larger run executes
+    // is executed, which is what a one-GPU test box can verify.)
+    if (c->transport == TAXOR_COMM_HOST) {
         // every replica through its own PCIe link, concurrently (a device listed twice gets two replicas)
         std::vector<std::thread> up;
         std::vector<std::string> errs(n);
@@ -289,7 +410,7 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
     }
     // Upload thread: the library's own upload into device 0 (pieces, possibly several threads; api.hip), which reports the
     // slab offset below which device 0 holds final bytes -- the watermark the broadcast follows.
-    static const uint64_t piece = [] { const char *e = getenv("TAXOR_COMM_PIECE_MB"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 1024) << 20; }();
+    static const uint64_t piece = [] { const char *e = tune_env("TAXOR_COMM_PIECE_MB"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 1024) << 20; }();
     std::atomic<uint64_t> watermark{0};
     std::atomic<int> up_rc{0};
     std::string up_err;
@@ -316,6 +437,7 @@ extern "C" int taxor_gpu_index_create_replicated(taxor_gpu_comm *c, const taxor_
         const ncclResult_t r2 = R.GroupEnd();
         if (r == ncclSuccess) r = r2;
         if (r != ncclSuccess) { rc = TAXOR_E_HIP; bc_err = std::string("ncclBroadcast of the index: ") + R.GetErrorString(r); break; }
+        c->stats.index_broadcast_calls++;
         sent = wm;
     }
     uploader.join();
@@ -395,20 +517,21 @@ extern "C" int taxor_gpu_gather_results(taxor_gpu_comm *c, taxor_gpu_searcher *c
             return TAXOR_E_HIP;
         hipStream_t s0 = c->streams[0];
         // rank 0's own part: device-to-device on device 0
-        if (nr[0]) {
+        const bool self = c->self_exchange;     // test hook: rank 0's part goes through the grouped send/recv below like a peer's
+        if (nr[0] && !self) {
             C_HIP(hipMemcpyAsync(c->g_off_tmp.p, d_ro[0], nr[0] * 8, hipMemcpyDeviceToDevice, s0));
             C_HIP(hipMemcpyAsync(c->g_nh.p, d_nh[0], nr[0] * 4, hipMemcpyDeviceToDevice, s0));
         }
-        if (nt[0]) {
+        if (nt[0] && !self) {
             C_HIP(hipMemcpyAsync(c->g_ub.p, d_ub[0], nt[0] * 8, hipMemcpyDeviceToDevice, s0));
             C_HIP(hipMemcpyAsync(c->g_cnt.p, d_ct[0], nt[0] * 4, hipMemcpyDeviceToDevice, s0));
         }
         // every peer -> rank 0, all transfers in one group: each pair (peer, 0) has its own xGMI link, so the n-1
         // transfers proceed side by side; byte counts, so one datatype serves all four arrays
-        if (n > 1) {
+        if (n > 1 || self) {
             C_NCCL(R.GroupStart());
             ncclResult_t r = ncclSuccess;
-            for (size_t i = 1; i < n && r == ncclSuccess; ++i) {
+            for (size_t i = self ? 0 : 1; i < n && r == ncclSuccess; ++i) {
                 (void)hipSetDevice(c->devices[i]);       // the sends belong to rank i's device ...
                 if (nr[i] && r == ncclSuccess) r = R.Send(d_ro[i], nr[i] * 8, ncclUint8, 0, c->comms[i], c->streams[i]);
                 if (nr[i] && r == ncclSuccess) r = R.Send(d_nh[i], nr[i] * 4, ncclUint8, 0, c->comms[i], c->streams[i]);
@@ -446,6 +569,7 @@ extern "C" int taxor_gpu_gather_results(taxor_gpu_comm *c, taxor_gpu_searcher *c
         }
         C_HIP(hipSetDevice(c->devices[0]));
         C_HIP(hipStreamSynchronize(s0));
+        if (self) c->stats.self_exchange_bytes += nr[0] * 12 + nt[0] * 12;
     }
     out->n_reads = NR;
     out->n_tuples = NT;

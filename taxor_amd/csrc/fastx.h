@@ -60,6 +60,7 @@ struct Batch {
     // bases.data() as pinned for DMA by the consumer (search_main.cpp); the producer keeps bases from reallocating
     void *pinned = nullptr;
     bool may_pin = false;
+    uint64_t pool_bytes = 0;    // what the CLI's buffer pool has on its books for this batch (search_main.cpp, BatchPool)
 };
 
 // ---- bzip2 input (seqan3's sequence_file_input reads .bz2 when built with bzip2, which the reference's CMake fetches).

@@ -18,6 +18,8 @@
 //     u64 seed | u64 ftype (= 8 fingerprint bits) | vector<uint8_t> data (u64 len + len bytes)
 // with len == 3 * seg_len * technical_bins.
 #include "../../include/taxor_gpu.h"
+#include "tuning.h"
+using taxor::tune_env;
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -351,7 +353,7 @@ int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bo
     for (size_t i = 0; i < h->ixf.size(); ++i) h->file_off[i] = (uint64_t)(h->ixf[i].data - (const uint8_t *)m.map);
     h->source.read = hixf_pread;
     h->source.ctx = h;
-    static const bool use_map = [] { const char *e = getenv("TAXOR_HIXF_UPLOAD_FROM_MAP"); return e && atoi(e) != 0; }();   // A/B knob: round-2 path
+    static const bool use_map = [] { const char *e = tune_env("TAXOR_HIXF_UPLOAD_FROM_MAP"); return e && atoi(e) != 0; }();   // A/B knob: round-2 path
     h->view.source = use_map ? nullptr : &h->source;
     *out = h;
     return TAXOR_OK;

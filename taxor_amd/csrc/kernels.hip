@@ -13,6 +13,7 @@
 // row segments; hashes run in the loop; per-bin counters live in registers as packed bytes.
 #include "kernels.h"
 #include "ixf_arith.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -871,8 +872,8 @@ void launch_syncmers_wave(const SyncmerArgs &a, int grid, hipStream_t st)
 
 bool syncmers_wave_applies(int k, int s)
 {
-    static const bool off = [] { const char *e = getenv("TAXOR_SYNC_WAVE"); return e && atoi(e) == 0; }();
-    static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
+    static const bool off = [] { const char *e = tune_env("TAXOR_SYNC_WAVE"); return e && atoi(e) == 0; }();
+    static const bool generic_only = [] { const char *e = tune_env("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
     return !off && !generic_only && k - s + 1 == 11 && s <= 13;
 }
 
@@ -1016,7 +1017,7 @@ int syncmers_grid(int device)
     if (hipGetDeviceProperties(&p, device) != hipSuccess) return 1024;
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_syncmers<11, false>, BLK, 0) != hipSuccess || per < 1) per = 2;
-    if (const char *e = getenv("TAXOR_SYNC_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+    if (const char *e = tune_env("TAXOR_SYNC_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
 
@@ -1027,7 +1028,7 @@ void launch_syncmers(const SyncmerArgs &a, int grid, hipStream_t st)
         hipLaunchKernelGGL(k_minimisers, dim3(grid), dim3(BLK), 0, st, a);
         return;
     }
-    static const bool generic_only = [] { const char *e = getenv("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
+    static const bool generic_only = [] { const char *e = tune_env("TAXOR_SYNC_GENERIC"); return e && atoi(e) != 0; }();
     if (!generic_only && a.k - a.s + 1 == 11 && a.s <= 13) {
         if (a.prof) hipLaunchKernelGGL((k_syncmers<11, true>), dim3(grid), dim3(BLK), 0, st, a);
         else hipLaunchKernelGGL((k_syncmers<11, false>), dim3(grid), dim3(BLK), 0, st, a);
@@ -1607,7 +1608,7 @@ int query_grid(int device, size_t lds_bytes, int want_per_cu)
     // reads (+14 % viral-class over two), four for short reads, whose items spend half their time outside the gather
     // loop (1-kb reads +4 % unrelated / +11 % family workload over three; 10-kb reads unchanged).  The caller asks.
     if (per > want_per_cu) per = want_per_cu;
-    if (const char *e = getenv("TAXOR_QUERY_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
+    if (const char *e = tune_env("TAXOR_QUERY_BPC")) { const int v = atoi(e); if (v >= 1 && v <= 8) per = v; }
     return p.multiProcessorCount * per;
 }
 
@@ -1620,7 +1621,7 @@ int query_grid_small(int device, size_t lds_bytes)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>, Q_BLK_SMALL, lds_bytes) != hipSuccess || per < 1)
         per = 8;
     if (per > 16) per = 16;
-    if (const char *e = getenv("TAXOR_QUERY_BPC_SMALL")) { const int v = atoi(e); if (v >= 1 && v <= 32) per = v; }
+    if (const char *e = tune_env("TAXOR_QUERY_BPC_SMALL")) { const int v = atoi(e); if (v >= 1 && v <= 32) per = v; }
     return p.multiProcessorCount * per;
 }
 
@@ -1629,15 +1630,15 @@ void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStrea
     // the root's rows: non-temporal when its table is far larger than the caches (random rows in tens of gigabytes: no
     // reuse to protect), plain when it is small enough for the 256 MB memory-side cache to matter (viral-class root,
     // 150 MB: +8 %; RefSeq-class, 4 GB: +3 %; GTDB-class, 45 GB: -1 %)
-    static const int nt_env = [] { const char *e = getenv("TAXOR_QUERY_NT"); return e ? atoi(e) : -1; }();
+    static const int nt_env = [] { const char *e = tune_env("TAXOR_QUERY_NT"); return e ? atoi(e) : -1; }();
     const bool nt0 = nt_env >= 0 ? nt_env != 0 : root_streams;
-    static const int unroll0 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
-    static const int unroll1 = [] { const char *e = getenv("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
+    static const int unroll0 = [] { const char *e = tune_env("TAXOR_QUERY_UNROLL"); return e ? atoi(e) : 2; }();
+    static const int unroll1 = [] { const char *e = tune_env("TAXOR_QUERY_UNROLL_L1"); return e ? atoi(e) : 0; }();   // levels below the root
     const int unroll = (a.level >= 1 && unroll1) ? unroll1 : unroll0;
     // levels below the root: their items arrive grouped by IXF (launch_queue_group_by_ixf), so consecutive items re-read
     // the rows of the same child -- plain loads let them stay in L2 / the memory-side cache; the root's rows are random
     // in tens of gigabytes and stream (non-temporal)
-    static const int nt1 = [] { const char *e = getenv("TAXOR_QUERY_NT_L1"); return e ? atoi(e) : 0; }();
+    static const int nt1 = [] { const char *e = tune_env("TAXOR_QUERY_NT_L1"); return e ? atoi(e) : 0; }();
     const bool nt = a.level >= 1 ? nt1 != 0 : nt0;
     if (small) {
         if (nt) hipLaunchKernelGGL((k_query_level<true, 2, false, Q_BLK_SMALL, Q_CAP_SMALL>), dim3(grid), dim3(Q_BLK_SMALL), lds_bytes, st, a);

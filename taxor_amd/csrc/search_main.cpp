@@ -4,6 +4,8 @@
 // reading (:181-184), batching (:315-326) and output (:268-311, :343).
 #include "../../include/taxor_gpu.h"
 #include "fastx.h"
+#include "tuning.h"
+using taxor::tune_env;
 
 #include <sys/resource.h>
 #include <sys/stat.h>
@@ -75,15 +77,23 @@ private:
 // Finished batches go back to the producers: their buffers stay mapped and warm, and at most `cap` batches exist at
 // a time (get() blocks), which bounds the host memory the pipeline touches -- faulting in and releasing fresh pages
 // costs more than parsing into them.
+// The bound is in BYTES as well as in buffers: a chunk's sequence buffer is ~128 MB, page-locked, and recycled rather than
+// released, so a count sized for the deepest queues (~150 buffers for one device, ~600 for eight) would let a run whose
+// parsers outrun the GPUs or the writer pin tens of gigabytes.  Beyond `floor` buffers -- what the stages need to hold one
+// each, so that the pipeline can never starve itself -- a new buffer is made only while the bytes of the existing ones stay
+// within `byte_budget`, and a buffer that comes back while the pool is over budget is released (unregistered and freed)
+// instead of kept.
 struct BatchPool {
     std::mutex mu;
     std::condition_variable cv;
     std::vector<std::unique_ptr<Batch>> free_;
-    size_t cap = 8, made = 0;
+    size_t cap = 8, made = 0, floor = 8;
+    uint64_t byte_budget = ~0ull, bytes = 0;   // bytes: sequence-buffer capacity of every live batch, as of its last return
+    uint64_t peak_bytes = 0, trimmed = 0;
     std::unique_ptr<Batch> get()
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return !free_.empty() || made < cap; });
+        cv.wait(lk, [&] { return !free_.empty() || (made < cap && (made < floor || bytes < byte_budget)); });
         if (free_.empty()) { ++made; return std::make_unique<Batch>(); }
         auto b = std::move(free_.back());
         free_.pop_back();
@@ -91,7 +101,21 @@ struct BatchPool {
     }
     void put(std::unique_ptr<Batch> b)
     {
-        std::lock_guard<std::mutex> lk(mu);
+        std::unique_lock<std::mutex> lk(mu);
+        const uint64_t now_bytes = b->bases.capacity();
+        bytes += now_bytes - b->pool_bytes;
+        b->pool_bytes = now_bytes;
+        peak_bytes = std::max(peak_bytes, bytes);
+        if (bytes > byte_budget && made > floor) {      // over budget: this buffer goes back to the system
+            bytes -= now_bytes;
+            --made;
+            ++trimmed;
+            lk.unlock();
+            if (b->pinned) { taxor_gpu_host_unregister(b->pinned); b->pinned = nullptr; }
+            b.reset();
+            cv.notify_one();
+            return;
+        }
         free_.push_back(std::move(b));
         cv.notify_one();
     }
@@ -171,7 +195,7 @@ double now()
 const double g_t0 = now();
 void trace(const char *what)
 {
-    static const bool on = getenv("TAXOR_CLI_TRACE") != nullptr;
+    static const bool on = tune_env("TAXOR_CLI_TRACE") != nullptr;
     if (on) fprintf(stderr, "[trace] %8.3f s  %s\n", now() - g_t0, what);
 }
 
@@ -803,12 +827,21 @@ int main(int argc, char **argv)
         const unsigned readers = (unsigned)std::max<size_t>(1, std::min<size_t>({nf, cfg.threads, 8}));
         const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 32u) / readers);
         const unsigned formatters = std::max(1u, std::min(cfg.threads, 32u) / 4u);
-        static const unsigned workers_per_gpu = [] { const char *e = getenv("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
+        static const unsigned workers_per_gpu = [] { const char *e = tune_env("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
         const uint64_t group_reads = cfg.group_reads ? cfg.group_reads : (cfg.batch_reads ? cfg.batch_reads : 131072);
         const size_t group_max_chunks = 32;
         BoundedQueue<std::unique_ptr<Batch>> q_parsed(16), q_in(32), q_fmt(8), q_out(8);
         BatchPool pool;
         pool.cap = readers * parse_threads + 16 + 2 + 32 + ng * workers_per_gpu * group_max_chunks + 8 + formatters + 8 + 8 + 2 * readers;
+        // ... by count for small chunks; by bytes for the usual ~128 MB ones: 6 GiB for the host stages + 6 GiB per device (two GPU
+        // batches of ~1.3 GB in flight per device, the chunks being parsed, formatted and written) instead of cap x 128 MB
+        // = 19 GB at one device and 75 GB at eight.  The floor lets every stage hold one buffer whatever the budget.
+        pool.floor = readers * parse_threads + 2 * readers + ng * workers_per_gpu + formatters + 8;
+        {
+            const char *e = tune_env("TAXOR_CLI_POOL_GB");
+            const double gb = e ? atof(e) : 0.0;
+            pool.byte_budget = gb > 0.0 ? (uint64_t)(gb * (double)(1ull << 30)) : (6ull + 6ull * ng) << 30;
+        }
         // a file that is not being written yet may run at most two chunks ahead, so that the file whose turn it is can
         // always get buffers
         std::mutex fmu;
@@ -947,7 +980,7 @@ int main(int argc, char **argv)
             if (taxor_gpu_index_create_replicated(comm, view, gidx.data()) != TAXOR_OK) die(taxor_gpu_last_error());
             taxor_gpu_comm_stats cs{};
             taxor_gpu_comm_info(comm, &cs);
-            if (getenv("TAXOR_CLI_TRACE"))
+            if (tune_env("TAXOR_CLI_TRACE"))
                 fprintf(stderr, "[trace] index on %zu devices (%s): %.2f GB per replica, %.2f GB over PCIe, %.2f GB by ncclBroadcast, %.3f s\n", ng,
                         gather.c_str(), cs.index_bytes / 1e9, cs.index_upload_bytes / 1e9, cs.index_broadcast_bytes / 1e9, cs.index_seconds);
         } else {
@@ -963,7 +996,7 @@ int main(int argc, char **argv)
         }
         t_index += now() - t0;
         trace("index resident in HBM");
-        if (getenv("TAXOR_CLI_TRACE"))
+        if (tune_env("TAXOR_CLI_TRACE"))
             fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
                     now() - t0, taxor_gpu_index_data_bytes(gidx[0]) / 1e9 / (now() - t0));
         // the host mapping of the index is not needed any more: its pages go back on a helper thread, beside the search
@@ -1158,7 +1191,7 @@ int main(int argc, char **argv)
         if (comm) {
             taxor_gpu_comm_stats cs{};
             taxor_gpu_comm_info(comm, &cs);
-            if (getenv("TAXOR_CLI_TRACE"))
+            if (tune_env("TAXOR_CLI_TRACE"))
                 fprintf(stderr, "[trace] %llu gathers (%s): %.1f MB from peer devices, %.3f s inside taxor_gpu_gather_results\n",
                         (unsigned long long)cs.gathers, gather.c_str(), cs.gather_bytes / 1e6, cs.gather_seconds);
             taxor_gpu_comm_destroy(comm);
@@ -1177,6 +1210,9 @@ int main(int argc, char **argv)
                 if (b->pinned) taxor_gpu_host_unregister(b->pinned);
         }
         pool.free_.clear();
+        if (tune_env("TAXOR_CLI_TRACE"))
+            fprintf(stderr, "[trace] chunk buffers: %zu made (floor %zu, cap %zu), peak %.2f GB on the books against a budget of %.2f GB, %llu released early\n",
+                    pool.made, pool.floor, pool.cap, pool.peak_bytes / 1073741824.0, pool.byte_budget / 1073741824.0, (unsigned long long)pool.trimmed);
         trace("batch buffers released");
     };
     if (index_files.size() == 1) {
@@ -1189,7 +1225,7 @@ int main(int argc, char **argv)
     }
     fclose(out);
     trace("output closed");
-    if (getenv("TAXOR_CLI_TRACE"))
+    if (tune_env("TAXOR_CLI_TRACE"))
         fprintf(stderr, "[trace] %llu chunks in %llu GPU batches: pin %.3f s, search %.3f s, gather %.3f s, copy-out %.3f s (summed over workers); "
                         "search phase %.3f s wall after the index was resident = %.1f Mbp/s\n", (unsigned long long)n_batches,
                 (unsigned long long)(n_gpu_batches ? n_gpu_batches : n_batches), t_pin, t_search, t_gather, t_compute - t_pin - t_search - t_gather, t_search_wall,

@@ -210,9 +210,11 @@ class Searcher:
     """One GPU-side agent: syncmers -> dedup -> threshold -> HIXF query -> per-read tuples."""
 
     def __init__(self, index: GpuIndex, error_rate=0.04, percentage=-1.0, ratio=None, sub_batch_reads=0,
-                 sub_batch_bases=0, time_kernels=False):
+                 sub_batch_bases=0, time_kernels=False, prune=True, group_always=False, small_path=True, split_always=False):
         self.index = index
-        prm = _lib.SearchParams(0.0, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0, _lib.THR_PERCENTAGE, error_rate)
+        flags = ((0 if prune else _lib.SEARCH_NO_PRUNE) | (_lib.SEARCH_GROUP_ALWAYS if group_always else 0)
+                 | (0 if small_path else _lib.SEARCH_NO_SMALL_PATH) | (_lib.SEARCH_SPLIT_ALWAYS if split_always else 0))
+        prm = _lib.SearchParams(0.0, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0, _lib.THR_PERCENTAGE, error_rate, flags)
         if ratio is not None:          # explicit (size_t)(n * ratio), whatever the index
             prm.ratio = float(ratio)
         else:                          # the reference's choice: percentage / syncmer / k-mer / FracMinHash model
@@ -366,6 +368,10 @@ class Comm:
             g._adopt(C.c_void_p(h), ixfs, n_user_bins, k, s, t, d, use_syncmer, window_size)
             idx.append(g)
         return idx
+
+    def set_self_exchange(self, on=True):
+        """test hook: rank 0's own results go through ncclSend/ncclRecv to itself (one-GPU boxes execute the exchange code)"""
+        check(_lib.lib().taxor_gpu_comm_set_self_exchange(self._h, 1 if on else 0))
 
     def gather(self, searchers) -> SearchResults:
         """per-read results of one round (searcher i ran its batch on devices[i]) as one CSR in device order"""

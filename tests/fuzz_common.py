@@ -29,7 +29,7 @@ def run_trial(seed, verbose=False):
     rng = np.random.default_rng(seed)
     # the trials' batches are small: below 4096 reads the library skips the grouping of the work queues by IXF (read per call),
     # so half of the trials force it on -- drawn from a generator of its own, the trial's other draws stay what they were
-    os.environ["TAXOR_QUERY_GROUP_MIN"] = "0" if np.random.default_rng(seed ^ 0x5EED).random() < 0.5 else "4096"
+    group_always = bool(np.random.default_rng(seed ^ 0x5EED).random() < 0.5)
     syncmer = rng.random() < 0.7
     if syncmer:
         k, s = [(22, 12), (16, 8), (20, 10), (28, 14), (30, 12), (22, 16), (24, 9)][int(rng.integers(0, 7))]
@@ -99,7 +99,7 @@ def run_trial(seed, verbose=False):
                bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith)
     if verbose:
         print(cfg, flush=True)
-    sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub)
+    sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub, group_always=group_always)
     n_seg = int(rng.choice([0, 0, 1, 2, 5]))
     if n_seg == 0 or len(reads) < n_seg:
         res = sr.search_batch(B, O)

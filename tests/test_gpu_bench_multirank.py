@@ -108,3 +108,36 @@ def test_bench_tracks_indexes_built_without_syncmers(mode, tmp_path):
     assert j["value"] > 0 and j["roofline"]["frac"] > 0 and j["roofline"]["unpruned"]["frac"] > 0
     assert j["config"]["hashes_per_read"] > (1500 if mode == "kmer" else 100)
     assert "bit-identical" in j["cpu_baseline"]["sample"]
+
+
+def test_forced_single_rank_rccl_run_equals_the_plain_run(tmp_path):
+    """TAXOR_BENCH_FORCE_DIST=1: the `world > 1` branches of bench.py with ONE rank on the REAL backend -- init_process_group("nccl",
+    device_id=...), the probe gather on device tensors, all_gather / all_reduce / barrier, the per-step result gather, the
+    solo-then-concurrent host-fed block, destroy_process_group -- launched through torch.distributed.run like the driver
+    launches N ranks.  What one GPU can execute of the 8-GPU run is executed here; the line must agree with the plain N = 1 run
+    (that is also the SCALE N=1 == BENCH check), the gathered CSR must be the plain run's, and host_fed_scaling must be ~1."""
+    common = ["bench.py", "--gpus", "1", "--workload", "viral", "--reads", "32768", "--steps", "6", "--warmup", "2", "--batches", "2",
+              "--traffic", "none", "--no-cpu-baseline", "--no-unpruned", "--no-ceiling", "--no-e04", "--sustained-reads", "400000"]
+    env = {k: v for k, v in os.environ.items() if k not in ("TAXOR_BENCH_BACKEND", "TAXOR_BENCH_SAME_GPU")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+
+    def run(cmd, env, dump):
+        cp = subprocess.run(cmd + ["--dump-results", str(dump)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert cp.returncode == 0, cp.stderr[-3000:]
+        lines = [l for l in cp.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, cp.stdout
+        return json.loads(lines[0]), np.load(dump)
+
+    plain, r0 = run([sys.executable] + common, env, tmp_path / "plain.npz")
+    forced, r1 = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                      "--master-port", str(_free_port())] + common, dict(env, TAXOR_BENCH_FORCE_DIST="1"), tmp_path / "forced.npz")
+    for key in ("read_off", "user_bin", "count", "n_hashes"):
+        assert np.array_equal(r0[key], r1[key]), key
+    assert r0["user_bin"].size > 0
+    assert forced["n_gpus"] == 1 and plain["n_gpus"] == 1
+    # the forced run adds the per-step export + all_gather of the sizes to every step: a few percent on this 6-ms step, < 1 % on the 49-ms default
+    assert abs(forced["value"] / plain["value"] - 1.0) < 0.08, (forced["value"], plain["value"])
+    pr = forced["pcie_inclusive_per_rank"]
+    assert len(pr["sustained_Mbp_s"]) == 1 and pr["solo_rank0"]["sustained_Mbp_s"] > 0
+    assert 0.8 < forced["host_fed_scaling"] < 1.25, forced["host_fed_scaling"]
+    assert forced["value_host_fed"] == pr["sustained_sum_Mbp_s"] and plain["value_host_fed"] == plain["sustained"]["value"]

@@ -98,7 +98,7 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
         out3 = tmp_path / "out_comm.tsv"
         cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--output-file",
                              str(out3), "--batch-reads", "23", "--threads", "3"] + extra, capture_output=True, text=True, timeout=300,
-                            env=dict(os.environ, TAXOR_CLI_TRACE="1"))
+                            env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1"))
         assert cp.returncode == 0, cp.stderr
         assert open(out3).read() == want, extra
         if "none" not in extra:
@@ -106,6 +106,16 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
     cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(fa), "--output-file", str(out), "--gpu-list", "0,0",
                          "--gather", "rccl"], capture_output=True, text=True, timeout=300)
     assert cp.returncode != 0 and "listed twice" in cp.stderr and "--gather host" in cp.stderr
+
+    # two real devices (skipped on the usual one-GPU box): RCCL between them against both other transports, byte for byte
+    import torch
+    if torch.cuda.device_count() >= 2:
+        for extra in (["--gpus", "2", "--gather", "rccl"], ["--gpus", "2"], ["--gpus", "2", "--gather", "host"], ["--gpus", "2", "--gather", "none"]):
+            out4 = tmp_path / "out_two.tsv"
+            cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--output-file",
+                                 str(out4), "--batch-reads", "23", "--threads", "3"] + extra, capture_output=True, text=True, timeout=300)
+            assert cp.returncode == 0, cp.stderr
+            assert open(out4).read() == want, extra
 
     # --error-rate / --percentage change the threshold exactly like the reference's models
     for extra, kw in ((["--error-rate", "0.1"], dict(err=0.1)), (["--percentage", "0.3"], dict(percentage=0.3))):

@@ -1,8 +1,13 @@
 """The C-ABI communicator (taxor_gpu_comm_*, taxor_amd/csrc/comm.hip): index replication and the per-round gather of the
-per-read results.  One GPU is what the test box has, so RCCL runs as a communicator of one rank (ncclCommInitAll over one
-device: the broadcast and the gather degenerate to their device-0 halves, which is the code every larger run also goes
-through for rank 0) and the several-replica logic is exercised through the host transport, which accepts a device twice.
-Both transports must hand out byte-identical CSRs, equal to the concatenation of the searchers' own results."""
+per-read results.  One GPU is what the usual test box has, so there RCCL runs as a communicator of ONE rank -- but through the
+code of a larger run: creation sends known bytes through ncclBroadcast and a grouped ncclSend/ncclRecv and verifies them, the
+index takes the create-empty / upload-with-watermark / broadcast-behind-it route (an in-place broadcast on one rank moves
+nothing, every line still executes), and with the self-exchange hook rank 0's results travel through ncclSend/ncclRecv to
+itself instead of a device-to-device copy.  The several-replica logic is exercised through the host transport, which accepts
+a device twice.  On a box with two or more GPUs the tests at the end run the real thing: Comm([0, 1], "rccl").  Every
+transport must hand out byte-identical CSRs, equal to the concatenation of the searchers' own results."""
+import threading
+
 import numpy as np
 import pytest
 
@@ -61,6 +66,22 @@ def test_single_rank_communicator(transport):
         assert got.user_bin.size > 0
     info = comm.info()
     assert info["n_devices"] == 1 and info["gathers"] == 2 and info["index_bytes"] == ref_idx.data_bytes
+    if transport == "rccl":
+        # the RCCL code of a larger run, executed on one rank: verified self-test bytes at creation, the broadcast loop
+        # behind the upload, and (hook) the grouped send/recv of the gather
+        assert info["rccl_version"] >= 2000 and info["selftest_bytes"] == 2 * 4 * 65536
+        assert info["index_broadcast_calls"] >= 1 and info["index_upload_bytes"] == ref_idx.data_bytes and info["index_broadcast_bytes"] == 0
+        comm.set_self_exchange(True)
+        for b, w in zip(batches, want):
+            sr.search_batch_begin(*b)
+            assert _same(comm.gather([sr]), (w.read_off, w.user_bin, w.count, w.n_hashes))
+        sr.search_batch_begin(np.zeros(0, np.uint8), np.zeros(1, np.uint64))        # an empty batch: nothing to send, the group is empty
+        assert comm.gather([sr]).n_hashes.size == 0
+        assert comm.info()["self_exchange_bytes"] == sum(12 * (w.n_hashes.size + w.user_bin.size) for w in want)
+    else:
+        assert info["rccl_version"] == 0 and info["selftest_bytes"] == 0
+        with pytest.raises(TaxorError, match="only the RCCL transport"):
+            comm.set_self_exchange(True)
     sr.close(); idx.close(); comm.close(); ref.close(); ref_idx.close()
 
 
@@ -129,3 +150,86 @@ def test_segments_are_one_batch():
     assert _same(got, (one.read_off, one.user_bin, one.count, one.n_hashes))
     assert _same(sr.search_segments([]), (np.zeros(1, np.uint64), np.zeros(0, np.int64), np.zeros(0, np.uint32), np.zeros(0, np.uint32)))
     sr.close(); idx.close()
+
+
+def test_gather_of_one_set_while_another_set_runs():
+    """the communicator contract (taxor_gpu.h): a gather waits for the searchers it is given; OTHER searchers on the same
+    devices may run batches meanwhile -- the CLI's two searcher sets, one gathering round i while the other classifies round
+    i+1.  Two sets on two replicas, one thread gathering set A again and again while the other keeps set B busy."""
+    host, nub, batches = _index_and_batches(4, seed=23)
+    comm = Comm([0, 0], "host")
+    idxs = comm.replicate_index(host, nub)
+    set_a = [Searcher(i) for i in idxs]
+    set_b = [Searcher(i) for i in idxs]
+    singles = [Searcher(idxs[0]).search_batch(*b) for b in batches]
+    want_a = _concat([singles[0], singles[1]])
+    stop = threading.Event()
+    errors = []
+
+    def keep_b_busy():
+        try:
+            while not stop.is_set():
+                for s, b, w in zip(set_b, batches[2:], singles[2:]):
+                    got = s.search_batch(*b)
+                    if not _same(got, (w.read_off, w.user_bin, w.count, w.n_hashes)):
+                        errors.append("set B result changed")
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    th = threading.Thread(target=keep_b_busy)
+    th.start()
+    try:
+        for _ in range(25):
+            for s, b in zip(set_a, batches[:2]):
+                s.search_batch_begin(*b)
+            assert _same(comm.gather(set_a), want_a)
+    finally:
+        stop.set()
+        th.join()
+    assert not errors, errors
+    for s in set_a + set_b:
+        s.close()
+    for i in idxs:
+        i.close()
+    comm.close()
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL between devices (the usual test box has one)")
+def test_rccl_between_two_devices():
+    """Comm([0, 1], "rccl"): the index crosses PCIe once and reaches device 1 by ncclBroadcast; the round's results reach device 0
+    by grouped ncclSend/ncclRecv -- against the host transport and the concatenation of single-searcher results, including an
+    empty batch on one rank"""
+    host, nub, batches = _index_and_batches(3, seed=31)
+    ref_idx = GpuIndex(host, nub)
+    ref = Searcher(ref_idx)
+    singles = [ref.search_batch(*b) for b in batches]
+    for transport in ("rccl", "host"):
+        comm = Comm([0, 1], transport)
+        idxs = comm.replicate_index(host, nub)
+        for idx in idxs:
+            for i in range(len(host)):
+                assert np.array_equal(idx.download_ixf(i), ref_idx.download_ixf(i)), (transport, idx.device, i)
+        srs = [Searcher(i) for i in idxs]
+        for s, b in zip(srs, batches):
+            s.search_batch_begin(*b)
+        assert _same(comm.gather(srs), _concat(singles[:2])), transport
+        srs[0].search_batch_begin(*batches[2])
+        srs[1].search_batch_begin(np.zeros(0, np.uint8), np.zeros(1, np.uint64))          # rank 1 has nothing this round
+        assert _same(comm.gather(srs), _concat([singles[2]])), transport
+        srs[0].search_batch_begin(np.zeros(0, np.uint8), np.zeros(1, np.uint64))          # rank 0 has nothing, rank 1 does
+        srs[1].search_batch_begin(*batches[1])
+        assert _same(comm.gather(srs), _concat([singles[1]])), transport
+        info = comm.info()
+        if transport == "rccl":
+            assert info["index_upload_bytes"] == ref_idx.data_bytes and info["index_broadcast_bytes"] > 0 and info["gather_bytes"] > 0
+        for s in srs:
+            s.close()
+        for i in idxs:
+            i.close()
+        comm.close()
+    ref.close(); ref_idx.close()

@@ -48,8 +48,7 @@ def test_viral_class_one_million_reads():
     assert st["n_hashes"] == int(res.n_hashes.astype(np.int64).sum())
     assert st["n_tuples"] == res.user_bin.size == int(res.read_off[-1])
     assert np.all(np.diff(res.read_off.astype(np.int64)) >= 0)
-    if os.environ.get("TAXOR_QUERY_PRUNE") != "0":
-        assert st["query_touched_bytes"] < st["query_bytes"]      # pruning removed traffic
+    assert st["query_touched_bytes"] < st["query_bytes"]      # pruning removed traffic
     # idempotence on the resident batch
     sr.run()
     assert _csr_equal(res, sr.fetch())
@@ -61,11 +60,7 @@ def test_viral_class_one_million_reads():
     s2.run()
     assert _csr_equal(res, s2.fetch())
     s2.close()
-    os.environ["TAXOR_QUERY_PRUNE"] = "0"
-    try:
-        s3 = Searcher(idx, sub_batch_reads=131072)
-    finally:
-        del os.environ["TAXOR_QUERY_PRUNE"]
+    s3 = Searcher(idx, sub_batch_reads=131072, prune=False)
     s3.upload(bases, offs)
     s3.run()
     r3 = s3.fetch()
@@ -136,11 +131,7 @@ def _full_size_class(workload, min_index_bytes, max_index_bytes):
     checks.append((n_batches - 1, reads_per_batch - S, reads_per_batch))
 
     sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
-    os.environ["TAXOR_QUERY_PRUNE"] = "0"
-    try:
-        dense = Searcher(idx, error_rate=args.error_rate, sub_batch_reads=65536)
-    finally:
-        del os.environ["TAXOR_QUERY_PRUNE"]
+    dense = Searcher(idx, error_rate=args.error_rate, sub_batch_reads=65536, prune=False)
     planted_ub = np.array([u if u is not None else -1 for u in lay["planted_user_bin"]], dtype=np.int64)
     total_reads = total_tuples = total_hashes = 0
     hit_own = n_planted = n_random = random_hit = 0

@@ -569,11 +569,10 @@ def test_single_wave_query_blocks_short_reads_with_long_outliers():
     idx.close()
 
 
-def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram(monkeypatch):
+def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram():
     """a hierarchy of 10 101 small IXFs (root -> 100 -> 10 000): the work queues of the deeper levels are grouped by IXF
     id with a counting sort whose per-block histogram covers ids below 8192 in LDS and takes the rest through global
     atomics -- genomes planted under IXFs on both sides of that boundary, against the oracle"""
-    monkeypatch.setenv("TAXOR_QUERY_GROUP_MIN", "0")     # sub-batches below 4096 reads are not grouped by default; this test is about the grouping
     rng = np.random.default_rng(77)
     g, go = synth.random_genomes(6, 6000, seed=77)
     planted = [np.unique(orc.seq_to_syncmers(bytes(g[int(go[i]):int(go[i + 1])]))) for i in range(6)]
@@ -618,7 +617,7 @@ def test_ten_thousand_ixfs_queue_grouping_beyond_the_lds_histogram(monkeypatch):
     h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
     bases, offs, origin = synth.synth_reads(g, go, 400, 1500, error_rate=0.02, frac_random=0.1, seed=5)
     for sub in (0, 57):
-        sr = Searcher(idx, sub_batch_reads=sub)
+        sr = Searcher(idx, sub_batch_reads=sub, group_always=True)
         res = sr.search_batch(bases, offs)
         _compare(res, h.search_batch(bases, offs, threads=8), 400)
         hit = sum(planted_ub[origin[i]] in [u for u, _ in res.tuples(i)] for i in range(400) if origin[i] >= 0)
@@ -697,4 +696,37 @@ def test_search_batch_begin_end_overlaps_two_searchers():
         Searcher(idx).search_batch_end()                    # nothing in flight
     s1.close()
     s2.close()
+    idx.close()
+
+
+def test_tuning_knobs_are_ignored_without_the_gate(monkeypatch):
+    """TAXOR_QUERY_PRUNE=0 in the environment of a process that loads the library must not switch pruning off unless
+    TAXOR_TUNING=1 says the environment is to be read (taxor_amd/csrc/tuning.h); the per-searcher flag always works"""
+    g, go, lay, host = _planted_setup(21)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    bases, offs, _ = synth.synth_reads(g, go, 300, 4000, error_rate=0.02, frac_random=0.1, seed=4)
+
+    def stats(**kw):
+        sr = Searcher(idx, time_kernels=True, **kw)
+        sr.upload(bases, offs)
+        sr.run()
+        res, st = sr.fetch(), sr.stats()
+        sr.close()
+        return res, st
+
+    want, st0 = stats()
+    assert st0["query_touched_bytes"] < st0["query_bytes"]
+    monkeypatch.delenv("TAXOR_TUNING", raising=False)
+    monkeypatch.setenv("TAXOR_QUERY_PRUNE", "0")
+    r1, st1 = stats()
+    assert st1["query_touched_bytes"] == st0["query_touched_bytes"] < st1["query_bytes"]      # the stray variable changed nothing
+    monkeypatch.setenv("TAXOR_TUNING", "1")
+    r2, st2 = stats()
+    assert st2["query_touched_bytes"] == st2["query_bytes"] == st0["query_bytes"]              # gate open: the knob is read
+    monkeypatch.delenv("TAXOR_TUNING")
+    monkeypatch.delenv("TAXOR_QUERY_PRUNE")
+    r3, st3 = stats(prune=False)
+    assert st3["query_touched_bytes"] == st3["query_bytes"]
+    for r in (r1, r2, r3):
+        assert np.array_equal(r.read_off, want.read_off) and np.array_equal(r.user_bin, want.user_bin) and np.array_equal(r.count, want.count)
     idx.close()
