@@ -917,9 +917,15 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
     finally:
         _interleave_host_memory(False)
 
-    def run(n, th):
+    # the worker is the port; the SCHEDULER is the reference's own hixf::do_parallel (do_parallel.hpp, compiled into oracle/_ref
+    # where /root/reference was mounted at build time; the file travels): 1024-record chunks, `threads` std::async tasks per
+    # chunk, floor(n/threads) records each with the remainder on the last, one barrier per chunk -- taxor_search.cpp:315-326.
+    # Without that library: the port's own OpenMP slices over the whole sample.
+    sched = "reference" if orc.ref_lib() is not None else "openmp"
+
+    def run(n, th, scheduler=None):
         t0 = time.perf_counter()
-        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=th, **hash_kw)
+        o = h.search_batch(bases[: int(offs[n])], offs[: n + 1], err=args.error_rate, threads=th, scheduler=scheduler or sched, **hash_kw)
         return time.perf_counter() - t0, o
 
     n = min(256 * threads // 8 + 64, len(offs) - 1)
@@ -935,6 +941,13 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
     if not same:
         raise SystemExit("PARITY FAILURE: GPU results differ from the CPU oracle on the baseline sample")
     extra = {}
+    if sched == "reference":     # beside it: the port's own scheduler (one OpenMP barrier per sample instead of one per 1024 records)
+        nq = max(1, n // 3)
+        dtq, oq = run(nq, threads, "openmp")
+        if not np.array_equal(oq[1], off[: nq + 1]):
+            raise SystemExit("PARITY FAILURE: the oracle's two schedulers disagree")
+        extra["openmp_slices"] = {"value": round(int(offs[nq]) / dtq / 1e6, 3), "reads": nq,
+                                  "note": "same worker, ceil(n/threads) slices of the whole sample under OpenMP"}
     if ncpu > threads:      # also at all hardware threads (the reference itself caps --threads at 32);
         na = max(1, n // 4)  # a quarter of the sample: beyond 32 threads the port gets slower (remote-socket row reads)
         dta, _ = run(na, ncpu)
@@ -947,6 +960,8 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
         pass
     return {**extra, "value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
             "cpu_model": model, "hardware_threads": ncpu, "index_copy_interleaved_over_numa_nodes": interleaved,
+            "scheduler": ("the reference's hixf::do_parallel (do_parallel.hpp compiled from /root/reference into oracle/_ref): 1024-record "
+                          "chunks, std::async tasks, one barrier per chunk" if sched == "reference" else "port: OpenMP slices of the whole sample"),
             "sample": f"first {n} reads of the last timed batch ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
                       f"{threads} threads in the reference's do_parallel shape; GPU results bit-identical on the sample"}
 

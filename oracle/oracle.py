@@ -77,6 +77,12 @@ def ref_lib(reference_root="/root/reference"):
     L.ref_xor_probe.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
     L.ref_xor_free.restype = None
     L.ref_xor_free.argtypes = [C.c_void_p]
+    L.ref_do_parallel_chunks.restype = C.c_uint64
+    L.ref_do_parallel_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_size_t, C.POINTER(C.c_double)]
+    L.ref_do_parallel_slices.restype = None
+    L.ref_do_parallel_slices.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p]
+    L.ref_sync_out_lines.restype = None
+    L.ref_sync_out_lines.argtypes = [C.c_char_p, C.c_int, C.c_int]
     _ref = L
     return _ref
 
@@ -143,6 +149,12 @@ def lib():
                                        C.c_void_p, C.c_uint64, C.c_void_p]
         L.orc_classify_filter.restype = None
         L.orc_classify_filter.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_batch_begin.restype = C.c_void_p
+        L.orc_batch_begin.argtypes = [C.POINTER(_Hixf), C.POINTER(_Params), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.orc_batch_worker.restype = None
+        L.orc_batch_worker.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.orc_batch_finish.restype = C.c_int
+        L.orc_batch_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -253,9 +265,11 @@ class Hixf:
         return ub[:n].copy(), cnt[:n].copy(), int(vb[0])
 
     def search_batch(self, bases: np.ndarray, offsets: np.ndarray, k=22, s=12, t=5, err=0.04,
-                     percentage=-1.0, threads=1, scaling=1, window=0):
+                     percentage=-1.0, threads=1, scaling=1, window=0, scheduler="openmp", chunk=1024, timing=None):
         """bases: np.uint8 ASCII (already dna4-normalised), offsets: uint64[n+1].
-        Returns (n_hashes u32[n], out_off u64[n+1], user_bin i64[], count u32[], visited_bytes)."""
+        Returns (n_hashes u32[n], out_off u64[n+1], user_bin i64[], count u32[], visited_bytes).
+        scheduler="reference": the worker runs under the REFERENCE's own hixf::do_parallel (oracle/_ref, do_parallel.hpp:17-36),
+        one call per `chunk` records like taxor_search.cpp:315-326; timing (a dict) then receives its compute_time."""
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         n = offsets.size - 1
@@ -264,6 +278,27 @@ class Hixf:
         off = np.zeros(n + 1, dtype=np.uint64)
         cap = max(4 * n, 1024)
         vb = np.zeros(1, dtype=np.uint64)
+        if scheduler == "reference":
+            R = ref_lib()
+            if R is None:
+                raise RuntimeError("scheduler='reference' needs oracle/_ref/libtaxor_ref.so (make -C oracle ref)")
+            L = lib()
+            ctx = L.orc_batch_begin(C.byref(self.c), C.byref(prm), _p(bases), _p(offsets), n, _p(nh))
+            ct = C.c_double(0.0)
+            R.ref_do_parallel_chunks(C.cast(L.orc_batch_worker, C.c_void_p), ctx, n, int(chunk), max(1, int(threads)), C.byref(ct))
+            if timing is not None:
+                timing["compute_time"] = ct.value
+            off[0] = 0
+            # sizes are known only after the run: assemble with a generous buffer, grow once if needed
+            ub = np.empty(max(cap, 64 * n + 1024), dtype=np.int64)
+            cnt = np.empty(ub.size, dtype=np.uint32)
+            rc = L.orc_batch_finish(ctx, _p(off), _p(ub), _p(cnt), ub.size, _p(vb))
+            if rc == -1:
+                raise RuntimeError(f"reference-scheduled batch produced {int(off[n])} tuples, more than the {ub.size} provided for")
+            if rc != 0:
+                raise RuntimeError("the scheduler's slices did not tile the batch")
+            tot = int(off[n])
+            return nh, off, ub[:tot].copy(), cnt[:tot].copy(), int(vb[0])
         while True:
             ub = np.empty(cap, dtype=np.int64)
             cnt = np.empty(cap, dtype=np.uint32)

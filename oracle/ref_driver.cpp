@@ -5,6 +5,9 @@
 //   * src/hixf/search/syncmer_model.hpp      get_min_syncmer_match_ratio          (on the search path, threshold.hpp:59)
 //   * src/hixf/search/{kmer_model,fracminhash_model,gaussian_inverse}.cpp         (thresholds of non-syncmer indexes)
 //   * src/hixf/build/adjust_seed.hpp         adjust_seed                          (minimiser seed)
+//   * src/hixf/search/do_parallel.hpp        hixf::do_parallel, the chunk loop's scheduler (taxor_search.cpp:325): `threads`
+//     std::async tasks over floor(n/threads)-sized slices, the remainder on the last one, one barrier per 1024-record chunk
+//   * src/hixf/search/sync_out.hpp           hixf::sync_out, the mutexed result stream (taxor_search.cpp:311)
 //   * src/main/xorfilter.hpp + hashutil.hpp  the in-repo XOR-filter prototype: NOT linked into the reference's search
 //     (which uses the un-vendored seqan3::interleaved_xor_filter) but the evidence the IXF restatement rests on --
 //     murmur64(key + seed), rotl64 by 21*i, multiply-shift reduction, 8-bit fingerprint, 32 + 1.23 n slots.
@@ -23,6 +26,11 @@
 #include "gaussian_inverse.hpp"
 #include "adjust_seed.hpp"
 #include "xorfilter.hpp"
+#include "do_parallel.hpp"
+#include "sync_out.hpp"
+
+#include <string>
+#include <thread>
 
 using Proto = xorfilter::XorFilter<uint64_t, uint8_t>;
 
@@ -74,5 +82,43 @@ void ref_xor_probe(const void *h, uint64_t key, uint64_t rows[3], uint8_t *fp)
 }
 
 void ref_xor_free(void *h) { delete static_cast<Proto *>(h); }
+
+// The reference's chunk loop (taxor_search.cpp:315-326) with the reference's own scheduler: the batch is cut into chunks of
+// `chunk` records (views::chunk(1024) there) and hixf::do_parallel runs `worker` over each chunk's slices.  worker(ctx, start,
+// end) gets GLOBAL record indices (the reference's worker indexes the chunk's own `records` vector; the base is added here).
+// Returns the number of worker invocations; *compute_time accumulates like the reference's (do_parallel.hpp:20,34-35).
+uint64_t ref_do_parallel_chunks(void (*worker)(void *, uint64_t, uint64_t), void *ctx, uint64_t n_records, uint64_t chunk, size_t threads,
+                                double *compute_time)
+{
+    uint64_t calls = 0;
+    if (chunk == 0) chunk = 1024;
+    for (uint64_t base = 0; base < n_records; base += chunk) {
+        const size_t n = (size_t)(n_records - base < chunk ? n_records - base : chunk);
+        hixf::do_parallel([=](size_t start, size_t end) { worker(ctx, base + start, base + end); }, n, threads, *compute_time);
+        calls += threads;
+    }
+    return calls;
+}
+
+// the slices do_parallel hands out for (n, threads): out[2*i], out[2*i+1] = start, end of task i (recorded under a mutex)
+void ref_do_parallel_slices(size_t n, size_t threads, uint64_t *out)
+{
+    std::mutex mu;
+    size_t k = 0;
+    double t = 0;
+    hixf::do_parallel([&](size_t start, size_t end) { std::lock_guard<std::mutex> lk(mu); out[2 * k] = start; out[2 * k + 1] = end; ++k; }, n, threads, t);
+}
+
+// hixf::sync_out: `threads` writers, `lines` lines each ("t<thread>:<line>\n") through operator<<; the caller reads the file back
+void ref_sync_out_lines(const char *path, int threads, int lines)
+{
+    hixf::sync_out out{std::filesystem::path{path}};
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; ++t)
+        th.emplace_back([&out, t, lines] {
+            for (int i = 0; i < lines; ++i) out << ("t" + std::to_string(t) + ":" + std::to_string(i) + "\n");
+        });
+    for (auto &x : th) x.join();
+}
 
 } // extern "C"

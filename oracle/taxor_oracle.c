@@ -620,61 +620,119 @@ size_t orc_search_read(const orc_hixf *h, const orc_search_params *p, const char
     return n;
 }
 
+/* ---- the chunk loop's worker (taxor_search.cpp:196-313) as a callable over a slice [start, end) of the batch, so that the
+ * SCHEDULER can be anybody's: the OpenMP loop of orc_search_batch below, or the reference's own hixf::do_parallel compiled
+ * into oracle/_ref (ref_driver.cpp, ref_do_parallel_chunks).  A slice fills a private growing buffer (the reference's per-thread
+ * result_string); slices are registered in the context and assembled in read order by orc_batch_finish. */
+typedef struct { uint64_t start, end; int64_t *ub; uint32_t *cnt; uint64_t n, cap, vbytes; } orc_slice;
+struct orc_batch_ctx {
+    const orc_hixf *h;
+    const orc_search_params *p;
+    const char *bases;
+    const uint64_t *offsets;
+    uint64_t n_reads;
+    uint32_t *n_hashes;
+    uint64_t *sizes;          /* tuples per read */
+    orc_slice *slices;
+    uint64_t n_slices, cap_slices;
+    volatile int lock;
+};
+
+orc_batch_ctx *orc_batch_begin(const orc_hixf *h, const orc_search_params *p, const char *bases, const uint64_t *offsets,
+                               uint64_t n_reads, uint32_t *n_hashes)
+{
+    orc_batch_ctx *c = (orc_batch_ctx *)calloc(1, sizeof(orc_batch_ctx));
+    c->h = h; c->p = p; c->bases = bases; c->offsets = offsets; c->n_reads = n_reads; c->n_hashes = n_hashes;
+    c->sizes = (uint64_t *)calloc(n_reads + 1, sizeof(uint64_t));
+    c->cap_slices = 64;
+    c->slices = (orc_slice *)calloc(c->cap_slices, sizeof(orc_slice));
+    return c;
+}
+
+void orc_batch_worker(orc_batch_ctx *c, uint64_t start, uint64_t end)     /* thread-safe; reads [start, end) of the batch */
+{
+    orc_slice b;
+    memset(&b, 0, sizeof b);
+    b.start = start; b.end = end;
+    b.cap = 1024;
+    b.ub = (int64_t *)malloc(b.cap * sizeof(int64_t));
+    b.cnt = (uint32_t *)malloc(b.cap * sizeof(uint32_t));
+    for (uint64_t r = start; r < end && r < c->n_reads; ++r) {
+        const char *seq = c->bases + c->offsets[r];
+        size_t len = (size_t)(c->offsets[r + 1] - c->offsets[r]);
+        uint32_t nh = 0;
+        uint64_t vb = 0;
+        for (;;) {
+            size_t n = orc_search_read(c->h, c->p, seq, len, &nh, b.ub + b.n, b.cnt + b.n, (size_t)(b.cap - b.n), &vb);
+            if (b.n + n <= b.cap) { c->sizes[r] = n; b.n += n; break; }
+            while (b.n + n > b.cap) b.cap *= 2;      /* rare: re-run this read with room */
+            b.ub = (int64_t *)realloc(b.ub, b.cap * sizeof(int64_t));
+            b.cnt = (uint32_t *)realloc(b.cnt, b.cap * sizeof(uint32_t));
+        }
+        c->n_hashes[r] = nh;
+        b.vbytes += vb;
+    }
+    while (__sync_lock_test_and_set(&c->lock, 1)) {}
+    if (c->n_slices == c->cap_slices) {
+        c->cap_slices *= 2;
+        c->slices = (orc_slice *)realloc(c->slices, c->cap_slices * sizeof(orc_slice));
+    }
+    c->slices[c->n_slices++] = b;
+    __sync_lock_release(&c->lock);
+}
+
+static int slice_cmp(const void *a, const void *b)
+{
+    const orc_slice *x = (const orc_slice *)a, *y = (const orc_slice *)b;
+    return x->start < y->start ? -1 : x->start > y->start;
+}
+
+int orc_batch_finish(orc_batch_ctx *c, uint64_t *out_off, int64_t *user_bin, uint32_t *count, uint64_t cap, uint64_t *visited_bytes)
+{
+    out_off[0] = 0;
+    for (uint64_t r = 0; r < c->n_reads; ++r) out_off[r + 1] = out_off[r] + c->sizes[r];
+    int rc = out_off[c->n_reads] > cap ? -1 : 0;
+    qsort(c->slices, c->n_slices, sizeof(orc_slice), slice_cmp);                     /* slice order = read order */
+    uint64_t pos = 0, vsum = 0, covered = 0;
+    for (uint64_t i = 0; i < c->n_slices; ++i) {
+        orc_slice *b = &c->slices[i];
+        if (b->start != covered && rc == 0) rc = -2;                                   /* the scheduler left a gap or an overlap */
+        covered = b->end;
+        if (rc == 0 && b->n) {
+            memcpy(user_bin + pos, b->ub, b->n * sizeof(int64_t));
+            memcpy(count + pos, b->cnt, b->n * sizeof(uint32_t));
+        }
+        pos += b->n;
+        vsum += b->vbytes;
+        free(b->ub);
+        free(b->cnt);
+    }
+    if (covered != c->n_reads && rc == 0) rc = -2;
+    if (visited_bytes) *visited_bytes = vsum;
+    free(c->slices);
+    free(c->sizes);
+    free(c);
+    return rc;
+}
+
 int orc_search_batch(const orc_hixf *h, const orc_search_params *p, const char *bases,
                      const uint64_t *offsets, uint64_t n_reads, int threads, uint32_t *n_hashes,
                      uint64_t *out_off, int64_t *user_bin, uint32_t *count, uint64_t cap,
                      uint64_t *visited_bytes)
 {
-    /* do_parallel.hpp:17-36 hands each of `threads` tasks one contiguous slice [start,end) of the
-     * chunk; each task here fills a private growing buffer (the reference's per-thread result_string),
-     * and the buffers are concatenated in task order, which is input order. */
+    /* this file's own scheduler: `threads` contiguous slices of the whole batch under OpenMP (one barrier per batch; the
+     * reference cuts 1024-record chunks and runs do_parallel.hpp:17-36 on each -- that shape, with the reference's own
+     * scheduler code, is ref_do_parallel_chunks in oracle/ref_driver.cpp) */
     if (threads < 1) threads = 1;
-    typedef struct { int64_t *ub; uint32_t *cnt; uint64_t n, cap, vbytes; } tbuf;
-    tbuf *tb = (tbuf *)calloc((size_t)threads, sizeof(tbuf));
-    uint64_t *sizes = (uint64_t *)calloc(n_reads + 1, sizeof(uint64_t));
+    orc_batch_ctx *c = orc_batch_begin(h, p, bases, offsets, n_reads, n_hashes);
     const uint64_t per = (n_reads + (uint64_t)threads - 1) / (uint64_t)threads;
 #pragma omp parallel for num_threads(threads) schedule(static, 1)
     for (int tsk = 0; tsk < threads; ++tsk) {
-        tbuf *b = &tb[tsk];
-        b->cap = 1024;
-        b->ub = (int64_t *)malloc(b->cap * sizeof(int64_t));
-        b->cnt = (uint32_t *)malloc(b->cap * sizeof(uint32_t));
         uint64_t lo = per * (uint64_t)tsk, hi = lo + per > n_reads ? n_reads : lo + per;
-        for (uint64_t r = lo; r < hi; ++r) {
-            const char *seq = bases + offsets[r];
-            size_t len = (size_t)(offsets[r + 1] - offsets[r]);
-            uint32_t nh = 0;
-            uint64_t vb = 0;
-            for (;;) {
-                size_t n = orc_search_read(h, p, seq, len, &nh, b->ub + b->n, b->cnt + b->n,
-                                           (size_t)(b->cap - b->n), &vb);
-                if (b->n + n <= b->cap) { sizes[r] = n; b->n += n; break; }
-                while (b->n + n > b->cap) b->cap *= 2;      /* rare: re-run this read with room */
-                b->ub = (int64_t *)realloc(b->ub, b->cap * sizeof(int64_t));
-                b->cnt = (uint32_t *)realloc(b->cnt, b->cap * sizeof(uint32_t));
-            }
-            n_hashes[r] = nh;
-            b->vbytes += vb;
-        }
+        if (lo > n_reads) lo = n_reads;
+        orc_batch_worker(c, lo, hi);
     }
-    out_off[0] = 0;
-    for (uint64_t r = 0; r < n_reads; ++r) out_off[r + 1] = out_off[r] + sizes[r];
-    int rc = out_off[n_reads] > cap ? -1 : 0;
-    uint64_t pos = 0, vsum = 0;
-    for (int tsk = 0; tsk < threads; ++tsk) {
-        if (rc == 0 && tb[tsk].n) {
-            memcpy(user_bin + pos, tb[tsk].ub, tb[tsk].n * sizeof(int64_t));
-            memcpy(count + pos, tb[tsk].cnt, tb[tsk].n * sizeof(uint32_t));
-        }
-        pos += tb[tsk].n;
-        vsum += tb[tsk].vbytes;
-        free(tb[tsk].ub);
-        free(tb[tsk].cnt);
-    }
-    if (visited_bytes) *visited_bytes = vsum;
-    free(tb);
-    free(sizes);
-    return rc;
+    return orc_batch_finish(c, out_off, user_bin, count, cap, visited_bytes);
 }
 
 void orc_classify_filter(const uint32_t *count, size_t n, uint8_t *keep)

@@ -155,6 +155,16 @@ int orc_search_batch(const orc_hixf *h, const orc_search_params *p, const char *
                      uint64_t *out_off, int64_t *user_bin, uint32_t *count, uint64_t cap,
                      uint64_t *visited_bytes);
 
+/* The same batch with the scheduler left to the caller: begin, then orc_batch_worker(ctx, start, end) from any number of
+ * threads over slices that tile [0, n_reads) exactly once (the worker lambda of taxor_search.cpp:196-313 over one slice), then
+ * finish (assembles the CSR in read order and frees the context; -1 = cap too small, -2 = the slices did not tile the batch).
+ * oracle/ref_driver.cpp drives it with the reference's own hixf::do_parallel over 1024-record chunks. */
+typedef struct orc_batch_ctx orc_batch_ctx;
+orc_batch_ctx *orc_batch_begin(const orc_hixf *h, const orc_search_params *p, const char *bases, const uint64_t *offsets,
+                               uint64_t n_reads, uint32_t *n_hashes);
+void orc_batch_worker(orc_batch_ctx *c, uint64_t start, uint64_t end);
+int orc_batch_finish(orc_batch_ctx *c, uint64_t *out_off, int64_t *user_bin, uint32_t *count, uint64_t cap, uint64_t *visited_bytes);
+
 /* Classification call (taxor_search.cpp:268-306): keep[i]=1 iff double(cnt) >= double(max)*0.8 */
 void orc_classify_filter(const uint32_t *count, size_t n, uint8_t *keep);
 

@@ -1,6 +1,7 @@
 """The oracle AND the product's host functions against the REAL reference wherever the reference compiles on its own:
 oracle/_ref/libtaxor_ref.so is built by `make -C oracle ref` straight from /root/reference (syncmer threshold table,
-k-mer / FracMinHash threshold models, adjust_seed, the in-repo XOR-filter prototype; see oracle/ref_driver.cpp).
+k-mer / FracMinHash threshold models, adjust_seed, the in-repo XOR-filter prototype, the chunk loop's scheduler
+do_parallel.hpp and the result stream sync_out.hpp; see oracle/ref_driver.cpp).
 The library travels to the GPU box prebuilt; where neither it nor /root/reference exists these tests skip."""
 import ctypes as C
 
@@ -91,3 +92,43 @@ def test_ixf_arithmetic_is_the_in_repo_prototypes():
 
 def ts_seg_len(n):
     return int(_lib.lib().taxor_ixf_seg_len(int(n)))
+
+
+def test_do_parallel_slices_are_the_references():
+    """hixf::do_parallel (do_parallel.hpp:22-29): `threads` tasks, floor(n / threads) records each, the remainder on the LAST task
+    -- observed from the reference's own object code -- and the oracle's worker driven by it over 1024-record chunks
+    (taxor_search.cpp:315-326) gives the same CSR as the oracle's OpenMP slices."""
+    for n, th in ((1024, 32), (1000, 32), (31, 32), (5, 3), (1, 1), (0, 4), (1024, 7)):
+        out = np.zeros(2 * th, dtype=np.uint64)
+        REF.ref_do_parallel_slices(n, th, out.ctypes.data_as(C.c_void_p))
+        got = sorted((int(out[2 * i]), int(out[2 * i + 1])) for i in range(th))
+        per = n // th
+        want = sorted((per * i, n if i == th - 1 else per * (i + 1)) for i in range(th))
+        assert got == want, (n, th)
+    from taxor_amd import synth
+    rng = np.random.default_rng(11)
+    g, go = synth.random_genomes(5, 8000, seed=11)
+    planted = [np.unique(orc.seq_to_syncmers(bytes(g[int(go[i]):int(go[i + 1])]))) for i in range(5)]
+    lay = synth.make_layout(planted, root_bins=64, child_bins=32, n_children=3, seed=11)
+    host = synth.materialize_host(lay)
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    bases, offs, _ = synth.synth_reads(g, go, 2500, 900, error_rate=0.02, frac_random=0.2, seed=12)
+    want = h.search_batch(bases, offs, threads=4)
+    for th, chunk in ((32, 1024), (3, 1024), (5, 700), (1, 1024)):
+        tm = {}
+        got = h.search_batch(bases, offs, threads=th, scheduler="reference", chunk=chunk, timing=tm)
+        for a, b in zip(got[:4], want[:4]):
+            assert np.array_equal(a, b), (th, chunk)
+        assert got[4] == want[4] and tm["compute_time"] > 0
+    assert want[2].size > 1000
+
+
+def test_sync_out_serialises_whole_writes(tmp_path):
+    """hixf::sync_out (sync_out.hpp:24-36): every operator<< is one mutexed write -- lines of concurrent writers never interleave"""
+    p = tmp_path / "out.txt"
+    REF.ref_sync_out_lines(str(p).encode(), 8, 500)
+    lines = open(p).read().split("\n")
+    assert lines[-1] == "" and len(lines) == 8 * 500 + 1
+    assert sorted(lines[:-1]) == sorted(f"t{t}:{i}" for t in range(8) for i in range(500))
+    for t in range(8):                        # each writer's own lines stay in its order
+        assert [l for l in lines if l.startswith(f"t{t}:")] == [f"t{t}:{i}" for i in range(500)]
