@@ -5,10 +5,15 @@
 #include "../../include/taxor_gpu.h"
 #include "fastx.h"
 #include "tuning.h"
+#include "ixf_arith.h"
 using taxor::tune_env;
+extern char **environ;
 
+#include <spawn.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -433,12 +438,63 @@ std::string arith_spec(const taxor_ixf_variant &v)
            std::to_string(v.reduce) + ",fp=" + std::to_string(v.fp_mode);
 }
 
+// the readings of the un-vendored IXF arithmetic that `taxor verify --variants` and `taxor pin` probe a root IXF under: seed
+// (the file's, the prototype's fixed start seed, none) x row stride / segment length as stored or as implied by the array
+// length x key hash x seed entry x rotation step x range reduction x fingerprint fold x layout
+std::vector<taxor_ixf_variant> variant_family(const taxor_ixf_view &root)
+{
+    const uint64_t data_len = 3 * root.seg_len * root.stride;
+    std::vector<uint64_t> seeds{root.seed};
+    for (uint64_t sd : {13572355802537770549ull, 0ull})
+        if (std::find(seeds.begin(), seeds.end(), sd) == seeds.end()) seeds.push_back(sd);
+    std::vector<std::pair<uint64_t, uint64_t>> shapes;          // (stride, seg_len)
+    for (uint64_t st : {root.stride, root.bins}) {
+        if (!st) continue;
+        for (uint64_t sg : {root.seg_len, data_len / st / 3}) {
+            if (!sg) continue;
+            if (std::find(shapes.begin(), shapes.end(), std::make_pair(st, sg)) == shapes.end()) shapes.push_back({st, sg});
+        }
+    }
+    std::vector<taxor_ixf_variant> vs;
+    for (uint64_t sd : seeds)
+        for (const auto &sh : shapes)
+            for (int kh = 0; kh < 4; ++kh)
+                for (int sm = 0; sm < 3; ++sm)
+                    for (int rot : {21, 16, 32})
+                        for (int red = 0; red < 3; ++red)
+                            for (int fp = 0; fp < 4; ++fp)
+                                for (int lay = 0; lay < 2; ++lay) {
+                                    if (sd == 0 && sm != 0) continue;        // without a seed the three seed modes coincide
+                                    taxor_ixf_variant v;
+                                    taxor_ixf_variant_default(&v, sd, sh.second, sh.first);
+                                    v.key_hash = (uint8_t)kh; v.seed_mode = (uint8_t)sm; v.rot = (uint8_t)rot;
+                                    v.reduce = (uint8_t)red; v.fp_mode = (uint8_t)fp; v.layout = (uint8_t)lay;
+                                    vs.push_back(v);
+                                }
+    return vs;
+}
+
+// (median best-bin match ratio over the hash lists, variant index), best first
+std::vector<std::pair<float, size_t>> rank_variants(const std::vector<taxor_ixf_variant> &vs, const std::vector<float> &ratio, size_t n_lists)
+{
+    std::vector<std::pair<float, size_t>> rank;
+    for (size_t i = 0; i < vs.size(); ++i) {
+        std::vector<float> r(ratio.begin() + i * n_lists, ratio.begin() + (i + 1) * n_lists);
+        std::sort(r.begin(), r.end());
+        rank.push_back({r[r.size() / 2], i});
+    }
+    std::sort(rank.begin(), rank.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    return rank;
+}
+
 uint64_t fnv1a(const char *p, size_t n)
 {
     uint64_t h = 1469598103934665603ull;
     for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
     return h;
 }
+
+#include "pin_cmd.h"
 
 } // namespace
 
@@ -553,43 +609,10 @@ int main(int argc, char **argv)
             const uint64_t *hoff = nullptr, *hs = nullptr;
             if (taxor_gpu_syncmers(sr, bases.data(), offsets.data(), n_lists, &hoff, &hs) != TAXOR_OK) die(taxor_gpu_last_error());
             const taxor_ixf_view &root = view->ixf[0];
-            const uint64_t data_len = 3 * root.seg_len * root.stride;
-            std::vector<uint64_t> seeds{root.seed};
-            for (uint64_t sd : {13572355802537770549ull, 0ull})
-                if (std::find(seeds.begin(), seeds.end(), sd) == seeds.end()) seeds.push_back(sd);
-            std::vector<std::pair<uint64_t, uint64_t>> shapes;          // (stride, seg_len)
-            for (uint64_t st : {root.stride, root.bins}) {
-                if (!st) continue;
-                for (uint64_t sg : {root.seg_len, data_len / st / 3}) {
-                    if (!sg) continue;
-                    if (std::find(shapes.begin(), shapes.end(), std::make_pair(st, sg)) == shapes.end()) shapes.push_back({st, sg});
-                }
-            }
-            std::vector<taxor_ixf_variant> vs;
-            for (uint64_t sd : seeds)
-                for (const auto &sh : shapes)
-                    for (int kh = 0; kh < 4; ++kh)
-                        for (int sm = 0; sm < 3; ++sm)
-                            for (int rot : {21, 16, 32})
-                                for (int red = 0; red < 3; ++red)
-                                    for (int fp = 0; fp < 4; ++fp)
-                                        for (int lay = 0; lay < 2; ++lay) {
-                                            if (sd == 0 && sm != 0) continue;        // without a seed the three seed modes coincide
-                                            taxor_ixf_variant v;
-                                            taxor_ixf_variant_default(&v, sd, sh.second, sh.first);
-                                            v.key_hash = (uint8_t)kh; v.seed_mode = (uint8_t)sm; v.rot = (uint8_t)rot;
-                                            v.reduce = (uint8_t)red; v.fp_mode = (uint8_t)fp; v.layout = (uint8_t)lay;
-                                            vs.push_back(v);
-                                        }
+            std::vector<taxor_ixf_variant> vs = variant_family(root);
             std::vector<float> ratio(vs.size() * n_lists);
             if (taxor_gpu_ixf_variant_scan(gi, 0, vs.data(), (uint32_t)vs.size(), hs, hoff, n_lists, ratio.data()) != TAXOR_OK) die(taxor_gpu_last_error());
-            std::vector<std::pair<float, size_t>> rank;
-            for (size_t i = 0; i < vs.size(); ++i) {
-                std::vector<float> r(ratio.begin() + i * n_lists, ratio.begin() + (i + 1) * n_lists);
-                std::sort(r.begin(), r.end());
-                rank.push_back({r[r.size() / 2], i});
-            }
-            std::sort(rank.begin(), rank.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            const std::vector<std::pair<float, size_t>> rank = rank_variants(vs, ratio, (size_t)n_lists);
             printf("variant scan of the root IXF (%zu readings of the fingerprint array, %llu hash lists): median best-bin match ratio\n", vs.size(),
                    (unsigned long long)n_lists);
             char desc[512];
@@ -623,6 +646,7 @@ int main(int argc, char **argv)
         taxor_hixf_free(h);
         return pass ? 0 : 2;
     }
+    if (argc > 1 && strcmp(argv[1], "pin") == 0) return pin_command(argc, argv);   // published .hixf + reference TSV -> committed parity fixture
     if (argc > 1 && strcmp(argv[1], "reads") == 0) {                       // reader check: id, length, FNV-1a of every record
         Config cfg;
         bool allow_ranges = true;
