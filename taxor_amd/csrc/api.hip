@@ -90,6 +90,10 @@ struct taxor_gpu_index {
     std::vector<int64_t> h_ubin;                 // host copies of the other per-bin tables: a replica on another device
     std::vector<uint32_t> h_dfs;                 // (comm.hip) gets them from here, its fingerprint slab over RCCL
     std::vector<uint64_t> slab_off;              // byte offset of every IXF inside the slab
+    // column parts of the ROOT's rows (QueryArgs::parts): root_pmax = 8, 4, 2 or 1 (no valid cut); root_cut[j] = first 16-bin unit of
+    // part j when the row is cut into root_pmax parts (every boundary is a unit boundary at which a bin run ends)
+    uint32_t root_pmax = 1;
+    uint16_t root_cut[9] = {};
 };
 
 struct SubBatch {
@@ -128,6 +132,8 @@ struct taxor_gpu_searcher {
     bool auto_sub_reads = true; // sub_batch_reads was left to the library: short reads get more of them per sub-batch
     bool prune = true;   // taxor_gpu_search_params::flags & TAXOR_SEARCH_NO_PRUNE disables the threshold-aware pruning (A/B measurements)
     bool group_always = false;   // TAXOR_SEARCH_GROUP_ALWAYS: the queue grouping also for sub-batches of a few thousand reads
+    bool split_always = false;   // TAXOR_SEARCH_SPLIT_ALWAYS: root items in column parts whatever the batch size (parity tests)
+    bool small_path = true;      // !TAXOR_SEARCH_NO_SMALL_PATH: calls of up to a few thousand reads go through the lanes below
     size_t lds_query = 0;
 
     // batch-resident input
@@ -164,6 +170,27 @@ struct taxor_gpu_searcher {
     std::vector<uint32_t> h_cnt, h_nh;
     void *h_small = nullptr;       // page-locked landing area for the results of SMALL batches (see taxor_gpu_batch_fetch)
     void *h_small_in = nullptr;    // page-locked staging of a small batch's per-read arrays (prepare_batch)
+
+    // small batches (a call of up to SMALL_MAX_READS reads, e.g. the reference's 1024-record chunk): pieces of the call run on
+    // LANES -- internal searchers with one stream each -- see small_begin()
+    struct SmallLane {
+        taxor_gpu_searcher *c = nullptr;    // the lane: streams, counters, queues, hit buffers of its own
+        hipEvent_t done = nullptr;
+        DBuf<uint8_t> d_in;                 // aoff | poff | hoff | rlen | hcap | order of the piece: ONE host-to-device copy
+        void *h_in = nullptr;               // its page-locked source
+        size_t h_in_cap = 0;
+        void *h_out = nullptr, *d_out = nullptr;   // results in host memory the device writes: status | read_off | nh | ub | cnt
+        uint32_t out_reads = 0, out_tuples = 0;    // capacities of that area
+        bool fresh = true;                  // counters / hit counts not known to be zero: clear them before the next piece
+    };
+    struct SmallPiece { uint32_t lane; uint64_t first, n; };
+    std::vector<SmallLane> lanes;
+    std::vector<SmallPiece> small_pieces;
+    const char *small_bases = nullptr;
+    const uint64_t *small_offsets = nullptr;
+    bool lane_mode = false;                 // this searcher IS a lane
+    bool small_active = false, small_done = false;   // the call in flight went through the lanes / its results are in the host arrays
+    bool dev_results_stale = false;         // ... and not (yet) in the device-resident CSR that export_device / the communicator read
 
     // timing
     std::vector<hipEvent_t> ev;
@@ -454,6 +481,32 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
                 }
             }
             binfo[bb + b] = info;
+        }
+    }
+    {   // where the root's rows may be cut into column parts: at a multiple of 16 bins whose predecessor ends a run (a merged bin
+        // is a run of its own), as close to the equal division as the layout allows; parts narrower than 128 B are not made
+        const uint32_t U = idx->h_ixf[0].units, B = idx->h_ixf[0].bins;
+        for (uint32_t P = 8; P >= 2 && idx->root_pmax == 1; P >>= 1) {
+            if (U / P < 8 || U > 60000) continue;
+            uint16_t cut[9];
+            cut[0] = 0;
+            cut[P] = (uint16_t)U;
+            bool ok = true;
+            for (uint32_t j = 1; j < P && ok; ++j) {
+                const uint32_t ideal = (uint32_t)((uint64_t)j * U / P);
+                const uint32_t slack = U / P / 4;
+                ok = false;
+                for (uint32_t d = 0; d <= slack && !ok; ++d)
+                    for (int sgn = -1; sgn <= 1 && !ok; sgn += 2) {
+                        const uint32_t u = sgn < 0 ? ideal - d : ideal + d;
+                        if (u <= cut[j - 1] || u >= U || (uint64_t)u * 16 >= B) continue;
+                        if (binfo[(size_t)u * 16 - 1] & BINFO_END) { cut[j] = (uint16_t)u; ok = true; }
+                    }
+            }
+            if (ok) {
+                idx->root_pmax = P;
+                for (uint32_t j = 0; j <= P; ++j) idx->root_cut[j] = cut[j];
+            }
         }
     }
     idx->h_binfo = binfo;
@@ -791,6 +844,8 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     }
     s->prune = !(prm->flags & TAXOR_SEARCH_NO_PRUNE);
     s->group_always = (prm->flags & TAXOR_SEARCH_GROUP_ALWAYS) != 0;
+    s->split_always = (prm->flags & TAXOR_SEARCH_SPLIT_ALWAYS) != 0;
+    s->small_path = !(prm->flags & TAXOR_SEARCH_NO_SMALL_PATH);
     if (const char *e = tune_env("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
     if (const char *e = tune_env("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
     if (const char *e = tune_env("TAXOR_SUB_READS")) { const long v = atol(e); if (v >= 1 && v <= (1 << 20)) { s->prm.sub_batch_reads = (uint32_t)v; s->auto_sub_reads = false; } }
@@ -827,6 +882,14 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->idx->device);
+    for (auto &L : s->lanes) {
+        if (L.c) { (void)hipStreamSynchronize(L.c->st); taxor_gpu_searcher_destroy(L.c); }
+        if (L.done) (void)hipEventDestroy(L.done);
+        L.d_in.release();
+        if (L.h_in) (void)hipHostFree(L.h_in);
+        if (L.h_out) (void)hipHostFree(L.h_out);
+    }
+    s->lanes.clear();
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
     if (s->st_sync2) (void)hipStreamSynchronize(s->st_sync2);
     if (s->st_sync) (void)hipStreamSynchronize(s->st_sync);
@@ -1079,11 +1142,13 @@ int ensure_scratch(taxor_gpu_searcher *s)
 // level loop + CSR assembly for one group of reads whose hashes / thresholds are already on the device
 int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d_hoff, const uint32_t *d_nh,
               const uint64_t *d_thr, uint32_t n_reads, uint64_t *d_read_off, int is_last, uint32_t *d_counts_out,
-              int only_ixf, const uint32_t *d_order = nullptr)
+              int only_ixf, const uint32_t *d_order = nullptr, uint32_t root_parts = 0, bool finalize = true)
 {
     const taxor_gpu_index *idx = s->idx;
-    HIP_TRY(hipMemsetAsync(s->d_read_hits.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
-    HIP_TRY(hipMemsetAsync(s->d_cursor.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
+    if (finalize) {            // (a lane's small finalize leaves the hit counts cleared and needs no scatter cursors)
+        HIP_TRY(hipMemsetAsync(s->d_read_hits.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
+        HIP_TRY(hipMemsetAsync(s->d_cursor.p, 0, (size_t)n_reads * sizeof(uint32_t), s->st));
+    }
     QueryArgs q{};
     q.ixf = idx->d_ixf;
     q.binfo = idx->d_binfo;
@@ -1107,6 +1172,12 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.prune_margin = margin_env;
     static const uint32_t tally_env = [] { const char *e = tune_env("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
     q.tally_mode = tally_env;
+    // root items in column parts (QueryArgs::parts): what the caller asks for (the small-batch lanes), or the widest valid
+    // division when the searcher was created with TAXOR_SEARCH_SPLIT_ALWAYS; never for the raw per-IXF entry points
+    if (root_parts == 0) root_parts = s->split_always ? idx->root_pmax : 1u;
+    if (d_counts_out || only_ixf >= 0 || root_parts > idx->root_pmax) root_parts = 1;
+    q.parts = root_parts;
+    for (uint32_t j = 0; j <= root_parts; ++j) q.part_cut[j] = idx->root_cut[j * (idx->root_pmax / root_parts)];
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     static const bool group_queue = [] { const char *e = tune_env("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
@@ -1141,8 +1212,9 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         static const int bpc_l1 = [] { const char *e = tune_env("TAXOR_QUERY_BPC_L1"); return e ? atoi(e) : 4; }();
         // (and for a root level whose items all fit ONE round of the wide grid but not of the narrow one -- the reference's
         // chunk of 1024 reads on 256 CUs; two searchers in flight gain ~10 %, one nothing)
+        const uint64_t items0 = (uint64_t)n_reads * root_parts;
         const bool wide_grid = s->mean_read_len < 6000 || (lvl >= 1 && bpc_l1 >= 4) ||
-                               (lvl == 0 && n_reads > (uint64_t)s->grid_query && n_reads <= (uint64_t)s->grid_query_short);
+                               (lvl == 0 && items0 > (uint64_t)s->grid_query && items0 <= (uint64_t)s->grid_query_short);
         const bool root_streams = idx->rows[0] * (uint64_t)idx->h_ixf[0].stride > (16ull << 30);   // root table beyond any cache
         // tiny items (a level of IXFs with <= 512 bins, reads short enough that their probes fit 256 LDS slots): the
         // single-wave instantiation, sixteen blocks per CU; raw bulk_count calls (d_counts_out) stay on the general one
@@ -1160,7 +1232,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         s->stats.query_launches++;
     }
     HIP_TRY(hipGetLastError());
-    if (d_counts_out) return 0;
+    if (d_counts_out || !finalize) return 0;
     FinalizeArgs f{};
     f.hits = s->d_hits.p;
     f.read_hits = s->d_read_hits.p;
@@ -1521,8 +1593,351 @@ int run_pipeline(taxor_gpu_searcher *s, bool host_ascii)
 
 } // namespace
 
+
+// =========================================================================================================
+// small batches
+// =========================================================================================================
+// The reference hands its workers 1024 records per call (taxor_search.cpp:315); a binding that replaces do_parallel one to one
+// calls this library with ~10 Mbp at a time.  Through the pipeline of large batches such a call was 1.0 ms for 0.39 ms of
+// kernel work at the resident rate (profiles/r03/small_calls.txt): ~35 runtime calls, the bases' copy (0.19 ms at PCIe speed)
+// exposed in front of everything, three levels that each end when their slowest item ends, six finalize launches and five
+// result copies.  Calls of up to SMALL_MAX_READS reads therefore take another route:
+//   * the call is cut into up to four PIECES; piece p runs on LANE p -- an internal searcher with ONE stream, its own
+//     counters, queues and hit buffers -- so piece p+1's bases cross PCIe (the blocking copy of pageable memory) while piece p
+//     is hashed and classified, and the tail of one piece's level overlaps the body of another's;
+//   * per piece ~10 runtime calls: one copy of the per-read arrays (laid out back to back in one device block, from
+//     page-locked staging), one copy of the bases, pack, syncmers, one launch per level, ONE finalize launch that writes the CSR
+//     straight into host memory the device can address and leaves the lane's counters cleared (no memsets, no result copies);
+//   * the root's work items are split into column parts (QueryArgs::parts) until a piece has ~a grid's worth of them: 256
+//     reads are 1024 parts, the chip is full and an item lasts a quarter as long.
+// Same kernels, same arithmetic, same results; anything unusual (a capacity overflow, reads too long for the LDS dedup, the
+// host-evaluated threshold models, kernel timing) goes through the pipeline above instead -- for a piece or for the call.
+namespace {
+
+constexpr uint64_t SMALL_MAX_READS = 16384, SMALL_MAX_BASES = 1ull << 28, SMALL_PIECE_MIN = 256, SMALL_TUPLES = 1u << 16;
+constexpr uint32_t SMALL_LANES = 4;
+
+bool small_applicable(const taxor_gpu_searcher *s, const uint64_t *offsets, uint64_t n_reads)
+{
+    static const bool off = [] { const char *e = tune_env("TAXOR_SMALL_PATH"); return e && atoi(e) == 0; }();
+    if (off || !s->small_path || s->lane_mode || s->prm.time_kernels || s->d_prof || s->idx->w_min != 0) return false;
+    if (s->prm.model != TAXOR_THR_PERCENTAGE && s->prm.model != TAXOR_THR_SYNCMER) return false;
+    if (n_reads == 0 || n_reads > SMALL_MAX_READS || offsets[n_reads] - offsets[0] > SMALL_MAX_BASES) return false;
+    return true;
+}
+
+int small_lane_ready(taxor_gpu_searcher *s, uint32_t li, uint32_t n_reads, uint32_t tuples)
+{
+    if (s->lanes.size() <= li) s->lanes.resize(li + 1);
+    taxor_gpu_searcher::SmallLane &L = s->lanes[li];
+    if (!L.c) {
+        taxor_gpu_search_params p = s->prm;
+        p.flags |= TAXOR_SEARCH_NO_SMALL_PATH;
+        p.time_kernels = 0;
+        if (int rc = taxor_gpu_searcher_create(s->idx, &p, &L.c)) return rc;
+        L.c->lane_mode = true;
+        L.c->prune = s->prune;
+        // a lane works on ONE stream: give the second one back (every stream a process holds is a candidate to share a
+        // hardware queue with, runtime_env_once)
+        if (L.c->st_sync) { (void)hipStreamDestroy(L.c->st_sync); L.c->st_sync = nullptr; }
+        HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        L.fresh = true;
+    }
+    if (L.out_reads < n_reads || L.out_tuples < tuples) {
+        if (L.h_out) { HIP_TRY(hipStreamSynchronize(L.c->st)); (void)hipHostFree(L.h_out); L.h_out = nullptr; }
+        L.out_reads = std::max<uint32_t>(n_reads, 1024);
+        L.out_tuples = std::max<uint32_t>(tuples, SMALL_TUPLES);
+        const size_t bytes = 64 + ((size_t)L.out_reads + 2) * 8 + (size_t)L.out_reads * 4 + 8 + (size_t)L.out_tuples * 12;
+        HIP_TRY(hipHostMalloc(&L.h_out, bytes, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&L.d_out, L.h_out, 0));
+    }
+    return 0;
+}
+
+// the result area of a lane: status[8] | read_off[out_reads + 1] | ub[out_tuples] | cnt[out_tuples] | nh[out_reads]
+struct SmallOut { uint64_t *status, *read_off; int64_t *ub; uint32_t *cnt, *nh; };
+SmallOut small_out(const taxor_gpu_searcher::SmallLane &L, void *base)
+{
+    SmallOut o;
+    char *p = (char *)base;
+    o.status = (uint64_t *)p; p += 64;
+    o.read_off = (uint64_t *)p; p += ((size_t)L.out_reads + 2) * 8;
+    o.ub = (int64_t *)p; p += (size_t)L.out_tuples * 8;
+    o.cnt = (uint32_t *)p; p += (size_t)L.out_tuples * 4;
+    o.nh = (uint32_t *)p;
+    return o;
+}
+
+// everything of one piece -- reads [first, first + n) of the call -- enqueued on its lane's stream
+int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const uint64_t *offsets, uint64_t first, uint32_t n)
+{
+    const taxor_gpu_index *idx = s->idx;
+    if (int rc = small_lane_ready(s, li, n, SMALL_TUPLES)) return rc;
+    taxor_gpu_searcher::SmallLane &L = s->lanes[li];
+    taxor_gpu_searcher *c = L.c;
+    const uint64_t *off = offsets + first;
+    const uint64_t a0 = off[0], nb = off[n] - a0;
+    // ---- layout of the piece, straight into the page-locked block the one copy reads (cf. layout_batch)
+    const size_t o_aoff = 0, o_poff = o_aoff + ((size_t)n + 1) * 8, o_hoff = o_poff + (size_t)n * 8, o_rlen = o_hoff + (size_t)n * 8,
+                 o_hcap = o_rlen + (((size_t)n * 4 + 7) & ~(size_t)7), o_order = o_hcap + (((size_t)n * 4 + 7) & ~(size_t)7),
+                 in_bytes = o_order + (((size_t)n * 4 + 7) & ~(size_t)7);
+    if (L.h_in_cap < in_bytes) {
+        if (L.h_in) { HIP_TRY(hipStreamSynchronize(c->st)); (void)hipHostFree(L.h_in); L.h_in = nullptr; }
+        L.h_in_cap = std::max<size_t>(in_bytes + in_bytes / 2, 64 << 10);
+        HIP_TRY(hipHostMalloc(&L.h_in, L.h_in_cap, hipHostMallocDefault));
+    }
+    char *hi = (char *)L.h_in;
+    uint64_t *aoff = (uint64_t *)(hi + o_aoff), *poff = (uint64_t *)(hi + o_poff), *hoff = (uint64_t *)(hi + o_hoff);
+    uint32_t *rlen = (uint32_t *)(hi + o_rlen), *hcap = (uint32_t *)(hi + o_hcap), *order = (uint32_t *)(hi + o_order);
+    const int w = idx->k - idx->s + 1;
+    const int gap = std::max(1, std::min(idx->t, w - idx->t + 1));
+    uint64_t words = 0, slots = 0, max_cap = 0;
+    uint32_t lo = ~0u, hi_len = 0;
+    for (uint32_t r = 0; r < n; ++r) {
+        if (off[r + 1] < off[r]) return fail(TAXOR_E_ARG, "offsets not monotone at read %llu", (unsigned long long)(first + r));
+        const uint64_t len = off[r + 1] - off[r];
+        if (len >= (1ull << 31)) return fail(TAXOR_E_ARG, "read %llu longer than 2^31 bases", (unsigned long long)(first + r));
+        const uint64_t nwin = len >= (uint64_t)idx->k ? len - idx->k + 1 : 0;
+        const uint64_t cap = round_up((uint64_t)((uint32_t)nwin / (uint32_t)gap) + 2, 16);
+        aoff[r] = off[r] - a0;
+        poff[r] = words;
+        hoff[r] = slots;
+        rlen[r] = (uint32_t)len;
+        hcap[r] = (uint32_t)cap;
+        order[r] = r;
+        words += round_up((len + 15) / 16, 4);
+        slots += cap;
+        max_cap = std::max(max_cap, cap);
+        lo = std::min(lo, (uint32_t)len);
+        hi_len = std::max(hi_len, (uint32_t)len);
+    }
+    aoff[n] = nb;
+    if (max_cap > SYNC_LDS_DEDUP_MAX) return 1;                      // a read whose dedup needs the global table: the other pipeline
+    if (lo != hi_len) std::stable_sort(order, order + n, [&](uint32_t a, uint32_t b) { return rlen[a] > rlen[b]; });   // longest first
+    uint32_t n_long = n;
+    if (syncmers_wave_applies(idx->k, idx->s)) {
+        n_long = 0;
+        while (n_long < n && hcap[order[n_long]] > SYNC_WAVE_CAND) ++n_long;
+    }
+    // ---- the lane's buffers (allocation only when a piece is larger than any before it)
+    c->n_reads = n;
+    c->n_bases = nb;
+    c->mean_read_len = std::max<uint64_t>(1, nb / n);
+    c->max_slots = slots;
+    c->max_read_slots = max_cap;
+    c->max_sub_reads = n;
+    c->subs.assign(1, SubBatch{0, n, n_long, slots, 0, nb});
+    const size_t cap_before = c->d_read_hits.cap;
+    Counters *ctr_before = c->d_ctr;
+    if (L.d_in.reserve(in_bytes) || c->d_ascii.reserve(nb + 64) || c->d_packed.reserve(words + 16) || c->d_nh.reserve(n + 1) || c->d_thr.reserve(n + 1))
+        return TAXOR_E_HIP;
+    if (int rc = ensure_scratch(c)) return rc;
+    if (c->d_read_hits.cap != cap_before || c->d_ctr != ctr_before) L.fresh = true;
+    hipStream_t st = c->st;
+    if (L.fresh) {            // first use, or the hit counts moved to a new allocation: clear what the small finalize otherwise leaves cleared
+        HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
+        HIP_TRY(hipMemsetAsync(c->d_read_hits.p, 0, c->d_read_hits.cap * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(c->d_sync_cursor.p, 0, 2 * sizeof(uint32_t), st));
+        L.fresh = false;
+    }
+    // ---- two copies
+    HIP_TRY(hipMemcpyAsync(L.d_in.p, L.h_in, in_bytes, hipMemcpyHostToDevice, st));
+    if (nb) HIP_TRY(hipMemcpyAsync(c->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, st));
+    const uint64_t *d_aoff = (const uint64_t *)(L.d_in.p + o_aoff), *d_poff = (const uint64_t *)(L.d_in.p + o_poff),
+                   *d_hoff = (const uint64_t *)(L.d_in.p + o_hoff);
+    const uint32_t *d_rlen = (const uint32_t *)(L.d_in.p + o_rlen), *d_hcap = (const uint32_t *)(L.d_in.p + o_hcap),
+                   *d_order = (const uint32_t *)(L.d_in.p + o_order);
+    // ---- pack, syncmers
+    launch_pack_dna4(c->d_ascii.p, d_aoff, d_poff, c->d_packed.p, n, c->d_ctr, st);
+    SyncmerArgs a{};
+    a.packed = c->d_packed.p;
+    a.poff = d_poff;
+    a.rlen = d_rlen;
+    a.hoff = d_hoff;
+    a.hcap = d_hcap;
+    a.cand = c->d_cand[0].p;
+    a.hashes = c->d_hashes[0].p;
+    a.cursor = c->d_sync_cursor.p;
+    a.order = d_order;
+    a.nh = c->d_nh.p;
+    a.thr = c->d_thr.p;
+    a.ratio = s->prm.ratio;
+    a.scaling_limit = idx->scaling > 1 ? (double)UINT64_MAX / (double)idx->scaling : 0.0;
+    a.gtab = nullptr;
+    a.gtab_stride = 0;
+    a.ctr = c->d_ctr;
+    a.chunk = 1;                       // few reads: one per cursor atomic, every block gets one as early as possible
+    a.k = idx->k;
+    a.s = idx->s;
+    a.t = idx->t;
+    a.w_min = 0;
+    a.thr_on_device = 1;
+    if (n_long) {
+        a.n_reads = n_long;
+        launch_syncmers(a, std::min<int>(c->grid_sync, (int)n_long), st);
+    }
+    if (n_long < n) {
+        SyncmerArgs b = a;
+        b.order = d_order + n_long;
+        b.n_reads = n - n_long;
+        b.cursor = a.cursor + 1;
+        b.chunk = 4;
+        launch_syncmers_wave(b, c->grid_wave, st);
+    }
+    HIP_TRY(hipGetLastError());
+    // ---- the levels; root items in column parts until the piece has about a grid's worth of them
+    uint32_t parts = 1;
+    static const int parts_env = [] { const char *e = tune_env("TAXOR_SMALL_PARTS"); return e ? atoi(e) : 0; }();
+    while (parts < idx->root_pmax && (uint64_t)n * parts < (uint64_t)c->grid_query_short) parts *= 2;
+    if (parts_env >= 1) parts = std::min<uint32_t>((uint32_t)parts_env, idx->root_pmax);
+    if (s->split_always) parts = idx->root_pmax;
+    c->stats = taxor_gpu_run_stats{};
+    if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, parts, false)) return rc;
+    // ---- CSR assembly into host memory, counters cleared for the lane's next piece
+    const SmallOut o = small_out(L, L.d_out);
+    SmallFinalizeArgs f{};
+    f.hits = c->d_hits.p;
+    f.read_hits = c->d_read_hits.p;
+    f.dfs_key = idx->d_dfs_key;
+    f.ubin = idx->d_ubin;
+    f.nh = c->d_nh.p;
+    f.key = c->d_out_key.p;
+    f.cnt = c->d_out_cnt.p;
+    f.ub = c->d_out_ub.p;
+    f.ctr = c->d_ctr;
+    f.sync_cursor = c->d_sync_cursor.p;
+    f.n_reads = n;
+    f.tuple_cap = (uint32_t)std::min<uint64_t>({c->tuple_cap, (uint64_t)L.out_tuples, 0x7FFFFFFFull});
+    f.hit_cap = c->hit_cap;
+    f.h_read_off = o.read_off;
+    f.h_nh = o.nh;
+    f.h_ub = o.ub;
+    f.h_cnt = o.cnt;
+    f.h_status = o.status;
+    launch_finalize_small(f, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(L.done, st));
+    return 0;
+}
+
+int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
+{
+    HIP_TRY(hipSetDevice(s->idx->device));
+    s->ran = s->synced = false;
+    s->small_active = s->small_done = false;
+    s->small_pieces.clear();
+    s->small_bases = bases;
+    s->small_offsets = offsets;
+    s->n_reads = n_reads;
+    s->n_bases = offsets[n_reads] - offsets[0];
+    static const uint64_t piece_env = [] { const char *e = tune_env("TAXOR_SMALL_PIECE"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
+    uint64_t per = piece_env ? piece_env : std::max<uint64_t>(SMALL_PIECE_MIN, (n_reads + SMALL_LANES - 1) / SMALL_LANES);
+    per = std::min<uint64_t>(per, SMALL_FIN_MAX);
+    uint32_t li = 0;
+    for (uint64_t first = 0; first < n_reads; first += per, ++li) {
+        const uint64_t n = std::min(per, n_reads - first);
+        if (li >= SMALL_LANES) return 1;                                     // (a piece size from the environment that does not fit four lanes)
+        const int rc = small_enqueue(s, li, bases, offsets, first, (uint32_t)n);
+        if (rc) {                                                          // > 0: not a case for the lanes; wait for what is in flight, then the other pipeline
+            for (const auto &p : s->small_pieces) (void)hipEventSynchronize(s->lanes[p.lane].done);
+            for (const auto &p : s->small_pieces) s->lanes[p.lane].fresh = true;
+            s->small_pieces.clear();
+            return rc;
+        }
+        s->small_pieces.push_back({li, first, n});
+    }
+    s->small_active = true;
+    s->ran = true;
+    return 0;
+}
+
+// wait for the pieces, in order, and put the call's CSR together in the host arrays the results point at
+int small_finish(taxor_gpu_searcher *s)
+{
+    if (s->small_done) return 0;
+    const uint64_t nr = s->n_reads;
+    s->h_read_off.resize(nr + 1);
+    s->h_nh.resize(nr);
+    s->h_ub.clear();
+    s->h_cnt.clear();
+    s->h_read_off[0] = 0;
+    taxor_gpu_run_stats &st = s->stats;
+    st = taxor_gpu_run_stats{};
+    uint64_t tbase = 0;
+    for (const auto &pc : s->small_pieces) {
+        taxor_gpu_searcher::SmallLane &L = s->lanes[pc.lane];
+        HIP_TRY(hipEventSynchronize(L.done));
+        const SmallOut o = small_out(L, L.h_out);
+        const uint32_t f = (uint32_t)o.status[0];
+        if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
+        if (f & FLAG_CAND_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated"); }
+        if (f & FLAG_DEDUP_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "dedup scratch too small"); }
+        const uint64_t *ro;
+        const int64_t *ub;
+        const uint32_t *cnt, *nh;
+        uint64_t nt;
+        taxor_gpu_results r{};
+        if (f & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TUPLE_OVERFLOW)) {
+            // a queue, the hit buffer or the result area was too small for this piece: the lane classifies it once more through
+            // the pipeline of large batches, which grows its buffers and reruns until everything fits (check_flags)
+            L.fresh = true;
+            if (ensure_stream(&L.c->st_sync)) return TAXOR_E_HIP;        // (a lane gave its second stream back; that pipeline wants it)
+            if (int rc = taxor_gpu_search_batch(L.c, s->small_bases, s->small_offsets + pc.first, pc.n, &r)) return rc;
+            ro = r.read_off; ub = r.user_bin; cnt = r.count; nh = r.n_hashes; nt = r.n_tuples;
+            st.n_hashes += L.c->stats.n_hashes;
+            st.n_work_items += L.c->stats.n_work_items;
+            st.query_bytes += L.c->stats.query_bytes;
+            st.query_touched_bytes += L.c->stats.query_touched_bytes;
+        } else {
+            ro = o.read_off; ub = o.ub; cnt = o.cnt; nh = o.nh; nt = o.status[1];
+            st.n_hashes += o.status[2];
+            st.n_work_items += o.status[3];
+            st.query_bytes += o.status[4];
+            st.query_touched_bytes += o.status[5];
+        }
+        for (uint64_t i = 0; i < pc.n; ++i) s->h_read_off[pc.first + i + 1] = tbase + ro[i + 1];
+        memcpy(s->h_nh.data() + pc.first, nh, pc.n * 4);
+        s->h_ub.insert(s->h_ub.end(), ub, ub + nt);
+        s->h_cnt.insert(s->h_cnt.end(), cnt, cnt + nt);
+        tbase += nt;
+    }
+    st.n_reads = nr;
+    st.n_bases = s->n_bases;
+    st.n_tuples = tbase;
+    st.query_launches = (uint32_t)(s->small_pieces.size() * s->idx->depth);
+    uint64_t packed_in = 0;
+    for (uint64_t r = 0; r < nr; ++r) packed_in += (s->small_offsets[r + 1] - s->small_offsets[r] + 3) / 4;
+    st.algorithmic_bytes = packed_in + st.query_bytes + 8 * nr + 12 * tbase;
+    s->h_ctr.tuple_total = tbase;
+    s->small_done = true;
+    s->synced = true;
+    s->dev_results_stale = true;
+    return 0;
+}
+
+// export_device / the communicator read the device-resident CSR of the last run: after a call that went through the lanes it
+// is put there from the host arrays (a few hundred kilobytes; the end-of-file batch of a multi-GPU CLI run)
+int small_device_results(taxor_gpu_searcher *s)
+{
+    if (!s->dev_results_stale) return 0;
+    const uint64_t nr = s->n_reads, nt = s->h_ctr.tuple_total;
+    if (s->d_read_off.reserve(nr + 1) || s->d_nh.reserve(nr + 1) || s->d_out_ub.reserve(nt + 1) || s->d_out_cnt.reserve(nt + 1)) return TAXOR_E_HIP;
+    HIP_TRY(hipMemcpyAsync(s->d_read_off.p, s->h_read_off.data(), (nr + 1) * 8, hipMemcpyHostToDevice, s->st));
+    if (nr) HIP_TRY(hipMemcpyAsync(s->d_nh.p, s->h_nh.data(), nr * 4, hipMemcpyHostToDevice, s->st));
+    if (nt) {
+        HIP_TRY(hipMemcpyAsync(s->d_out_ub.p, s->h_ub.data(), nt * 8, hipMemcpyHostToDevice, s->st));
+        HIP_TRY(hipMemcpyAsync(s->d_out_cnt.p, s->h_cnt.data(), nt * 4, hipMemcpyHostToDevice, s->st));
+    }
+    HIP_TRY(hipStreamSynchronize(s->st));
+    s->dev_results_stale = false;
+    return 0;
+}
+
+} // namespace
+
 extern "C" int taxor_gpu_batch_upload(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
+    if (s) s->small_active = false;
     if (int rc = prepare_batch(s, bases, offsets, n_reads, false)) return rc;
     const uint64_t a0 = offsets[0], nb = offsets[n_reads] - a0;
     if (nb) HIP_TRY(hipMemcpyAsync(s->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, s->st));
@@ -1544,6 +1959,7 @@ extern "C" int taxor_gpu_batch_sync(taxor_gpu_searcher *s)
     if (!s) return fail(TAXOR_E_ARG, "batch_sync: null searcher");
     if (!s->ran) return fail(TAXOR_E_ARG, "batch_sync: no run in flight");
     HIP_TRY(hipSetDevice(s->idx->device));
+    if (s->small_active) return small_finish(s);
     for (int attempt = 0; attempt < 40; ++attempt) {
         bool rerun;
         if (int rc = check_flags(s, &rerun)) return rc;
@@ -1615,6 +2031,8 @@ extern "C" int taxor_gpu_batch_export_device(taxor_gpu_searcher *s, void *d_read
     if (!s) return fail(TAXOR_E_ARG, "export_device: null searcher");
     if (!s->synced)
         if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    if (s->small_active)
+        if (int rc = small_device_results(s)) return rc;
     const uint64_t nt = s->h_ctr.tuple_total, nr = s->n_reads;
     if (d_read_off) HIP_TRY(hipMemcpyAsync(d_read_off, s->d_read_off.p, (nr + 1) * 8, hipMemcpyDeviceToDevice, s->st));
     if (d_user_bin && nt) HIP_TRY(hipMemcpyAsync(d_user_bin, s->d_out_ub.p, nt * 8, hipMemcpyDeviceToDevice, s->st));
@@ -1633,6 +2051,8 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_searcher_device_resul
     if (!s) return fail(TAXOR_E_ARG, "device_results: null searcher");
     if (!s->synced)
         if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    if (s->small_active)
+        if (int rc = small_device_results(s)) return rc;
     *d_read_off = s->d_read_off.p;
     *d_user_bin = s->d_out_ub.p;
     *d_count = s->d_out_cnt.p;
@@ -1648,6 +2068,15 @@ extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *o
     if (!s || !out) return fail(TAXOR_E_ARG, "batch_fetch: null argument");
     if (!s->synced)
         if (int rc = taxor_gpu_batch_sync(s)) return rc;
+    if (s->small_active) {              // the lanes' results are in the host arrays already (small_finish)
+        out->n_reads = s->n_reads;
+        out->n_tuples = s->h_ctr.tuple_total;
+        out->read_off = s->h_read_off.data();
+        out->user_bin = s->h_ub.data();
+        out->count = s->h_cnt.data();
+        out->n_hashes = s->h_nh.data();
+        return TAXOR_OK;
+    }
     const uint64_t nt = s->h_ctr.tuple_total, nr = s->n_reads;
     s->h_read_off.resize(nr + 1);
     s->h_ub.resize(nt);
@@ -1691,6 +2120,11 @@ extern "C" int taxor_gpu_batch_fetch(taxor_gpu_searcher *s, taxor_gpu_results *o
 
 extern "C" int taxor_gpu_search_batch_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
+    if (s && bases && offsets && small_applicable(s, offsets, n_reads)) {
+        const int rc = small_begin(s, bases, offsets, n_reads);
+        if (rc <= 0) return rc;             // done, or an error; > 0: not a case for the lanes after all
+    }
+    if (s) s->small_active = false;
     // streamed: the bases of sub-batch i+1 are copied and packed while sub-batch i is being classified
     if (int rc = prepare_batch(s, bases, offsets, n_reads, true)) return rc;
     // (page-locking the caller's buffer for the duration of the call was measured and is slower: the registration
@@ -1729,6 +2163,7 @@ extern "C" int taxor_gpu_search_segments_begin(taxor_gpu_searcher *s, const taxo
         vb += len;
     }
     static const char nothing = 0;
+    s->small_active = false;
     if (int rc = prepare_batch(s, &nothing, off.data(), n_reads, true)) return rc;
     s->host_spans = std::move(spans);
     return run_pipeline(s, n_reads != 0);
@@ -1795,6 +2230,7 @@ int stage_hash_list(taxor_gpu_searcher *s, const uint64_t *hashes, uint64_t n, u
     if (n >= (1ull << 32)) return fail(TAXOR_E_ARG, "hash list too long");
     HIP_TRY(hipSetDevice(s->idx->device));
     s->ran = s->synced = false;
+    s->small_active = false;
     s->n_reads = 1;
     s->n_bases = 0;
     s->mean_read_len = 1u << 20;

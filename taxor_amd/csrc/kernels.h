@@ -125,6 +125,11 @@ struct QueryArgs {
     uint32_t sparse_stages;   // stages of the pruned phase for long hash lists (0 = 3); between stages the alive set is re-evaluated
     uint32_t xcd_slices;      // 8 = the (IXF-grouped) queue is cut into eight slices and block b starts in slice b % 8 -- the XCD the
                               // dispatcher places it on -- so an IXF's items meet in one XCD's L2 instead of all eight; 0 = one cursor
+    uint32_t parts;           // level 0 only (q_in == nullptr): > 1 = every root item is split into `parts` column ranges, each a work
+                              // item of its own (item i = part i / n_level0 of read order0[i % n_level0]); the ranges are cut at unit
+                              // boundaries where a bin run ends (part_cut, in 16-bin units), so a part sees whole runs and prunes,
+                              // tallies and reports on its own -- small batches then fill the chip and finish sooner (api.hip)
+    uint16_t part_cut[10];
     uint32_t tally_mode;      // measurement aid (TAXOR_QUERY_TALLY): bit 0 = tally walks every bin, bit 1 = bin info fetched per item
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };
@@ -148,6 +153,31 @@ struct FinalizeArgs {
     uint32_t hit_cap;
     int is_last;
 };
+
+// CSR assembly of a SMALL batch (<= SMALL_FIN_MAX reads) in ONE launch of one block, results written straight into host
+// memory the device can address (hipHostMalloc): scan of the per-read tuple counts, scatter of the hit records, per-read sort by
+// DFS key, and -- so that the next batch on the same lane needs no memset launches -- the counters block, the per-read hit counts
+// and the syncmer cursors are cleared at the end.  h_status: [0] flags, [1] tuples, [2] distinct hashes, [3] work items, [4] query
+// bytes (algorithmic), [5] bytes requested.
+static constexpr uint32_t SMALL_FIN_MAX = 4096;
+struct SmallFinalizeArgs {
+    const uint4 *hits;
+    uint32_t *read_hits;
+    const uint32_t *dfs_key;
+    const int64_t *ubin;
+    const uint32_t *nh;
+    uint32_t *key, *cnt;       // device scratch for the tuples, tuple_cap entries each
+    int64_t *ub;
+    Counters *ctr;
+    uint32_t *sync_cursor;     // two words
+    uint32_t n_reads, tuple_cap, hit_cap;
+    uint64_t *h_read_off;      // [n_reads + 1], batch-local
+    uint32_t *h_nh;            // [n_reads]
+    int64_t *h_ub;             // [tuple_cap]
+    uint32_t *h_cnt;           // [tuple_cap]
+    uint64_t *h_status;        // [8]
+};
+void launch_finalize_small(const SmallFinalizeArgs &a, hipStream_t st);
 
 // launch wrappers (all asynchronous on `st`)
 void launch_pack_dna4(const uint8_t *ascii, const uint64_t *aoff, const uint64_t *poff, uint32_t *packed,

@@ -1230,7 +1230,8 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     // This kernel is HBM-bound and needs few issue slots, but it needs them promptly: when the (VALU/LDS heavy)
     // syncmer kernel of the next sub-batch shares the CU, age-based arbitration would starve these waves.
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0;
+    const uint32_t n_parts = (!a.q_in && a.parts > 1u) ? a.parts : 1u;
+    const uint32_t n_items = a.q_in ? min(a.ctr->q_n[lvl].v, a.q_cap) : a.n_level0 * n_parts;
     unsigned long long st_bytes = 0, st_touched = 0, st_work = 0, st_rows = 0, st_sparse = 0;
 
     // Returning atomics on one word are served serially by one L2 channel, ~13 ns each.  A launch of small work items
@@ -1301,11 +1302,23 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 if (item >= n_items) break;
             }
             if (tid < item_end - item) {                             // one lane per item of the chunk
-                uint32_t r_, v_;
+                uint32_t r_, v_, part = 0;
                 if (a.q_in) { const uint2 it = a.q_in[item + tid]; r_ = it.x; v_ = it.y; }
-                else { r_ = a.order0 ? a.order0[item + tid] : item + tid; v_ = 0; }
+                else {
+                    uint32_t ri = item + tid;
+                    if (n_parts > 1u) { part = ri / a.n_level0; ri -= part * a.n_level0; }      // part-major: a block's consecutive items share their bin info
+                    r_ = a.order0 ? a.order0[ri] : ri;
+                    v_ = 0;
+                }
                 ItemMeta m;
                 m.D = a.ixf[v_];
+                if (n_parts > 1u) {       // this item is one column range of the row: a narrower IXF of its own as far as the rest of the kernel is concerned
+                    const uint32_t u0 = a.part_cut[part], u1 = a.part_cut[part + 1u];
+                    m.D.data += (size_t)u0 * 16u;
+                    m.D.bin_base += u0 * 16u;
+                    m.D.bins = min(m.D.bins, u1 * 16u) - u0 * 16u;
+                    m.D.units = u1 - u0;
+                }
                 m.thr = a.thr[r_];
                 m.hoff = a.hoff[r_];
                 m.r = r_;
@@ -1381,7 +1394,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         __syncthreads();
         PMARK(1)                                                     // 1: clearing the tally, bin info + probe staging
         query_dense_range<NT, U, BS, QC>(D, hp, 0, dense_end, sProbe, sC, staged);
-        touched += (uint64_t)dense_end * 3ull * stride;
+        touched += (uint64_t)dense_end * 3ull * (D.units * 16u);      // (= stride for a whole row; a column part reads its own units)
         rows_read += (uint64_t)dense_end * 3ull;
         __syncthreads();
         PMARK(2)                                                     // 2: dense phase (row gathers)
@@ -1450,7 +1463,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 if (n_alive == 0) break;
                 if (n_alive > (uint32_t)Q_MAXU) { // too many survivors (long split runs, tiny thresholds): stay dense
                     query_dense_range<NT, U, BS, QC>(D, hp, done, n, sProbe, sC, staged);
-                    touched += rem * 3ull * stride;
+                    touched += rem * 3ull * (D.units * 16u);
                     rows_read += rem * 3ull;
                     break;
                 }
@@ -1946,6 +1959,138 @@ void launch_finalize(const FinalizeArgs &a, hipStream_t st)
     if (grid == 0) grid = 1;
     hipLaunchKernelGGL(k_sort_small, dim3(grid), dim3(BLK), 0, st, a);
     hipLaunchKernelGGL(k_sort_big, dim3(256), dim3(BLK), 0, st, a);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_finalize_small: the six launches above as one block, for batches of up to SMALL_FIN_MAX reads (the reference's chunk is
+// 1024 records, taxor_search.cpp:315) whose results leave through host memory the device writes directly -- a call of that size
+// is a millisecond, and six launches, five result copies and three memsets were a fifth of it.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_finalize_small(const SmallFinalizeArgs a)
+{
+    __shared__ uint32_t sRoff[SMALL_FIN_MAX + 1];
+    __shared__ uint32_t sCur[SMALL_FIN_MAX];
+    __shared__ uint32_t sW[16];
+    __shared__ uint32_t sBig[64];
+    __shared__ uint32_t sNBig;
+    const uint32_t tid = threadIdx.x, n = a.n_reads;
+    const uint32_t flags = a.ctr->flags;
+    const uint32_t n_hits = min(a.ctr->n_hits.v, a.hit_cap);
+    // exclusive scan of the per-read tuple counts (four reads per thread)
+    uint32_t c[4], v = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t r = tid * 4u + j;
+        c[j] = r < n ? a.read_hits[r] : 0u;
+        v += c[j];
+        if (r < SMALL_FIN_MAX) sCur[r] = 0u;
+    }
+    if (tid == 0) sNBig = 0u;
+    const uint32_t incl = wave_incl_add(v);
+    if (lane_id() == 63) sW[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t off = incl - v, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < (tid >> 6)) off += sW[w];
+        total += sW[w];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t r = tid * 4u + j;
+        if (r < n) sRoff[r] = off;
+        off += c[j];
+    }
+    if (tid == 0) sRoff[n] = total;
+    const bool overflow = (flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW)) != 0u || total > a.tuple_cap;
+    if (tid == 0) {
+        a.h_status[0] = (uint64_t)flags | (total > a.tuple_cap ? (uint64_t)FLAG_TUPLE_OVERFLOW : 0ull);
+        a.h_status[1] = total;
+        a.h_status[2] = a.ctr->n_hashes;
+        a.h_status[3] = a.ctr->n_work;
+        a.h_status[4] = a.ctr->query_bytes;
+        a.h_status[5] = a.ctr->touched_bytes;
+    }
+    __syncthreads();
+    if (!overflow) {
+        for (uint32_t r = tid; r <= n; r += 1024u) a.h_read_off[r] = sRoff[r];
+        for (uint32_t r = tid; r < n; r += 1024u) a.h_nh[r] = a.nh[r];
+        // hit records -> their read's slice, in arrival order
+        for (uint32_t i = tid; i < n_hits; i += 1024u) {
+            const uint4 h = a.hits[i];
+            const uint32_t pos = sRoff[h.x] + atomicAdd(&sCur[h.x], 1u);
+            a.key[pos] = a.dfs_key[h.y];
+            a.ub[pos] = a.ubin[h.y];
+            a.cnt[pos] = h.z;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // DFS order within a read (hierarchical_interleaved_xor_filter.hpp:313-338): one wave per read, ranks by comparison;
+        // the sorted tuples go straight to the host arrays
+        const uint32_t wave = tid >> 6, l = lane_id();
+        for (uint32_t r = wave; r < n; r += 16u) {
+            const uint32_t base = sRoff[r], m = sRoff[r + 1] - base;
+            if (m == 0u) continue;
+            if (m > 64u) {
+                if (l == 0) { const uint32_t k = atomicAdd(&sNBig, 1u); if (k < 64u) sBig[k] = r; }
+                continue;
+            }
+            uint32_t key = 0xFFFFFFFFu, cnt = 0;
+            int64_t ub = 0;
+            if (l < m) { key = a.key[base + l]; ub = a.ub[base + l]; cnt = a.cnt[base + l]; }
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; ++j) rank += (__shfl(key, (int)j) < key) ? 1u : 0u;
+            if (l < m) { a.h_ub[base + rank] = ub; a.h_cnt[base + rank] = cnt; }
+        }
+        __syncthreads();
+        // reads with more than 64 tuples (a threshold-0 read reports every leaf run): block-wide sorting network in the device
+        // scratch, then out; more than 64 such reads in one small batch are found by a second sweep
+        const uint32_t n_big = sNBig;
+        for (uint32_t bi = 0; bi < n_big; ++bi) {
+            uint32_t r;
+            if (bi < 64u) r = sBig[bi];
+            else {            // beyond the list: the bi-th read with more than 64 tuples, found by counting (block-uniform)
+                uint32_t seen = 0;
+                r = 0;
+                for (uint32_t q = 0; q < n; ++q)
+                    if (sRoff[q + 1] - sRoff[q] > 64u && seen++ == bi) { r = q; break; }
+            }
+            const uint32_t base = sRoff[r], m = sRoff[r + 1] - base;
+            uint32_t N = 1;
+            while (N < m) N <<= 1;
+            auto stage = [&](uint32_t x) {                                     // ascending compare-exchange with partner i ^ x
+                for (uint32_t i = tid; i < N; i += 1024u) {
+                    const uint32_t p = i ^ x;
+                    if (p > i && p < m) {
+                        const uint32_t ki = a.key[base + i], kp = a.key[base + p];
+                        if (kp < ki) {
+                            a.key[base + i] = kp; a.key[base + p] = ki;
+                            const int64_t ui = a.ub[base + i]; a.ub[base + i] = a.ub[base + p]; a.ub[base + p] = ui;
+                            const uint32_t ci = a.cnt[base + i]; a.cnt[base + i] = a.cnt[base + p]; a.cnt[base + p] = ci;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+            };
+            for (uint32_t kk = 2; kk <= N; kk <<= 1) {
+                stage(kk - 1u);                                                // mirror within blocks of kk
+                for (uint32_t j = kk >> 2; j > 0; j >>= 1) stage(j);           // half-cleaners
+            }
+            for (uint32_t i = tid; i < m; i += 1024u) { a.h_ub[base + i] = a.ub[base + i]; a.h_cnt[base + i] = a.cnt[base + i]; }
+            __syncthreads();
+        }
+    }
+    // leave the lane's counters as a fresh searcher has them: the next batch on this lane starts without memset launches
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024u) a.read_hits[r] = 0u;
+    uint32_t *cw = reinterpret_cast<uint32_t *>(a.ctr);
+    for (uint32_t i = tid; i < (uint32_t)(sizeof(Counters) / 4u); i += 1024u) cw[i] = 0u;
+    if (tid < 2u) a.sync_cursor[tid] = 0u;
+}
+
+void launch_finalize_small(const SmallFinalizeArgs &a, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_finalize_small, dim3(1), dim3(1024), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -99,7 +99,8 @@ def run_trial(seed, verbose=False):
                bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith)
     if verbose:
         print(cfg, flush=True)
-    sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub, group_always=group_always)
+    sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub, group_always=group_always,
+                  small_path=bool(rng.random() < 0.7), split_always=bool(rng.random() < 0.3))
     n_seg = int(rng.choice([0, 0, 1, 2, 5]))
     if n_seg == 0 or len(reads) < n_seg:
         res = sr.search_batch(B, O)
