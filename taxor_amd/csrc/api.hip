@@ -1142,7 +1142,7 @@ int ensure_scratch(taxor_gpu_searcher *s)
 // level loop + CSR assembly for one group of reads whose hashes / thresholds are already on the device
 int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d_hoff, const uint32_t *d_nh,
               const uint64_t *d_thr, uint32_t n_reads, uint64_t *d_read_off, int is_last, uint32_t *d_counts_out,
-              int only_ixf, const uint32_t *d_order = nullptr, uint32_t root_parts = 0, bool finalize = true)
+              int only_ixf, const uint32_t *d_order = nullptr, uint32_t root_parts = 0, bool finalize = true, bool tree = false)
 {
     const taxor_gpu_index *idx = s->idx;
     if (finalize) {            // (a lane's small finalize leaves the hit counts cleared and needs no scatter cursors)
@@ -1178,6 +1178,22 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     if (d_counts_out || only_ixf >= 0 || root_parts > idx->root_pmax) root_parts = 1;
     q.parts = root_parts;
     for (uint32_t j = 0; j <= root_parts; ++j) q.part_cut[j] = idx->root_cut[j * (idx->root_pmax / root_parts)];
+    if (tree) {        // a lane's piece: the whole traversal in one launch (k_query_level<..., TREE>), children through the one queue d_q[0]
+        q.level = 0;
+        q.q_in = nullptr;
+        q.q_out = s->d_q[0].p;
+        q.n_level0 = n_reads;
+        q.order0 = d_order;
+        q.cursor_chunk = 1;
+        q.xcd_slices = 0;
+        const uint64_t items0 = (uint64_t)n_reads * root_parts;
+        // blocks beyond the items a piece can have at one time only poll: the root's items, or a couple per read below it
+        const int grid = (int)std::min<uint64_t>((uint64_t)s->grid_query_short, std::max<uint64_t>(items0, 2ull * n_reads) + 64);
+        launch_query_tree(q, grid, s->lds_query, s->st);
+        s->stats.query_launches++;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const uint32_t levels = only_ixf >= 0 ? 1u : idx->depth;
     static const bool group_queue = [] { const char *e = tune_env("TAXOR_QUERY_GROUP"); return !e || atoi(e) != 0; }();
     for (uint32_t lvl = 0; lvl < levels; ++lvl) {
@@ -1727,17 +1743,18 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     c->max_read_slots = max_cap;
     c->max_sub_reads = n;
     c->subs.assign(1, SubBatch{0, n, n_long, slots, 0, nb});
-    const size_t cap_before = c->d_read_hits.cap;
+    const size_t cap_before = c->d_read_hits.cap, qcap_before = c->d_q[0].cap;
     Counters *ctr_before = c->d_ctr;
     if (L.d_in.reserve(in_bytes) || c->d_ascii.reserve(nb + 64) || c->d_packed.reserve(words + 16) || c->d_nh.reserve(n + 1) || c->d_thr.reserve(n + 1))
         return TAXOR_E_HIP;
     if (int rc = ensure_scratch(c)) return rc;
-    if (c->d_read_hits.cap != cap_before || c->d_ctr != ctr_before) L.fresh = true;
+    if (c->d_read_hits.cap != cap_before || c->d_ctr != ctr_before || c->d_q[0].cap != qcap_before) L.fresh = true;
     hipStream_t st = c->st;
     if (L.fresh) {            // first use, or the hit counts moved to a new allocation: clear what the small finalize otherwise leaves cleared
         HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
         HIP_TRY(hipMemsetAsync(c->d_read_hits.p, 0, c->d_read_hits.cap * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(c->d_sync_cursor.p, 0, 2 * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(c->d_q[0].p, 0xFF, c->d_q[0].cap * sizeof(uint2), st));      // the one queue of the tree launch: every slot empty (~0)
         L.fresh = false;
     }
     // ---- two copies
@@ -1792,7 +1809,8 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     if (parts_env >= 1) parts = std::min<uint32_t>((uint32_t)parts_env, idx->root_pmax);
     if (s->split_always) parts = idx->root_pmax;
     c->stats = taxor_gpu_run_stats{};
-    if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, parts, false)) return rc;
+    static const bool tree_off = [] { const char *e = tune_env("TAXOR_SMALL_TREE"); return e && atoi(e) == 0; }();
+    if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, parts, false, !tree_off)) return rc;
     // ---- CSR assembly into host memory, counters cleared for the lane's next piece
     const SmallOut o = small_out(L, L.d_out);
     SmallFinalizeArgs f{};
@@ -1872,6 +1890,7 @@ int small_finish(taxor_gpu_searcher *s)
         if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
         if (f & FLAG_CAND_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated"); }
         if (f & FLAG_DEDUP_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "dedup scratch too small"); }
+        if (f & FLAG_TREE_STALL) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "the one-launch traversal of a small batch stalled"); }
         const uint64_t *ro;
         const int64_t *ub;
         const uint32_t *cnt, *nh;

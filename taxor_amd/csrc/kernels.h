@@ -36,7 +36,8 @@ enum : uint32_t {
     FLAG_QUEUE_OVERFLOW = 4u, // work queue too small  -> host grows and reruns
     FLAG_HITS_OVERFLOW = 8u,  // hit buffer too small   -> host grows and reruns
     FLAG_TUPLE_OVERFLOW = 16u,// batch tuple arrays too small -> host grows and reruns
-    FLAG_DEDUP_OVERFLOW = 32u // dedup scratch too small (internal invariant)
+    FLAG_DEDUP_OVERFLOW = 32u,// dedup scratch too small (internal invariant)
+    FLAG_TREE_STALL = 64u     // the one-launch traversal of a small batch stopped waiting for work that never came (internal invariant)
 };
 
 // counters block (one per searcher).  Hot words sit on their own 128-B lines: returning atomics on one line are
@@ -190,6 +191,9 @@ bool syncmers_wave_applies(int k, int s);
 int syncmers_grid(int device);
 // small = the single-wave instantiation for launches of tiny items (IXFs of <= 512 bins under short reads)
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small = false, bool root_streams = true);
+// the whole traversal of a small batch in one launch (k_query_level<..., TREE>): a.q_in = nullptr, a.q_out = the one queue, whose
+// slots hold ~0 (all bytes 0xFF) before and after; a.level = 0
+void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
 int query_grid(int device, size_t lds_bytes, int want_per_cu);
 int query_grid_small(int device, size_t lds_bytes);
 size_t query_lds_bytes(uint32_t max_stride, bool small = false);

@@ -1209,7 +1209,16 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 // launches of TINY items -- levels of narrow IXFs (<= 512 bins) under short reads -- where an item is a handful of memory
 // round trips and fixed cost: sixteen single-wave blocks per CU keep four times as many items in flight as four
 // four-wave blocks, and a single-wave block's barriers cost nothing.
-template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP>
+//
+// TREE = true: ONE launch for the whole traversal of a small batch (api.hip, "small batches").  The root's items are implicit as
+// at level 0; every child a block pushes goes into the one queue a.q_out and is taken from there by whichever block asks next --
+// no level ends when its slowest item ends, and a read's child starts when ITS parent is done, not when every parent is.  The
+// queue's 64-bit entries are published with release stores into slots that hold ~0 (invalid) until then; a block whose claimed
+// index has no entry yet flushes its own pending pushes first (nobody ever waits on a block that waits) and then polls its slot
+// until the entry arrives or everything that exists has been completed:  completed == roots + reserved, read in that order, is
+// final -- an unfinished item is the only thing that can reserve more.  Consumers put ~0 back, so the queue is clean for the
+// next launch.  A poll loop that outlives any plausible run raises FLAG_TREE_STALL and leaves (never a hung GPU).
+template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP, bool TREE = false>
 __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
 {
     uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1242,25 +1251,34 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     __shared__ uint4 sOutH[Q_OB];
     __shared__ uint2 sOutQ[Q_OB];
     if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
+    unsigned long long *q64 = reinterpret_cast<unsigned long long *>(a.q_out);      // TREE: the one queue, entries (ixf << 32 | read), ~0 = empty slot
+    if (tid == 0) sScal[8] = 0u;                                                     // TREE: items finished since the last flush
     auto flush_out = [&](bool force) {          // block-uniform; the caller has just passed a barrier
         const uint32_t nq = min(sScal[2], (uint32_t)Q_OB), nh = min(sScal[3], (uint32_t)Q_OB);
-        if (!(force ? (nq | nh) != 0u : (nq >= (uint32_t)Q_OB / 2u || nh >= (uint32_t)Q_OB / 2u))) return;
+        const uint32_t n_done = TREE ? sScal[8] : 0u;
+        if (!(force ? (nq | nh | n_done) != 0u : (nq >= (uint32_t)Q_OB / 2u || nh >= (uint32_t)Q_OB / 2u))) return;
         if (tid == 0) {
-            sScal[4] = nq ? atomicAdd(&a.ctr->q_n[lvl + 1].v, nq) : 0u;
+            sScal[4] = nq ? atomicAdd(&a.ctr->q_n[lvl + 1].v, nq) : 0u;       // TREE: q_n[1] = children reserved so far, all levels
             sScal[5] = nh ? atomicAdd(&a.ctr->n_hits.v, nh) : 0u;
         }
         __syncthreads();
         const uint32_t bq = sScal[4], bh = sScal[5];
         for (uint32_t i = tid; i < nq; i += BS) {
-            if (bq + i < a.q_cap) a.q_out[bq + i] = sOutQ[i];
-            else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+            if (bq + i < a.q_cap) {
+                if constexpr (TREE) __hip_atomic_store(&q64[bq + i], (unsigned long long)sOutQ[i].y << 32 | sOutQ[i].x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                else a.q_out[bq + i] = sOutQ[i];
+            } else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
         }
         for (uint32_t i = tid; i < nh; i += BS) {
             if (bh + i < a.hit_cap) a.hits[bh + i] = sOutH[i];
             else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
         }
+        if constexpr (TREE) __threadfence();          // the pushes are out before the items that made them count as completed
         __syncthreads();
-        if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
+        if (tid == 0) {
+            if (TREE && n_done) atomicAdd(&a.ctr->q_n[2].v, n_done);             // TREE: q_n[2] = items completed
+            sScal[2] = 0u; sScal[3] = 0u; sScal[8] = 0u;
+        }
     };
 
     const uint32_t chunk = min(max(a.cursor_chunk, 1u), (uint32_t)Q_CHUNK_MAX);
@@ -1271,6 +1289,69 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         __syncthreads();
         if (item == item_end) {
             flush_out(false);
+            if constexpr (TREE) {
+                const uint32_t n0 = a.n_level0 * n_parts;                   // the root's items; everything else comes out of the queue
+                if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[0].v, 1u);
+                __syncthreads();
+                const uint32_t idx = sScal[0];
+                uint32_t got = 1u;                                           // 1 = an item to work on, 0 = all done, 2 = a slot beyond the queue's capacity
+                if (idx >= n0) {
+                    flush_out(true);                                         // nobody may wait for pushes this block still holds
+                    if (tid == 0) {
+                        const uint32_t k = idx - n0;
+                        unsigned long long e = ~0ull;
+                        got = 3u;
+                        for (uint32_t spin = 0; spin < (1u << 23); ++spin) {
+                            if (k < a.q_cap) {
+                                e = __hip_atomic_load(&q64[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                                if (e != ~0ull) { got = 1u; break; }
+                            }
+                            const uint32_t c = __hip_atomic_load(&a.ctr->q_n[2].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            const uint32_t rsv = __hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            if (k >= a.q_cap && k < rsv) { got = 2u; break; }      // pushed past the queue's end (FLAG_QUEUE_OVERFLOW is up): nothing to run
+                            if (c == n0 + rsv) { got = 0u; break; }                 // every item that exists is completed: no more will come
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (got == 3u) { atomicOr(&a.ctr->flags, FLAG_TREE_STALL); got = 0u; }
+                        if (got == 1u) {
+                            q64[k] = ~0ull;                                  // the slot is empty again for the next launch
+                            ItemMeta m;
+                            m.r = (uint32_t)e;
+                            m.D = a.ixf[(uint32_t)(e >> 32)];
+                            m.thr = a.thr[m.r];
+                            m.hoff = a.hoff[m.r];
+                            m.n = a.nh[m.r];
+                            sItems[0] = m;
+                        }
+                        if (got == 2u) sScal[8] += 1u;                       // completed without work
+                        sScal[7] = got;
+                    }
+                    __syncthreads();
+                    got = sScal[7];
+                    if (got == 0u) break;
+                    if (got == 2u) continue;
+                } else if (tid == 0) {
+                    uint32_t part = 0, ri = idx;
+                    if (n_parts > 1u) { part = ri / a.n_level0; ri -= part * a.n_level0; }
+                    ItemMeta m;
+                    m.r = a.order0 ? a.order0[ri] : ri;
+                    m.D = a.ixf[0];
+                    if (n_parts > 1u) {
+                        const uint32_t u0 = a.part_cut[part], u1 = a.part_cut[part + 1u];
+                        m.D.data += (size_t)u0 * 16u;
+                        m.D.bin_base += u0 * 16u;
+                        m.D.bins = min(m.D.bins, u1 * 16u) - u0 * 16u;
+                        m.D.units = u1 - u0;
+                    }
+                    m.thr = a.thr[m.r];
+                    m.hoff = a.hoff[m.r];
+                    m.n = a.nh[m.r];
+                    sItems[0] = m;
+                }
+                item = item0 = 0u;            // (indices are only used relative to item0 from here on)
+                item_end = 1u;
+                __syncthreads();
+            } else
             if (a.xcd_slices) {
                 // Eight slices of the grouped queue, eight cursors.  A block starts in the slice of its XCD (the dispatcher is
                 // observed to place block b on XCD b % 8; a wrong guess is slower, not wrong) and moves on to the next slice when
@@ -1301,7 +1382,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 item_end = min(item + chunk, n_items);
                 if (item >= n_items) break;
             }
-            if (tid < item_end - item) {                             // one lane per item of the chunk
+            if (!TREE && tid < item_end - item) {                    // one lane per item of the chunk
                 uint32_t r_, v_, part = 0;
                 if (a.q_in) { const uint2 it = a.q_in[item + tid]; r_ = it.x; v_ = it.y; }
                 else {
@@ -1569,8 +1650,10 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 if (qs < (uint32_t)Q_OB) sOutQ[qs] = rec;
                 else {
                     const uint32_t g = atomicAdd(&a.ctr->q_n[lvl + 1].v, 1u);
-                    if (g < a.q_cap) a.q_out[g] = rec;
-                    else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
+                    if (g < a.q_cap) {
+                        if constexpr (TREE) __hip_atomic_store(&q64[g], (unsigned long long)rec.y << 32 | rec.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        else a.q_out[g] = rec;
+                    } else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
                 }
             }
             const uint32_t hs = wave_append(push_hit, &sScal[3]);
@@ -1591,6 +1674,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         st_sparse += sparse_loads;
         st_work += 1ull;
         ++item;
+        if (TREE && tid == 0) sScal[8] += 1u;                         // counted as completed when this block's pushes are out (flush_out)
         PMARK(5)                                                     // 5: run tally, child pushes, hit records
     }
     flush_out(true);           // the break above is taken by the whole block right after a barrier
@@ -1607,6 +1691,11 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         atomicAdd(&a.ctr->lvl_rows[min(lvl, 7u)], st_rows);
         if (st_sparse) atomicAdd(&a.ctr->lvl_sparse[min(lvl, 7u)], st_sparse);
     }
+}
+
+void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_query_level<false, 2, false, BLK, Q_CAP, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
 }
 
 int query_grid(int device, size_t lds_bytes, int want_per_cu)
@@ -2039,8 +2128,9 @@ __global__ __launch_bounds__(1024) void k_finalize_small(const SmallFinalizeArgs
             if (l < m) { key = a.key[base + l]; ub = a.ub[base + l]; cnt = a.cnt[base + l]; }
             uint32_t rank = 0;
             for (uint32_t j = 0; j < m; ++j) rank += (__shfl(key, (int)j) < key) ? 1u : 0u;
-            if (l < m) { a.h_ub[base + rank] = ub; a.h_cnt[base + rank] = cnt; }
+            if (l < m) { a.ub[base + rank] = ub; a.cnt[base + rank] = cnt; }       // in place: the wave has read all m before it writes
         }
+        __threadfence_block();
         __syncthreads();
         // reads with more than 64 tuples (a threshold-0 read reports every leaf run): block-wide sorting network in the device
         // scratch, then out; more than 64 such reads in one small batch are found by a second sweep
@@ -2076,9 +2166,9 @@ __global__ __launch_bounds__(1024) void k_finalize_small(const SmallFinalizeArgs
                 stage(kk - 1u);                                                // mirror within blocks of kk
                 for (uint32_t j = kk >> 2; j > 0; j >>= 1) stage(j);           // half-cleaners
             }
-            for (uint32_t i = tid; i < m; i += 1024u) { a.h_ub[base + i] = a.ub[base + i]; a.h_cnt[base + i] = a.cnt[base + i]; }
-            __syncthreads();
         }
+        // out to the host in whole lines (scattered 8-byte stores over PCIe were most of this kernel's time)
+        for (uint32_t i = tid; i < total; i += 1024u) { a.h_ub[i] = a.ub[i]; a.h_cnt[i] = a.cnt[i]; }
     }
     // leave the lane's counters as a fresh searcher has them: the next batch on this lane starts without memset launches
     __syncthreads();
