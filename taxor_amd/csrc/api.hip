@@ -1186,6 +1186,8 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.order0 = d_order;
         q.cursor_chunk = 1;
         q.xcd_slices = 0;
+        static const int polls_env = [] { const char *e = tune_env("TAXOR_TREE_POLLS"); return e ? atoi(e) : -1; }();
+        q.tree_polls = polls_env >= 0 ? (uint32_t)polls_env : 8u;
         const uint64_t items0 = (uint64_t)n_reads * root_parts;
         // blocks beyond the items a piece can have at one time only poll: the root's items, or a couple per read below it
         const int grid = (int)std::min<uint64_t>((uint64_t)s->grid_query_short, std::max<uint64_t>(items0, 2ull * n_reads) + 64);

@@ -131,6 +131,7 @@ struct QueryArgs {
                               // boundaries where a bin run ends (part_cut, in 16-bin units), so a part sees whole runs and prunes,
                               // tallies and reports on its own -- small batches then fill the chip and finish sooner (api.hip)
     uint16_t part_cut[10];
+    uint32_t tree_polls;      // TREE launches: how often an idle block looks again (about 3 us apart) before it leaves
     uint32_t tally_mode;      // measurement aid (TAXOR_QUERY_TALLY): bit 0 = tally walks every bin, bit 1 = bin info fetched per item
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };
