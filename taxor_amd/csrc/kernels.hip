@@ -1213,7 +1213,10 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 // TREE = true: ONE launch for the whole traversal of a small batch (api.hip, "small batches").  The root's items are implicit as
 // at level 0; every child a block pushes goes into the one queue a.q_out and is taken from there by whichever block asks next --
 // no level ends when its slowest item ends, and a read's child starts when ITS parent is done, not when every parent is.  The
-// queue's 64-bit entries are published with release stores into slots that hold ~0 (invalid) until then.  An entry is claimed
+// queue's 64-bit entries are published with single agent-scope atomic stores into slots that hold ~0 (invalid) until then, and
+// read the same way: the entry IS the message (read, IXF), everything else an item needs was written by earlier launches, so
+// relaxed ordering suffices -- acquire / release at agent scope would write back and invalidate the XCD's L2 on every poll and
+// every push (measured: the launch then takes milliseconds).  An entry is claimed
 // by compare-and-swap on the queue's cursor and only while cursor < reserved, so no block ever holds a claim on something that
 // does not exist yet, and a block that finds nothing (after putting out its own pending pushes) may simply leave: a later push
 // can only come from a block that is still running an item, and that block returns here and takes it.  Leaving at once would
@@ -1267,7 +1270,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         const uint32_t bq = sScal[4], bh = sScal[5];
         for (uint32_t i = tid; i < nq; i += BS) {
             if (bq + i < a.q_cap) {
-                if constexpr (TREE) __hip_atomic_store(&q64[bq + i], (unsigned long long)sOutQ[i].y << 32 | sOutQ[i].x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                if constexpr (TREE) __hip_atomic_store(&q64[bq + i], (unsigned long long)sOutQ[i].y << 32 | sOutQ[i].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else a.q_out[bq + i] = sOutQ[i];
             } else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
         }
@@ -1320,13 +1323,13 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                         got = 0u;
                         uint32_t cur = __hip_atomic_load(&a.ctr->q_cursor[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         for (uint32_t polls = 0;;) {
-                            const uint32_t avail = min(__hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), a.q_cap);
+                            const uint32_t avail = min(__hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.q_cap);
                             if (cur < avail) {
                                 const uint32_t old = atomicCAS(&a.ctr->q_cursor[1].v, cur, cur + 1u);
                                 if (old != cur) { cur = old; continue; }
                                 unsigned long long e = ~0ull;                // reserved, and written a moment later by a block that waits for nobody
                                 for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-                                    e = __hip_atomic_load(&q64[cur], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                                    e = __hip_atomic_load(&q64[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                     if (e != ~0ull) break;
                                     __builtin_amdgcn_s_sleep(2);
                                 }
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                 else {
                     const uint32_t g = atomicAdd(&a.ctr->q_n[lvl + 1].v, 1u);
                     if (g < a.q_cap) {
-                        if constexpr (TREE) __hip_atomic_store(&q64[g], (unsigned long long)rec.y << 32 | rec.x, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        if constexpr (TREE) __hip_atomic_store(&q64[g], (unsigned long long)rec.y << 32 | rec.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         else a.q_out[g] = rec;
                     } else atomicOr(&a.ctr->flags, FLAG_QUEUE_OVERFLOW);
                 }
