@@ -1216,14 +1216,15 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 // queue's 64-bit entries are published with single agent-scope atomic stores into slots that hold ~0 (invalid) until then, and
 // read the same way: the entry IS the message (read, IXF), everything else an item needs was written by earlier launches, so
 // relaxed ordering suffices -- acquire / release at agent scope would write back and invalidate the XCD's L2 on every poll and
-// every push (measured: the launch then takes milliseconds).  An entry is claimed
-// by compare-and-swap on the queue's cursor and only while cursor < reserved, so no block ever holds a claim on something that
-// does not exist yet, and a block that finds nothing (after putting out its own pending pushes) may simply leave: a later push
-// can only come from a block that is still running an item, and that block returns here and takes it.  Leaving at once would
-// leave late children to the few blocks that pushed them, so an idle block first polls for a few microseconds (tree_polls).
-// Consumers put ~0 back, so the queue is clean for the next launch.  The one wait left -- for the store of a slot that is
-// reserved already -- ends as soon as the reserving block, which waits for nobody, has written it; a bound on it raises
-// FLAG_TREE_STALL instead of ever hanging the GPU.
+// every push (measured: the launch then takes milliseconds).  Work is handed out by TICKET (one
+// atomic add on one counter: root items first, then queue slots in order); a block whose ticket has no entry yet first puts out
+// its own pending pushes (nobody ever waits on a block that waits) and then polls ITS slot -- a word of its own, no shared hot
+// spot -- until the entry arrives or the launch is complete.  Complete means completed == roots + reserved: an unfinished item is
+// the only thing that can reserve more, so the block whose flush makes the two equal knows it is final and says so through 64
+// copies of one word, each polled by a sixty-fourth of the waiting blocks.  (Tried first: claiming entries by compare-and-swap
+// while cursor < reserved, idle blocks leaving -- a thousand blocks retrying a CAS on one word serialise into O(n^2) atomics,
+// milliseconds per launch.)  Consumers put ~0 back, so the queue is clean for the next launch.  A wait that outlives any
+// plausible run raises FLAG_TREE_STALL and leaves -- never a hung GPU.
 template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP, bool TREE = false>
 __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
 {
@@ -1258,10 +1259,12 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     __shared__ uint2 sOutQ[Q_OB];
     if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
     unsigned long long *q64 = reinterpret_cast<unsigned long long *>(a.q_out);      // TREE: the one queue, entries (ixf << 32 | read), ~0 = empty slot
-    bool roots_done = false;                                                         // TREE (thread 0): the root's counter has run out
+    const uint32_t tree_n0 = a.n_level0 * n_parts;                                   // TREE: the root's items; everything else comes out of the queue
+    if (tid == 0) sScal[8] = 0u;                                                     // TREE: items finished since the last flush
     auto flush_out = [&](bool force) {          // block-uniform; the caller has just passed a barrier
         const uint32_t nq = min(sScal[2], (uint32_t)Q_OB), nh = min(sScal[3], (uint32_t)Q_OB);
-        if (!(force ? (nq | nh) != 0u : (nq >= (uint32_t)Q_OB / 2u || nh >= (uint32_t)Q_OB / 2u))) return;
+        const uint32_t n_done = TREE ? sScal[8] : 0u;
+        if (!(force ? (nq | nh | n_done) != 0u : (nq >= (uint32_t)Q_OB / 2u || nh >= (uint32_t)Q_OB / 2u))) return;
         if (tid == 0) {
             sScal[4] = nq ? atomicAdd(&a.ctr->q_n[lvl + 1].v, nq) : 0u;       // TREE: q_n[1] = children reserved so far, all levels
             sScal[5] = nh ? atomicAdd(&a.ctr->n_hits.v, nh) : 0u;
@@ -1279,7 +1282,20 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
             else atomicOr(&a.ctr->flags, FLAG_HITS_OVERFLOW);
         }
         __syncthreads();
-        if (tid == 0) { sScal[2] = 0u; sScal[3] = 0u; }
+        if (tid == 0) {
+            sScal[2] = 0u; sScal[3] = 0u;
+            if constexpr (TREE) {
+                sScal[8] = 0u;
+                if (n_done) {
+                    // the items this block finished count as completed now that their pushes are reserved and written.  Whoever
+                    // makes completed == roots + reserved knows that nothing is running and nothing more can be pushed: it tells
+                    // the waiting blocks through 64 copies of one word (each polled by a sixty-fourth of them)
+                    const uint32_t c = atomicAdd(&a.ctr->q_n[2].v, n_done) + n_done;
+                    if (c == tree_n0 + __hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        for (uint32_t g = 0; g < 64u; ++g) __hip_atomic_store(&a.ctr->q_xcur[g >> 3][g & 7u].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
     };
 
     const uint32_t chunk = min(max(a.cursor_chunk, 1u), (uint32_t)Q_CHUNK_MAX);
@@ -1291,74 +1307,64 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         if (item == item_end) {
             flush_out(false);
             if constexpr (TREE) {
-                const uint32_t n0 = a.n_level0 * n_parts;                   // the root's items; everything else comes out of the queue
-                uint32_t got = 1u;                                           // 1 = an item to work on, 0 = nothing left for this block, 4 = flush first
-                if (tid == 0) {
-                    uint32_t idx = n0;
-                    if (!roots_done) {
-                        idx = atomicAdd(&a.ctr->q_cursor[0].v, 1u);         // the root's items: a plain counter (overshooting it costs nothing)
-                        if (idx >= n0) roots_done = true;
-                    }
-                    if (idx < n0) {
-                        uint32_t part = 0, ri = idx;
-                        if (n_parts > 1u) { part = ri / a.n_level0; ri -= part * a.n_level0; }
-                        ItemMeta m;
-                        m.r = a.order0 ? a.order0[ri] : ri;
-                        m.D = a.ixf[0];
-                        if (n_parts > 1u) {
-                            const uint32_t u0 = a.part_cut[part], u1 = a.part_cut[part + 1u];
-                            m.D.data += (size_t)u0 * 16u;
-                            m.D.bin_base += u0 * 16u;
-                            m.D.bins = min(m.D.bins, u1 * 16u) - u0 * 16u;
-                            m.D.units = u1 - u0;
-                        }
-                        m.thr = a.thr[m.r];
-                        m.hoff = a.hoff[m.r];
-                        m.n = a.nh[m.r];
-                        sItems[0] = m;
-                    } else {
-                        // a pushed item: claimed by compare-and-swap, and only while one is there to claim -- so a block that finds
-                        // nothing may simply LEAVE: whoever pushes later is alive and comes back here itself.  Before leaving it
-                        // gives the others a few microseconds (children of items still running elsewhere), polling two words.
-                        got = 0u;
-                        uint32_t cur = __hip_atomic_load(&a.ctr->q_cursor[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        for (uint32_t polls = 0;;) {
-                            const uint32_t avail = min(__hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a.q_cap);
-                            if (cur < avail) {
-                                const uint32_t old = atomicCAS(&a.ctr->q_cursor[1].v, cur, cur + 1u);
-                                if (old != cur) { cur = old; continue; }
-                                unsigned long long e = ~0ull;                // reserved, and written a moment later by a block that waits for nobody
-                                for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
-                                    e = __hip_atomic_load(&q64[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (e != ~0ull) break;
-                                    __builtin_amdgcn_s_sleep(2);
-                                }
-                                if (e == ~0ull) { atomicOr(&a.ctr->flags, FLAG_TREE_STALL); break; }
-                                q64[cur] = ~0ull;                            // the slot is empty again for the next launch
-                                ItemMeta m;
-                                m.r = (uint32_t)e;
-                                m.D = a.ixf[(uint32_t)(e >> 32)];
-                                m.thr = a.thr[m.r];
-                                m.hoff = a.hoff[m.r];
-                                m.n = a.nh[m.r];
-                                sItems[0] = m;
-                                got = 1u;
-                                break;
-                            }
-                            if (sScal[2] | sScal[3]) { got = 4u; break; }    // pushes of its own still in LDS: out with them, then look again
-                            if (polls++ >= a.tree_polls) break;
-                            __builtin_amdgcn_s_sleep(100);
-                            cur = __hip_atomic_load(&a.ctr->q_cursor[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                    sScal[7] = got;
-                }
+                if (tid == 0) sScal[0] = atomicAdd(&a.ctr->q_cursor[0].v, 1u);          // a ticket: root items first, then queue slots in order
                 __syncthreads();
-                got = sScal[7];
-                if (got == 0u) break;
-                if (got == 4u) { flush_out(true); continue; }
+                const uint32_t idx = sScal[0];
+                uint32_t got = 1u;                                           // 1 = an item to work on, 0 = all done, 2 = a slot beyond the queue's capacity
+                if (idx >= tree_n0) {
+                    flush_out(true);                                         // nobody may wait for pushes (or completions) this block still holds
+                    if (tid == 0) {
+                        const uint32_t k = idx - tree_n0;
+                        const uint32_t *done = &a.ctr->q_xcur[(blockIdx.x >> 3) & 7u][blockIdx.x & 7u].v;      // this block's copy of the "all done" word
+                        unsigned long long e = ~0ull;
+                        got = 3u;
+                        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+                            if (k < a.q_cap) {
+                                e = __hip_atomic_load(&q64[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (e != ~0ull) { got = 1u; break; }
+                            } else if (k < __hip_atomic_load(&a.ctr->q_n[1].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 2u; break; }
+                            if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 0u; break; }
+                            __builtin_amdgcn_s_sleep(16);
+                        }
+                        if (got == 3u) { atomicOr(&a.ctr->flags, FLAG_TREE_STALL); got = 0u; }
+                        if (got == 1u) {
+                            q64[k] = ~0ull;                                  // the slot is empty again for the next launch
+                            ItemMeta m;
+                            m.r = (uint32_t)e;
+                            m.D = a.ixf[(uint32_t)(e >> 32)];
+                            m.thr = a.thr[m.r];
+                            m.hoff = a.hoff[m.r];
+                            m.n = a.nh[m.r];
+                            sItems[0] = m;
+                        }
+                        if (got == 2u) sScal[8] += 1u;                       // pushed past the queue's end (FLAG_QUEUE_OVERFLOW is up): completed without work
+                        sScal[7] = got;
+                    }
+                    __syncthreads();
+                    got = sScal[7];
+                    if (got == 0u) break;
+                    if (got == 2u) continue;
+                } else if (tid == 0) {
+                    uint32_t part = 0, ri = idx;
+                    if (n_parts > 1u) { part = ri / a.n_level0; ri -= part * a.n_level0; }
+                    ItemMeta m;
+                    m.r = a.order0 ? a.order0[ri] : ri;
+                    m.D = a.ixf[0];
+                    if (n_parts > 1u) {
+                        const uint32_t u0 = a.part_cut[part], u1 = a.part_cut[part + 1u];
+                        m.D.data += (size_t)u0 * 16u;
+                        m.D.bin_base += u0 * 16u;
+                        m.D.bins = min(m.D.bins, u1 * 16u) - u0 * 16u;
+                        m.D.units = u1 - u0;
+                    }
+                    m.thr = a.thr[m.r];
+                    m.hoff = a.hoff[m.r];
+                    m.n = a.nh[m.r];
+                    sItems[0] = m;
+                }
                 item = item0 = 0u;            // (indices are only used relative to item0 from here on)
                 item_end = 1u;
+                __syncthreads();
             } else
             if (a.xcd_slices) {
                 // Eight slices of the grouped queue, eight cursors.  A block starts in the slice of its XCD (the dispatcher is
@@ -1682,6 +1688,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         st_sparse += sparse_loads;
         st_work += 1ull;
         ++item;
+        if (TREE && tid == 0) sScal[8] += 1u;                         // counted as completed when this block's pushes are out (flush_out)
         PMARK(5)                                                     // 5: run tally, child pushes, hit records
     }
     flush_out(true);           // the break above is taken by the whole block right after a barrier
