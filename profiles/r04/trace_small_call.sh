@@ -24,12 +24,11 @@ def short(n):
     return m.group(1) if m else n[:28]
 fins=[i for i,r in enumerate(rows) if "k_finalize_small" in r[2] or "k_sort_big" in r[2]]
 packs=[i for i,r in enumerate(rows) if "k_pack_dna4" in r[2]]
-# one call from the single-searcher phase: starts after a gap of > 60 us of nothing, a quarter of the way into the run
+# a window of the single-searcher phase: from a few rows before a pack kernel a quarter of the way into the run, ROWS rows on
+ROWS=int(os.environ.get("ROWS","70"))
 i0=packs[len(packs)//4]
-start=i0
-while start>0 and rows[start][0]-max(r[1] for r in rows[max(0,start-12):start]) < 60_000: start-=1
-end=start+1
-while end<len(rows) and rows[end][0]-max(r[1] for r in rows[max(0,end-12):end]) < 60_000: end+=1
+start=max(0,i0-3)
+end=min(len(rows),start+ROWS)
 t0=rows[start][0]
 prev_end=t0
 for r in rows[start:end]:

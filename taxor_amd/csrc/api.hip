@@ -1690,7 +1690,12 @@ SmallOut small_out(const taxor_gpu_searcher::SmallLane &L, void *base)
 int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const uint64_t *offsets, uint64_t first, uint32_t n)
 {
     const taxor_gpu_index *idx = s->idx;
+    static const bool trace = tune_env("TAXOR_TRACE_BATCH") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); };
+    double t_ready = 0, t_layout = 0, t_scratch = 0, t_arrays = 0, t_bases = 0, t_hash = 0, t_query = 0;
     if (int rc = small_lane_ready(s, li, n, SMALL_TUPLES)) return rc;
+    t_ready = us();
     taxor_gpu_searcher::SmallLane &L = s->lanes[li];
     taxor_gpu_searcher *c = L.c;
     const uint64_t *off = offsets + first;
@@ -1737,6 +1742,7 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
         n_long = 0;
         while (n_long < n && hcap[order[n_long]] > SYNC_WAVE_CAND) ++n_long;
     }
+    t_layout = us();
     // ---- the lane's buffers (allocation only when a piece is larger than any before it)
     c->n_reads = n;
     c->n_bases = nb;
@@ -1752,6 +1758,7 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     if (int rc = ensure_scratch(c)) return rc;
     if (c->d_read_hits.cap != cap_before || c->d_ctr != ctr_before || c->d_q[0].cap != qcap_before) L.fresh = true;
     hipStream_t st = c->st;
+    t_scratch = us();
     if (L.fresh) {            // first use, or the hit counts moved to a new allocation: clear what the small finalize otherwise leaves cleared
         HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
         HIP_TRY(hipMemsetAsync(c->d_read_hits.p, 0, c->d_read_hits.cap * sizeof(uint32_t), st));
@@ -1761,7 +1768,9 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     }
     // ---- two copies
     HIP_TRY(hipMemcpyAsync(L.d_in.p, L.h_in, in_bytes, hipMemcpyHostToDevice, st));
+    t_arrays = us();
     if (nb) HIP_TRY(hipMemcpyAsync(c->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, st));
+    t_bases = us();
     const uint64_t *d_aoff = (const uint64_t *)(L.d_in.p + o_aoff), *d_poff = (const uint64_t *)(L.d_in.p + o_poff),
                    *d_hoff = (const uint64_t *)(L.d_in.p + o_hoff);
     const uint32_t *d_rlen = (const uint32_t *)(L.d_in.p + o_rlen), *d_hcap = (const uint32_t *)(L.d_in.p + o_hcap),
@@ -1804,6 +1813,7 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
         launch_syncmers_wave(b, c->grid_wave, st);
     }
     HIP_TRY(hipGetLastError());
+    t_hash = us();
     // ---- the levels; root items in column parts until the piece has about a grid's worth of them
     uint32_t parts = 1;
     static const int parts_env = [] { const char *e = tune_env("TAXOR_SMALL_PARTS"); return e ? atoi(e) : 0; }();
@@ -1813,6 +1823,7 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     c->stats = taxor_gpu_run_stats{};
     static const bool tree_off = [] { const char *e = tune_env("TAXOR_SMALL_TREE"); return e && atoi(e) == 0; }();
     if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, parts, false, !tree_off)) return rc;
+    t_query = us();
     // ---- CSR assembly into host memory, counters cleared for the lane's next piece
     const SmallOut o = small_out(L, L.d_out);
     SmallFinalizeArgs f{};
@@ -1837,6 +1848,9 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     launch_finalize_small(f, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(L.done, st));
+    if (trace)
+        fprintf(stderr, "[small piece %u: %u reads] lane ready %.0f us, layout %.0f, buffers %.0f, arrays copy issued %.0f, bases copied %.0f, pack+syncmers launched %.0f, "
+                        "traversal launched %.0f, finalize + event %.0f\n", li, n, t_ready, t_layout, t_scratch, t_arrays, t_bases, t_hash, t_query, us());
     return 0;
 }
 
