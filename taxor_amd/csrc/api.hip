@@ -189,6 +189,7 @@ struct taxor_gpu_searcher {
     const char *small_bases = nullptr;
     const uint64_t *small_offsets = nullptr;
     bool lane_mode = false;                 // this searcher IS a lane
+    bool st_borrowed = false;               // ... working on a stream that belongs to the searcher it serves
     bool small_active = false, small_done = false;   // the call in flight went through the lanes / its results are in the host arrays
     bool dev_results_stale = false;         // ... and not (yet) in the device-resident CSR that export_device / the communicator read
 
@@ -800,8 +801,18 @@ extern "C" int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t
 // =========================================================================================================
 // searcher
 // =========================================================================================================
+static int searcher_create_impl(taxor_gpu_index *idx, const taxor_gpu_search_params *prm, taxor_gpu_searcher **out, hipStream_t lane_stream);
+
 extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_search_params *prm,
                                          taxor_gpu_searcher **out)
+{
+    return searcher_create_impl(idx, prm, out, nullptr);
+}
+
+// lane_stream != nullptr: the searcher becomes a lane of another one (small batches) and works on that stream, which stays the
+// other searcher's; it gets no second stream of its own (every stream a process holds is a candidate to share a hardware queue
+// with -- runtime_env_once -- and four lanes with two streams each were measured to run two of their pieces one after the other)
+static int searcher_create_impl(taxor_gpu_index *idx, const taxor_gpu_search_params *prm, taxor_gpu_searcher **out, hipStream_t lane_stream)
 {
     if (!idx || !prm || !out) return fail(TAXOR_E_ARG, "searcher_create: null argument");
     const bool by_ratio = prm->model == TAXOR_THR_PERCENTAGE || prm->model == TAXOR_THR_SYNCMER;
@@ -820,8 +831,14 @@ extern "C" int taxor_gpu_searcher_create(taxor_gpu_index *idx, const taxor_gpu_s
     if (s->prm.sub_batch_reads == 0) s->prm.sub_batch_reads = 32768;
     if (s->prm.sub_batch_bases == 0) s->prm.sub_batch_bases = 1ull << 29;
     if (s->prm.sub_batch_reads > (1u << 20)) s->prm.sub_batch_reads = 1u << 20;
-    hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+    if (lane_stream) {
+        s->st = lane_stream;
+        s->st_borrowed = s->lane_mode = true;
+    } else {
+        e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->st_sync, hipStreamNonBlocking);
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_wave, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_ctr, sizeof(Counters));
@@ -916,7 +933,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     for (auto ev : s->ev) (void)hipEventDestroy(ev);
     if (s->d_ctr) (void)hipFree(s->d_ctr);
     if (s->d_prof) (void)hipFree(s->d_prof);
-    if (s->st) (void)hipStreamDestroy(s->st);
+    if (s->st && !s->st_borrowed) (void)hipStreamDestroy(s->st);
     delete s;
 }
 
@@ -1652,12 +1669,11 @@ int small_lane_ready(taxor_gpu_searcher *s, uint32_t li, uint32_t n_reads, uint3
         taxor_gpu_search_params p = s->prm;
         p.flags |= TAXOR_SEARCH_NO_SMALL_PATH;
         p.time_kernels = 0;
-        if (int rc = taxor_gpu_searcher_create(s->idx, &p, &L.c)) return rc;
-        L.c->lane_mode = true;
+        // the four streams this searcher has (or would make for its pipeline of large batches) carry the four lanes: no new ones
+        hipStream_t *slot[SMALL_LANES] = {&s->st, &s->st_sync, &s->st_copy, &s->st_sync2};
+        if (ensure_stream(slot[li])) return TAXOR_E_HIP;
+        if (int rc = searcher_create_impl(s->idx, &p, &L.c, *slot[li])) return rc;
         L.c->prune = s->prune;
-        // a lane works on ONE stream: give the second one back (every stream a process holds is a candidate to share a
-        // hardware queue with, runtime_env_once)
-        if (L.c->st_sync) { (void)hipStreamDestroy(L.c->st_sync); L.c->st_sync = nullptr; }
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         L.fresh = true;
     }
