@@ -182,6 +182,7 @@ struct taxor_gpu_searcher {
         void *h_out = nullptr, *d_out = nullptr;   // results in host memory the device writes: status | read_off | nh | ub | cnt
         uint32_t out_reads = 0, out_tuples = 0;    // capacities of that area
         bool fresh = true;                  // counters / hit counts not known to be zero: clear them before the next piece
+        bool q_dirty = false;               // the queue's slots are not known to be empty (a level-by-level piece used it): ~0 before a tree launch
     };
     struct SmallPiece { uint32_t lane; uint64_t first, n; };
     std::vector<SmallLane> lanes;
@@ -191,6 +192,8 @@ struct taxor_gpu_searcher {
     bool lane_mode = false;                 // this searcher IS a lane
     bool st_borrowed = false;               // ... working on a stream that belongs to the searcher it serves
     bool small_active = false, small_done = false;   // the call in flight went through the lanes / its results are in the host arrays
+    size_t small_harvested = 0;             // pieces whose results have been appended to the host arrays
+    uint64_t small_tbase = 0;
     bool dev_results_stale = false;         // ... and not (yet) in the device-resident CSR that export_device / the communicator read
 
     // timing
@@ -1206,9 +1209,14 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         static const int polls_env = [] { const char *e = tune_env("TAXOR_TREE_POLLS"); return e ? atoi(e) : -1; }();
         q.tree_polls = polls_env >= 0 ? (uint32_t)polls_env : 8u;
         const uint64_t items0 = (uint64_t)n_reads * root_parts;
-        // blocks beyond the items a piece can have at one time only poll: the root's items, or a couple per read below it
-        const int grid = (int)std::min<uint64_t>((uint64_t)s->grid_query_short, std::max<uint64_t>(items0, 2ull * n_reads) + 64);
-        launch_query_tree(q, grid, s->lds_query, s->st);
+        // Blocks beyond the items a piece can have at one time only poll (the root's items, or a couple per read below it) -- and a
+        // block that polls holds its place on a CU until ITS launch is complete, so a launch is also kept to half the chip: two
+        // lanes' traversals then run side by side, one's tail under the other's body, instead of one after the other
+        static const int grid_env = [] { const char *e = tune_env("TAXOR_TREE_GRID"); return e ? atoi(e) : 0; }();
+        static const int unroll_env = [] { const char *e = tune_env("TAXOR_TREE_UNROLL"); return e ? atoi(e) : 0; }();
+        const uint64_t grid_cap = grid_env > 0 ? (uint64_t)grid_env : (uint64_t)s->grid_query_short / 2;
+        const int grid = (int)std::min<uint64_t>(grid_cap, std::max<uint64_t>(items0, 2ull * n_reads) + 64);
+        launch_query_tree(q, grid, s->lds_query, s->st, unroll_env == 2 ? 2 : 4);
         s->stats.query_launches++;
         HIP_TRY(hipGetLastError());
         return 0;
@@ -1779,9 +1787,16 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
         HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(Counters), st));
         HIP_TRY(hipMemsetAsync(c->d_read_hits.p, 0, c->d_read_hits.cap * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(c->d_sync_cursor.p, 0, 2 * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(c->d_q[0].p, 0xFF, c->d_q[0].cap * sizeof(uint2), st));      // the one queue of the tree launch: every slot empty (~0)
+        L.q_dirty = true;
         L.fresh = false;
     }
+    static const int tree_max = [] { const char *e = tune_env("TAXOR_SMALL_TREE"); return e ? atoi(e) : 1024; }();
+    const bool tree = (int)n <= tree_max;
+    if (tree && L.q_dirty) {
+        HIP_TRY(hipMemsetAsync(c->d_q[0].p, 0xFF, c->d_q[0].cap * sizeof(uint2), st));      // the one queue of the tree launch: every slot empty (~0)
+        L.q_dirty = false;
+    }
+    if (!tree) L.q_dirty = true;
     // ---- two copies
     HIP_TRY(hipMemcpyAsync(L.d_in.p, L.h_in, in_bytes, hipMemcpyHostToDevice, st));
     t_arrays = us();
@@ -1833,12 +1848,13 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     // ---- the levels; root items in column parts until the piece has about a grid's worth of them
     uint32_t parts = 1;
     static const int parts_env = [] { const char *e = tune_env("TAXOR_SMALL_PARTS"); return e ? atoi(e) : 0; }();
-    while (parts < idx->root_pmax && (uint64_t)n * parts < (uint64_t)c->grid_query_short) parts *= 2;
+    while (parts < idx->root_pmax && (uint64_t)n * parts * 2 <= (uint64_t)c->grid_query_short / 2) parts *= 2;
     if (parts_env >= 1) parts = std::min<uint32_t>((uint32_t)parts_env, idx->root_pmax);
     if (s->split_always) parts = idx->root_pmax;
     c->stats = taxor_gpu_run_stats{};
-    static const bool tree_off = [] { const char *e = tune_env("TAXOR_SMALL_TREE"); return e && atoi(e) == 0; }();
-    if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, parts, false, !tree_off)) return rc;
+    // one launch for the whole traversal up to TREE_MAX reads; larger pieces keep the chip busy level by level, and from 4096 reads
+    // on the grouping of the work items by IXF pays (run_query)
+    if (int rc = run_query(c, c->d_hashes[0].p, d_hoff, c->d_nh.p, c->d_thr.p, n, nullptr, 1, nullptr, -1, d_order, tree ? parts : 1u, false, tree)) return rc;
     t_query = us();
     // ---- CSR assembly into host memory, counters cleared for the lane's next piece
     const SmallOut o = small_out(L, L.d_out);
@@ -1870,31 +1886,101 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     return 0;
 }
 
+// the results of the next piece in line -> the host arrays (waits for its lane); reruns it through the other pipeline if a
+// queue, the hit buffer or the result area was too small for it
+int small_harvest_one(taxor_gpu_searcher *s)
+{
+    const auto &pc = s->small_pieces[s->small_harvested];
+    taxor_gpu_searcher::SmallLane &L = s->lanes[pc.lane];
+    taxor_gpu_run_stats &st = s->stats;
+    HIP_TRY(hipEventSynchronize(L.done));
+    const SmallOut o = small_out(L, L.h_out);
+    const uint32_t f = (uint32_t)o.status[0];
+    if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
+    if (f & FLAG_CAND_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated"); }
+    if (f & FLAG_DEDUP_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "dedup scratch too small"); }
+    if (f & FLAG_TREE_STALL) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "the one-launch traversal of a small batch stalled"); }
+    const uint64_t *ro;
+    const int64_t *ub;
+    const uint32_t *cnt, *nh;
+    uint64_t nt;
+    taxor_gpu_results r{};
+    if (f & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TUPLE_OVERFLOW)) {
+        // the lane classifies the piece once more through the pipeline of large batches, which grows its buffers and reruns until
+        // everything fits (check_flags)
+        L.fresh = true;
+        if (ensure_stream(&L.c->st_sync)) return TAXOR_E_HIP;        // (a lane has no second stream of its own; that pipeline wants one)
+        if (int rc = taxor_gpu_search_batch(L.c, s->small_bases, s->small_offsets + pc.first, pc.n, &r)) return rc;
+        ro = r.read_off; ub = r.user_bin; cnt = r.count; nh = r.n_hashes; nt = r.n_tuples;
+        st.n_hashes += L.c->stats.n_hashes;
+        st.n_work_items += L.c->stats.n_work_items;
+        st.query_bytes += L.c->stats.query_bytes;
+        st.query_touched_bytes += L.c->stats.query_touched_bytes;
+    } else {
+        ro = o.read_off; ub = o.ub; cnt = o.cnt; nh = o.nh; nt = o.status[1];
+        st.n_hashes += o.status[2];
+        st.n_work_items += o.status[3];
+        st.query_bytes += o.status[4];
+        st.query_touched_bytes += o.status[5];
+    }
+    const uint64_t tbase = s->small_tbase;
+    for (uint64_t i = 0; i < pc.n; ++i) s->h_read_off[pc.first + i + 1] = tbase + ro[i + 1];
+    memcpy(s->h_nh.data() + pc.first, nh, pc.n * 4);
+    s->h_ub.insert(s->h_ub.end(), ub, ub + nt);
+    s->h_cnt.insert(s->h_cnt.end(), cnt, cnt + nt);
+    s->small_tbase += nt;
+    ++s->small_harvested;
+    return 0;
+}
+
 int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offsets, uint64_t n_reads)
 {
     HIP_TRY(hipSetDevice(s->idx->device));
     s->ran = s->synced = false;
     s->small_active = s->small_done = false;
     s->small_pieces.clear();
+    s->small_harvested = 0;
+    s->small_tbase = 0;
     s->small_bases = bases;
     s->small_offsets = offsets;
     s->n_reads = n_reads;
     s->n_bases = offsets[n_reads] - offsets[0];
+    s->h_read_off.resize(n_reads + 1);
+    s->h_nh.resize(n_reads);
+    s->h_ub.clear();
+    s->h_cnt.clear();
+    s->h_read_off[0] = 0;
+    s->stats = taxor_gpu_run_stats{};
+    // Pieces.  Up to 2048 reads: four equal ones of at least 256 reads.  Beyond: a first piece of an eighth of the call -- nothing
+    // runs until its bases have crossed PCIe -- and the rest in equal pieces of at most SMALL_FIN_MAX reads; piece p runs on lane
+    // p mod 4, and a lane is reused once its previous piece's results have been taken over.
     static const uint64_t piece_env = [] { const char *e = tune_env("TAXOR_SMALL_PIECE"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
-    uint64_t per = piece_env ? piece_env : std::max<uint64_t>(SMALL_PIECE_MIN, (n_reads + SMALL_LANES - 1) / SMALL_LANES);
-    per = std::min<uint64_t>(per, SMALL_FIN_MAX);
-    uint32_t li = 0;
-    for (uint64_t first = 0; first < n_reads; first += per, ++li) {
-        const uint64_t n = std::min(per, n_reads - first);
-        if (li >= SMALL_LANES) return 1;                                     // (a piece size from the environment that does not fit four lanes)
-        const int rc = small_enqueue(s, li, bases, offsets, first, (uint32_t)n);
-        if (rc) {                                                          // > 0: not a case for the lanes; wait for what is in flight, then the other pipeline
-            for (const auto &p : s->small_pieces) (void)hipEventSynchronize(s->lanes[p.lane].done);
-            for (const auto &p : s->small_pieces) s->lanes[p.lane].fresh = true;
+    std::vector<uint64_t> sizes;
+    if (piece_env) {
+        for (uint64_t f = 0; f < n_reads; f += std::min<uint64_t>(piece_env, SMALL_FIN_MAX)) sizes.push_back(std::min<uint64_t>(std::min<uint64_t>(piece_env, SMALL_FIN_MAX), n_reads - f));
+    } else if (n_reads <= 2048) {
+        const uint64_t per = std::max<uint64_t>(SMALL_PIECE_MIN, (n_reads + SMALL_LANES - 1) / SMALL_LANES);
+        for (uint64_t f = 0; f < n_reads; f += per) sizes.push_back(std::min(per, n_reads - f));
+    } else {
+        const uint64_t first = std::max<uint64_t>(SMALL_PIECE_MIN, round_up(n_reads / 8, 64)), rest = n_reads - first;
+        const uint64_t k = std::max<uint64_t>(3, (rest + SMALL_FIN_MAX - 1) / SMALL_FIN_MAX), per = std::min<uint64_t>(SMALL_FIN_MAX, round_up((rest + k - 1) / k, 64));
+        sizes.push_back(first);
+        for (uint64_t f = first; f < n_reads; f += per) sizes.push_back(std::min(per, n_reads - f));
+    }
+    uint64_t first = 0;
+    for (size_t p = 0; p < sizes.size(); ++p) {
+        const uint32_t li = (uint32_t)(p % SMALL_LANES);
+        int rc = 0;
+        while (rc == 0 && p >= SMALL_LANES && s->small_harvested + SMALL_LANES <= p) rc = small_harvest_one(s);   // the lane's previous piece first
+        if (rc == 0) rc = small_enqueue(s, li, bases, offsets, first, (uint32_t)sizes[p]);
+        if (rc) {                  // > 0: not a case for the lanes; wait for what is in flight, then the other pipeline (or the error)
+            for (size_t q = s->small_harvested; q < s->small_pieces.size(); ++q) (void)hipEventSynchronize(s->lanes[s->small_pieces[q].lane].done);
+            for (auto &L : s->lanes) L.fresh = true;
             s->small_pieces.clear();
             return rc;
         }
-        s->small_pieces.push_back({li, first, n});
+        s->small_pieces.push_back({li, first, sizes[p]});
+        first += sizes[p];
     }
     s->small_active = true;
     s->ran = true;
@@ -1905,53 +1991,10 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
 int small_finish(taxor_gpu_searcher *s)
 {
     if (s->small_done) return 0;
-    const uint64_t nr = s->n_reads;
-    s->h_read_off.resize(nr + 1);
-    s->h_nh.resize(nr);
-    s->h_ub.clear();
-    s->h_cnt.clear();
-    s->h_read_off[0] = 0;
+    while (s->small_harvested < s->small_pieces.size())
+        if (int rc = small_harvest_one(s)) return rc;
+    const uint64_t nr = s->n_reads, tbase = s->small_tbase;
     taxor_gpu_run_stats &st = s->stats;
-    st = taxor_gpu_run_stats{};
-    uint64_t tbase = 0;
-    for (const auto &pc : s->small_pieces) {
-        taxor_gpu_searcher::SmallLane &L = s->lanes[pc.lane];
-        HIP_TRY(hipEventSynchronize(L.done));
-        const SmallOut o = small_out(L, L.h_out);
-        const uint32_t f = (uint32_t)o.status[0];
-        if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
-        if (f & FLAG_CAND_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated"); }
-        if (f & FLAG_DEDUP_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "dedup scratch too small"); }
-        if (f & FLAG_TREE_STALL) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "the one-launch traversal of a small batch stalled"); }
-        const uint64_t *ro;
-        const int64_t *ub;
-        const uint32_t *cnt, *nh;
-        uint64_t nt;
-        taxor_gpu_results r{};
-        if (f & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TUPLE_OVERFLOW)) {
-            // a queue, the hit buffer or the result area was too small for this piece: the lane classifies it once more through
-            // the pipeline of large batches, which grows its buffers and reruns until everything fits (check_flags)
-            L.fresh = true;
-            if (ensure_stream(&L.c->st_sync)) return TAXOR_E_HIP;        // (a lane gave its second stream back; that pipeline wants it)
-            if (int rc = taxor_gpu_search_batch(L.c, s->small_bases, s->small_offsets + pc.first, pc.n, &r)) return rc;
-            ro = r.read_off; ub = r.user_bin; cnt = r.count; nh = r.n_hashes; nt = r.n_tuples;
-            st.n_hashes += L.c->stats.n_hashes;
-            st.n_work_items += L.c->stats.n_work_items;
-            st.query_bytes += L.c->stats.query_bytes;
-            st.query_touched_bytes += L.c->stats.query_touched_bytes;
-        } else {
-            ro = o.read_off; ub = o.ub; cnt = o.cnt; nh = o.nh; nt = o.status[1];
-            st.n_hashes += o.status[2];
-            st.n_work_items += o.status[3];
-            st.query_bytes += o.status[4];
-            st.query_touched_bytes += o.status[5];
-        }
-        for (uint64_t i = 0; i < pc.n; ++i) s->h_read_off[pc.first + i + 1] = tbase + ro[i + 1];
-        memcpy(s->h_nh.data() + pc.first, nh, pc.n * 4);
-        s->h_ub.insert(s->h_ub.end(), ub, ub + nt);
-        s->h_cnt.insert(s->h_cnt.end(), cnt, cnt + nt);
-        tbase += nt;
-    }
     st.n_reads = nr;
     st.n_bases = s->n_bases;
     st.n_tuples = tbase;

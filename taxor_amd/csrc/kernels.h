@@ -194,7 +194,7 @@ int syncmers_grid(int device);
 void launch_query_level(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, bool small = false, bool root_streams = true);
 // the whole traversal of a small batch in one launch (k_query_level<..., TREE>): a.q_in = nullptr, a.q_out = the one queue, whose
 // slots hold ~0 (all bytes 0xFF) before and after; a.level = 0
-void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st);
+void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, int unroll = 2);
 int query_grid(int device, size_t lds_bytes, int want_per_cu);
 int query_grid_small(int device, size_t lds_bytes);
 size_t query_lds_bytes(uint32_t max_stride, bool small = false);

@@ -1707,9 +1707,12 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
     }
 }
 
-void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st)
+void launch_query_tree(const QueryArgs &a, int grid, size_t lds_bytes, hipStream_t st, int unroll)
 {
-    hipLaunchKernelGGL((k_query_level<false, 2, false, BLK, Q_CAP, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+    // a small batch leaves the chip mostly idle: its items are latency chains, and four hashes (twelve row loads) in flight per
+    // lane halve the round trips of the dense phase; the registers that costs (134: three waves per SIMD) are not missed here
+    if (unroll == 4) hipLaunchKernelGGL((k_query_level<false, 4, false, BLK, Q_CAP, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
+    else hipLaunchKernelGGL((k_query_level<false, 2, false, BLK, Q_CAP, true>), dim3(grid), dim3(BLK), lds_bytes, st, a);
 }
 
 int query_grid(int device, size_t lds_bytes, int want_per_cu)
