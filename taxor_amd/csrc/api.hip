@@ -11,8 +11,6 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <functional>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -196,18 +194,9 @@ struct taxor_gpu_searcher {
     bool small_active = false, small_done = false;   // the call in flight went through the lanes / its results are in the host arrays
     size_t small_harvested = 0;             // pieces whose results have been appended to the host arrays
     uint64_t small_tbase = 0;
-    // A second host thread for the odd pieces of a call of up to four pieces.  The blocking copy of a piece's pageable bases is
-    // 51 us on the wire and 75-95 us in the call (the runtime page-locks the caller's pages around it); two threads keep the wire
-    // busy while one of them locks or unlocks.
-    struct SmallHelper {
-        std::thread th;
-        std::mutex mu;
-        std::condition_variable cv;
-        std::function<void()> job;
-        bool has_job = false, quit = false;
-        std::atomic<int> busy{0};
-    };
-    SmallHelper *helper = nullptr;
+    // (Tried: a second host thread enqueueing the odd pieces, so that one blocking copy of pageable bases page-locks the caller's
+    // pages while the other's bytes are on the wire -- the runtime serialises pageable copies process-wide; the helper's first
+    // copy returned after both of the caller's, 350 us into a 390-us enqueue.)
     bool dev_results_stale = false;         // ... and not (yet) in the device-resident CSR that export_device / the communicator read
 
     // timing
@@ -916,16 +905,6 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->idx->device);
-    if (s->helper) {
-        {
-            std::lock_guard<std::mutex> lk(s->helper->mu);
-            s->helper->quit = true;
-        }
-        s->helper->cv.notify_one();
-        s->helper->th.join();
-        delete s->helper;
-        s->helper = nullptr;
-    }
     for (auto &L : s->lanes) {
         if (L.c) { (void)hipStreamSynchronize(L.c->st); taxor_gpu_searcher_destroy(L.c); }
         if (L.done) (void)hipEventDestroy(L.done);
@@ -1980,7 +1959,16 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
     // p mod 4, and a lane is reused once its previous piece's results have been taken over.
     static const uint64_t piece_env = [] { const char *e = tune_env("TAXOR_SMALL_PIECE"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
     std::vector<uint64_t> sizes;
-    if (piece_env) {
+    static const std::vector<uint64_t> sizes_env = [] {       // TAXOR_SMALL_SIZES=768,256: these pieces for a call of exactly their sum (experiments)
+        std::vector<uint64_t> v;
+        if (const char *e = tune_env("TAXOR_SMALL_SIZES"))
+            for (const char *p = e; *p;) { char *q; const unsigned long x = strtoul(p, &q, 10); if (q == p) break; if (x) v.push_back(x); p = *q ? q + 1 : q; }
+        return v;
+    }();
+    uint64_t env_sum = 0;
+    for (uint64_t x : sizes_env) env_sum += x;
+    if (env_sum == n_reads && !sizes_env.empty() && *std::max_element(sizes_env.begin(), sizes_env.end()) <= SMALL_FIN_MAX) sizes = sizes_env;
+    else if (piece_env) {
         for (uint64_t f = 0; f < n_reads; f += std::min<uint64_t>(piece_env, SMALL_FIN_MAX)) sizes.push_back(std::min<uint64_t>(std::min<uint64_t>(piece_env, SMALL_FIN_MAX), n_reads - f));
     } else if (n_reads <= 2048) {
         const uint64_t per = std::max<uint64_t>(SMALL_PIECE_MIN, (n_reads + SMALL_LANES - 1) / SMALL_LANES);
@@ -1992,60 +1980,6 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
         for (uint64_t f = first; f < n_reads; f += per) sizes.push_back(std::min(per, n_reads - f));
     }
     if (s->lanes.size() < SMALL_LANES) s->lanes.resize(SMALL_LANES);
-    static const bool helper_off = [] { const char *e = tune_env("TAXOR_SMALL_HELPER"); return e && atoi(e) == 0; }();
-    if (sizes.size() >= 2 && sizes.size() <= SMALL_LANES && !helper_off) {
-        // the odd pieces on the helper thread, the even ones here, both in order; every piece has a lane of its own
-        std::vector<uint64_t> firsts(sizes.size(), 0);
-        for (size_t p = 1; p < sizes.size(); ++p) firsts[p] = firsts[p - 1] + sizes[p - 1];
-        if (!s->helper) {
-            s->helper = new taxor_gpu_searcher::SmallHelper();
-            taxor_gpu_searcher::SmallHelper *H = s->helper;
-            const int device = s->idx->device;
-            H->th = std::thread([H, device] {
-                (void)hipSetDevice(device);
-                for (;;) {
-                    std::function<void()> job;
-                    {
-                        std::unique_lock<std::mutex> lk(H->mu);
-                        H->cv.wait(lk, [&] { return H->has_job || H->quit; });
-                        if (H->quit) return;
-                        job = std::move(H->job);
-                        H->has_job = false;
-                    }
-                    job();
-                    H->busy.store(0, std::memory_order_release);
-                }
-            });
-        }
-        taxor_gpu_searcher::SmallHelper *H = s->helper;
-        int rc_helper = 0, rc_main = 0;
-        std::string err_helper;
-        H->busy.store(1, std::memory_order_relaxed);
-        {
-            std::lock_guard<std::mutex> lk(H->mu);
-            H->job = [&] {
-                for (size_t p = 1; p < sizes.size() && rc_helper == 0; p += 2) {
-                    rc_helper = small_enqueue(s, (uint32_t)p, bases, offsets, firsts[p], (uint32_t)sizes[p]);
-                    if (rc_helper < 0) err_helper = g_err;
-                }
-            };
-            H->has_job = true;
-        }
-        H->cv.notify_one();
-        for (size_t p = 0; p < sizes.size() && rc_main == 0; p += 2) rc_main = small_enqueue(s, (uint32_t)p, bases, offsets, firsts[p], (uint32_t)sizes[p]);
-        while (H->busy.load(std::memory_order_acquire)) {}          // (its last piece's copy: tens of microseconds)
-        const int rc = rc_main ? rc_main : rc_helper;
-        if (rc) {
-            for (auto &L : s->lanes)
-                if (L.c && L.done) { (void)hipStreamSynchronize(L.c->st); L.fresh = true; }
-            if (!rc_main && rc_helper < 0) g_err = err_helper;
-            return rc;
-        }
-        for (size_t p = 0; p < sizes.size(); ++p) s->small_pieces.push_back({(uint32_t)p, firsts[p], sizes[p]});
-        s->small_active = true;
-        s->ran = true;
-        return 0;
-    }
     uint64_t first = 0;
     for (size_t p = 0; p < sizes.size(); ++p) {
         const uint32_t li = (uint32_t)(p % SMALL_LANES);
