@@ -1896,7 +1896,13 @@ int small_harvest_one(taxor_gpu_searcher *s)
     const auto &pc = s->small_pieces[s->small_harvested];
     taxor_gpu_searcher::SmallLane &L = s->lanes[pc.lane];
     taxor_gpu_run_stats &st = s->stats;
-    HIP_TRY(hipEventSynchronize(L.done));
+    {   // the caller waits for a fraction of a millisecond: poll (a blocking wait's wake-up is tens of microseconds of it)
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e;
+        while ((e = hipEventQuery(L.done)) == hipErrorNotReady)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { e = hipEventSynchronize(L.done); break; }
+        if (e != hipSuccess) return fail(TAXOR_E_HIP, "small batch: %s", hipGetErrorString(e));
+    }
     const SmallOut o = small_out(L, L.h_out);
     const uint32_t f = (uint32_t)o.status[0];
     if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
@@ -1954,9 +1960,12 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
     s->h_cnt.clear();
     s->h_read_off[0] = 0;
     s->stats = taxor_gpu_run_stats{};
-    // Pieces.  Up to 2048 reads: four equal ones of at least 256 reads.  Beyond: a first piece of an eighth of the call -- nothing
-    // runs until its bases have crossed PCIe -- and the rest in equal pieces of at most SMALL_FIN_MAX reads; piece p runs on lane
-    // p mod 4, and a lane is reused once its previous piece's results have been taken over.
+    // Pieces.  A blocking copy of pageable bases costs ~35 us beyond its bytes (the runtime page-locks the caller's pages around it)
+    // and a piece's chain of launches ~270 us however small it is, so few pieces: one up to 512 reads; two -- five and three eighths
+    // of the call -- up to 2048 (1024 reads, A/B on one box: 640+384 0.770 ms, 512+512 0.770, 768+256 0.794, 4 x 256 0.795,
+    // 384+384+256 0.800; profiles/r04/small_calls.txt).  Beyond: a first piece of an eighth of the call -- nothing runs until its
+    // bases have crossed PCIe -- and the rest in equal pieces of at most SMALL_FIN_MAX reads; piece p runs on lane p mod 4, and a
+    // lane is reused once its previous piece's results have been taken over.
     static const uint64_t piece_env = [] { const char *e = tune_env("TAXOR_SMALL_PIECE"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 0); }();
     std::vector<uint64_t> sizes;
     static const std::vector<uint64_t> sizes_env = [] {       // TAXOR_SMALL_SIZES=768,256: these pieces for a call of exactly their sum (experiments)
@@ -1970,9 +1979,12 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
     if (env_sum == n_reads && !sizes_env.empty() && *std::max_element(sizes_env.begin(), sizes_env.end()) <= SMALL_FIN_MAX) sizes = sizes_env;
     else if (piece_env) {
         for (uint64_t f = 0; f < n_reads; f += std::min<uint64_t>(piece_env, SMALL_FIN_MAX)) sizes.push_back(std::min<uint64_t>(std::min<uint64_t>(piece_env, SMALL_FIN_MAX), n_reads - f));
+    } else if (n_reads <= 512) {
+        sizes.push_back(n_reads);
     } else if (n_reads <= 2048) {
-        const uint64_t per = std::max<uint64_t>(SMALL_PIECE_MIN, (n_reads + SMALL_LANES - 1) / SMALL_LANES);
-        for (uint64_t f = 0; f < n_reads; f += per) sizes.push_back(std::min(per, n_reads - f));
+        const uint64_t a = round_up(n_reads * 5 / 8, 64);
+        sizes.push_back(std::min(a, n_reads));
+        if (a < n_reads) sizes.push_back(n_reads - a);
     } else {
         const uint64_t first = std::max<uint64_t>(SMALL_PIECE_MIN, round_up(n_reads / 8, 64)), rest = n_reads - first;
         const uint64_t k = std::max<uint64_t>(3, (rest + SMALL_FIN_MAX - 1) / SMALL_FIN_MAX), per = std::min<uint64_t>(SMALL_FIN_MAX, round_up((rest + k - 1) / k, 64));
