@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="gtdb")
 ap.add_argument("--read-len", type=int, default=0)
 ap.add_argument("--sizes", default="256,1024,4096,16384,65536,131072")
+ap.add_argument("--registered", action="store_true", help="page-lock the caller's buffer once (taxor_gpu_host_register): the copies are then asynchronous")
 a = ap.parse_args()
 extra = ["--read-len", str(a.read_len)] if a.read_len else []
 args = bench.parse_args(["--workload", a.workload, "--batches", "1"] + extra)
@@ -47,6 +48,10 @@ def run(sr, cs, reps):
     return t
 
 
+if a.registered:
+    import ctypes as C
+    from taxor_amd import _lib
+    assert _lib.lib().taxor_gpu_host_register(bases.ctypes.data_as(C.c_void_p), bases.nbytes) == 0
 srs = [Searcher(idx, error_rate=args.error_rate) for _ in range(2)]
 for n in [int(x) for x in a.sizes.split(",")]:
     if n > n_all:

@@ -1962,7 +1962,7 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
     s->stats = taxor_gpu_run_stats{};
     // Pieces.  A blocking copy of pageable bases costs ~35 us beyond its bytes (the runtime page-locks the caller's pages around it)
     // and a piece's chain of launches ~270 us however small it is, so few pieces: one up to 512 reads; two -- five and three eighths
-    // of the call -- up to 2048 (1024 reads, A/B on one box: 640+384 0.770 ms, 512+512 0.770, 768+256 0.794, 4 x 256 0.795,
+    // of the call -- up to 1280, four equal ones up to 2048 (1024 reads, A/B on one box: 640+384 0.770 ms, 512+512 0.770, 768+256 0.794, 4 x 256 0.795,
     // 384+384+256 0.800; profiles/r04/small_calls.txt).  Beyond: a first piece of an eighth of the call -- nothing runs until its
     // bases have crossed PCIe -- and the rest in equal pieces of at most SMALL_FIN_MAX reads; piece p runs on lane p mod 4, and a
     // lane is reused once its previous piece's results have been taken over.
@@ -1981,10 +1981,13 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
         for (uint64_t f = 0; f < n_reads; f += std::min<uint64_t>(piece_env, SMALL_FIN_MAX)) sizes.push_back(std::min<uint64_t>(std::min<uint64_t>(piece_env, SMALL_FIN_MAX), n_reads - f));
     } else if (n_reads <= 512) {
         sizes.push_back(n_reads);
-    } else if (n_reads <= 2048) {
+    } else if (n_reads <= 1280) {
         const uint64_t a = round_up(n_reads * 5 / 8, 64);
         sizes.push_back(std::min(a, n_reads));
         if (a < n_reads) sizes.push_back(n_reads - a);
+    } else if (n_reads <= 2048) {
+        const uint64_t per = round_up((n_reads + SMALL_LANES - 1) / SMALL_LANES, 64);          // (2048 reads: 4 x 512 1.24-1.30 ms, 1280 + 768 1.51)
+        for (uint64_t f = 0; f < n_reads; f += per) sizes.push_back(std::min(per, n_reads - f));
     } else {
         const uint64_t first = std::max<uint64_t>(SMALL_PIECE_MIN, round_up(n_reads / 8, 64)), rest = n_reads - first;
         const uint64_t k = std::max<uint64_t>(3, (rest + SMALL_FIN_MAX - 1) / SMALL_FIN_MAX), per = std::min<uint64_t>(SMALL_FIN_MAX, round_up((rest + k - 1) / k, 64));
