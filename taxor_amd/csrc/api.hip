@@ -175,7 +175,7 @@ struct taxor_gpu_searcher {
     // LANES -- internal searchers with one stream each -- see small_begin()
     struct SmallLane {
         taxor_gpu_searcher *c = nullptr;    // the lane: streams, counters, queues, hit buffers of its own
-        hipEvent_t done = nullptr;
+        hipEvent_t done = nullptr, copied = nullptr;   // piece finished / its bases are on the device
         DBuf<uint8_t> d_in;                 // aoff | poff | hoff | rlen | hcap | order of the piece: ONE host-to-device copy
         void *h_in = nullptr;               // its page-locked source
         size_t h_in_cap = 0;
@@ -908,6 +908,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
     for (auto &L : s->lanes) {
         if (L.c) { (void)hipStreamSynchronize(L.c->st); taxor_gpu_searcher_destroy(L.c); }
         if (L.done) (void)hipEventDestroy(L.done);
+        if (L.copied) (void)hipEventDestroy(L.copied);
         L.d_in.release();
         if (L.h_in) (void)hipHostFree(L.h_in);
         if (L.h_out) (void)hipHostFree(L.h_out);
@@ -1686,6 +1687,7 @@ int small_lane_ready(taxor_gpu_searcher *s, uint32_t li, uint32_t n_reads, uint3
         if (int rc = searcher_create_impl(s->idx, &p, &L.c, *slot[li])) return rc;
         L.c->prune = s->prune;
         HIP_TRY(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&L.copied, hipEventDisableTiming));
         L.fresh = true;
     }
     if (L.out_reads < n_reads || L.out_tuples < tuples) {
@@ -1714,7 +1716,7 @@ SmallOut small_out(const taxor_gpu_searcher::SmallLane &L, void *base)
 }
 
 // everything of one piece -- reads [first, first + n) of the call -- enqueued on its lane's stream
-int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const uint64_t *offsets, uint64_t first, uint32_t n)
+int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const uint64_t *offsets, uint64_t first, uint32_t n, hipEvent_t copy_after = nullptr)
 {
     const taxor_gpu_index *idx = s->idx;
     static const bool trace = tune_env("TAXOR_TRACE_BATCH") != nullptr;
@@ -1803,7 +1805,12 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     // ---- two copies
     HIP_TRY(hipMemcpyAsync(L.d_in.p, L.h_in, in_bytes, hipMemcpyHostToDevice, st));
     t_arrays = us();
+    // Page-locked input: the copies of all pieces are enqueued within microseconds, and on four streams they would cross PCIe side
+    // by side and all arrive late; each waits for its predecessor's instead, so the pieces arrive -- and start -- one after the
+    // other as from pageable memory (where the call itself blocks until the bytes are over)
+    if (copy_after) HIP_TRY(hipStreamWaitEvent(st, copy_after, 0));
     if (nb) HIP_TRY(hipMemcpyAsync(c->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(L.copied, st));
     t_bases = us();
     const uint64_t *d_aoff = (const uint64_t *)(L.d_in.p + o_aoff), *d_poff = (const uint64_t *)(L.d_in.p + o_poff),
                    *d_hoff = (const uint64_t *)(L.d_in.p + o_hoff);
@@ -2000,7 +2007,7 @@ int small_begin(taxor_gpu_searcher *s, const char *bases, const uint64_t *offset
         const uint32_t li = (uint32_t)(p % SMALL_LANES);
         int rc = 0;
         while (rc == 0 && p >= SMALL_LANES && s->small_harvested + SMALL_LANES <= p) rc = small_harvest_one(s);   // the lane's previous piece first
-        if (rc == 0) rc = small_enqueue(s, li, bases, offsets, first, (uint32_t)sizes[p]);
+        if (rc == 0) rc = small_enqueue(s, li, bases, offsets, first, (uint32_t)sizes[p], p ? s->lanes[(p - 1) % SMALL_LANES].copied : nullptr);
         if (rc) {                  // > 0: not a case for the lanes; wait for what is in flight, then the other pipeline (or the error)
             for (size_t q = s->small_harvested; q < s->small_pieces.size(); ++q) (void)hipEventSynchronize(s->lanes[s->small_pieces[q].lane].done);
             for (auto &L : s->lanes) L.fresh = true;

@@ -1,0 +1,703 @@
+// pgz.h -- parallel inflate of ONE gzip member (the commonest real input: reads.fastq.gz as the sequencer or `gzip` wrote it).
+//
+// The reference reads .gz through seqan3's stream layer, i.e. one zlib stream on one thread (taxor_search.cpp:181-184): about
+// 0.55 GB/s of text, a twentieth of what the GPU path classifies.  A deflate stream has no index and every byte may refer to the
+// 32 KiB before it, so it cannot simply be cut -- but it can be decoded SPECULATIVELY from the middle (the scheme of pugz and
+// rapidgzip, restated here on a deflate decoder of this file's own; the image carries zlib only, which cannot start inside a
+// stream):
+//   1. the compressed bytes are cut into chunks; for every chunk but the first a worker looks for the first position at which a
+//      dynamic-Huffman block header parses under strict checks (code-length code and both alphabets complete, end-of-block
+//      present) and whose whole block decodes to text -- deflate blocks start at arbitrary BIT offsets, so every bit is tried;
+//   2. from there the chunk is decoded with its 32 KiB history UNKNOWN: the output is 16 bits per symbol, a literal byte or a
+//      marker "byte w of the window before this chunk"; back-references copy markers like anything else.  A chunk ends at the
+//      first block boundary at or behind the next chunk's nominal start;
+//   3. in order, the consumer checks that chunk i+1 started exactly where chunk i ended (a start that does not match -- a false
+//      positive of the search, a stored or fixed block at the boundary, a chunk that failed -- is decoded again from the right
+//      position, with nothing speculative left), resolves the last 32 KiB of chunk i against its window to get chunk i+1's
+//      window, and hands the full resolution (markers -> bytes, CRC-32) back to the workers;
+//   4. resolved chunks are delivered in order; at the end the member's CRC-32 and length (combined from the chunks') must equal
+//      the trailer, as zlib checks them.  Further members, if any, are taken the same way one after the other.
+// Nothing speculative is ever delivered: a chunk's bytes leave only after its start has been tied to its predecessor's end, so
+// what comes out is the one decoding of the stream -- or an exception naming the corruption, as from zlib.
+#pragma once
+
+#include <zlib.h>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace fastx {
+
+namespace pgz_detail {
+
+constexpr uint32_t WIN = 32768;
+
+struct BitIn {
+    const uint8_t *base = nullptr, *p = nullptr, *end = nullptr;
+    uint64_t bb = 0;
+    int bc = 0;
+    void seek(const uint8_t *b, const uint8_t *e, uint64_t bit)
+    {
+        base = b;
+        end = e;
+        p = b + (bit >> 3);
+        bb = 0;
+        bc = 0;
+        refill();
+        const int s = (int)(bit & 7);
+        bb >>= s;
+        bc -= s;
+    }
+    inline void refill()
+    {
+        if (p + 8 <= end) {
+            uint64_t v;
+            memcpy(&v, p, 8);
+            bb |= v << bc;
+            p += (63 - bc) >> 3;
+            bc |= 56;
+        } else {
+            while (bc <= 56 && p < end) { bb |= (uint64_t)*p++ << bc; bc += 8; }
+        }
+    }
+    inline uint32_t peek(int n) const { return (uint32_t)(bb & ((1ull << n) - 1)); }
+    inline void drop(int n) { bb >>= n; bc -= n; }
+    uint64_t bitpos() const { return (uint64_t)(p - base) * 8 - (uint64_t)bc; }   // negative bc (ran past the end) shows up as pos > size
+    bool overrun() const { return bc < 0; }
+};
+
+inline uint32_t rev_bits(uint32_t c, int n)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < n; ++i) { r = (r << 1) | (c & 1); c >>= 1; }
+    return r;
+}
+
+// two-level decoding table of a canonical prefix code: entry = symbol << 16 | bits to drop; a primary entry with bit 15 set
+// points at a sub-table (offset << 16 | 0x8000 | index bits)
+template <int PB, int MAXSYM> struct Huff {
+    uint32_t tab[1 << PB];
+    std::vector<uint32_t> sub;                     // sub-tables of the prefixes that have codes longer than PB bits
+    // returns 0 complete code, 1 incomplete but usable (a single code, or no code at all), -1 invalid (over-subscribed / incomplete)
+    int build(const uint8_t *len, int n)
+    {
+        int count[16] = {0};
+        for (int i = 0; i < n; ++i) count[len[i]]++;
+        if (count[0] == n) { for (auto &e : primary()) e = 0; sub.clear(); return 1; }
+        int left = 1;
+        for (int l = 1; l <= 15; ++l) {
+            left <<= 1;
+            left -= count[l];
+            if (left < 0) return -1;
+        }
+        const int used = n - count[0];
+        if (left > 0 && !(used == 1 && count[1] == 1)) return -1;                // incomplete: only the one-code case is legal (zlib: inflate_table)
+        uint32_t next[16];
+        {   // first canonical code of every length (RFC 1951, 3.2.2)
+            uint32_t code = 0;
+            for (int l = 1; l <= 15; ++l) { code = (code + (uint32_t)(l > 1 ? count[l - 1] : 0)) << 1; next[l] = code; }
+        }
+        for (auto &e : primary()) e = 0;
+        sub.clear();
+        // sub-tables: for every PB-bit prefix that has longer codes, one table indexed by the next (maxlen - PB) bits
+        int sub_bits_of[1 << PB];
+        for (int i = 0; i < (1 << PB); ++i) sub_bits_of[i] = 0;
+        {   // first pass: longest code under each prefix
+            uint32_t nx[16];
+            memcpy(nx, next, sizeof nx);
+            for (int s = 0; s < n; ++s) {
+                const int l = len[s];
+                if (l <= PB) { if (l) nx[l]++; continue; }
+                const uint32_t r = rev_bits(nx[l]++, l);
+                const int pre = (int)(r & ((1u << PB) - 1));
+                sub_bits_of[pre] = std::max(sub_bits_of[pre], l - PB);
+            }
+        }
+        uint32_t off = 0;
+        uint32_t *P = primary().data();
+        for (int i = 0; i < (1 << PB); ++i)
+            if (sub_bits_of[i]) {
+                P[i] = (off << 16) | 0x8000u | (uint32_t)sub_bits_of[i];
+                off += 1u << sub_bits_of[i];
+            }
+        sub.assign(off, 0);
+        for (int s = 0; s < n; ++s) {
+            const int l = len[s];
+            if (!l) continue;
+            const uint32_t r = rev_bits(next[l]++, l);
+            if (l <= PB) {
+                for (uint32_t i = r; i < (1u << PB); i += 1u << l) P[i] = ((uint32_t)s << 16) | (uint32_t)l;
+            } else {
+                const uint32_t pre = r & ((1u << PB) - 1), e = P[pre];
+                const int sb = (int)(e & 0xFF);
+                const uint32_t o = e >> 16, hi = r >> PB;
+                for (uint32_t i = hi; i < (1u << sb); i += 1u << (l - PB)) sub[o + i] = ((uint32_t)s << 16) | (uint32_t)l;
+            }
+        }
+        return left > 0 ? 1 : 0;
+    }
+    struct Span { uint32_t *b, *e; uint32_t *data() { return b; } uint32_t *begin() { return b; } uint32_t *end() { return e; } };
+    Span primary() { return Span{tab, tab + (1 << PB)}; }
+    // entry for the bits at the bottom of `bb` (0 = no such code)
+    inline uint32_t lookup(uint64_t bb) const
+    {
+        uint32_t e = tab[bb & ((1u << PB) - 1)];
+        if (e & 0x8000u) e = sub[(e >> 16) + (uint32_t)((bb >> PB) & ((1u << (e & 0xFF)) - 1))];
+        return e;
+    }
+};
+
+static const uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Codes {
+    Huff<10, 288> lit;
+    Huff<8, 32> dist;
+    bool have_dist = true;
+};
+
+// the header of a dynamic block at the reader's position; strict = what a block START SEARCH demands beyond validity (complete
+// alphabets); false on anything a decoder must reject
+inline bool read_dynamic_header(BitIn &in, Codes &c, bool strict)
+{
+    in.refill();
+    const uint32_t hlit = in.peek(5) + 257;
+    in.drop(5);
+    const uint32_t hdist = in.peek(5) + 1;
+    in.drop(5);
+    const uint32_t hclen = in.peek(4) + 4;
+    in.drop(4);
+    if (hlit > 286 || hdist > 30) return false;
+    uint8_t cl[19] = {0};
+    in.refill();
+    for (uint32_t i = 0; i < hclen; ++i) {
+        if (in.bc < 3) in.refill();
+        cl[CLORD[i]] = (uint8_t)in.peek(3);
+        in.drop(3);
+    }
+    Huff<7, 19> clh;
+    const int clr = clh.build(cl, 19);
+    if (clr < 0 || (strict && clr != 0)) return false;
+    uint8_t lens[286 + 30 + 140];
+    uint32_t n = 0;
+    const uint32_t total = hlit + hdist;
+    while (n < total) {
+        in.refill();
+        if (in.overrun()) return false;
+        const uint32_t e = clh.lookup(in.bb);
+        const int l = (int)(e & 0xFF);
+        if (!l) return false;
+        in.drop(l);
+        const uint32_t sym = e >> 16;
+        if (sym < 16) { lens[n++] = (uint8_t)sym; continue; }
+        uint32_t rep, val = 0;
+        if (sym == 16) {
+            if (n == 0) return false;
+            val = lens[n - 1];
+            rep = 3 + in.peek(2);
+            in.drop(2);
+        } else if (sym == 17) {
+            rep = 3 + in.peek(3);
+            in.drop(3);
+        } else {
+            rep = 11 + in.peek(7);
+            in.drop(7);
+        }
+        if (n + rep > total) return false;
+        while (rep--) lens[n++] = (uint8_t)val;
+    }
+    if (lens[256] == 0) return false;                       // no end-of-block code: the block could never end
+    const int lr = c.lit.build(lens, (int)hlit);
+    if (lr < 0 || (strict && lr != 0)) return false;
+    const int dr = c.dist.build(lens + hlit, (int)hdist);
+    if (dr < 0) return false;
+    c.have_dist = true;
+    return !in.overrun();
+}
+
+inline void fixed_codes(Codes &c)
+{
+    uint8_t l[288];
+    for (int i = 0; i < 144; ++i) l[i] = 8;
+    for (int i = 144; i < 256; ++i) l[i] = 9;
+    for (int i = 256; i < 280; ++i) l[i] = 7;
+    for (int i = 280; i < 288; ++i) l[i] = 8;
+    c.lit.build(l, 288);
+    uint8_t d[30];
+    for (int i = 0; i < 30; ++i) d[i] = 5;
+    c.dist.build(d, 30);
+}
+
+struct TextSet {
+    bool ok[256];
+    TextSet()
+    {
+        for (int i = 0; i < 256; ++i) ok[i] = (i >= 0x20 && i <= 0x7E) || i == '\n' || i == '\r' || i == '\t';
+    }
+};
+
+// One block's symbols -> out (16 bits each: a byte, or 256 + window index).  out holds WIN window slots in front of the chunk's
+// own symbols, so a reference behind the chunk's start copies markers like anything else.  Returns false on invalid data.
+// max_out bounds the chunk (a trial decode of a candidate block start must not run away).
+inline bool decode_block_symbols(BitIn &in, const Codes &c, std::vector<uint16_t> &out, size_t &n, size_t max_out, const bool *text_ok)
+{
+    for (;;) {
+        if (n + 320 > out.size()) {
+            if (n + 320 > max_out) return false;
+            out.resize(std::min(max_out + 320, std::max<size_t>(out.size() * 2, 1u << 20)));
+        }
+        in.refill();
+        if (in.bc < 0) return false;                        // ran past the end of the input
+        uint32_t e = c.lit.lookup(in.bb);
+        int l = (int)(e & 0xFF);
+        if (!l) return false;
+        in.drop(l);
+        uint32_t sym = e >> 16;
+        if (sym < 256) {
+            if (text_ok && !text_ok[sym]) return false;
+            out[n++] = (uint16_t)sym;
+            // a second literal out of the same refill (most symbols of text are literals)
+            e = c.lit.lookup(in.bb);
+            l = (int)(e & 0xFF);
+            sym = e >> 16;
+            if (l && sym < 256 && in.bc >= l) {
+                if (text_ok && !text_ok[sym]) return false;
+                in.drop(l);
+                out[n++] = (uint16_t)sym;
+            }
+            continue;
+        }
+        if (sym == 256) return !in.overrun();
+        sym -= 257;
+        if (sym >= 29) return false;
+        const uint32_t len = LBASE[sym] + in.peek(LEXT[sym]);
+        in.drop(LEXT[sym]);
+        const uint32_t de = c.dist.lookup(in.bb);
+        const int dl = (int)(de & 0xFF);
+        if (!dl) return false;
+        in.drop(dl);
+        const uint32_t ds = de >> 16;
+        if (ds >= 30) return false;
+        const uint32_t d = DBASE[ds] + in.peek(DEXT[ds]);
+        in.drop(DEXT[ds]);
+        if (d > n) return false;                            // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid)
+        if (in.overrun()) return false;
+        uint16_t *o = out.data() + n;
+        const uint16_t *s = o - d;
+        if (d >= len) memcpy(o, s, (size_t)len * 2);
+        else for (uint32_t i = 0; i < len; ++i) o[i] = s[i];
+        n += len;
+    }
+}
+
+struct ChunkOut {
+    std::vector<uint16_t> sym;     // WIN window slots (markers 256 + w) followed by the chunk's symbols
+    size_t n = WIN;                 // symbols used, window slots included
+    uint64_t start_bit = 0, end_bit = 0;
+    bool final_block = false;       // the member's last block ends at end_bit
+    bool ok = false;
+};
+
+// blocks from start_bit on until a block boundary at or behind stop_bit (or the member's final block); text_ok != nullptr: every
+// literal must be text.  max_out bounds the output.
+inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_bit, uint64_t stop_bit, ChunkOut &co, size_t max_out, const bool *text_ok,
+                        int max_blocks = 1 << 30)
+{
+    BitIn in;
+    in.seek(base, end, start_bit);
+    if (co.sym.size() < WIN + (1u << 16)) co.sym.resize(WIN + (1u << 16));
+    for (uint32_t w = 0; w < WIN; ++w) co.sym[w] = (uint16_t)(256 + w);
+    co.n = WIN;
+    co.start_bit = start_bit;
+    co.final_block = false;
+    co.ok = false;
+    static thread_local Codes codes;
+    const uint64_t size_bits = (uint64_t)(end - base) * 8;
+    for (int blocks = 0;; ++blocks) {
+        const uint64_t pos = in.bitpos();
+        if (pos >= stop_bit || blocks >= max_blocks) { co.end_bit = pos; co.ok = true; return true; }
+        if (pos + 3 > size_bits) return false;
+        in.refill();
+        const uint32_t bfinal = in.peek(1);
+        in.drop(1);
+        const uint32_t btype = in.peek(2);
+        in.drop(2);
+        if (btype == 3) return false;
+        if (btype == 0) {
+            in.drop(in.bc & 7);                              // to the byte boundary
+            in.refill();
+            if (in.bc < 32) return false;
+            const uint32_t len = in.peek(16);
+            in.drop(16);
+            const uint32_t nlen = in.peek(16);
+            in.drop(16);
+            if ((len ^ nlen) != 0xFFFFu) return false;
+            const uint8_t *src = base + (in.bitpos() >> 3);
+            if (src + len > end) return false;
+            if (co.n + len + 320 > co.sym.size()) {
+                if (co.n + len > max_out) return false;
+                co.sym.resize(std::min(max_out + 320, std::max<size_t>(co.sym.size() * 2, co.n + len + 320)));
+            }
+            for (uint32_t i = 0; i < len; ++i) {
+                if (text_ok && !text_ok[src[i]]) return false;
+                co.sym[co.n + i] = src[i];
+            }
+            co.n += len;
+            in.seek(base, end, (uint64_t)(src + len - base) * 8);
+        } else {
+            if (btype == 1) fixed_codes(codes);
+            else if (!read_dynamic_header(in, codes, false)) return false;
+            if (!decode_block_symbols(in, codes, co.sym, co.n, max_out, text_ok)) return false;
+        }
+        if (bfinal) { co.final_block = true; co.end_bit = in.bitpos(); co.ok = true; return true; }
+    }
+}
+
+// the first bit position in [from_bit, to_bit) at which a non-final dynamic block starts whose header passes the strict checks and
+// whose whole block decodes (to text, if text_ok); ~0 if there is none
+inline uint64_t find_block(const uint8_t *base, const uint8_t *end, uint64_t from_bit, uint64_t to_bit, const bool *text_ok)
+{
+    static thread_local Codes codes;
+    static thread_local ChunkOut trial;
+    const uint64_t size_bits = (uint64_t)(end - base) * 8;
+    if (to_bit + 64 > size_bits) to_bit = size_bits > 64 ? size_bits - 64 : 0;
+    for (uint64_t b = from_bit; b < to_bit; ++b) {
+        uint64_t v;
+        memcpy(&v, base + (b >> 3), 8);
+        v >>= (b & 7);
+        if ((v & 7) != 4) continue;                          // BFINAL = 0, BTYPE = 2 (bits: final, then type LSB first -> 0b100)
+        if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;      // HLIT <= 286 symbols, HDIST <= 30
+        BitIn in;
+        in.seek(base, end, b + 3);
+        if (!read_dynamic_header(in, codes, true)) continue;
+        // the whole block must decode (at most 8 MiB of output) and be followed by something that can be a block header
+        if (!decode_from(base, end, b, ~0ull, trial, WIN + (8u << 20), text_ok, 1)) continue;
+        if (trial.n == WIN) continue;
+        const uint64_t e = trial.end_bit;
+        if (e + 3 <= size_bits) {
+            uint64_t w;
+            memcpy(&w, base + (e >> 3), std::min<size_t>(8, (size_t)(end - (base + (e >> 3)))));
+            if ((((w >> (e & 7)) >> 1) & 3) == 3) continue;
+        }
+        return b;
+    }
+    return ~0ull;
+}
+
+// gzip member header at p: returns its length, 0 if there is none
+inline size_t gzip_header_len(const uint8_t *p, size_t n)
+{
+    if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return 0;
+    const uint8_t flg = p[3];
+    size_t o = 10;
+    if (flg & 4) { if (o + 2 > n) return 0; o += 2 + (size_t)(p[o] | (p[o + 1] << 8)); }
+    if (flg & 8) { while (o < n && p[o]) ++o; ++o; }
+    if (flg & 16) { while (o < n && p[o]) ++o; ++o; }
+    if (flg & 2) o += 2;
+    return o < n ? o : 0;
+}
+
+} // namespace pgz_detail
+
+class ParallelGz {
+public:
+    ~ParallelGz() { shutdown(); if (map_) munmap(const_cast<uint8_t *>(map_), size_); }
+
+    // true: `path` is a gzip file large enough to be worth the threads; inflating starts at once.  chunk_bytes = compressed bytes
+    // per chunk (0: 4 MiB).
+    bool open(const std::string &path, unsigned threads, size_t chunk_bytes = 0, size_t min_size = 8u << 20)
+    {
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < std::max<size_t>(min_size, 64)) { ::close(fd); return false; }
+        size_ = (size_t)sb.st_size;
+        void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        map_ = (const uint8_t *)m;
+        if (!pgz_detail::gzip_header_len(map_, size_)) return false;
+        threads_ = std::max(1u, threads);
+        chunk_bytes_ = chunk_bytes ? chunk_bytes : (4u << 20);
+        lookahead_ = 2 * threads_ + 2;
+        start_member(0);
+        for (unsigned t = 0; t < threads_; ++t) th_.emplace_back([this] { worker(); });
+        return true;
+    }
+
+    // next bytes of the decompressed stream; 0 at the end.  Throws std::runtime_error on a corrupt stream.
+    size_t read(char *dst, size_t n)
+    {
+        size_t got = 0;
+        while (got < n) {
+            if (cur_out_ && cur_pos_ < cur_out_->size()) {
+                const size_t take = std::min(n - got, cur_out_->size() - cur_pos_);
+                memcpy(dst + got, cur_out_->data() + cur_pos_, take);
+                cur_pos_ += take;
+                got += take;
+                continue;
+            }
+            if (!next_chunk()) break;
+        }
+        return got;
+    }
+
+    // statistics for the diagnostic command
+    uint64_t chunks_total = 0, chunks_redecoded = 0, bytes_out = 0, members = 0;
+    std::atomic<uint64_t> ns_find{0}, ns_decode{0}, ns_resolve{0};     // summed over the worker threads
+
+private:
+    using ChunkOut = pgz_detail::ChunkOut;
+    struct Chunk {
+        uint64_t nominal_start = 0, nominal_stop = 0;   // bits
+        ChunkOut co;
+        int state = 0;                                  // 0 waiting, 1 decoding, 2 decoded, 3 resolving, 4 ready, 5 consumed
+        std::vector<uint8_t> window;                    // the 32 KiB before this chunk (set when it is tied to its predecessor)
+        std::vector<uint8_t> out;
+        uint32_t crc = 0;
+    };
+
+    void shutdown()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (auto &t : th_) t.join();
+        th_.clear();
+    }
+
+    // lay the chunks of the member whose header starts at byte `off`
+    void start_member(size_t off)
+    {
+        using namespace pgz_detail;
+        const size_t h = gzip_header_len(map_ + off, size_ - off);
+        if (!h) throw std::runtime_error("gzip: bad member header");
+        std::unique_lock<std::mutex> lk(mu_);
+        n_live_ = 0;                                           // no new decodes of the old member ...
+        cv_done_.wait(lk, [&] { return busy_ == 0; });         // ... and none of them still running on its chunks
+        chunks_.clear();
+        resolve_q_.clear();
+        member_data_ = off + h;
+        const uint64_t first = (uint64_t)member_data_ * 8, endb = (uint64_t)size_ * 8;
+        for (uint64_t b = first; b < endb; b += (uint64_t)chunk_bytes_ * 8) {
+            chunks_.emplace_back();
+            chunks_.back().nominal_start = b;
+            chunks_.back().nominal_stop = std::min(endb, b + (uint64_t)chunk_bytes_ * 8);
+        }
+        next_decode_ = 0;
+        tied_ = 0;
+        cur_ = 0;
+        n_live_ = chunks_.size();
+        member_crc_ = crc32(0L, Z_NULL, 0);
+        member_len_ = 0;
+        text_ = true;
+        ++members;
+        cv_work_.notify_all();
+    }
+
+    void worker()
+    {
+        using namespace pgz_detail;
+        static const TextSet ts;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return stop_ || !resolve_q_.empty() || (next_decode_ < n_live_ && next_decode_ < cur_ + lookahead_); });
+            if (stop_) return;
+            if (!resolve_q_.empty()) {
+                const size_t i = resolve_q_.front();
+                resolve_q_.pop_front();
+                Chunk &c = chunks_[i];
+                ++busy_;
+                lk.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                resolve(c);
+                ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                lk.lock();
+                --busy_;
+                c.state = 4;
+                cv_done_.notify_all();
+                continue;
+            }
+            const size_t i = next_decode_++;
+            Chunk &c = chunks_[i];
+            c.state = 1;
+            ++busy_;
+            const bool text = text_;
+            lk.unlock();
+            const uint8_t *base = map_, *end = map_ + size_;
+            uint64_t s = c.nominal_start;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (i > 0) s = find_block(base, end, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr);
+            const auto t1 = std::chrono::steady_clock::now();
+            bool ok = false;
+            if (s != ~0ull) ok = decode_from(base, end, s, c.nominal_stop, c.co, WIN + max_chunk_out(), (i > 0 && text) ? ts.ok : nullptr);
+            ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            ns_decode += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
+            if (!ok) { c.co.ok = false; c.co.sym.clear(); c.co.sym.shrink_to_fit(); }
+            lk.lock();
+            --busy_;
+            c.state = 2;
+            cv_done_.notify_all();
+        }
+    }
+
+    size_t max_chunk_out() const { return (size_t)1032 * chunk_bytes_ + (1u << 20); }    // deflate expands at most ~1032:1
+
+    static void resolve(Chunk &c)
+    {
+        using namespace pgz_detail;
+        const size_t n = c.co.n - WIN;
+        c.out.resize(n);
+        const uint16_t *s = c.co.sym.data() + WIN;
+        const uint8_t *w = c.window.data();
+        uint8_t *o = c.out.data();
+        for (size_t i = 0; i < n; ++i) {
+            const uint16_t v = s[i];
+            o[i] = v < 256 ? (uint8_t)v : w[v - 256];
+        }
+        c.co.sym.clear();
+        c.co.sym.shrink_to_fit();
+        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t p = 0; p < n; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(n - p, 1u << 30));
+        c.crc = crc;
+    }
+
+    // tie chunk i to its predecessor (mu_ held on entry and exit; released while a chunk is decoded again): its start must be the
+    // predecessor's end.  Sets its window, computes the next one, queues the resolution.  Returns false if chunk i is not decoded yet.
+    bool tie(std::unique_lock<std::mutex> &lk, size_t i)
+    {
+        using namespace pgz_detail;
+        Chunk &c = chunks_[i];
+        if (c.state < 2) return false;
+        const uint64_t want = i == 0 ? (uint64_t)member_data_ * 8 : prev_end_;
+        if (!c.co.ok || c.co.start_bit != want) {
+            // not where the stream says the chunk starts (or it failed): decode it from the right place -- nothing speculative
+            lk.unlock();
+            ChunkOut co;
+            const bool ok = decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr);
+            lk.lock();
+            if (!ok) throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
+            c.co = std::move(co);
+            ++chunks_redecoded;
+        }
+        if (i == 0) {
+            c.window.assign(WIN, 0);
+            // is it text?  (then candidate block starts of later chunks must decode to text as well)
+            bool text = true;
+            static const TextSet ts;
+            for (size_t k = WIN; k < std::min<size_t>(c.co.n, WIN + (1u << 16)); ++k)
+                if (c.co.sym[k] >= 256 || !ts.ok[c.co.sym[k]]) { text = false; break; }
+            text_ = text;
+        } else
+            c.window = next_window_;
+        // the window of the next chunk: the last WIN bytes of (window ++ this chunk), markers resolved
+        const size_t n = c.co.n - WIN;
+        std::vector<uint8_t> nw(WIN);
+        for (size_t k = 0; k < WIN; ++k) {
+            const size_t pos = n + k;                          // index into (window ++ chunk), counted from the start of the window
+            if (pos < WIN + n && pos >= WIN) {
+                const uint16_t v = c.co.sym[pos];
+                nw[k] = v < 256 ? (uint8_t)v : c.window[v - 256];
+            }
+        }
+        for (size_t k = 0; k < WIN; ++k) {
+            const size_t pos = n + k;
+            if (pos < WIN) nw[k] = c.window[pos];
+        }
+        next_window_.swap(nw);
+        prev_end_ = c.co.end_bit;
+        ++chunks_total;
+        if (c.co.final_block) n_live_ = i + 1;                 // nothing behind the final block belongs to this member
+        c.state = 3;
+        resolve_q_.push_back(i);
+        cv_work_.notify_all();
+        return true;
+    }
+
+    // make the next chunk's bytes current; false at the end of the file
+    bool next_chunk()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (cur_out_) {                                       // the chunk just finished
+            Chunk &c = chunks_[cur_];
+            member_crc_ = (uint32_t)crc32_combine(member_crc_, c.crc, (z_off_t)c.out.size());
+            member_len_ += c.out.size();
+            bytes_out += c.out.size();
+            std::vector<uint8_t>().swap(c.out);
+            c.state = 5;
+            cur_out_ = nullptr;
+            ++cur_;
+            cv_work_.notify_all();
+        }
+        for (;;) {
+            while (tied_ < n_live_ && tied_ < cur_ + lookahead_ && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
+                if (!tie(lk, tied_)) break;
+                ++tied_;
+            }
+            if (cur_ >= n_live_) {
+                // member complete: trailer (CRC-32, ISIZE) at the next byte boundary behind the final block
+                if (tied_ == 0 || !chunks_[n_live_ - 1].co.final_block) throw std::runtime_error("gzip: stream ends before its final block");
+                const size_t t = (size_t)((prev_end_ + 7) / 8);
+                if (t + 8 > size_) throw std::runtime_error("gzip: truncated trailer");
+                uint32_t crc, isize;
+                memcpy(&crc, map_ + t, 4);
+                memcpy(&isize, map_ + t + 4, 4);
+                if (crc != member_crc_ || isize != (uint32_t)member_len_) throw std::runtime_error("gzip: CRC or length mismatch at the end of the member");
+                size_t nx = t + 8;
+                while (nx < size_ && map_[nx] == 0) ++nx;        // zero padding behind a member is legal
+                if (nx >= size_) return false;
+                lk.unlock();
+                start_member(nx);                                // another member: the same way
+                lk.lock();
+                continue;
+            }
+            if (chunks_[cur_].state == 4) {
+                cur_out_ = &chunks_[cur_].out;
+                cur_pos_ = 0;
+                if (cur_out_->empty()) { lk.unlock(); return next_chunk(); }
+                return true;
+            }
+            cv_done_.wait(lk);
+        }
+    }
+
+    const uint8_t *map_ = nullptr;
+    size_t size_ = 0, chunk_bytes_ = 4u << 20, member_data_ = 0;
+    unsigned threads_ = 1;
+    size_t lookahead_ = 4;
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::deque<Chunk> chunks_;
+    std::deque<size_t> resolve_q_;
+    size_t next_decode_ = 0, tied_ = 0, cur_ = 0, n_live_ = 0, busy_ = 0;
+    uint64_t prev_end_ = 0;
+    std::vector<uint8_t> next_window_;
+    uint32_t member_crc_ = 0;
+    uint64_t member_len_ = 0;
+    bool text_ = true, stop_ = false;
+    const std::vector<uint8_t> *cur_out_ = nullptr;
+    size_t cur_pos_ = 0;
+};
+
+} // namespace fastx
