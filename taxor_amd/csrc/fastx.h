@@ -10,6 +10,7 @@
 #pragma once
 
 #include "gzmembers.h"
+#include "pgz.h"
 
 #include <zlib.h>
 
@@ -160,6 +161,7 @@ struct FastxReader {
     int fd = -1;         // range mode: bytes [rpos, rend) of a plain file, read with pread
     uint64_t rpos = 0, rend = 0;
     GzMembers *members = nullptr;   // multi-member gzip inflated in parallel (gzmembers.h)
+    ParallelGz *pgz = nullptr;      // ONE gzip member inflated in parallel (pgz.h)
     std::unique_ptr<Bz2Reader> bz;  // bzip2 input, all of its streams
 
     bool strict4 = false;           // range mode on FASTQ: records must be the four-line kind the ranges were cut for
@@ -204,6 +206,8 @@ struct FastxReader {
         long n;
         if (members) {
             n = (long)members->read(buf.data(), buf.size());
+        } else if (pgz) {
+            n = (long)pgz->read(buf.data(), buf.size());
         } else if (fd >= 0) {
             const uint64_t want = std::min<uint64_t>(buf.size(), rend - rpos);
             n = want ? (long)pread(fd, buf.data(), want, (off_t)rpos) : 0;

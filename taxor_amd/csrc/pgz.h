@@ -22,6 +22,9 @@
 #pragma once
 
 #include <zlib.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -241,10 +244,37 @@ inline void fixed_codes(Codes &c)
     for (int i = 256; i < 280; ++i) l[i] = 7;
     for (int i = 280; i < 288; ++i) l[i] = 8;
     c.lit.build(l, 288);
-    uint8_t d[30];
-    for (int i = 0; i < 30; ++i) d[i] = 5;
-    c.dist.build(d, 30);
+    uint8_t d[32];                       // 32 five-bit codes; 30 and 31 never occur in valid data (rejected where they are decoded)
+    for (int i = 0; i < 32; ++i) d[i] = 5;
+    c.dist.build(d, 32);
 }
+
+// symbols of a chunk: grown by realloc, never value-initialised (a std::vector would zero 32 MB per chunk before it is written),
+// and handed back to a pool when the chunk has been resolved
+struct SymBuf {
+    uint16_t *p = nullptr;
+    size_t cap = 0;
+    SymBuf() = default;
+    SymBuf(const SymBuf &) = delete;
+    SymBuf &operator=(const SymBuf &) = delete;
+    SymBuf(SymBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    SymBuf &operator=(SymBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~SymBuf() { free(p); }
+    size_t size() const { return cap; }
+    uint16_t *data() { return p; }
+    const uint16_t *data() const { return p; }
+    uint16_t &operator[](size_t i) { return p[i]; }
+    const uint16_t &operator[](size_t i) const { return p[i]; }
+    void resize(size_t n)
+    {
+        if (n <= cap) return;
+        uint16_t *q = (uint16_t *)realloc(p, n * sizeof(uint16_t));
+        if (!q) throw std::bad_alloc();
+        p = q;
+        cap = n;
+    }
+    void release() { free(p); p = nullptr; cap = 0; }
+};
 
 struct TextSet {
     bool ok[256];
@@ -256,60 +286,84 @@ struct TextSet {
 
 // One block's symbols -> out (16 bits each: a byte, or 256 + window index).  out holds WIN window slots in front of the chunk's
 // own symbols, so a reference behind the chunk's start copies markers like anything else.  Returns false on invalid data.
-// max_out bounds the chunk (a trial decode of a candidate block start must not run away).
-inline bool decode_block_symbols(BitIn &in, const Codes &c, std::vector<uint16_t> &out, size_t &n, size_t max_out, const bool *text_ok)
+// max_out bounds the chunk (a trial decode of a candidate block start must not run away).  TEXT: every literal must be text (the
+// trial decode of a candidate block start); the check is a flag OR-ed per literal and looked at once per block, not a branch.
+template <bool TEXT>
+inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t &n_io, size_t max_out, const bool *text_ok)
 {
+    size_t n = n_io;
+    uint32_t bad = 0;
     for (;;) {
         if (n + 320 > out.size()) {
             if (n + 320 > max_out) return false;
             out.resize(std::min(max_out + 320, std::max<size_t>(out.size() * 2, 1u << 20)));
         }
-        in.refill();
-        if (in.bc < 0) return false;                        // ran past the end of the input
-        uint32_t e = c.lit.lookup(in.bb);
-        int l = (int)(e & 0xFF);
-        if (!l) return false;
-        in.drop(l);
-        uint32_t sym = e >> 16;
-        if (sym < 256) {
-            if (text_ok && !text_ok[sym]) return false;
-            out[n++] = (uint16_t)sym;
-            // a second literal out of the same refill (most symbols of text are literals)
-            e = c.lit.lookup(in.bb);
-            l = (int)(e & 0xFF);
-            sym = e >> 16;
-            if (l && sym < 256 && in.bc >= l) {
-                if (text_ok && !text_ok[sym]) return false;
+        uint16_t *const o0 = out.data();
+        // a stretch that cannot run out of room or of input: up to 64 rounds of (refill, up to three literals or one match)
+        size_t room = (out.size() - n - 320) / 264;
+        if (room > 64) room = 64;
+        if (in.p + 8 * (room + 1) > in.end) room = 0;           // near the end of the input: one careful round at a time
+        size_t rounds = room ? room : 1;
+        while (rounds--) {
+            in.refill();
+            if (in.bc < 0) return false;                          // ran past the end of the input
+            uint32_t e = c.lit.lookup(in.bb);
+            int l = (int)(e & 0xFF);
+            uint32_t sym = e >> 16;
+            if (sym < 256 && l) {
+                if (TEXT) bad |= (uint32_t)!text_ok[sym];
                 in.drop(l);
-                out[n++] = (uint16_t)sym;
+                o0[n++] = (uint16_t)sym;
+                e = c.lit.lookup(in.bb);
+                l = (int)(e & 0xFF);
+                sym = e >> 16;
+                if (sym < 256 && l) {
+                    if (TEXT) bad |= (uint32_t)!text_ok[sym];
+                    in.drop(l);
+                    o0[n++] = (uint16_t)sym;
+                    e = c.lit.lookup(in.bb);
+                    l = (int)(e & 0xFF);
+                    sym = e >> 16;
+                    if (sym < 256 && l) {
+                        if (TEXT) bad |= (uint32_t)!text_ok[sym];
+                        in.drop(l);
+                        o0[n++] = (uint16_t)sym;
+                        continue;
+                    }
+                }
+                // not a literal: it needs up to 48 bits of its own
+                in.refill();
+                if (in.bc < 0) return false;
             }
-            continue;
+            if (!l) return false;
+            in.drop(l);
+            if (sym == 256) { n_io = n; return !in.overrun() && !bad; }
+            sym -= 257;
+            if (sym >= 29) return false;
+            const uint32_t len = LBASE[sym] + in.peek(LEXT[sym]);
+            in.drop(LEXT[sym]);
+            const uint32_t de = c.dist.lookup(in.bb);
+            const int dl = (int)(de & 0xFF);
+            if (!dl) return false;
+            in.drop(dl);
+            const uint32_t ds = de >> 16;
+            if (ds >= 30) return false;
+            const uint32_t d = DBASE[ds] + in.peek(DEXT[ds]);
+            in.drop(DEXT[ds]);
+            if (d > n) return false;                            // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid)
+            if (in.overrun()) return false;
+            uint16_t *o = o0 + n;
+            const uint16_t *s = o - d;
+            if (d >= len) memcpy(o, s, (size_t)len * 2);
+            else for (uint32_t i = 0; i < len; ++i) o[i] = s[i];
+            n += len;
         }
-        if (sym == 256) return !in.overrun();
-        sym -= 257;
-        if (sym >= 29) return false;
-        const uint32_t len = LBASE[sym] + in.peek(LEXT[sym]);
-        in.drop(LEXT[sym]);
-        const uint32_t de = c.dist.lookup(in.bb);
-        const int dl = (int)(de & 0xFF);
-        if (!dl) return false;
-        in.drop(dl);
-        const uint32_t ds = de >> 16;
-        if (ds >= 30) return false;
-        const uint32_t d = DBASE[ds] + in.peek(DEXT[ds]);
-        in.drop(DEXT[ds]);
-        if (d > n) return false;                            // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid)
-        if (in.overrun()) return false;
-        uint16_t *o = out.data() + n;
-        const uint16_t *s = o - d;
-        if (d >= len) memcpy(o, s, (size_t)len * 2);
-        else for (uint32_t i = 0; i < len; ++i) o[i] = s[i];
-        n += len;
+        if (TEXT && bad) return false;
     }
 }
 
 struct ChunkOut {
-    std::vector<uint16_t> sym;     // WIN window slots (markers 256 + w) followed by the chunk's symbols
+    SymBuf sym;                    // WIN window slots (markers 256 + w) followed by the chunk's symbols
     size_t n = WIN;                 // symbols used, window slots included
     uint64_t start_bit = 0, end_bit = 0;
     bool final_block = false;       // the member's last block ends at end_bit
@@ -365,7 +419,7 @@ inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_
         } else {
             if (btype == 1) fixed_codes(codes);
             else if (!read_dynamic_header(in, codes, false)) return false;
-            if (!decode_block_symbols(in, codes, co.sym, co.n, max_out, text_ok)) return false;
+            if (!(text_ok ? decode_block_symbols<true>(in, codes, co.sym, co.n, max_out, text_ok) : decode_block_symbols<false>(in, codes, co.sym, co.n, max_out, text_ok))) return false;
         }
         if (bfinal) { co.final_block = true; co.end_bit = in.bitpos(); co.ok = true; return true; }
     }
@@ -428,7 +482,7 @@ public:
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         struct stat sb;
-        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < std::max<size_t>(min_size, 64)) { ::close(fd); return false; }
+        if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode) || (size_t)sb.st_size < std::max<size_t>(min_size, 18)) { ::close(fd); return false; }
         size_ = (size_t)sb.st_size;
         void *m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
         ::close(fd);
@@ -542,6 +596,10 @@ private:
             Chunk &c = chunks_[i];
             c.state = 1;
             ++busy_;
+            {
+                std::lock_guard<std::mutex> pl(pool_mu_);
+                if (!pool_.empty()) { c.co.sym = std::move(pool_.back()); pool_.pop_back(); }
+            }
             const bool text = text_;
             lk.unlock();
             const uint8_t *base = map_, *end = map_ + size_;
@@ -550,10 +608,10 @@ private:
             if (i > 0) s = find_block(base, end, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr);
             const auto t1 = std::chrono::steady_clock::now();
             bool ok = false;
-            if (s != ~0ull) ok = decode_from(base, end, s, c.nominal_stop, c.co, WIN + max_chunk_out(), (i > 0 && text) ? ts.ok : nullptr);
+            if (s != ~0ull) ok = decode_from(base, end, s, c.nominal_stop, c.co, WIN + max_chunk_out(), nullptr);      // (the start's first block was held to text by the search)
             ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
             ns_decode += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
-            if (!ok) { c.co.ok = false; c.co.sym.clear(); c.co.sym.shrink_to_fit(); }
+            if (!ok) { c.co.ok = false; give_back(c.co.sym); }
             lk.lock();
             --busy_;
             c.state = 2;
@@ -563,7 +621,15 @@ private:
 
     size_t max_chunk_out() const { return (size_t)1032 * chunk_bytes_ + (1u << 20); }    // deflate expands at most ~1032:1
 
-    static void resolve(Chunk &c)
+    void give_back(pgz_detail::SymBuf &b)
+    {
+        if (!b.p) return;
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        if (pool_.size() < 4 * (size_t)threads_) pool_.push_back(std::move(b));
+        else b.release();
+    }
+
+    void resolve(Chunk &c)
     {
         using namespace pgz_detail;
         const size_t n = c.co.n - WIN;
@@ -571,12 +637,23 @@ private:
         const uint16_t *s = c.co.sym.data() + WIN;
         const uint8_t *w = c.window.data();
         uint8_t *o = c.out.data();
-        for (size_t i = 0; i < n; ++i) {
+        size_t i = 0;
+#if defined(__SSE2__)
+        // sixteen symbols at a time while none of them is a marker (behind the first stretch of a chunk hardly any is)
+        const __m128i zero = _mm_setzero_si128();
+        for (; i + 16 <= n; i += 16) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(s + i)), b = _mm_loadu_si128((const __m128i *)(s + i + 8));
+            if (_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_srli_epi16(_mm_or_si128(a, b), 8), zero)) == 0xFFFF)
+                _mm_storeu_si128((__m128i *)(o + i), _mm_packus_epi16(a, b));
+            else
+                for (size_t k = i; k < i + 16; ++k) { const uint16_t v = s[k]; o[k] = v < 256 ? (uint8_t)v : w[v - 256]; }
+        }
+#endif
+        for (; i < n; ++i) {
             const uint16_t v = s[i];
             o[i] = v < 256 ? (uint8_t)v : w[v - 256];
         }
-        c.co.sym.clear();
-        c.co.sym.shrink_to_fit();
+        give_back(c.co.sym);
         uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
         for (size_t p = 0; p < n; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(n - p, 1u << 30));
         c.crc = crc;
@@ -690,6 +767,8 @@ private:
     std::condition_variable cv_work_, cv_done_;
     std::deque<Chunk> chunks_;
     std::deque<size_t> resolve_q_;
+    std::vector<pgz_detail::SymBuf> pool_;
+    std::mutex pool_mu_;
     size_t next_decode_ = 0, tied_ = 0, cur_ = 0, n_live_ = 0, busy_ = 0;
     uint64_t prev_end_ = 0;
     std::vector<uint8_t> next_window_;

@@ -285,12 +285,20 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
     }
     fastx::FastxReader rd;
     fastx::GzMembers members;
-    bool multi = false;
+    fastx::ParallelGz pgz;
+    bool multi = false, single = false;
+    const unsigned gz_threads = parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, 16u));
     try {
-        multi = allow_ranges && members.open(query, parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, 16u)));
+        multi = allow_ranges && members.open(query, gz_threads);
+        // one member (what `gzip reads.fastq` writes): inflated speculatively from the middle on all of this file's threads (pgz.h);
+        // --sequential and small files keep the one zlib stream
+        if (!multi && allow_ranges && gz_threads > 1) single = pgz.open(query, gz_threads);
     } catch (const std::exception &ex) { die(ex.what()); }
     if (multi) {
         rd.members = &members;
+        rd.buf.resize(8u << 20);
+    } else if (single) {
+        rd.pgz = &pgz;
         rd.buf.resize(8u << 20);
     } else if (!rd.open(query)) die("cannot open query file " + query);
     std::string id;
@@ -645,6 +653,41 @@ int main(int argc, char **argv)
         taxor_gpu_index_destroy(gi);
         taxor_hixf_free(h);
         return pass ? 0 : 2;
+    }
+    if (argc > 1 && strcmp(argv[1], "inflate") == 0) {
+        // the parallel gzip reader alone: `taxor inflate --query-file x.fastq.gz [--threads n] [--chunk-mb m] [--output-file out]`
+        // decompresses (to a file, or nowhere) and reports the rate, the output's CRC-32 and how many chunks had to be decoded twice
+        std::string in, out_path;
+        unsigned threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        size_t chunk = 0;
+        for (int i = 2; i < argc; ++i) {
+            if (strcmp(argv[i], "--query-file") == 0 && i + 1 < argc) in = argv[++i];
+            else if (strcmp(argv[i], "--threads") == 0 && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
+            else if (strcmp(argv[i], "--chunk-mb") == 0 && i + 1 < argc) chunk = (size_t)(atof(argv[++i]) * 1048576.0);
+            else if (strcmp(argv[i], "--output-file") == 0 && i + 1 < argc) out_path = argv[++i];
+        }
+        if (in.empty() || !file_exists(in)) die("usage: taxor inflate --query-file <x.gz> [--threads n] [--chunk-mb m] [--output-file out]");
+        fastx::ParallelGz g;
+        const double t0 = now();
+        if (!g.open(in, threads, chunk, 0)) die(in + " is not a gzip file");
+        FILE *of = out_path.empty() ? nullptr : fopen(out_path.c_str(), "wb");
+        if (!out_path.empty() && !of) die("cannot write " + out_path);
+        std::vector<char> buf(16u << 20);
+        uint64_t total = 0;
+        try {
+            for (;;) {
+                const size_t n = g.read(buf.data(), buf.size());
+                if (!n) break;
+                total += n;
+                if (of && fwrite(buf.data(), 1, n, of) != n) die("write error on " + out_path);
+            }
+        } catch (const std::exception &e) { die(e.what()); }
+        if (of) fclose(of);
+        const double dt = now() - t0;
+        printf("%llu bytes in %.3f s = %.2f GB/s on %u threads; %llu member(s), %llu chunks, %llu decoded again from a corrected start; CRC-32 and length of every member verified\n",
+               (unsigned long long)total, dt, total / 1e9 / dt, threads, (unsigned long long)g.members, (unsigned long long)g.chunks_total, (unsigned long long)g.chunks_redecoded);
+        printf("worker seconds: block search %.3f, decode %.3f, marker resolution + CRC %.3f\n", g.ns_find / 1e9, g.ns_decode / 1e9, g.ns_resolve / 1e9);
+        return 0;
     }
     if (argc > 1 && strcmp(argv[1], "pin") == 0) return pin_command(argc, argv);   // published .hixf + reference TSV -> committed parity fixture
     if (argc > 1 && strcmp(argv[1], "reads") == 0) {                       // reader check: id, length, FNV-1a of every record

@@ -465,3 +465,28 @@ def test_cli_several_index_files(tmp_path):
                         capture_output=True, text=True, timeout=120)
     assert cp.returncode != 0 and "different kmer selection schemes" in cp.stderr
 
+
+
+def test_cli_single_member_gzip_equals_plain(tmp_path):
+    """reads.fastq.gz as `gzip` writes it -- ONE member, here 9 MB -- is inflated speculatively from the middle on the reader's
+    threads (taxor_amd/csrc/pgz.h): the TSV must be the plain file's, byte for byte, and --sequential (one zlib stream) agrees"""
+    g, go, host, sp, idx_path = _setup(tmp_path, 53)
+    rng = np.random.default_rng(4)
+    bases, offs, origin = synth.synth_reads(g, go, 2400, 4000, error_rate=0.02, frac_random=0.3, seed=6)
+    q = np.frombuffer(b"#$%&'()*+,-./0123456789:;<=>?@ABCDEFGHI", np.uint8)
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "wb") as f:
+        for i in range(2400):
+            r = bytes(bases[int(offs[i]):int(offs[i + 1])])
+            f.write(b"@read_%d runid=abc ch=%d\n" % (i, i % 97) + r + b"\n+\n" + bytes(rng.choice(q, size=len(r))) + b"\n")
+    gz = tmp_path / "reads.fastq.gz"
+    gz.write_bytes(gzip.compress(fq.read_bytes(), 6))
+    assert gz.stat().st_size > (8 << 20)
+    outs = []
+    for path, extra in ((fq, []), (gz, []), (gz, ["--sequential"]), (gz, ["--threads", "2"])):
+        out = tmp_path / f"o{len(outs)}.tsv"
+        cp = subprocess.run([TAXOR, "search", "--index-file", str(idx_path), "--query-file", str(path), "--output-file", str(out), "--threads", "8"] + extra,
+                            capture_output=True, text=True, timeout=600)
+        assert cp.returncode == 0, cp.stderr
+        outs.append(open(out).read())
+    assert outs[0].count("\n") > 2400 and all(o == outs[0] for o in outs[1:])
