@@ -62,6 +62,7 @@ struct Batch {
     void *pinned = nullptr;
     bool may_pin = false;
     uint64_t pool_bytes = 0;    // what the CLI's buffer pool has on its books for this batch (search_main.cpp, BatchPool)
+    uint32_t fills = 0;         // how often this buffer has been filled by a parser: it is page-locked when it comes round again
 };
 
 // ---- bzip2 input (seqan3's sequence_file_input reads .bz2 when built with bzip2, which the reference's CMake fetches).

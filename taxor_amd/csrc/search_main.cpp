@@ -252,6 +252,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                         if (!rf.next_range(b, e, seq)) { pool.put(std::move(bt)); break; }
                         bt->seq = seq;
                         bt->may_pin = true;
+                        ++bt->fills;
                         const size_t need = fastx::bases_bound(e - b, rf.kind);
                         if (need > bt->bases.capacity()) {  // grow before parsing, and only with the old block unpinned
                             if (bt->pinned) { taxor_gpu_host_unregister(bt->pinned); bt->pinned = nullptr; }
@@ -938,13 +939,17 @@ int main(int argc, char **argv)
             });
         // Page-locking a chunk buffer (once per buffer: chunks are recycled) costs ~50-90 ms per GB inside the driver.  Neither
         // the parsers nor the GPU workers pay it: a small stage of its own between them does, so that a registration queued
-        // behind the driver's 113 GB allocation stalls nobody who has other work.
+        // behind the driver's 113 GB allocation stalls nobody who has other work.  And a buffer is only registered when it comes
+        // round the SECOND time: a query file smaller than the pool (13 GB of reads against the RefSeq-class index: a search phase
+        // of 0.4 s) uses every buffer once, and registering all of them was 0.5 s of driver time for copies the library makes from
+        // pageable memory at 0.94 of the page-locked rate anyway; a long run reaches the same steady state one lap later.
+        static const uint32_t pin_after = [] { const char *e = tune_env("TAXOR_CLI_PIN_AFTER"); const int v = e ? atoi(e) : 2; return (uint32_t)(v >= 1 ? v : 1); }();
         std::vector<std::thread> pinners;
         for (int pt = 0; pt < 2; ++pt)
             pinners.emplace_back([&] {
                 std::unique_ptr<Batch> b;
                 while (q_parsed.pop(b)) {
-                    if (!b->end_of_file && b->may_pin && !b->pinned && b->bases.capacity() >= (1u << 20) &&
+                    if (!b->end_of_file && b->may_pin && !b->pinned && b->fills >= pin_after && b->bases.capacity() >= (1u << 20) &&
                         taxor_gpu_host_register(&b->bases[0], b->bases.capacity()) == TAXOR_OK)
                         b->pinned = &b->bases[0];       // recycled with the chunk: a DMA source from then on
                     q_in.push(std::move(b));
@@ -1076,7 +1081,7 @@ int main(int argc, char **argv)
                 if (taxor_gpu_searcher_create(gidx[g], &prm, &sr[g * wpg + w]) != TAXOR_OK) die(taxor_gpu_last_error());
 
         auto pin = [](Batch &bt) {      // recycled with the chunk: pinned once, DMA source from then on
-            if (bt.may_pin && !bt.pinned && bt.bases.capacity() >= (1u << 20) &&
+            if (bt.may_pin && !bt.pinned && bt.fills >= pin_after && bt.bases.capacity() >= (1u << 20) &&
                 taxor_gpu_host_register(&bt.bases[0], bt.bases.capacity()) == TAXOR_OK)
                 bt.pinned = &bt.bases[0];
         };

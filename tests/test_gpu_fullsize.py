@@ -258,10 +258,12 @@ def test_cli_search_phase_keeps_up_with_the_library(tmp_path):
              for m in re.finditer(r"RATE .*?search phase ([0-9.]+) Mbp/s = ([0-9.]+) x library sustained; teardown .*? ([0-9.]+) s;", cp.stdout)]
     assert len(rates) == 4, cp.stdout[-3000:]
     print(cp.stdout[-2500:])
-    # the bar the review set: 0.8 x the GTDB-class sustained rate = 20 Gbp/s (profiles/r03/cli_e2e_gtdb.txt: 0.90-0.99 x on that
-    # index) -- plus a floor on the ratio against this index's own library figure.  That figure is 37-40 Gbp/s, depending on
-    # the box, where the CLI's 13 GB run (every chunk buffer fresh, no steady state) gives 23-30: ratios of 0.58-0.80 were
-    # seen, the floors sit below the worst of them (round 2's CLI: 9.4 Gbp/s, 0.38 x)
-    assert max(v for v, _, _ in rates[1:]) >= 18000.0, rates
-    assert max(r for _, r, _ in rates[1:]) >= 0.5, rates
+    # the bar the review set: on the MEDIAN of the judged runs, >= 20 Gbp/s and >= 0.8 x the library's own sustained
+    # rate on the same reads.  (Round 3 sat below it on this 13-GB input -- 0.58-0.80 -- because every chunk buffer was page-locked
+    # on its first and only use; buffers are now registered when they come round the second time, search_main.cpp.)
+    judged = sorted(rates[1:])
+    med_rate = sorted(v for v, _, _ in judged)[len(judged) // 2]
+    med_ratio = sorted(r for _, r, _ in judged)[len(judged) // 2]
+    assert med_rate >= 20000.0, rates
+    assert med_ratio >= 0.8, rates
     assert max(t for _, _, t in rates) < 0.3, rates
