@@ -1196,6 +1196,10 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.prune_margin = margin_env;
     static const uint32_t tally_env = [] { const char *e = tune_env("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
     q.tally_mode = tally_env;
+    static const uint32_t sort_env = [] { const char *e = tune_env("TAXOR_QUERY_SORT_UNITS"); return e ? (uint32_t)(atoi(e) != 0) : 1u; }();
+    q.sort_units = sort_env;
+    static const uint32_t dense_stride_env = [] { const char *e = tune_env("TAXOR_QUERY_DENSE_STRIDE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    q.dense_max_stride = dense_stride_env;
     // root items in column parts (QueryArgs::parts): what the caller asks for (the small-batch lanes), or the widest valid
     // division when the searcher was created with TAXOR_SEARCH_SPLIT_ALWAYS; never for the raw per-IXF entry points
     if (root_parts == 0) root_parts = s->split_always ? idx->root_pmax : 1u;

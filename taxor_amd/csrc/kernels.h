@@ -131,7 +131,11 @@ struct QueryArgs {
                               // boundaries where a bin run ends (part_cut, in 16-bin units), so a part sees whole runs and prunes,
                               // tallies and reports on its own -- small batches then fill the chip and finish sooner (api.hip)
     uint16_t part_cut[10];
-    uint32_t tree_polls;      // TREE launches: how often an idle block looks again (about 3 us apart) before it leaves
+    uint32_t tree_polls;      // (unused)
+    uint32_t sort_units;      // 1 = the alive units of a sparse stage are put in ascending order, so that units sharing a 128-B line of a
+                              // row are fetched by neighbouring lanes of one load instruction (one request to the memory side, not several)
+    uint32_t dense_max_stride;// rows of at most this many bytes are counted densely to the end (a 16-B load of the sparse phase costs HBM
+                              // the same 128-B line as the row itself): no alive-unit bookkeeping for them; 0 = prune every width
     uint32_t tally_mode;      // measurement aid (TAXOR_QUERY_TALLY): bit 0 = tally walks every bin, bit 1 = bin info fetched per item
     unsigned long long *prof; // measurement aid (TAXOR_PROFILE_PHASES=1): 16 per-phase cycle sums, else nullptr
 };

@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
         // (expected count dense_end/256) below the bound, so normally only true matches stay alive and the
         // remaining hashes probe just their 16-bin units.  Runs that stay alive are counted exactly.
         uint32_t dense_end = n;
-        if (a.prune && thr > 0) {
+        if (a.prune && thr > 0 && stride > a.dense_max_stride) {
             // margin above the minimum n - thr + 1: a random bin collects ~Poisson((n-thr)/256) matches in the dense
             // phase; mean + 4 sigma + 3.5 keeps the expected number of falsely surviving units per item below ~0.1 (a
             // constant of 4.5 until round 3: 3.5 is 2 % faster on 1-kb reads, whose margin is mostly this constant, and
@@ -1553,6 +1553,19 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                     }
                 }
                 __syncthreads();
+                if (a.sort_units && sScal[1] > 1u && sScal[1] <= (uint32_t)Q_MAXU) {
+                    // ascending units: the lanes of one load instruction that work on neighbouring units of one row share its 128-B
+                    // lines (the units arrive here in the order of the LDS atomics above).  Q_MAXU <= 64: the first wave ranks them.
+                    const uint32_t na = sScal[1];
+                    uint32_t x = 0xFFFFFFFFu, rank = 0;
+                    if (tid < na) x = sUnits[tid];
+                    if (tid < 64u) {
+                        for (uint32_t j = 0; j < na; ++j) rank += (__shfl(x, (int)j) < x) ? 1u : 0u;
+                    }
+                    __syncthreads();
+                    if (tid < na) sUnits[rank] = x;
+                    __syncthreads();
+                }
                 if (first_eval) { PMARK(3) }                             // 3: which runs can still reach the threshold
                 const uint32_t n_alive = sScal[1];
                 if (n_alive == 0) break;
