@@ -1196,7 +1196,7 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     q.prune_margin = margin_env;
     static const uint32_t tally_env = [] { const char *e = tune_env("TAXOR_QUERY_TALLY"); return e ? (uint32_t)atoi(e) & 3u : 0u; }();
     q.tally_mode = tally_env;
-    static const uint32_t sort_env = [] { const char *e = tune_env("TAXOR_QUERY_SORT_UNITS"); return e ? (uint32_t)(atoi(e) != 0) : 1u; }();
+    static const uint32_t sort_env = [] { const char *e = tune_env("TAXOR_QUERY_SORT_UNITS"); return e ? (uint32_t)(atoi(e) != 0) : 0u; }();     // measured: no fewer requests (profiles/r04/sparse_lines.txt)
     q.sort_units = sort_env;
     static const uint32_t dense_stride_env = [] { const char *e = tune_env("TAXOR_QUERY_DENSE_STRIDE"); return e ? (uint32_t)atoi(e) : 0u; }();
     q.dense_max_stride = dense_stride_env;
