@@ -137,7 +137,8 @@ for thr in runs:
     extra = ["--threads", thr.split(":")[0]] + thr.split(":")[1:]       # "16:--gpu-list:0,0" = extra arguments after the thread count
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
-                        capture_output=True, text=True, env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1"))
+                        capture_output=True, text=True,
+                        env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1", **dict(kv.split("=", 1) for kv in os.environ.get("TAXOR_E2E_ENV", "").split())))
     dt = time.time() - t0
     print(" ".join(extra), "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end (index load included)")
     print(cp.stdout.strip().replace("\n", " | "))

@@ -51,6 +51,36 @@ int main(int argc, char **argv)
             if (map) munmap(map, total);
             close(fd);
         }
+    // what the CLI's writer does: one thread write()s 64-MiB blocks while a helper preallocates a gigabyte ahead (FALLOC_FL_KEEP_SIZE)
+    for (int helper = 0; helper < 2; ++helper) {
+        unlink(path.c_str());
+        const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_TRUNC, 0644);
+        std::atomic<size_t> written{0}, allocated{0};
+        std::atomic<bool> stop{false};
+        std::thread h([&] {
+            if (!helper) return;
+            while (!stop.load()) {
+                if (allocated.load() < written.load() + (1ull << 30)) {
+                    if (fallocate(fd, FALLOC_FL_KEEP_SIZE, (off_t)allocated.load(), 1 << 30) != 0) { perror("fallocate keep_size"); return; }
+                    allocated += 1ull << 30;
+                } else
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+            }
+        });
+        std::vector<char> big(64u << 20, 'x');
+        const auto t0 = std::chrono::steady_clock::now();
+        for (size_t off = 0; off < total; off += big.size()) {
+            size_t done = 0;
+            while (done < big.size()) { const ssize_t w = write(fd, big.data() + done, big.size() - done); if (w <= 0) { perror("write"); return 1; } done += (size_t)w; }
+            written += big.size();
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        stop = true;
+        h.join();
+        if (ftruncate(fd, (off_t)total) != 0) perror("ftruncate");
+        printf("one writer, 64-MiB write() calls, %s: %6.2f GB/s\n", helper ? "helper preallocating 1 GiB ahead (KEEP_SIZE)" : "no preallocation", total / 1e9 / dt);
+        close(fd);
+    }
     unlink(path.c_str());
     return 0;
 }

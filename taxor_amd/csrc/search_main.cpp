@@ -954,7 +954,8 @@ int main(int argc, char **argv)
         // pageable memory at 0.94 of the page-locked rate anyway; a long run reaches the same steady state one lap later.
         static const uint32_t pin_after = [] { const char *e = tune_env("TAXOR_CLI_PIN_AFTER"); const int v = e ? atoi(e) : 2; return (uint32_t)(v >= 1 ? v : 1); }();
         std::vector<std::thread> pinners;
-        for (int pt = 0; pt < 2; ++pt)
+        static const int n_pinners = [] { const char *e = tune_env("TAXOR_CLI_PINNERS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 32 ? v : 2; }();
+        for (int pt = 0; pt < n_pinners; ++pt)
             pinners.emplace_back([&] {
                 std::unique_ptr<Batch> b;
                 while (q_parsed.pop(b)) {
@@ -1017,6 +1018,7 @@ int main(int argc, char **argv)
         const int out_fd = fileno(out);
         struct stat out_sb {};
         std::atomic<uint64_t> out_written{0}, out_allocated{0};
+        double t_write = 0;            // seconds the writer spent inside write()
         std::atomic<bool> alloc_stop{false};
         bool prealloc = fstat(out_fd, &out_sb) == 0 && S_ISREG(out_sb.st_mode) && !tune_env("TAXOR_CLI_NO_PREALLOC");
         if (prealloc) {
@@ -1057,11 +1059,13 @@ int main(int argc, char **argv)
                     }
                     ++next_seq;
                     // one stream, one thread, straight write() calls of whole chunk texts (see above)
+                    const double tw0 = now();
                     for (size_t done = 0; done < cur->text.size();) {
                         const ssize_t w = ::write(out_fd, cur->text.data() + done, cur->text.size() - done);
                         if (w <= 0) die("cannot write to " + cfg.report_file);
                         done += (size_t)w;
                     }
+                    t_write += now() - tw0;
                     out_written += cur->text.size();
                     {
                         std::lock_guard<std::mutex> lk(fmu);
@@ -1302,6 +1306,9 @@ int main(int argc, char **argv)
         allocator.join();
         if (prealloc && ftruncate(out_fd, (off_t)out_written.load()) != 0) die("cannot set the size of " + cfg.report_file);    // gives back what was preallocated beyond the end
         trace("writer done");
+        if (tune_env("TAXOR_CLI_TRACE"))
+            fprintf(stderr, "[trace] report: %.2f GB in %.3f s of write() = %.1f GB/s (%s)\n", out_written.load() / 1e9, t_write, t_write > 0 ? out_written.load() / 1e9 / t_write : 0.0,
+                    prealloc ? "file preallocated ahead of the writer" : "no preallocation");
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
         for (auto *x : sr) taxor_gpu_searcher_destroy(x);
         if (comm) {
