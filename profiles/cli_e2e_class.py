@@ -114,7 +114,17 @@ with open(fq, "wb") as f, open(want_path, "w") as wf:
         rec[:, 16:16 + read_len] = bb.reshape(n, read_len)
         if not fasta:
             rec[:, 16 + read_len:19 + read_len] = np.frombuffer(b"\n+\n", np.uint8)
-            rec[:, 19 + read_len:19 + 2 * read_len] = ord("I")
+            if os.environ.get("TAXOR_E2E_QUAL") == "skewed":
+                # quality strings as a sequencer writes them (a skewed alphabet, no structure): windows of one 64-MB random block at
+                # random offsets -- repeats lie far outside deflate's 32 KiB, so the text compresses like real FASTQ (about 2:1)
+                if "qblock" not in globals():
+                    _q = np.frombuffer(b"%&'()*+,-./0123456789:;<=>?@ABCDEFGHIJK", np.uint8)
+                    _p = np.exp(-0.5 * ((np.arange(_q.size) - 24) / 7.0) ** 2)
+                    globals()["qblock"] = np.random.default_rng(9).choice(_q, size=(64 << 20) + read_len, p=_p / _p.sum())
+                qo = np.random.default_rng(done).integers(0, 64 << 20, size=n)
+                rec[:, 19 + read_len:19 + 2 * read_len] = qblock[qo[:, None] + np.arange(read_len)[None, :]]
+            else:
+                rec[:, 19 + read_len:19 + 2 * read_len] = ord("I")
         rec[:, -1] = 10
         rec.tofile(f)
         done += n
@@ -131,6 +141,29 @@ del keep, kept
 idx.close()                      # the CLI loads its own replica
 print(f"fastq {os.path.getsize(fq)/1e9:.2f} GB ({n_reads} reads) written and searched through the library in {time.time()-t0:.1f}s", flush=True)
 out = os.path.join(tmp, "out.tsv")
+if os.environ.get("TAXOR_E2E_GZ"):
+    # the same reads as ONE gzip member (pieces deflated in parallel, each primed with the 32 KiB before it: back-references across
+    # every piece boundary, like gzip's own output; profiles/r04/gz_single_member.py) -- the CLI then runs on reads.fastq.gz
+    import importlib.util
+    from multiprocessing import Pool
+    _spec = importlib.util.spec_from_file_location("gzsm", os.path.join(ROOT, "profiles", "r04", "gz_single_member.py"))
+    gzsm = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(gzsm)
+    t0 = time.time()
+    size = os.path.getsize(fq)
+    jobs = [(fq, off, min(gzsm.PIECE, size - off), off + gzsm.PIECE >= size, 6) for off in range(0, size, gzsm.PIECE)]
+    crc, total = 0, 0
+    with Pool(min(len(os.sched_getaffinity(0)), 96)) as pool, open(fq + ".gz", "wb") as f:
+        f.write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03")
+        for o, c, n in pool.imap(gzsm.deflate_piece, jobs, chunksize=1):
+            f.write(o)
+            crc = gzsm.crc_combine(crc, c, n) if total else c
+            total += n
+        f.write(crc.to_bytes(4, "little") + (total & 0xFFFFFFFF).to_bytes(4, "little"))
+    print(f"one gzip member: {os.path.getsize(fq + '.gz')/1e9:.2f} GB of {size/1e9:.2f} GB, {time.time()-t0:.0f} s", flush=True)
+    if os.environ.get("TAXOR_E2E_GZ") == "only":
+        os.remove(fq)
+    fq = fq + ".gz"
 _r = os.environ.get("TAXOR_E2E_RUNS", "32,32,8")
 runs = _r.split(";") if ";" in _r else _r.split(",")       # "16;16:--gpu-list:0,0" when a run's extra arguments contain commas
 for thr in runs:

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <stdexcept>
 #include <memory>
@@ -163,6 +164,8 @@ struct FastxReader {
     uint64_t rpos = 0, rend = 0;
     GzMembers *members = nullptr;   // multi-member gzip inflated in parallel (gzmembers.h)
     ParallelGz *pgz = nullptr;      // ONE gzip member inflated in parallel (pgz.h)
+    std::deque<std::vector<char>> mem;   // memory mode: the input is these buffers, one after the other (open_mem)
+    bool mem_mode = false;
     std::unique_ptr<Bz2Reader> bz;  // bzip2 input, all of its streams
 
     bool strict4 = false;           // range mode on FASTQ: records must be the four-line kind the ranges were cut for
@@ -177,6 +180,16 @@ struct FastxReader {
         eof = false;
         pending.clear();
         if (buf.size() < (4u << 20)) buf.resize(4u << 20);
+    }
+    // the input is a list of buffers in memory (whole records from the first byte to the last; the parallel gzip reader's chunks)
+    void open_mem(std::deque<std::vector<char>> &&parts, bool fastq_ranges)
+    {
+        strict4 = fastq_ranges;
+        mem = std::move(parts);
+        mem_mode = true;
+        pos = len = 0;
+        eof = false;
+        pending.clear();
     }
     bool open(const std::string &path)
     {
@@ -204,6 +217,15 @@ struct FastxReader {
     bool refill()
     {
         if (eof) return false;
+        if (mem_mode) {
+            while (!mem.empty() && mem.front().empty()) mem.pop_front();
+            if (mem.empty()) { eof = true; return false; }
+            buf.swap(mem.front());
+            mem.pop_front();
+            pos = 0;
+            len = buf.size();
+            return true;
+        }
         long n;
         if (members) {
             n = (long)members->read(buf.data(), buf.size());

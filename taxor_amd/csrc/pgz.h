@@ -514,6 +514,20 @@ public:
         return got;
     }
 
+    // the next chunk of the decompressed stream as a whole (its buffer changes hands, nothing is copied); false at the end.  Not to
+    // be mixed with read() on one object.
+    bool take(std::vector<char> &dst)
+    {
+        if (!next_chunk()) return false;
+        dst.swap(*cur_out_);
+        cur_pos_ = 0;
+        cur_out_->clear();
+        return true;
+    }
+
+    // after take(): go on with read() (the caller has consumed what it took)
+    void switch_to_read() { cur_pos_ = cur_out_ ? cur_out_->size() : 0; }
+
     // statistics for the diagnostic command
     uint64_t chunks_total = 0, chunks_redecoded = 0, bytes_out = 0, members = 0;
     std::atomic<uint64_t> ns_find{0}, ns_decode{0}, ns_resolve{0};     // summed over the worker threads
@@ -525,7 +539,8 @@ private:
         ChunkOut co;
         int state = 0;                                  // 0 waiting, 1 decoding, 2 decoded, 3 resolving, 4 ready, 5 consumed
         std::vector<uint8_t> window;                    // the 32 KiB before this chunk (set when it is tied to its predecessor)
-        std::vector<uint8_t> out;
+        std::vector<char> out;
+        size_t out_len = 0;                             // out.size() when it was resolved (the vector itself may have been taken)
         uint32_t crc = 0;
     };
 
@@ -634,9 +649,10 @@ private:
         using namespace pgz_detail;
         const size_t n = c.co.n - WIN;
         c.out.resize(n);
+        c.out_len = n;
         const uint16_t *s = c.co.sym.data() + WIN;
         const uint8_t *w = c.window.data();
-        uint8_t *o = c.out.data();
+        uint8_t *o = reinterpret_cast<uint8_t *>(c.out.data());
         size_t i = 0;
 #if defined(__SSE2__)
         // sixteen symbols at a time while none of them is a marker (behind the first stretch of a chunk hardly any is)
@@ -717,10 +733,10 @@ private:
         std::unique_lock<std::mutex> lk(mu_);
         if (cur_out_) {                                       // the chunk just finished
             Chunk &c = chunks_[cur_];
-            member_crc_ = (uint32_t)crc32_combine(member_crc_, c.crc, (z_off_t)c.out.size());
-            member_len_ += c.out.size();
-            bytes_out += c.out.size();
-            std::vector<uint8_t>().swap(c.out);
+            member_crc_ = (uint32_t)crc32_combine(member_crc_, c.crc, (z_off_t)c.out_len);
+            member_len_ += c.out_len;
+            bytes_out += c.out_len;
+            std::vector<char>().swap(c.out);
             c.state = 5;
             cur_out_ = nullptr;
             ++cur_;
@@ -775,7 +791,7 @@ private:
     uint32_t member_crc_ = 0;
     uint64_t member_len_ = 0;
     bool text_ = true, stop_ = false;
-    const std::vector<uint8_t> *cur_out_ = nullptr;
+    std::vector<char> *cur_out_ = nullptr;
     size_t cur_pos_ = 0;
 };
 

@@ -302,11 +302,146 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         // --sequential and small files keep the one zlib stream
         if (!multi && allow_ranges && gz_threads > 1) single = pgz.open(query, gz_threads);
     } catch (const std::exception &ex) { die(ex.what()); }
-    if (multi) {
+    if (single) {
+        // The inflated stream arrives in chunks of ~16 MB that change hands without a copy (ParallelGz::take).  This thread only CUTS:
+        // it collects chunks up to ~64 MB, finds the last record start in the last one (the range reader's test: an '@' line whose
+        // second successor starts with '+', or a '>' line), and hands everything before it -- whole records -- to a parser thread;
+        // what follows the cut is carried into the next segment.  The parsers work like those of a plain file's byte ranges, the
+        // buffers are their input directly.  A file whose first records are not of the kind the cut can recognise (FASTQ that wraps
+        // its lines) is parsed front to back on this thread instead.
+        std::vector<char> first;
+        bool have = false;
+        try { have = pgz.take(first); } catch (const std::exception &ex) { die(ex.what()); }
+        size_t i0 = 0;
+        while (i0 < first.size() && (first[i0] == '\n' || first[i0] == '\r')) ++i0;
+        char kind = have && i0 < first.size() ? first[i0] : 0;
+        bool cuttable = kind == '>' || kind == '@';
+        if (kind == '@') {
+            const char *p = first.data() + i0, *e = first.data() + std::min<size_t>(first.size(), i0 + (1u << 16));
+            for (int rec = 0; rec < 16 && p < e && cuttable; ++rec) {
+                const char *l3 = fastx::next_line(fastx::next_line(p, e), e);
+                if (l3 >= e) break;
+                if (*l3 != '+') cuttable = false;
+                const char *nx = fastx::next_line(fastx::next_line(l3, e), e);
+                if (nx < e && *nx != '@' && *nx != '\n' && *nx != '\r') cuttable = false;
+                p = nx;
+            }
+        }
+        if (have && kind && !cuttable && kind != '@' && kind != '>') die("query file is neither FASTA nor FASTQ");
+        if (!have || !cuttable) {
+            rd.pgz = &pgz;                                   // front to back: the chunk already taken first, then the stream
+            rd.buf.swap(first);
+            rd.pos = 0;
+            rd.len = rd.buf.size();
+            if (rd.buf.size() < (8u << 20)) rd.buf.resize(8u << 20);
+            pgz.switch_to_read();
+        } else {
+            struct Job { std::deque<std::vector<char>> parts; uint64_t seq = 0; size_t bytes = 0; };
+            std::mutex jmu;
+            std::condition_variable jcv_put, jcv_get;
+            std::deque<Job> jobs;
+            bool jdone = false;
+            const unsigned np = std::max(2u, gz_threads / 4);
+            std::vector<std::thread> parsers;
+            for (unsigned t = 0; t < np; ++t)
+                parsers.emplace_back([&] {
+                    fastx::FastxReader prd;
+                    std::string pid;
+                    size_t prev_records = 0, prev_id_bytes = 0;
+                    for (;;) {
+                        Job job;
+                        {
+                            std::unique_lock<std::mutex> lk(jmu);
+                            jcv_get.wait(lk, [&] { return !jobs.empty() || jdone; });
+                            if (jobs.empty()) return;
+                            job = std::move(jobs.front());
+                            jobs.pop_front();
+                            jcv_put.notify_one();
+                        }
+                        if (gate) gate();
+                        auto bt = pool.get();
+                        try {
+                            bt->seq = job.seq;
+                            bt->may_pin = true;
+                            ++bt->fills;
+                            const size_t need = fastx::bases_bound(job.bytes, kind);
+                            if (need > bt->bases.capacity()) {
+                                if (bt->pinned) { taxor_gpu_host_unregister(bt->pinned); bt->pinned = nullptr; }
+                                bt->bases.clear();
+                                bt->bases.reserve((need + need / 16 + (2u << 20)) & ~size_t((2u << 20) - 1));
+                                const uintptr_t a = ((uintptr_t)&bt->bases[0] + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+                                const uintptr_t e = ((uintptr_t)&bt->bases[0] + bt->bases.capacity()) & ~(uintptr_t)((2u << 20) - 1);
+                                if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+                            }
+                            bt->ids.clear();
+                            bt->bases.clear();
+                            bt->offsets.assign(1, 0);
+                            const size_t guess = prev_records + prev_records / 8 + 1024;
+                            if (bt->offsets.capacity() < guess) bt->offsets.reserve(guess + 1);
+                            if (bt->ids.off.capacity() < guess || bt->ids.data.capacity() < prev_id_bytes) bt->ids.reserve(guess, prev_id_bytes + prev_id_bytes / 8 + 4096);
+                            prd.open_mem(std::move(job.parts), kind == '@');
+                            while (prd.next(pid, bt->bases)) {
+                                bt->ids.push_back(pid);
+                                bt->offsets.push_back(bt->bases.size());
+                            }
+                            prev_records = bt->ids.size();
+                            prev_id_bytes = bt->ids.data.size();
+                        } catch (const std::exception &ex) { die(ex.what()); }
+                        push(std::move(bt));
+                    }
+                });
+            const size_t target = (size_t)std::min<uint64_t>(cfg.batch_bases, kind == '@' ? (64u << 20) : (32u << 20));     // bytes of text per parser job
+            Job cur;
+            uint64_t seq = 0;
+            auto submit = [&](Job &&j) {
+                if (j.bytes == 0) return;
+                j.seq = seq++;
+                std::unique_lock<std::mutex> lk(jmu);
+                jcv_put.wait(lk, [&] { return jobs.size() < np + 2; });
+                jobs.push_back(std::move(j));
+                jcv_get.notify_one();
+            };
+            auto add = [&](std::vector<char> &&v) { cur.bytes += v.size(); cur.parts.push_back(std::move(v)); };
+            try {
+                if (i0) first.erase(first.begin(), first.begin() + (long)i0);
+                add(std::move(first));
+                for (;;) {
+                    if (cur.bytes >= target) {
+                        // the last record start in the last part, looked for in its final megabyte (a record is tens of kilobytes)
+                        std::vector<char> &last = cur.parts.back();
+                        const char *b = last.data(), *e = b + last.size();
+                        const char *w = last.size() > (1u << 20) ? e - (1u << 20) : b;
+                        const char *p = w == b ? b : fastx::next_line(w, e);
+                        const char *cut = nullptr;
+                        for (const char *r = fastx::resync(p, e, kind); r < e; r = fastx::resync(fastx::next_line(r, e), e, kind)) cut = r;
+                        if (cut && (cut > b || cur.parts.size() > 1)) {
+                            std::vector<char> carry(cut, e);
+                            cur.bytes -= (size_t)(e - cut);
+                            last.resize((size_t)(cut - b));
+                            Job next;
+                            next.bytes = carry.size();
+                            next.parts.push_back(std::move(carry));
+                            submit(std::move(cur));
+                            cur = std::move(next);
+                        }
+                    }
+                    std::vector<char> ck;
+                    if (!pgz.take(ck)) break;
+                    add(std::move(ck));
+                }
+                submit(std::move(cur));
+            } catch (const std::exception &ex) { die(ex.what()); }
+            {
+                std::lock_guard<std::mutex> lk(jmu);
+                jdone = true;
+            }
+            jcv_get.notify_all();
+            for (auto &t : parsers) t.join();
+            finish();
+            return now() - t_begin;
+        }
+    } else if (multi) {
         rd.members = &members;
-        rd.buf.resize(8u << 20);
-    } else if (single) {
-        rd.pgz = &pgz;
         rd.buf.resize(8u << 20);
     } else if (!rd.open(query)) die("cannot open query file " + query);
     std::string id;
