@@ -1143,36 +1143,16 @@ int main(int argc, char **argv)
                 }
             });
         // The report is ONE file and the kernel serialises a file's buffered writes, so several writing threads gain nothing
-        // (profiles/r04/pwrite_scaling.txt: pwrite from 1 / 2 / 8 threads 9.9 / 9.8 / 9.5 GB/s into a RAM-backed file).  What one
-        // writer spends its time on is the allocation of the file's pages -- and that can run AHEAD of it: a helper thread
-        // preallocates the file a gigabyte at a time beyond what has been written (fallocate, the size untouched), and the writer's
-        // write() then only copies: 17.6 instead of 9.9 GB/s on the same box.  Regular files only; a file system that cannot
-        // preallocate is written as before.  Short reads are where it matters: a 1-kb read of the family workload is 870 bytes of
-        // text per 1000 bases.
+        // (profiles/r04/pwrite_scaling.txt, a RAM-backed file on the pool's box: pwrite of 1-MiB blocks from 1 / 2 / 8 threads 9.9 / 9.8 /
+        // 9.5 GB/s; one writer with 64-MiB blocks that are not in its cache -- what a formatter hands over -- 6.4 GB/s; a helper thread
+        // preallocating the file a gigabyte ahead of the writer 5.9: no gain; copies into a mapping of a fully preallocated file scale to
+        // 11 GB/s on four threads, but the preallocation is 21 GB/s of one thread by itself and the mapping costs the GPU calls of the
+        // process their address-space lock -- round 3).  So: one writer, straight write() calls of whole chunk texts, no stdio copy.
+        // Short reads are where this is the limit: a 1-kb read of the family workload is ~620-870 bytes of text per 1000 bases.
         fflush(out);
         const int out_fd = fileno(out);
-        struct stat out_sb {};
-        std::atomic<uint64_t> out_written{0}, out_allocated{0};
+        std::atomic<uint64_t> out_written{0};
         double t_write = 0;            // seconds the writer spent inside write()
-        std::atomic<bool> alloc_stop{false};
-        bool prealloc = fstat(out_fd, &out_sb) == 0 && S_ISREG(out_sb.st_mode) && !tune_env("TAXOR_CLI_NO_PREALLOC");
-        if (prealloc) {
-            const off_t pos = lseek(out_fd, 0, SEEK_CUR);
-            out_written = out_allocated = pos > 0 ? (uint64_t)pos : 0;
-            if (fallocate(out_fd, FALLOC_FL_KEEP_SIZE, (off_t)out_allocated.load(), 256 << 20) != 0) prealloc = false;
-            else out_allocated += 256 << 20;
-        }
-        std::thread allocator([&] {
-            if (!prealloc) return;
-            constexpr uint64_t step = 1ull << 30;
-            while (!alloc_stop.load(std::memory_order_acquire)) {
-                if (out_allocated.load() < out_written.load() + step) {
-                    if (fallocate(out_fd, FALLOC_FL_KEEP_SIZE, (off_t)out_allocated.load(), (off_t)step) != 0) return;     // e.g. the disk is full: the writer will say so
-                    out_allocated += step;
-                } else
-                    std::this_thread::sleep_for(std::chrono::microseconds(200));
-            }
-        });
         std::thread writer([&] {
             std::unique_ptr<Batch> b;
             std::map<std::pair<uint32_t, uint64_t>, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
@@ -1437,13 +1417,9 @@ int main(int argc, char **argv)
         q_out.close();
         reader.join();
         writer.join();
-        alloc_stop.store(true, std::memory_order_release);
-        allocator.join();
-        if (prealloc && ftruncate(out_fd, (off_t)out_written.load()) != 0) die("cannot set the size of " + cfg.report_file);    // gives back what was preallocated beyond the end
         trace("writer done");
         if (tune_env("TAXOR_CLI_TRACE"))
-            fprintf(stderr, "[trace] report: %.2f GB in %.3f s of write() = %.1f GB/s (%s)\n", out_written.load() / 1e9, t_write, t_write > 0 ? out_written.load() / 1e9 / t_write : 0.0,
-                    prealloc ? "file preallocated ahead of the writer" : "no preallocation");
+            fprintf(stderr, "[trace] report: %.2f GB in %.3f s of write() = %.1f GB/s\n", out_written.load() / 1e9, t_write, t_write > 0 ? out_written.load() / 1e9 / t_write : 0.0);
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
         for (auto *x : sr) taxor_gpu_searcher_destroy(x);
         if (comm) {

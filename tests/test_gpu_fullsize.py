@@ -236,7 +236,7 @@ def test_refseq_class_hixf_file_through_the_cli(tmp_path):
 
 def test_cli_search_phase_keeps_up_with_the_library(tmp_path):
     """the drop-in CLI must not be slower than the library it wraps.  RefSeq-class `.hixf` (11 GB) and 1.3 M x
-    10 kb reads as FASTA (13 GB) in tmpfs: once the index is resident, the CLI's search phase (parse -> GPU batches made of
+    10 kb reads as FASTA (round 4: 4.2 M reads, 42 GB) in tmpfs: once the index is resident, the CLI's search phase (parse -> GPU batches made of
     parsed chunks -> TSV text -> file) keeps up with the library's own host-fed `sustained` rate on the same reads, and after
     the last line is written the command is done within 0.3 s (no host mapping of the index to tear down).  The first run
     reads tmpfs pages that were written a moment ago (every page is promoted on the LRU under 32 readers) and is not the one
@@ -247,11 +247,13 @@ def test_cli_search_phase_keeps_up_with_the_library(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    scratch = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 80e9 else str(tmp_path)
-    if shutil.disk_usage(scratch).free < 80e9:
-        pytest.skip("needs 80 GB of scratch space")
-    cp = subprocess.run([sys.executable, os.path.join(root, "profiles", "cli_e2e_class.py"), "refseq", "1310720"], capture_output=True, text=True,
-                        timeout=1200, env=dict(os.environ, TAXOR_E2E_TMP=scratch, TAXOR_E2E_RUNS="32,32,16,8", TAXOR_E2E_FORMAT="fasta"))
+    scratch = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 120e9 else str(tmp_path)
+    if shutil.disk_usage(scratch).free < 120e9:
+        pytest.skip("needs 120 GB of scratch space")
+    # 4 M reads (42 GB of FASTA): the search phase is then ~1 s.  Round 3 ran 1.3 M reads, a phase of 0.4 s of which the first GPU
+    # batch -- which nothing can overlap -- is a fifth; the library figure it is held against is a steady-state rate over 2 M reads
+    cp = subprocess.run([sys.executable, os.path.join(root, "profiles", "cli_e2e_class.py"), "refseq", "4194304"], capture_output=True, text=True,
+                        timeout=1800, env=dict(os.environ, TAXOR_E2E_TMP=scratch, TAXOR_E2E_RUNS="32,32,32,16", TAXOR_E2E_FORMAT="fasta"))
     assert cp.returncode == 0, cp.stdout[-3000:] + cp.stderr[-2000:]
     assert "identical to formatter(searcher results): True" in cp.stdout
     rates = [(float(m.group(1)), float(m.group(2)), float(m.group(3)))
