@@ -144,11 +144,9 @@ out = os.path.join(tmp, "out.tsv")
 if os.environ.get("TAXOR_E2E_GZ"):
     # the same reads as ONE gzip member (pieces deflated in parallel, each primed with the 32 KiB before it: back-references across
     # every piece boundary, like gzip's own output; profiles/r04/gz_single_member.py) -- the CLI then runs on reads.fastq.gz
-    import importlib.util
     from multiprocessing import Pool
-    _spec = importlib.util.spec_from_file_location("gzsm", os.path.join(ROOT, "profiles", "r04", "gz_single_member.py"))
-    gzsm = importlib.util.module_from_spec(_spec)
-    _spec.loader.exec_module(gzsm)
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "r04"))
+    import gz_single_member as gzsm       # (a plain import: the pool's workers must be able to find the module by name)
     t0 = time.time()
     size = os.path.getsize(fq)
     jobs = [(fq, off, min(gzsm.PIECE, size - off), off + gzsm.PIECE >= size, 6) for off in range(0, size, gzsm.PIECE)]
