@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <stdexcept>
 #include <memory>
@@ -166,6 +167,7 @@ struct FastxReader {
     ParallelGz *pgz = nullptr;      // ONE gzip member inflated in parallel (pgz.h)
     std::deque<std::vector<char>> mem;   // memory mode: the input is these buffers, one after the other (open_mem)
     bool mem_mode = false;
+    std::function<void(std::vector<char> &&)> mem_recycle;   // memory mode: a buffer that has been parsed goes back to its maker
     std::unique_ptr<Bz2Reader> bz;  // bzip2 input, all of its streams
 
     bool strict4 = false;           // range mode on FASTQ: records must be the four-line kind the ranges were cut for
@@ -221,6 +223,7 @@ struct FastxReader {
             while (!mem.empty() && mem.front().empty()) mem.pop_front();
             if (mem.empty()) { eof = true; return false; }
             buf.swap(mem.front());
+            if (mem_recycle && mem.front().capacity()) mem_recycle(std::move(mem.front()));
             mem.pop_front();
             pos = 0;
             len = buf.size();

@@ -525,6 +525,16 @@ public:
         return true;
     }
 
+    // a buffer that take() handed out, when the caller is done with it: the next chunk is resolved into it instead of into fresh
+    // pages (a chunk's 16 MB from the allocator are mapped, faulted in and zeroed before the first byte is written -- on 32 threads
+    // that is the allocator's lock and the kernel's, not memory bandwidth).  Any thread.
+    void recycle(std::vector<char> &&v)
+    {
+        if (v.capacity() < (1u << 20)) return;
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        if (out_pool_.size() < 2 * (size_t)threads_ + 8) out_pool_.push_back(std::move(v));
+    }
+
     // after take(): go on with read() (the caller has consumed what it took)
     void switch_to_read() { cur_pos_ = cur_out_ ? cur_out_->size() : 0; }
 
@@ -648,6 +658,22 @@ private:
     {
         using namespace pgz_detail;
         const size_t n = c.co.n - WIN;
+        {
+            // the largest recycled buffer (they are not cleared: resize() then touches only what it has to add)
+            std::lock_guard<std::mutex> lk(pool_mu_);
+            if (!out_pool_.empty()) {
+                size_t best = 0;
+                for (size_t k = 1; k < out_pool_.size(); ++k)
+                    if (out_pool_[k].capacity() > out_pool_[best].capacity()) best = k;
+                c.out.swap(out_pool_[best]);
+                out_pool_[best].swap(out_pool_.back());
+                out_pool_.pop_back();
+            }
+        }
+        if (c.out.capacity() < n) {
+            std::vector<char>().swap(c.out);
+            c.out.reserve(n + n / 8);
+        }
         c.out.resize(n);
         c.out_len = n;
         const uint16_t *s = c.co.sym.data() + WIN;
@@ -736,6 +762,7 @@ private:
             member_crc_ = (uint32_t)crc32_combine(member_crc_, c.crc, (z_off_t)c.out_len);
             member_len_ += c.out_len;
             bytes_out += c.out_len;
+            recycle(std::move(c.out));                          // (read(): consumed; take(): an empty vector, dropped)
             std::vector<char>().swap(c.out);
             c.state = 5;
             cur_out_ = nullptr;
@@ -784,6 +811,7 @@ private:
     std::deque<Chunk> chunks_;
     std::deque<size_t> resolve_q_;
     std::vector<pgz_detail::SymBuf> pool_;
+    std::vector<std::vector<char>> out_pool_;
     std::mutex pool_mu_;
     size_t next_decode_ = 0, tied_ = 0, cur_ = 0, n_live_ = 0, busy_ = 0;
     uint64_t prev_end_ = 0;

@@ -346,6 +346,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             for (unsigned t = 0; t < np; ++t)
                 parsers.emplace_back([&] {
                     fastx::FastxReader prd;
+                    prd.mem_recycle = [&pgz](std::vector<char> &&v) { pgz.recycle(std::move(v)); };
                     std::string pid;
                     size_t prev_records = 0, prev_id_bytes = 0;
                     for (;;) {
