@@ -165,11 +165,14 @@ if os.environ.get("TAXOR_E2E_GZ"):
 _r = os.environ.get("TAXOR_E2E_RUNS", "32,32,8")
 runs = _r.split(";") if ";" in _r else _r.split(",")       # "16;16:--gpu-list:0,0" when a run's extra arguments contain commas
 for thr in runs:
+    thr, *run_env = thr.split("@")                                      # "32@TAXOR_CLI_FILL_MS=5": tuning variables of this run only
     extra = ["--threads", thr.split(":")[0]] + thr.split(":")[1:]       # "16:--gpu-list:0,0" = extra arguments after the thread count
+    if run_env:
+        print("run with", " ".join(run_env))
     t0 = time.time()
     cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
                         capture_output=True, text=True,
-                        env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1", **dict(kv.split("=", 1) for kv in os.environ.get("TAXOR_E2E_ENV", "").split())))
+                        env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1", **dict(kv.split("=", 1) for kv in os.environ.get("TAXOR_E2E_ENV", "").split() + run_env)))
     dt = time.time() - t0
     print(" ".join(extra), "rc", cp.returncode, f"wall {dt:.2f}s -> {n_reads*read_len/dt/1e6:.0f} Mbp/s end to end (index load included)")
     print(cp.stdout.strip().replace("\n", " | "))

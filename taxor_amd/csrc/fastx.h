@@ -16,8 +16,11 @@
 
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -48,12 +51,82 @@ struct IdList {
     std::string str(size_t i) const { return std::string(ptr(i), len(i)); }
 };
 
+// The sequence bytes of a chunk: filled once by a parser, read once by the DMA engine -- never by this process again.  Unlike a
+// std::string it (i) grows without zeroing what it adds, (ii) sits on 2-MiB boundaries and asks for huge pages, and (iii) copies long
+// lines with non-temporal stores: a cached store first READS the line it is about to overwrite (three units of memory traffic per
+// byte parsed instead of two) and evicts what the other threads of the core complex keep in their cache.  The subset of the string
+// interface the readers and the CLI use.
+inline bool &stream_stores()
+{
+    static bool on = true;
+    return on;
+}
+// bytes a range reader asks pread() for at a time (its staging buffer between the page cache and the chunk)
+inline size_t &range_buffer_bytes()
+{
+    static size_t n = 4u << 20;
+    return n;
+}
+struct BaseBuf {
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    BaseBuf() = default;
+    BaseBuf(const BaseBuf &) = delete;
+    BaseBuf &operator=(const BaseBuf &) = delete;
+    ~BaseBuf() { free(p); }
+    const char *data() const { return p; }
+    char *data() { return p; }
+    size_t size() const { return n; }
+    size_t capacity() const { return cap; }
+    bool empty() const { return n == 0; }
+    void clear() { n = 0; }
+    char &operator[](size_t i) { return p[i]; }
+    char &back() { return p[n - 1]; }
+    void pop_back() { --n; }
+    void resize(size_t m) { if (m > cap) reserve(m); n = m; }      // added bytes are NOT initialised
+    void reserve(size_t want)
+    {
+        if (want <= cap) return;
+        const size_t a = 2u << 20, c = (want + a - 1) & ~(a - 1);
+        void *q = nullptr;
+        if (posix_memalign(&q, a, c) != 0 || !q) throw std::bad_alloc();
+        (void)madvise(q, c, MADV_HUGEPAGE);
+        if (n) memcpy(q, p, n);
+        free(p);
+        p = (char *)q;
+        cap = c;
+    }
+    void append(const char *s, size_t len)
+    {
+        if (n + len > cap) reserve(std::max(n + len, cap + cap / 2));
+        char *d = p + n;
+        n += len;
+#if defined(__SSE2__)
+        if (len >= 1024 && stream_stores()) {
+            const size_t head = (64 - ((uintptr_t)d & 63)) & 63;
+            memcpy(d, s, head);
+            d += head; s += head; len -= head;
+            for (; len >= 64; len -= 64, d += 64, s += 64) {
+                const __m128i a = _mm_loadu_si128((const __m128i *)s), b = _mm_loadu_si128((const __m128i *)(s + 16));
+                const __m128i c = _mm_loadu_si128((const __m128i *)(s + 32)), e = _mm_loadu_si128((const __m128i *)(s + 48));
+                _mm_stream_si128((__m128i *)d, a);
+                _mm_stream_si128((__m128i *)(d + 16), b);
+                _mm_stream_si128((__m128i *)(d + 32), c);
+                _mm_stream_si128((__m128i *)(d + 48), e);
+            }
+            _mm_sfence();
+        }
+#endif
+        memcpy(d, s, len);
+    }
+};
+
 struct Batch {
     uint64_t seq = 0;   // position of this chunk in its query file
     uint32_t file = 0;  // position of the query file in --query-file
     bool end_of_file = false;   // marker that follows the last chunk of a file (seq = number of chunks), carries no records
     IdList ids;
-    std::string bases;
+    BaseBuf bases;
     std::vector<uint64_t> offsets;
     // results copied out of the searcher (its buffers are reused by the next batch)
     std::vector<uint64_t> read_off;
@@ -181,7 +254,7 @@ struct FastxReader {
         pos = len = 0;
         eof = false;
         pending.clear();
-        if (buf.size() < (4u << 20)) buf.resize(4u << 20);
+        if (buf.size() != range_buffer_bytes()) buf.resize(range_buffer_bytes());
     }
     // the input is a list of buffers in memory (whole records from the first byte to the last; the parallel gzip reader's chunks)
     void open_mem(std::deque<std::vector<char>> &&parts, bool fastq_ranges)
@@ -251,7 +324,8 @@ struct FastxReader {
     }
     // next line -> appended to `out` (if non-null); returns false at end of input with nothing read.  *count (if
     // non-null) receives the line's length without its line terminator.
-    bool line_to(std::string *out, size_t *count = nullptr)
+    bool line_to(std::nullptr_t, size_t *count = nullptr) { return line_to((std::string *)nullptr, count); }
+    template <class Out> bool line_to(Out *out, size_t *count = nullptr)
     {
         bool any = false;
         size_t total = 0;
@@ -295,7 +369,7 @@ struct FastxReader {
     }
     // appends the record's sequence to `bases`; returns false at end of file
     std::string line;    // the header line of the record being read (a member: its buffer is reused from record to record)
-    bool next(std::string &id, std::string &bases)
+    template <class Bases> bool next(std::string &id, Bases &bases)
     {
         if (pending.empty()) {
             do {

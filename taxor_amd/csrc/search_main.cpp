@@ -56,6 +56,16 @@ public:
         not_full_.notify_one();
         return true;
     }
+    bool pop_for(T &out, double seconds) // like pop, but gives up (false) after `seconds`
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        not_empty_.wait_for(lk, std::chrono::duration<double>(seconds), [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return true;
+    }
     bool try_pop(T &out) // false if nothing is queued right now
     {
         std::lock_guard<std::mutex> lk(m_);
@@ -64,6 +74,11 @@ public:
         q_.pop_front();
         not_full_.notify_one();
         return true;
+    }
+    bool done() // closed and drained
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        return closed_ && q_.empty();
     }
     void close()
     {
@@ -656,6 +671,8 @@ int main(int argc, char **argv)
     // runtime_env_once -- the library would set it at its first call, by which time this host has threads that read the
     // environment)
     setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    if (const char *e = tune_env("TAXOR_CLI_NT")) fastx::stream_stores() = atoi(e) != 0;
+    if (const char *e = tune_env("TAXOR_CLI_RDBUF_KB")) fastx::range_buffer_bytes() = (size_t)std::max(64, atoi(e)) << 10;
     int a = 1;
     if (argc > 1 && strcmp(argv[1], "probe") == 0) {                       // hixf-probe: report a file's IXF record layout
         const char *path = nullptr;
@@ -1264,6 +1281,9 @@ int main(int argc, char **argv)
             }
             if (r0 != res.n_reads) die("internal: a batch's results do not cover its chunks");
         };
+        static const double fill_seconds = [] { const char *e = tune_env("TAXOR_CLI_FILL_MS"); return e ? atof(e) * 1e-3 : 0.0; }();
+        static const int fill_running = [] { const char *e = tune_env("TAXOR_CLI_FILL_RUNNING"); return e ? atoi(e) : 1; }();
+        std::atomic<int> n_running{0};      // GPU batches in flight (single-device workers)
         std::vector<std::thread> workers;
         std::mutex comm_mu;     // a communicator is single-caller, and its result arrays live until its next gather
         if (comm)
@@ -1373,13 +1393,23 @@ int main(int argc, char **argv)
                         group.push_back(std::move(b));
                         // (short reads: more of them, until the batch holds 2^29 bases -- the library's sub-batches then reach
                         // their full size)
+                        const double t_fill0 = now();
                         while ((gr < group_reads || (!cfg.batch_reads && !cfg.group_reads && gb < (1ull << 29) && gr < (1u << 20))) &&
-                               gb < (3ull << 30) && group.size() < group_max_chunks && q_in.try_pop(b)) {
+                               gb < (3ull << 30) && group.size() < group_max_chunks) {
+                            if (!q_in.try_pop(b)) {
+                                // nothing queued: the GPU is the faster side right now.  Launching what there is makes the batches
+                                // small exactly then (a quarter of the size the kernels are fastest at); while enough OTHER batches
+                                // are in flight to keep the device busy this worker goes on collecting instead -- for a bounded
+                                // time, because the chunks it holds may be what the writer is waiting for
+                                if (!(gr < group_reads && gb < (1ull << 29) && now() - t_fill0 < fill_seconds && n_running.load() >= fill_running)) break;
+                                if (!q_in.pop_for(b, 100e-6)) { if (q_in.done()) break; continue; }
+                            }
                             if (b->end_of_file) { eofs.push_back(std::move(b)); continue; }
                             gr += b->ids.size();
                             gb += b->bases.size();
                             group.push_back(std::move(b));
                         }
+                        ++n_running;
                         const double t1 = now();
                         for (auto &bt : group) pin(*bt);
                         const double t2 = now();
@@ -1397,6 +1427,7 @@ int main(int argc, char **argv)
                             if (any) rc = run();
                         }
                         if (rc != TAXOR_OK) die(taxor_gpu_last_error());
+                        --n_running;
                         const double t3 = now();
                         split_results(group, res);
                         {
