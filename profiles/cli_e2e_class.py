@@ -169,8 +169,10 @@ for thr in runs:
     extra = ["--threads", thr.split(":")[0]] + thr.split(":")[1:]       # "16:--gpu-list:0,0" = extra arguments after the thread count
     if run_env:
         print("run with", " ".join(run_env))
+    binary = next((kv[4:] for kv in run_env if kv.startswith("BIN=")), os.path.join(ROOT, "taxor_amd", "taxor"))     # "32@BIN=/path/taxor_old": A/B of two builds
+    run_env = [kv for kv in run_env if not kv.startswith("BIN=")]
     t0 = time.time()
-    cp = subprocess.run([os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
+    cp = subprocess.run([binary, "search", "--index-file", idx_path, "--query-file", fq, "--output-file", out] + extra,
                         capture_output=True, text=True,
                         env=dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_TRACE="1", **dict(kv.split("=", 1) for kv in os.environ.get("TAXOR_E2E_ENV", "").split() + run_env)))
     dt = time.time() - t0

@@ -54,8 +54,10 @@ struct IdList {
 // The sequence bytes of a chunk: filled once by a parser, read once by the DMA engine -- never by this process again.  Unlike a
 // std::string it (i) grows without zeroing what it adds, (ii) sits on 2-MiB boundaries and asks for huge pages, and (iii) copies long
 // lines with non-temporal stores: a cached store first READS the line it is about to overwrite (three units of memory traffic per
-// byte parsed instead of two) and evicts what the other threads of the core complex keep in their cache.  The subset of the string
-// interface the readers and the CLI use.
+// byte parsed instead of two) and evicts what the other threads of the core complex keep in their cache.  RefSeq-class CLI runs on
+// three boxes (profiles/r04/cli_variants.txt, cli_variants2.txt, cli_ab_prev.txt): 0.81-0.85 x the library's rate with (seven runs,
+// mean 0.83), 0.79-0.85 without (six runs, mean 0.82; TAXOR_CLI_NT=0 under TAXOR_TUNING), the round's earlier build with its
+// std::string 0.73-0.77 beside them.  The subset of the string interface the readers and the CLI use.
 inline bool &stream_stores()
 {
     static bool on = true;

@@ -1281,7 +1281,9 @@ int main(int argc, char **argv)
             }
             if (r0 != res.n_reads) die("internal: a batch's results do not cover its chunks");
         };
-        static const double fill_seconds = [] { const char *e = tune_env("TAXOR_CLI_FILL_MS"); return e ? atof(e) * 1e-3 : 0.0; }();
+        static const double fill_seconds = [] { const char *e = tune_env("TAXOR_CLI_FILL_MS"); return e ? atof(e) * 1e-3 : 0.020; }();
+        // (a third and fourth worker per device that copy their results out and collect the next batch while two "slots" stay taken:
+        // 25-32 Gbp/s against 33-35 with two workers, profiles/r04/cli_variants.txt -- more searchers share the same hardware queues)
         static const int fill_running = [] { const char *e = tune_env("TAXOR_CLI_FILL_RUNNING"); return e ? atoi(e) : 1; }();
         std::atomic<int> n_running{0};      // GPU batches in flight (single-device workers)
         std::vector<std::thread> workers;
