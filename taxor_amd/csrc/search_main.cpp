@@ -1047,20 +1047,20 @@ int main(int argc, char **argv)
         //   GPU workers       : chunks -> one GPU batch of useful size (as many queued chunks as make ~131072 reads, handed
         //                       over as segments, no copy) -> streamed upload, kernels, fetch (:325); two per device, so
         //                       that one batch's transfers run beside the other's kernels
-        //   formatter threads : tuples -> 0.8*max filter -> TSV text of a chunk (:266-306)
-        //   writer thread     : chunk texts -> file, in file and chunk order (:311)
+        //   sequencer + piece threads : tuples -> 0.8*max filter -> TSV text (:266-306) -> file, in file and chunk order (:311); below
         // Output stays in input order (the reference's order at --threads 1).  The host stages start BEFORE the index goes to
         // the devices: the first chunks are parsed while it uploads.
         const size_t nf = queries.size();
         const unsigned readers = (unsigned)std::max<size_t>(1, std::min<size_t>({nf, cfg.threads, 8}));
         const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 32u) / readers);
-        const unsigned formatters = std::max(1u, std::min(cfg.threads, 32u) / 4u);
+        static const unsigned fmt_div = [] { const char *e = tune_env("TAXOR_CLI_FORMATTER_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (unsigned)v : 2u; }();
+        const unsigned formatters = std::max(1u, std::min(cfg.threads, 32u) / fmt_div);
         static const unsigned workers_per_gpu = [] { const char *e = tune_env("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
         const uint64_t group_reads = cfg.group_reads ? cfg.group_reads : (cfg.batch_reads ? cfg.batch_reads : 131072);
         const size_t group_max_chunks = 32;
         // (q_parsed / q_in are as deep as the pool allows: what bounds the parsers is the pool's byte budget, not a queue -- while the
         // index uploads they parse ahead, and a query file smaller than the budget is parsed completely by the time it is resident)
-        BoundedQueue<std::unique_ptr<Batch>> q_parsed(4096), q_in(4096), q_fmt(8), q_out(8);
+        BoundedQueue<std::unique_ptr<Batch>> q_parsed(4096), q_in(4096), q_fmt(8);
         BatchPool pool;
         pool.cap = readers * parse_threads + 16 + 2 + 32 + ng * workers_per_gpu * group_max_chunks + 8 + formatters + 8 + 8 + 2 * readers;
         // ... by count for small chunks; by bytes for the usual ~128 MB ones: 6 GiB for the host stages + 6 GiB per device (two GPU
@@ -1125,64 +1125,55 @@ int main(int argc, char **argv)
             q_in.close();
             trace("readers done");
         });
-        std::vector<std::thread> fmt_threads;
-        for (unsigned ft = 0; ft < formatters; ++ft)
-            fmt_threads.emplace_back([&] {
-                std::unique_ptr<Batch> b;
-                std::vector<const char *> idp;
-                std::vector<uint64_t> idl, rl;
-                size_t line_bytes_guess = 192;             // bytes of text per tuple, learnt from the chunks this thread formatted
-                while (q_fmt.pop(b)) {
-                    if (!b->end_of_file) {
-                        const size_t n = b->ids.size();
-                        idp.resize(n); idl.resize(n); rl.resize(n);
-                        for (size_t r = 0; r < n; ++r) {
-                            idp[r] = b->ids.ptr(r);
-                            idl[r] = b->ids.len(r);
-                            rl[r] = b->offsets[r + 1] - b->offsets[r];
-                        }
-                        {   // a recycled chunk's buffer usually fits; a fresh one is sized from the tuple count (formatting twice
-                            // because the first pass only measured costs as much as the pass that writes)
-                            const size_t guess = (size_t)b->user_bin.size() * line_bytes_guess + n * 96 + b->ids.data.size() * 2 + 4096;
-                            if (b->text.capacity() < guess) b->text.reserve(guess + guess / 8);
-                        }
-                        b->text.resize(b->text.capacity());
-                        uint64_t need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), b->n_hashes.data(), b->read_off.data(),
-                                                           b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
-                        if (need > b->text.size()) {
-                            b->text.resize(need + need / 8 + 4096);
-                            need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), b->n_hashes.data(), b->read_off.data(),
-                                                      b->user_bin.data(), b->count.data(), &b->text[0], b->text.size());
-                        }
-                        b->text.resize(need);
-                        if (!b->user_bin.empty()) line_bytes_guess = std::max<size_t>(64, (size_t)(need / b->user_bin.size()) + 16);
-                    }
-                    q_out.push(std::move(b));
-                }
-            });
-        // The report is ONE file and the kernel serialises a file's buffered writes, so several writing threads gain nothing
-        // (profiles/r04/pwrite_scaling.txt, a RAM-backed file on the pool's box: pwrite of 1-MiB blocks from 1 / 2 / 8 threads 9.9 / 9.8 /
-        // 9.5 GB/s; one writer with 64-MiB blocks that are not in its cache -- what a formatter hands over -- 6.4 GB/s; a helper thread
-        // preallocating the file a gigabyte ahead of the writer 5.9: no gain; copies into a mapping of a fully preallocated file scale to
-        // 11 GB/s on four threads, but the preallocation is 21 GB/s of one thread by itself and the mapping costs the GPU calls of the
-        // process their address-space lock -- round 3).  So: one writer, straight write() calls of whole chunk texts, no stdio copy.
-        // Short reads are where this is the limit: a 1-kb read of the family workload is ~620-870 bytes of text per 1000 bases.
+        // ---- TSV text and the report file.  The report is ONE file and the kernel serialises a file's buffered writes: several threads
+        // writing gain nothing (profiles/r04/pwrite_scaling.txt, a RAM-backed file on the pool's box: pwrite of 1-MiB blocks from 1 / 2 /
+        // 8 threads 9.9 / 9.8 / 9.5 GB/s).  But those figures are for blocks that are in the writing core's cache; one writer thread
+        // handed 64-MiB texts by formatter threads -- rounds 2-4a -- copies them out of DRAM at 5-6 GB/s, and short reads (a 1-kb read of
+        // the family workload is ~620-870 bytes of text per 1000 bases) were bound by exactly that.  So the text is made in PIECES of
+        // about a megabyte, each written by the thread that formatted it while it is still in that core's cache:
+        //   sequencer       : chunks (GPU workers, any order) -> file and chunk order -> pieces (ranges of a chunk's reads), numbered
+        //   piece threads   : tuples -> 0.8*max filter -> TSV text of the piece (:266-306) -> wait for the piece's turn to learn its
+        //                     file offset (its predecessor's offset + size: known as soon as the predecessor is FORMATTED) -> pwrite
+        // The writes of different pieces overlap with the formatting of others; the kernel orders them.  An output that cannot seek
+        // (a pipe) is written inside the turn instead, one piece after the other.
+        // (Also tried: a helper thread preallocating the file a gigabyte ahead of one writer, 5.9 GB/s -- no gain; copies into a mapping
+        // of a fully preallocated file, 11 GB/s on four threads, but the preallocation is 21 GB/s of one thread by itself and the mapping
+        // costs the GPU calls of the process their address-space lock -- round 3.)
+        struct Hold { std::unique_ptr<Batch> b; std::atomic<uint32_t> left{0}; };
+        struct Piece { Hold *h = nullptr; uint32_t r0 = 0, r1 = 0; uint64_t ticket = 0; };
+        BoundedQueue<Piece> q_piece(4 * formatters + 16);
         fflush(out);
         const int out_fd = fileno(out);
-        std::atomic<uint64_t> out_written{0};
-        double t_write = 0;            // seconds the writer spent inside write()
-        std::thread writer([&] {
+        const off_t out_base = lseek(out_fd, 0, SEEK_CUR);
+        const bool out_seeks = out_base >= 0 && tune_env("TAXOR_CLI_NO_PWRITE") == nullptr;
+        static const uint64_t piece_bytes = [] { const char *e = tune_env("TAXOR_CLI_PIECE_KB"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 16 ? v : 1024) << 10; }();
+        std::atomic<uint64_t> out_written{0}, write_ns{0};
+        std::mutex turn_mu;
+        std::condition_variable turn_cv;
+        uint64_t next_ticket = 0, file_off = out_seeks ? (uint64_t)out_base : 0;
+        double t_first_write = 0, t_last_write = 0;
+        std::atomic<uint64_t> line_bytes_guess{192};   // bytes of text per tuple, learnt from the pieces formatted so far
+        auto chunk_done = [&](Hold *hd) {
+            {
+                std::lock_guard<std::mutex> lk(fmu);
+                --ahead[hd->b->file];
+                fcv.notify_all();
+            }
+            pool.put(std::move(hd->b));
+            delete hd;
+        };
+        std::thread sequencer([&] {
             std::unique_ptr<Batch> b;
             std::map<std::pair<uint32_t, uint64_t>, std::unique_ptr<Batch>> pending; // chunks that arrived ahead of their turn
             uint32_t cur_file = 0;
-            uint64_t next_seq = 0;
-            while (q_out.pop(b)) {
+            uint64_t next_seq = 0, ticket = 0;
+            while (q_fmt.pop(b)) {
                 const auto key = std::make_pair(b->file, b->seq);
                 pending.emplace(key, std::move(b));
                 while (!pending.empty() && pending.begin()->first == std::make_pair(cur_file, next_seq)) {
                     std::unique_ptr<Batch> cur = std::move(pending.begin()->second);
                     pending.erase(pending.begin());
-                    if (cur->end_of_file) {                 // every chunk of this file is written: the next file's turn
+                    if (cur->end_of_file) {                 // every chunk of this file is on its way: the next file's turn
                         ++cur_file;
                         next_seq = 0;
                         std::lock_guard<std::mutex> lk(fmu);
@@ -1191,24 +1182,81 @@ int main(int argc, char **argv)
                         continue;
                     }
                     ++next_seq;
-                    // one stream, one thread, straight write() calls of whole chunk texts (see above)
-                    const double tw0 = now();
-                    for (size_t done = 0; done < cur->text.size();) {
-                        const ssize_t w = ::write(out_fd, cur->text.data() + done, cur->text.size() - done);
-                        if (w <= 0) die("cannot write to " + cfg.report_file);
-                        done += (size_t)w;
+                    Hold *hd = new Hold;
+                    hd->b = std::move(cur);
+                    const Batch &bt = *hd->b;
+                    const size_t n = bt.ids.size();
+                    if (n == 0) { chunk_done(hd); continue; }
+                    // cut where the estimated text passes piece_bytes
+                    const uint64_t per_tuple = line_bytes_guess.load();
+                    std::vector<uint32_t> cuts{0};
+                    uint64_t est = 0;
+                    for (size_t r = 0; r < n; ++r) {
+                        est += (bt.read_off[r + 1] - bt.read_off[r]) * per_tuple + bt.ids.len(r) + 32;
+                        if (est >= piece_bytes && r + 1 < n) { cuts.push_back((uint32_t)(r + 1)); est = 0; }
                     }
-                    t_write += now() - tw0;
-                    out_written += cur->text.size();
-                    {
-                        std::lock_guard<std::mutex> lk(fmu);
-                        --ahead[cur->file];
-                        fcv.notify_all();
-                    }
-                    pool.put(std::move(cur));
+                    cuts.push_back((uint32_t)n);
+                    hd->left = (uint32_t)(cuts.size() - 1);
+                    for (size_t c = 0; c + 1 < cuts.size(); ++c) q_piece.push(Piece{hd, cuts[c], cuts[c + 1], ticket++});
                 }
             }
+            q_piece.close();
         });
+        std::vector<std::thread> fmt_threads;
+        for (unsigned ft = 0; ft < formatters; ++ft)
+            fmt_threads.emplace_back([&] {
+                Piece pc;
+                std::vector<const char *> idp;
+                std::vector<uint64_t> idl, rl;
+                std::vector<char> text(piece_bytes + piece_bytes / 2);
+                while (q_piece.pop(pc)) {
+                    const Batch &bt = *pc.h->b;
+                    const size_t n = pc.r1 - pc.r0;
+                    idp.resize(n); idl.resize(n); rl.resize(n);
+                    for (size_t r = 0; r < n; ++r) {
+                        idp[r] = bt.ids.ptr(pc.r0 + r);
+                        idl[r] = bt.ids.len(pc.r0 + r);
+                        rl[r] = bt.offsets[pc.r0 + r + 1] - bt.offsets[pc.r0 + r];
+                    }
+                    uint64_t need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), bt.n_hashes.data() + pc.r0, bt.read_off.data() + pc.r0,
+                                                       bt.user_bin.data(), bt.count.data(), text.data(), text.size());
+                    if (need > text.size()) {
+                        text.resize(need + need / 8 + 4096);
+                        need = taxor_format_reads(h, n, idp.data(), idl.data(), rl.data(), bt.n_hashes.data() + pc.r0, bt.read_off.data() + pc.r0,
+                                                  bt.user_bin.data(), bt.count.data(), text.data(), text.size());
+                    }
+                    const uint64_t tuples = bt.read_off[pc.r1] - bt.read_off[pc.r0];
+                    if (tuples > 64) line_bytes_guess = std::max<uint64_t>(64, need / tuples + 16);
+                    auto put = [&](uint64_t off) {
+                        const auto w0 = std::chrono::steady_clock::now();
+                        for (uint64_t done = 0; done < need;) {
+                            const ssize_t w = out_seeks ? ::pwrite(out_fd, text.data() + done, need - done, (off_t)(off + done))
+                                                        : ::write(out_fd, text.data() + done, need - done);
+                            if (w <= 0) die("cannot write to " + cfg.report_file);
+                            done += (uint64_t)w;
+                        }
+                        write_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
+                    };
+                    uint64_t off;
+                    {
+                        std::unique_lock<std::mutex> lk(turn_mu);
+                        turn_cv.wait(lk, [&] { return next_ticket == pc.ticket; });
+                        off = file_off;
+                        file_off += need;
+                        if (t_first_write == 0) t_first_write = now();
+                        if (!out_seeks) put(off);                       // a pipe: in order, inside the turn
+                        ++next_ticket;
+                    }
+                    turn_cv.notify_all();
+                    if (out_seeks) put(off);
+                    out_written += need;
+                    {
+                        std::lock_guard<std::mutex> lk(turn_mu);
+                        t_last_write = std::max(t_last_write, now());
+                    }
+                    if (pc.h->left.fetch_sub(1) == 1) chunk_done(pc.h);
+                }
+            });
 
         // ---- the index: one replica per device (reads are independent, taxor_search.cpp:214: the index is replicated,
         // batches are sharded).  Several devices (north star: "reads sharded across the GPUs, per-read results gathered over
@@ -1447,13 +1495,15 @@ int main(int argc, char **argv)
         trace("GPU workers done");
         t_search_wall += now() - t_search0;
         q_fmt.close();
+        sequencer.join();
         for (auto &t : fmt_threads) t.join();
-        q_out.close();
         reader.join();
-        writer.join();
+        if (out_seeks && lseek(out_fd, (off_t)file_off, SEEK_SET) < 0) die("cannot write to " + cfg.report_file);     // behind the last piece
         trace("writer done");
         if (tune_env("TAXOR_CLI_TRACE"))
-            fprintf(stderr, "[trace] report: %.2f GB in %.3f s of write() = %.1f GB/s\n", out_written.load() / 1e9, t_write, t_write > 0 ? out_written.load() / 1e9 / t_write : 0.0);
+            fprintf(stderr, "[trace] report: %.2f GB in %llu pieces by %u threads, %.3f s from the first write to the last = %.1f GB/s (%.3f s inside %s, summed)\n",
+                    out_written.load() / 1e9, (unsigned long long)next_ticket, formatters, t_last_write - t_first_write,
+                    t_last_write > t_first_write ? out_written.load() / 1e9 / (t_last_write - t_first_write) : 0.0, write_ns.load() / 1e9, out_seeks ? "pwrite()" : "write()");
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
         for (auto *x : sr) taxor_gpu_searcher_destroy(x);
         if (comm) {

@@ -84,6 +84,30 @@ def test_cli_fastq_gz_fasta_multi(tmp_path):
     assert cp.returncode == 0, cp.stderr
     assert open(out_eq).read() == want
 
+    # the report is written in pieces by the threads that format them (pwrite at offsets handed out in order): pieces of 16 KiB on eight
+    # threads; the same into a pipe, which cannot seek (the pieces are then written inside their turn); and with pwrite switched off
+    for kind in ("file", "pipe", "nopwrite"):
+        out_p = tmp_path / f"out_pieces_{kind}.tsv"
+        env = dict(os.environ, TAXOR_TUNING="1", TAXOR_CLI_PIECE_KB="16", TAXOR_CLI_TRACE="1", **({"TAXOR_CLI_NO_PWRITE": "1"} if kind == "nopwrite" else {}))
+        cmd = [TAXOR, "search", "--index-file", str(idx_path), "--query-file", f"{fq},{fa}", "--threads", "16", "--batch-reads", "50"]
+        if kind == "pipe":
+            fifo = tmp_path / "report.fifo"
+            os.mkfifo(fifo)
+            with open(out_p, "wb") as sink:
+                p2 = subprocess.Popen(["cat", str(fifo)], stdout=sink)
+                cp = subprocess.run(cmd + ["--output-file", str(fifo)], capture_output=True, text=True, timeout=300, env=env)
+                assert cp.returncode == 0 and p2.wait(timeout=60) == 0, cp.stderr
+            assert open(out_p).read() == want
+            assert "inside write()" in cp.stderr
+        else:
+            cp = subprocess.run(cmd + ["--output-file", str(out_p)], capture_output=True, text=True, timeout=300, env=env)
+            assert cp.returncode == 0, cp.stderr
+            assert open(out_p).read() == want, kind
+            assert ("inside pwrite()" if kind == "file" else "inside write()") in cp.stderr
+            if kind == "file":
+                import re
+                assert int(re.search(r"in (\d+) pieces", cp.stderr).group(1)) > 6, cp.stderr
+
     # two (three) workers sharding the chunks -- here on the same device -- must give the identical file in input order
     for devs in ("0,0", "0,0,0"):
         out2 = tmp_path / "out_multi.tsv"
