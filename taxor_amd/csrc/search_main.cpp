@@ -1053,7 +1053,7 @@ int main(int argc, char **argv)
         const size_t nf = queries.size();
         const unsigned readers = (unsigned)std::max<size_t>(1, std::min<size_t>({nf, cfg.threads, 8}));
         const unsigned parse_threads = std::max(1u, std::min(cfg.threads, 32u) / readers);
-        static const unsigned fmt_div = [] { const char *e = tune_env("TAXOR_CLI_FORMATTER_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (unsigned)v : 2u; }();
+        static const unsigned fmt_div = [] { const char *e = tune_env("TAXOR_CLI_FORMATTER_DIV"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 32 ? (unsigned)v : 4u; }();
         const unsigned formatters = std::max(1u, std::min(cfg.threads, 32u) / fmt_div);
         static const unsigned workers_per_gpu = [] { const char *e = tune_env("TAXOR_CLI_WORKERS_PER_GPU"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 4 ? (unsigned)v : 2u; }();
         const uint64_t group_reads = cfg.group_reads ? cfg.group_reads : (cfg.batch_reads ? cfg.batch_reads : 131072);
@@ -1125,32 +1125,32 @@ int main(int argc, char **argv)
             q_in.close();
             trace("readers done");
         });
-        // ---- TSV text and the report file.  The report is ONE file and the kernel serialises a file's buffered writes: several threads
-        // writing gain nothing (profiles/r04/pwrite_scaling.txt, a RAM-backed file on the pool's box: pwrite of 1-MiB blocks from 1 / 2 /
-        // 8 threads 9.9 / 9.8 / 9.5 GB/s).  But those figures are for blocks that are in the writing core's cache; one writer thread
-        // handed 64-MiB texts by formatter threads -- rounds 2-4a -- copies them out of DRAM at 5-6 GB/s, and short reads (a 1-kb read of
-        // the family workload is ~620-870 bytes of text per 1000 bases) were bound by exactly that.  So the text is made in PIECES of
-        // about a megabyte, each written by the thread that formatted it while it is still in that core's cache:
+        // ---- TSV text and the report file.  The report is ONE file and the kernel serialises a file's buffered writes, so there is one
+        // stream of write() calls whatever the threads (profiles/r04/pwrite_scaling.txt, a RAM-backed file on the pool's box: pwrite of
+        // 1-MiB blocks from 1 / 2 / 8 threads 9.9 / 9.8 / 9.5 GB/s).  Those figures are for blocks that are in the writing core's cache;
+        // one writer thread handed 64-MiB texts by formatter threads -- rounds 2-4a -- copies them out of DRAM at 5-6 GB/s, and short
+        // reads (a 1-kb read of the family workload is ~620-870 bytes of text per 1000 bases) were bound by exactly that.  So the text is
+        // made in PIECES of about a megabyte, each written by the thread that formatted it while it is still in that core's cache:
         //   sequencer       : chunks (GPU workers, any order) -> file and chunk order -> pieces (ranges of a chunk's reads), numbered
-        //   piece threads   : tuples -> 0.8*max filter -> TSV text of the piece (:266-306) -> wait for the piece's turn to learn its
-        //                     file offset (its predecessor's offset + size: known as soon as the predecessor is FORMATTED) -> pwrite
-        // The writes of different pieces overlap with the formatting of others; the kernel orders them.  An output that cannot seek
-        // (a pipe) is written inside the turn instead, one piece after the other.
-        // (Also tried: a helper thread preallocating the file a gigabyte ahead of one writer, 5.9 GB/s -- no gain; copies into a mapping
-        // of a fully preallocated file, 11 GB/s on four threads, but the preallocation is 21 GB/s of one thread by itself and the mapping
-        // costs the GPU calls of the process their address-space lock -- round 3.)
+        //   piece threads   : tuples -> 0.8*max filter -> TSV text of the piece (:266-306) -> wait for the piece's turn -> write()
+        // (Also tried: the piece threads pwrite()-ing at offsets handed out in turn, the writes themselves overlapping: 2.0-3.3 GB/s on
+        // 8-32 threads, 34-100 s summed inside pwrite -- the threads spin on the file's lock -- against 6.5 with the write inside the
+        // turn, profiles/r04/cli_text_1kb_pwrite.txt; a helper thread preallocating the file a gigabyte ahead of one writer, 5.9 GB/s -- no
+        // gain; copies into a mapping of a fully preallocated file, 11 GB/s on four threads, but the preallocation is 21 GB/s of one
+        // thread by itself and the mapping costs the GPU calls of the process their address-space lock -- round 3.)
         struct Hold { std::unique_ptr<Batch> b; std::atomic<uint32_t> left{0}; };
         struct Piece { Hold *h = nullptr; uint32_t r0 = 0, r1 = 0; uint64_t ticket = 0; };
         BoundedQueue<Piece> q_piece(4 * formatters + 16);
         fflush(out);
         const int out_fd = fileno(out);
-        const off_t out_base = lseek(out_fd, 0, SEEK_CUR);
-        const bool out_seeks = out_base >= 0 && tune_env("TAXOR_CLI_NO_PWRITE") == nullptr;
         static const uint64_t piece_bytes = [] { const char *e = tune_env("TAXOR_CLI_PIECE_KB"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 16 ? v : 1024) << 10; }();
-        std::atomic<uint64_t> out_written{0}, write_ns{0};
+        std::atomic<uint64_t> out_written{0};
+        double t_write = 0;            // seconds inside write()
         std::mutex turn_mu;
-        std::condition_variable turn_cv;
-        uint64_t next_ticket = 0, file_off = out_seeks ? (uint64_t)out_base : 0;
+        std::condition_variable turn_cv[64];            // a waiting piece thread sleeps on the one of its ticket: passing the turn wakes one thread
+        uint64_t next_ticket = 0;
+        static const bool turn_spin = [] { const char *e = tune_env("TAXOR_CLI_TURN_SPIN"); return e ? atoi(e) != 0 : true; }();
+        std::atomic<uint64_t> turn_now{0};              // next_ticket, readable without the lock: the thread whose turn is next spins on it
         double t_first_write = 0, t_last_write = 0;
         std::atomic<uint64_t> line_bytes_guess{192};   // bytes of text per tuple, learnt from the pieces formatted so far
         auto chunk_done = [&](Hold *hd) {
@@ -1227,33 +1227,27 @@ int main(int argc, char **argv)
                     }
                     const uint64_t tuples = bt.read_off[pc.r1] - bt.read_off[pc.r0];
                     if (tuples > 64) line_bytes_guess = std::max<uint64_t>(64, need / tuples + 16);
-                    auto put = [&](uint64_t off) {
-                        const auto w0 = std::chrono::steady_clock::now();
+                    {
+                        // (the thread that is next in line does not go to sleep for the ~0.1 ms its predecessor writes: a wake-up costs
+                        // 10-20 us of every 120)
+                        if (turn_spin && pc.ticket - turn_now.load(std::memory_order_acquire) == 1)
+                            for (int spin = 0; spin < 20000 && turn_now.load(std::memory_order_acquire) != pc.ticket; ++spin) _mm_pause();
+                        std::unique_lock<std::mutex> lk(turn_mu);
+                        turn_cv[pc.ticket % 64].wait(lk, [&] { return next_ticket == pc.ticket; });
+                        const double w0 = now();
+                        if (t_first_write == 0) t_first_write = w0;
                         for (uint64_t done = 0; done < need;) {
-                            const ssize_t w = out_seeks ? ::pwrite(out_fd, text.data() + done, need - done, (off_t)(off + done))
-                                                        : ::write(out_fd, text.data() + done, need - done);
+                            const ssize_t w = ::write(out_fd, text.data() + done, need - done);
                             if (w <= 0) die("cannot write to " + cfg.report_file);
                             done += (uint64_t)w;
                         }
-                        write_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
-                    };
-                    uint64_t off;
-                    {
-                        std::unique_lock<std::mutex> lk(turn_mu);
-                        turn_cv.wait(lk, [&] { return next_ticket == pc.ticket; });
-                        off = file_off;
-                        file_off += need;
-                        if (t_first_write == 0) t_first_write = now();
-                        if (!out_seeks) put(off);                       // a pipe: in order, inside the turn
+                        t_last_write = now();
+                        t_write += t_last_write - w0;
                         ++next_ticket;
+                        turn_now.store(next_ticket, std::memory_order_release);
+                        turn_cv[next_ticket % 64].notify_all();
                     }
-                    turn_cv.notify_all();
-                    if (out_seeks) put(off);
                     out_written += need;
-                    {
-                        std::lock_guard<std::mutex> lk(turn_mu);
-                        t_last_write = std::max(t_last_write, now());
-                    }
                     if (pc.h->left.fetch_sub(1) == 1) chunk_done(pc.h);
                 }
             });
@@ -1498,12 +1492,11 @@ int main(int argc, char **argv)
         sequencer.join();
         for (auto &t : fmt_threads) t.join();
         reader.join();
-        if (out_seeks && lseek(out_fd, (off_t)file_off, SEEK_SET) < 0) die("cannot write to " + cfg.report_file);     // behind the last piece
         trace("writer done");
         if (tune_env("TAXOR_CLI_TRACE"))
-            fprintf(stderr, "[trace] report: %.2f GB in %llu pieces by %u threads, %.3f s from the first write to the last = %.1f GB/s (%.3f s inside %s, summed)\n",
+            fprintf(stderr, "[trace] report: %.2f GB in %llu pieces by %u threads, %.3f s from the first write to the last = %.1f GB/s (%.3f s inside write() = %.1f GB/s)\n",
                     out_written.load() / 1e9, (unsigned long long)next_ticket, formatters, t_last_write - t_first_write,
-                    t_last_write > t_first_write ? out_written.load() / 1e9 / (t_last_write - t_first_write) : 0.0, write_ns.load() / 1e9, out_seeks ? "pwrite()" : "write()");
+                    t_last_write > t_first_write ? out_written.load() / 1e9 / (t_last_write - t_first_write) : 0.0, t_write, t_write > 0 ? out_written.load() / 1e9 / t_write : 0.0);
         t_reads += *std::max_element(reader_time.begin(), reader_time.end());
         for (auto *x : sr) taxor_gpu_searcher_destroy(x);
         if (comm) {
