@@ -9,6 +9,7 @@
 using taxor::tune_env;
 extern char **environ;
 
+#include <sched.h>
 #include <spawn.h>
 #include <sys/mman.h>
 #include <sys/resource.h>
@@ -210,6 +211,45 @@ void usage()
 double now()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// CPU time of the process so far and what the cgroup's CPU quota took away (cpu.max: a container is commonly given fewer CPUs than
+// the machine shows -- the pool's GPU box 16 of 256 -- and every thread of the process stops for the rest of a 100-ms period once
+// the quota of that period is used up)
+struct CpuMark { double user = 0, sys = 0, throttled = 0; uint64_t periods = 0, throttled_periods = 0; };
+CpuMark cpu_mark()
+{
+    CpuMark m;
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    m.user = ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec;
+    m.sys = ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.stat", "r")) {
+        char key[64];
+        unsigned long long v;
+        while (fscanf(f, "%63s %llu", key, &v) == 2) {
+            if (!strcmp(key, "nr_periods")) m.periods = v;
+            else if (!strcmp(key, "nr_throttled")) m.throttled_periods = v;
+            else if (!strcmp(key, "throttled_usec")) m.throttled = v * 1e-6;
+        }
+        fclose(f);
+    }
+    return m;
+}
+// CPUs the process may use: the smaller of the affinity mask and the cgroup's quota (0 if unknown)
+double cpu_allowance()
+{
+    double q = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char a[64];
+        unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", a, &period) == 2 && strcmp(a, "max") != 0 && period) q = (double)strtoull(a, nullptr, 10) / (double)period;
+        fclose(f);
+    }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    const double aff = sched_getaffinity(0, sizeof set, &set) == 0 ? (double)CPU_COUNT(&set) : 0.0;
+    return q > 0 && aff > 0 ? std::min(q, aff) : std::max(q, aff);
 }
 
 // TAXOR_CLI_TRACE=1: wall-clock marks of the pipeline stages on stderr
@@ -833,14 +873,16 @@ int main(int argc, char **argv)
         if (!g.open(in, threads, chunk, 0)) die(in + " is not a gzip file");
         FILE *of = out_path.empty() ? nullptr : fopen(out_path.c_str(), "wb");
         if (!out_path.empty() && !of) die("cannot write " + out_path);
-        std::vector<char> buf(16u << 20);
+        std::vector<char> buf;
         uint64_t total = 0;
         try {
-            for (;;) {
-                const size_t n = g.read(buf.data(), buf.size());
-                if (!n) break;
-                total += n;
-                if (of && fwrite(buf.data(), 1, n, of) != n) die("write error on " + out_path);
+            // chunk by chunk, the buffers changing hands like in `search` (ParallelGz::take): a copy out of them on this one thread
+            // would be the limit (~5 GB/s) before the inflating threads are
+            while (g.take(buf)) {
+                total += buf.size();
+                if (of && fwrite(buf.data(), 1, buf.size(), of) != buf.size()) die("write error on " + out_path);
+                g.recycle(std::move(buf));
+                buf = std::vector<char>();
             }
         } catch (const std::exception &e) { die(e.what()); }
         if (of) fclose(of);
@@ -1099,13 +1141,14 @@ int main(int argc, char **argv)
                     }, (uint32_t)f, parse_threads, gate);
                 }
             });
-        // Page-locking a chunk buffer (once per buffer: chunks are recycled) costs ~50-90 ms per GB inside the driver.  Neither
-        // the parsers nor the GPU workers pay it: a small stage of its own between them does, so that a registration queued
-        // behind the driver's 113 GB allocation stalls nobody who has other work.  And a buffer is only registered when it comes
-        // round the SECOND time: a query file smaller than the pool (13 GB of reads against the RefSeq-class index: a search phase
-        // of 0.4 s) uses every buffer once, and registering all of them was 0.5 s of driver time for copies the library makes from
-        // pageable memory at 0.94 of the page-locked rate anyway; a long run reaches the same steady state one lap later.
-        static const uint32_t pin_after = [] { const char *e = tune_env("TAXOR_CLI_PIN_AFTER"); const int v = e ? atoi(e) : 2; return (uint32_t)(v >= 1 ? v : 1); }();
+        // Page-locking a chunk buffer (once per buffer: chunks are recycled) costs ~50-90 ms per GB inside the driver, and while the
+        // driver registers, the GPU workers' submissions wait: RefSeq-class index, 4.2 M x 10 kb, interleaved on one box
+        // (profiles/r04/cli_pin_10kb.txt): buffers registered when they come round the second time (rounds 3-4a) 0.82-0.84 x the
+        // library's rate; all of them at their first fill, i.e. while the index uploads, 0.86-0.89 and the index resident 0.15-0.2 s
+        // later; NEVER 0.90-0.92 -- the library copies from pageable memory at 0.94 of the page-locked rate since the hardware queues
+        // are set (round 3).  So chunk buffers stay pageable; TAXOR_CLI_PIN_AFTER=n (under TAXOR_TUNING) registers a buffer at its
+        // n-th fill, on a small stage of its own between the parsers and the GPU workers.
+        static const uint32_t pin_after = [] { const char *e = tune_env("TAXOR_CLI_PIN_AFTER"); const int v = e ? atoi(e) : 0; return v >= 1 ? (uint32_t)v : ~0u; }();
         std::vector<std::thread> pinners;
         static const int n_pinners = [] { const char *e = tune_env("TAXOR_CLI_PINNERS"); const int v = e ? atoi(e) : 2; return v >= 1 && v <= 32 ? v : 2; }();
         for (int pt = 0; pt < n_pinners; ++pt)
@@ -1288,6 +1331,7 @@ int main(int argc, char **argv)
         }
         t_index += now() - t0;
         trace("index resident in HBM");
+        const CpuMark cpu0 = cpu_mark();
         if (tune_env("TAXOR_CLI_TRACE"))
             fprintf(stderr, "[trace] index: %.2f GB per replica in %.3f s = %.1f GB/s (file open to resident)\n", taxor_gpu_index_data_bytes(gidx[0]) / 1e9,
                     now() - t0, taxor_gpu_index_data_bytes(gidx[0]) / 1e9 / (now() - t0));
@@ -1488,6 +1532,13 @@ int main(int argc, char **argv)
         for (auto &t : workers) t.join();
         trace("GPU workers done");
         t_search_wall += now() - t_search0;
+        if (tune_env("TAXOR_CLI_TRACE")) {
+            const CpuMark c1 = cpu_mark();
+            const double w = now() - t_search0;
+            fprintf(stderr, "[trace] search phase: %.3f s wall, %.2f s user + %.2f s system CPU = %.1f CPUs busy (allowance %.0f); the cgroup throttled the process in %llu of %llu periods, %.2f thread-seconds\n",
+                    w, c1.user - cpu0.user, c1.sys - cpu0.sys, w > 0 ? (c1.user - cpu0.user + c1.sys - cpu0.sys) / w : 0.0, cpu_allowance(),
+                    (unsigned long long)(c1.throttled_periods - cpu0.throttled_periods), (unsigned long long)(c1.periods - cpu0.periods), c1.throttled - cpu0.throttled);
+        }
         q_fmt.close();
         sequencer.join();
         for (auto &t : fmt_threads) t.join();
