@@ -261,16 +261,15 @@ def test_cli_search_phase_keeps_up_with_the_library(tmp_path):
     assert len(rates) == 4, cp.stdout[-3000:]
     print(cp.stdout[-2500:])
     # The review's bar is >= 20 Gbp/s and >= 0.8 x the library's sustained rate on the MEDIAN run.  Measured with the
-    # round's last pipeline on three boxes (profiles/r04/cli_variants.txt, cli_variants2.txt, cli_ab_prev.txt): 33.2-35.1 Gbp/s =
-    # 0.81-0.85 x on every judged run (32, 24 and 16 threads; seven runs, mean 0.83), the library alone at 40.8-41.3 Gbp/s -- the bar
-    # is met, by 0.01-0.05.  (Round 3 on 1.3 M reads: 0.58-0.80 and `max` over the runs; this round's earlier build, side by side on the
-    # same box: 0.73-0.77.  What moved it: the chunks' sequence buffers are no std::strings any more -- 2-MiB boundaries, huge
-    # pages, long lines stored past the caches; a GPU worker goes on collecting its batch for up to 20 ms while another batch keeps
-    # the device busy instead of launching what happens to be queued.)  The assertion is the MEDIAN of the judged runs against 0.77:
-    # the suite runs with -x, and the spread between boxes and runs is 0.04.
+    # round's last pipeline (profiles/r04/cli_nopin_10kb.txt, cli_pin_10kb.txt): 36.5-38.8 Gbp/s = 0.88-0.93 x on every judged run (32
+    # and 16 threads), the library alone at 41.5 Gbp/s.  Round 3 on 1.3 M reads: 0.58-0.80 and `max` over the runs; this round, step by
+    # step and side by side on one box each time: 0.72-0.79 (start) -> 0.81-0.85 (sequence buffers of their own kind instead of
+    # std::strings: 2-MiB boundaries, huge pages, streaming stores; bounded batch collecting) -> 0.88-0.93 (chunk buffers are not
+    # page-locked any more: every registration made the GPU workers' submissions wait in the driver).  Asserted: the MEDIAN of the
+    # judged runs reaches the review's bar.
     judged = sorted(rates[1:])
     med_rate = sorted(v for v, _, _ in judged)[len(judged) // 2]
     med_ratio = sorted(r for _, r, _ in judged)[len(judged) // 2]
     assert med_rate >= 30000.0, rates
-    assert med_ratio >= 0.77, rates
+    assert med_ratio >= 0.8, rates
     assert max(t for _, _, t in rates) < 0.3, rates
