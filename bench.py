@@ -896,12 +896,26 @@ def _interleave_host_memory(on):
         return 0
 
 
+def cpu_quota():
+    """CPUs the container's cgroup allows (cpu.max: quota / period), or None.  The pool's GPU box shows 256 hardware threads and
+    allows 16 (profiles/r04/cpu_quota_probe.txt): beyond 16 runnable threads every thread of the process is stopped for the rest of
+    each 100-ms period."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
     """The CPU oracle (a port of the reference path) on a bounded sample of the same reads + index, same box."""
     from oracle import oracle as orc
     hash_kw = hash_kw or {}
     bases, offs = batch
-    threads = min(ncpu, 32)                      # the reference caps --threads at 32 (taxor_search.cpp:51-55)
+    quota = cpu_quota()
+    cap32 = min(ncpu, 32)                        # the reference caps --threads at 32 (taxor_search.cpp:51-55)
+    threads = max(1, min(cap32, int(quota + 0.5))) if quota else cap32      # ... and the box may allow fewer CPUs than that
     # host copy of the IXFs the sample can visit: the root plus every IXF holding a planted path; the rest get
     # untouched virtual memory (never read: the traversal enters a child only when its merged bin passes the
     # threshold, which random fingerprints cannot)
@@ -956,10 +970,15 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
             raise SystemExit("PARITY FAILURE: the oracle's two schedulers disagree")
         extra["openmp_slices"] = {"value": round(int(offs[nq]) / dtq / 1e6, 3), "reads": nq,
                                   "note": "same worker, ceil(n/threads) slices of the whole sample under OpenMP"}
-    if ncpu > threads:      # also at all hardware threads (the reference itself caps --threads at 32);
+    if cap32 > threads:     # the reference's own cap, over the quota: 32 threads on `quota` CPUs
+        nb = max(1, n // 3)
+        dtb, _ = run(nb, cap32)
+        extra["threads_32"] = {"value": round(int(offs[nb]) / dtb / 1e6, 3), "threads": cap32, "reads": nb,
+                               "note": f"the reference's cap of 32 threads on the {quota:g} CPUs the cgroup allows"}
+    if ncpu > threads and not quota:     # also at all hardware threads (the reference itself caps --threads at 32);
         na = max(1, n // 4)  # a quarter of the sample: beyond 32 threads the port gets slower (remote-socket row reads)
         dta, _ = run(na, ncpu)
-        extra = {"all_cores": {"value": round(int(offs[na]) / dta / 1e6, 3), "cores": ncpu, "reads": na}}
+        extra["all_cores"] = {"value": round(int(offs[na]) / dta / 1e6, 3), "cores": ncpu, "reads": na}
     model = ""
     try:
         with open("/proc/cpuinfo") as f:
@@ -967,7 +986,7 @@ def cpu_baseline(args, idx, lay, res, batch, read_len, ncpu, hash_kw=None):
     except OSError:
         pass
     return {**extra, "value": round(int(offs[n]) / dt / 1e6, 3), "unit": "Mbp/s", "cores": threads, "kind": "port",
-            "cpu_model": model, "hardware_threads": ncpu, "index_copy_interleaved_over_numa_nodes": interleaved,
+            "cpu_model": model, "hardware_threads": ncpu, "cpu_quota": quota, "index_copy_interleaved_over_numa_nodes": interleaved,
             "scheduler": ("the reference's hixf::do_parallel (do_parallel.hpp compiled from /root/reference into oracle/_ref): 1024-record "
                           "chunks, std::async tasks, one barrier per chunk" if sched == "reference" else "port: OpenMP slices of the whole sample"),
             "sample": f"first {n} reads of the last timed batch ({int(offs[n])/1e6:.1f} Mbp), same index, {dt:.1f} s wall, "
