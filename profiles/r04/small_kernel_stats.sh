@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=8 TAXOR_TUNING=1
 for cfg in "$@"; do
   O=$R/gpurun_out/r04_kstats; rm -rf $O; mkdir -p $O
-  env $cfg rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python3 $R/profiles/small_calls.py --sizes $N > $O/out.txt 2>&1
+  env $cfg rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python3 $R/profiles/small_calls.py --sizes $N $SMALL_ARGS > $O/out.txt 2>&1
   echo "== $N reads per call, $cfg: $(grep 'reads per call' $O/out.txt | sed 's/^ *//')"
   O=$O python3 - <<'PY'
 import csv, glob, os, re
