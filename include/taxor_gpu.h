@@ -493,6 +493,34 @@ int taxor_synth_reads(const char *genomes, const uint64_t *genome_off, uint64_t 
                       uint32_t read_len, double error_rate, double frac_random, double frac_reverse,
                       uint64_t seed, int threads, char *bases, uint64_t cap, uint64_t *offsets, int32_t *origin);
 
+/* ---- Deflate chunks decoded on the device (taxor_amd/csrc/inflate.hip): the reader of single-member .gz query files (the
+ * reference reads .gz through seqan3's stream layer, one zlib stream on one thread, src/main/taxor_search.cpp:181-184).  The host
+ * (taxor_amd/csrc/pgz.h) cuts the member's deflate stream into chunks, finds a block start in each, and hands a batch over:
+ * every chunk is decoded from its start bit to the first block boundary at or behind its stop bit into 16-bit symbols -- a byte,
+ * or 256 + w for "byte w of the 32 KiB before this chunk".  The host then checks that every chunk starts where its predecessor
+ * ended; a chunk that does not, or that the device gave up on (status != 0), is decoded on the host and its symbols are put in
+ * its place (taxor_gpu_inflate_replace).  taxor_gpu_inflate_resolve chains the 32-KiB windows from chunk to chunk, turns every
+ * symbol into its byte and copies the bytes of chunk first + i to out[i].  Bits are counted from the first byte of `in`.  One
+ * caller at a time per inflater. */
+typedef struct taxor_gpu_inflater taxor_gpu_inflater;
+typedef struct taxor_inflate_chunk { uint64_t start_bit, stop_bit; } taxor_inflate_chunk;
+typedef struct taxor_inflate_result {
+    uint64_t end_bit;     /* the block boundary the chunk ended at (>= stop_bit), or the end of the member's final block */
+    uint64_t n_out;       /* symbols = bytes of output */
+    uint32_t status;      /* 0 decoded; 2 invalid deflate data from this start; 3 more output than the chunk's share of the arena; 4 ran past the input */
+    uint32_t final_block; /* the member's last block ended this chunk */
+} taxor_inflate_result;
+/* max_symbols: 16-bit symbols the arena holds for one batch (every chunk needs 32768 + its output + 256) */
+int taxor_gpu_inflater_create(int device, uint64_t max_in_bytes, uint32_t max_chunks, uint64_t max_symbols, taxor_gpu_inflater **out);
+void taxor_gpu_inflater_destroy(taxor_gpu_inflater *h);
+int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n_chunks,
+                             taxor_inflate_result *results);
+int taxor_gpu_inflate_replace(taxor_gpu_inflater *h, uint32_t chunk, const uint16_t *symbols, uint64_t n_out, uint64_t end_bit, uint32_t final_block);
+int taxor_gpu_inflate_resolve(taxor_gpu_inflater *h, const uint8_t *window_in /* 32768 bytes */, uint32_t first, uint32_t count, uint8_t *const *out,
+                              uint8_t *window_out /* 32768 bytes, may be NULL */);
+/* a decoded chunk's symbols, n_out of them (parity tests against the host decoder) */
+int taxor_gpu_inflate_symbols(taxor_gpu_inflater *h, uint32_t chunk, uint16_t *out);
+
 #ifdef __cplusplus
 }
 #endif

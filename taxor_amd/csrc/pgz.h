@@ -473,11 +473,21 @@ inline size_t gzip_header_len(const uint8_t *p, size_t n)
 
 class ParallelGz {
 public:
-    ~ParallelGz() { shutdown(); if (map_) munmap(const_cast<uint8_t *>(map_), size_); }
+    ~ParallelGz()
+    {
+        shutdown();
+#ifdef TAXOR_PGZ_DEVICE
+        if (dev_) taxor_gpu_inflater_destroy(dev_);
+#endif
+        if (map_) munmap(const_cast<uint8_t *>(map_), size_);
+    }
 
     // true: `path` is a gzip file large enough to be worth the threads; inflating starts at once.  chunk_bytes = compressed bytes
     // per chunk (0: 4 MiB).
-    bool open(const std::string &path, unsigned threads, size_t chunk_bytes = 0, size_t min_size = 8u << 20)
+    // device >= 0 (builds with TAXOR_PGZ_DEVICE): the chunks are decoded on that GPU, see open_device below; if it has no room the
+    // host path stays and *device_note says why.
+    bool open(const std::string &path, unsigned threads, size_t chunk_bytes = 0, size_t min_size = 8u << 20, int device = -1, size_t batch_chunks = 0,
+              std::string *device_note = nullptr)
     {
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
@@ -492,10 +502,44 @@ public:
         threads_ = std::max(1u, threads);
         chunk_bytes_ = chunk_bytes ? chunk_bytes : (4u << 20);
         lookahead_ = 2 * threads_ + 2;
+#ifdef TAXOR_PGZ_DEVICE
+        if (device >= 0) (void)open_device(device, batch_chunks, 6.0, device_note);
+#else
+        (void)device; (void)batch_chunks; (void)device_note;
+#endif
         start_member(0);
         for (unsigned t = 0; t < threads_; ++t) th_.emplace_back([this] { worker(); });
         return true;
     }
+
+#ifdef TAXOR_PGZ_DEVICE
+    // The chunks' decoding on a GPU (taxor_amd/csrc/inflate.hip through the C ABI): the host threads only look for the block starts
+    // and check the CRCs; a driver thread hands batches of consecutive chunks to the device (one wave per chunk), ties them on the
+    // host (a chunk that does not start where its predecessor ended, or that the device gave up on, is decoded here and put in its
+    // place), and has the device chain the windows and resolve the symbols.  Call right after open(); false (and the host path
+    // stays) if the device has no room.  batch_chunks: chunks per batch (0: 512); ratio_cap: output bytes per input byte the arena
+    // is sized for (chunks beyond it are decoded on the host).  Called by open() before any thread runs.
+    uint64_t chunks_device = 0, chunks_host_fallback = 0;
+    std::atomic<uint64_t> ns_device{0};
+private:
+    bool open_device(int device, size_t batch_chunks = 0, double ratio_cap = 6.0, std::string *why = nullptr)
+    {
+        const size_t n_total = (size_ + chunk_bytes_ - 1) / chunk_bytes_;
+        dev_batch_ = std::max<size_t>(1, std::min<size_t>(batch_chunks ? batch_chunks : 512, n_total));
+        dev_slack_ = std::max<size_t>(chunk_bytes_, 1u << 20);
+        const uint64_t in_cap = (uint64_t)dev_batch_ * chunk_bytes_ + dev_slack_ + 64;
+        const uint64_t syms = (uint64_t)dev_batch_ * ((uint64_t)(ratio_cap * (double)chunk_bytes_) + pgz_detail::WIN + 256) + (uint64_t)(ratio_cap * (double)chunk_bytes_) * 2;
+        if (taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_) != TAXOR_OK) {
+            if (why) *why = taxor_gpu_last_error();
+            dev_ = nullptr;
+            return false;
+        }
+        lookahead_ = std::max(lookahead_, 2 * dev_batch_ + 2);
+        th_.emplace_back([this] { device_driver(); });
+        return true;
+    }
+public:
+#endif
 
     // next bytes of the decompressed stream; 0 at the end.  Throws std::runtime_error on a corrupt stream.
     size_t read(char *dst, size_t n)
@@ -552,6 +596,7 @@ private:
         std::vector<char> out;
         size_t out_len = 0;                             // out.size() when it was resolved (the vector itself may have been taken)
         uint32_t crc = 0;
+        uint64_t found_start = ~0ull;                   // device mode: the block start the host found (state 2), ~0 if none
     };
 
     void shutdown()
@@ -561,6 +606,7 @@ private:
             stop_ = true;
         }
         cv_work_.notify_all();
+        cv_done_.notify_all();
         for (auto &t : th_) t.join();
         th_.clear();
     }
@@ -590,8 +636,18 @@ private:
         member_crc_ = crc32(0L, Z_NULL, 0);
         member_len_ = 0;
         text_ = true;
+        if (device_mode()) {
+            // is it text?  (then candidate block starts must decode to text as well.)  The host path learns it from chunk 0's symbols
+            // when it ties them; here they never come to the host, so the member's first block is decoded for it now
+            static const TextSet ts;
+            ChunkOut trial;
+            if (decode_from(map_, map_ + size_, first, ~0ull, trial, WIN + (8u << 20), nullptr, 1))
+                for (size_t k = WIN; k < std::min<size_t>(trial.n, WIN + (1u << 16)); ++k)
+                    if (trial.sym[k] >= 256 || !ts.ok[trial.sym[k]]) { text_ = false; break; }
+        }
         ++members;
         cv_work_.notify_all();
+        cv_done_.notify_all();
     }
 
     void worker()
@@ -609,6 +665,14 @@ private:
                 ++busy_;
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
+#ifdef TAXOR_PGZ_DEVICE
+                if (dev_) {
+                    const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
+                    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+                    for (size_t p = 0; p < c.out_len; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(c.out_len - p, 1u << 30));
+                    c.crc = crc;
+                } else
+#endif
                 resolve(c);
                 ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
@@ -621,6 +685,21 @@ private:
             Chunk &c = chunks_[i];
             c.state = 1;
             ++busy_;
+#ifdef TAXOR_PGZ_DEVICE
+            if (dev_) {       // only the block start; the decoding is the device's
+                const bool text = text_;
+                lk.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                const uint64_t s = i > 0 ? find_block(map_, map_ + size_, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr) : c.nominal_start;
+                ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                lk.lock();
+                c.found_start = s;
+                --busy_;
+                c.state = 2;
+                cv_done_.notify_all();
+                continue;
+            }
+#endif
             {
                 std::lock_guard<std::mutex> pl(pool_mu_);
                 if (!pool_.empty()) { c.co.sym = std::move(pool_.back()); pool_.pop_back(); }
@@ -753,6 +832,147 @@ private:
         return true;
     }
 
+    bool device_mode() const
+    {
+#ifdef TAXOR_PGZ_DEVICE
+        return dev_ != nullptr;
+#else
+        return false;
+#endif
+    }
+
+#ifdef TAXOR_PGZ_DEVICE
+    // batches of consecutive chunks whose block starts are known -> device -> tied on the host -> resolved on the device -> CRC queue
+    void device_driver()
+    {
+        using namespace pgz_detail;
+        std::vector<taxor_inflate_chunk> req;
+        std::vector<taxor_inflate_result> res;
+        std::vector<uint8_t *> outp;
+        std::vector<uint8_t> win(WIN, 0), win_next(WIN, 0);
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            size_t b0 = 0, k = 0;
+            cv_done_.wait(lk, [&] {
+                if (stop_) return true;
+                b0 = tied_;
+                if (b0 >= n_live_ || b0 >= cur_ + lookahead_) return false;
+                k = std::min(dev_batch_, n_live_ - b0);
+                if (b0 + k > cur_ + lookahead_) k = cur_ + lookahead_ - b0;
+                for (size_t i = 0; i < k; ++i)
+                    if (chunks_[b0 + i].state != 2) {
+                        // a batch need not be full when the stream's first chunks are waited for (the first batch: latency) -- but
+                        // never split at a chunk whose start is still being looked for unless something is ready in front of it
+                        k = i;
+                        break;
+                    }
+                return k >= std::min<size_t>(dev_batch_, n_live_ - b0) || (k > 0 && b0 == cur_);
+            });
+            if (stop_) return;
+            ++busy_;
+            const uint64_t want0 = b0 == 0 ? (uint64_t)member_data_ * 8 : prev_end_;
+            if (b0 == 0) std::fill(win.begin(), win.end(), 0);
+            lk.unlock();
+            std::string err;
+            size_t count = 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            try {
+                // the batch's input: from the byte of the first start (or of where the stream is) to the last chunk's nominal end plus
+                // slack for its last block
+                uint64_t lo_bit = want0;
+                for (size_t i = 0; i < k; ++i)
+                    if (chunks_[b0 + i].found_start != ~0ull) lo_bit = std::min(lo_bit, chunks_[b0 + i].found_start);
+                const uint64_t lo_byte = (lo_bit / 8) & ~3ull;
+                const uint64_t hi_byte = std::min<uint64_t>(size_, chunks_[b0 + k - 1].nominal_stop / 8 + 1 + dev_slack_);
+                const uint64_t base = lo_byte * 8;
+                req.assign(k, taxor_inflate_chunk{0, 0});
+                res.assign(k, taxor_inflate_result{});
+                for (size_t i = 0; i < k; ++i) {
+                    const Chunk &c = chunks_[b0 + i];
+                    if (c.found_start == ~0ull || c.found_start < base) continue;        // no start found: a slot that decodes nothing
+                    req[i].start_bit = c.found_start - base;
+                    req[i].stop_bit = std::max(c.found_start, c.nominal_stop) - base;
+                }
+                if (taxor_gpu_inflate_decode(dev_, map_ + lo_byte, hi_byte - lo_byte, req.data(), (uint32_t)k, res.data()) != TAXOR_OK)
+                    throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+                // tie: every chunk must start where its predecessor ended
+                uint64_t want = want0;
+                for (size_t i = 0; i < k; ++i) {
+                    Chunk &c = chunks_[b0 + i];
+                    const bool usable = c.found_start != ~0ull && c.found_start >= base && res[i].status == 0 && c.found_start == want;
+                    if (usable) {
+                        c.co.start_bit = want;
+                        c.co.end_bit = res[i].end_bit + base;
+                        c.co.final_block = res[i].final_block != 0;
+                        c.co.n = WIN + (size_t)res[i].n_out;
+                        c.co.ok = true;
+                        ++chunks_device;
+                    } else {
+                        ChunkOut co;
+                        if (!decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr))
+                            throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
+                        if (taxor_gpu_inflate_replace(dev_, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) != TAXOR_OK)
+                            throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+                        c.co.start_bit = want;
+                        c.co.end_bit = co.end_bit;
+                        c.co.final_block = co.final_block;
+                        c.co.n = co.n;
+                        c.co.ok = true;
+                        give_back(co.sym);
+                        ++chunks_host_fallback;
+                        if (c.found_start != ~0ull) ++chunks_redecoded;
+                    }
+                    want = c.co.end_bit;
+                    count = i + 1;
+                    if (c.co.final_block) break;
+                }
+                outp.resize(count);
+                for (size_t i = 0; i < count; ++i) {
+                    Chunk &c = chunks_[b0 + i];
+                    const size_t n = c.co.n - WIN;
+                    {
+                        std::lock_guard<std::mutex> pl(pool_mu_);
+                        if (!out_pool_.empty()) {
+                            size_t best = 0;
+                            for (size_t q = 1; q < out_pool_.size(); ++q)
+                                if (out_pool_[q].capacity() > out_pool_[best].capacity()) best = q;
+                            c.out.swap(out_pool_[best]);
+                            out_pool_[best].swap(out_pool_.back());
+                            out_pool_.pop_back();
+                        }
+                    }
+                    if (c.out.capacity() < n) { std::vector<char>().swap(c.out); c.out.reserve(n + n / 8); }
+                    c.out.resize(n);
+                    c.out_len = n;
+                    outp[i] = reinterpret_cast<uint8_t *>(c.out.data());
+                }
+                if (taxor_gpu_inflate_resolve(dev_, win.data(), 0, (uint32_t)count, outp.data(), win_next.data()) != TAXOR_OK)
+                    throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+                win.swap(win_next);
+            } catch (const std::exception &ex) { err = ex.what(); }
+            ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            lk.lock();
+            --busy_;
+            if (!err.empty()) {
+                dev_error_ = err;
+                cv_done_.notify_all();
+                return;
+            }
+            for (size_t i = 0; i < count; ++i) {
+                Chunk &c = chunks_[b0 + i];
+                prev_end_ = c.co.end_bit;
+                ++chunks_total;
+                if (c.co.final_block) n_live_ = b0 + i + 1;
+                c.state = 3;
+                resolve_q_.push_back(b0 + i);
+            }
+            tied_ = b0 + count;
+            cv_work_.notify_all();
+            cv_done_.notify_all();
+        }
+    }
+#endif
+
     // make the next chunk's bytes current; false at the end of the file
     bool next_chunk()
     {
@@ -768,12 +988,14 @@ private:
             cur_out_ = nullptr;
             ++cur_;
             cv_work_.notify_all();
+            if (device_mode()) cv_done_.notify_all();
         }
         for (;;) {
-            while (tied_ < n_live_ && tied_ < cur_ + lookahead_ && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
+            while (!device_mode() && tied_ < n_live_ && tied_ < cur_ + lookahead_ && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
                 if (!tie(lk, tied_)) break;
                 ++tied_;
             }
+            if (!dev_error_.empty()) throw std::runtime_error(dev_error_);
             if (cur_ >= n_live_) {
                 // member complete: trailer (CRC-32, ISIZE) at the next byte boundary behind the final block
                 if (tied_ == 0 || !chunks_[n_live_ - 1].co.final_block) throw std::runtime_error("gzip: stream ends before its final block");
@@ -821,6 +1043,11 @@ private:
     bool text_ = true, stop_ = false;
     std::vector<char> *cur_out_ = nullptr;
     size_t cur_pos_ = 0;
+    std::string dev_error_;
+#ifdef TAXOR_PGZ_DEVICE
+    taxor_gpu_inflater *dev_ = nullptr;
+    size_t dev_batch_ = 512, dev_slack_ = 4u << 20;
+#endif
 };
 
 } // namespace fastx

@@ -3,6 +3,7 @@
 // (include/taxor_gpu.h).  Host work here: argument parsing (:32-80), sanity checks (:97-151), FASTA/FASTQ(.gz)
 // reading (:181-184), batching (:315-326) and output (:268-311, :343).
 #include "../../include/taxor_gpu.h"
+#define TAXOR_PGZ_DEVICE 1      // pgz.h: the chunks of a single-member .gz may be decoded on a GPU (inflate.hip through the C ABI)
 #include "fastx.h"
 #include "tuning.h"
 #include "ixf_arith.h"
@@ -860,17 +861,22 @@ int main(int argc, char **argv)
         // decompresses (to a file, or nowhere) and reports the rate, the output's CRC-32 and how many chunks had to be decoded twice
         std::string in, out_path;
         unsigned threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        size_t chunk = 0;
+        size_t chunk = 0, batch = 0;
+        int gpu = -1;
         for (int i = 2; i < argc; ++i) {
             if (strcmp(argv[i], "--query-file") == 0 && i + 1 < argc) in = argv[++i];
             else if (strcmp(argv[i], "--threads") == 0 && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
             else if (strcmp(argv[i], "--chunk-mb") == 0 && i + 1 < argc) chunk = (size_t)(atof(argv[++i]) * 1048576.0);
+            else if (strcmp(argv[i], "--gpu") == 0 && i + 1 < argc) gpu = atoi(argv[++i]);                 // decode the chunks on this device
+            else if (strcmp(argv[i], "--batch-chunks") == 0 && i + 1 < argc) batch = (size_t)atoi(argv[++i]);
             else if (strcmp(argv[i], "--output-file") == 0 && i + 1 < argc) out_path = argv[++i];
         }
         if (in.empty() || !file_exists(in)) die("usage: taxor inflate --query-file <x.gz> [--threads n] [--chunk-mb m] [--output-file out]");
         fastx::ParallelGz g;
         const double t0 = now();
-        if (!g.open(in, threads, chunk, 0)) die(in + " is not a gzip file");
+        std::string note;
+        if (!g.open(in, threads, chunk, 0, gpu, batch, &note)) die(in + " is not a gzip file");
+        if (!note.empty()) fprintf(stderr, "device decoding not available (%s): decoding on the host\n", note.c_str());
         FILE *of = out_path.empty() ? nullptr : fopen(out_path.c_str(), "wb");
         if (!out_path.empty() && !of) die("cannot write " + out_path);
         std::vector<char> buf;
@@ -890,6 +896,10 @@ int main(int argc, char **argv)
         printf("%llu bytes in %.3f s = %.2f GB/s on %u threads; %llu member(s), %llu chunks, %llu decoded again from a corrected start; CRC-32 and length of every member verified\n",
                (unsigned long long)total, dt, total / 1e9 / dt, threads, (unsigned long long)g.members, (unsigned long long)g.chunks_total, (unsigned long long)g.chunks_redecoded);
         printf("worker seconds: block search %.3f, decode %.3f, marker resolution + CRC %.3f\n", g.ns_find / 1e9, g.ns_decode / 1e9, g.ns_resolve / 1e9);
+        if (gpu >= 0)
+            printf("device: %llu chunks decoded on GPU %d, %llu on the host (no block start found, a start that was none, or more output than the arena's share); "
+                   "%.3f s of the driver thread inside batches (upload, decode, tie, resolve, download)\n",
+                   (unsigned long long)g.chunks_device, gpu, (unsigned long long)g.chunks_host_fallback, g.ns_device / 1e9);
         return 0;
     }
     if (argc > 1 && strcmp(argv[1], "pin") == 0) return pin_command(argc, argv);   // published .hixf + reference TSV -> committed parity fixture
