@@ -503,7 +503,10 @@ int taxor_synth_reads(const char *genomes, const uint64_t *genome_off, uint64_t 
  * symbol into its byte and copies the bytes of chunk first + i to out[i].  Bits are counted from the first byte of `in`.  One
  * caller at a time per inflater. */
 typedef struct taxor_gpu_inflater taxor_gpu_inflater;
-typedef struct taxor_inflate_chunk { uint64_t start_bit, stop_bit; } taxor_inflate_chunk;
+typedef struct taxor_inflate_chunk {
+    uint64_t start_bit, stop_bit; /* start == stop: nothing to decode (the host will put the chunk's symbols in place) */
+    uint64_t weight;              /* compressed bits the chunk stands for: the arena is shared out by it */
+} taxor_inflate_chunk;
 typedef struct taxor_inflate_result {
     uint64_t end_bit;     /* the block boundary the chunk ended at (>= stop_bit), or the end of the member's final block */
     uint64_t n_out;       /* symbols = bytes of output */

@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--tmp", default="/dev/shm/taxor_gz")
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--inflate-args", default="", help='extra arguments of `taxor inflate`, e.g. "--gpu 0 --batch-chunks 1024"')
     a = ap.parse_args()
     os.makedirs(a.tmp, exist_ok=True)
     plain, gz = os.path.join(a.tmp, "reads.fastq"), os.path.join(a.tmp, "reads.fastq.gz")
@@ -116,7 +117,7 @@ def main():
     out = os.path.join(a.tmp, "inflated.fastq")
     first = True
     for th in [int(x) for x in a.threads.split(",")]:
-        cmd = [TAXOR, "inflate", "--query-file", gz, "--threads", str(th)] + (["--output-file", out] if first else [])
+        cmd = [TAXOR, "inflate", "--query-file", gz, "--threads", str(th)] + a.inflate_args.split() + (["--output-file", out] if first else [])
         cp = subprocess.run(cmd, capture_output=True, text=True)
         print(f"taxor inflate --threads {th}{' (written to tmpfs)' if first else ''}: " + cp.stdout.strip().replace("\n", " | "), cp.stderr.strip()[-300:], flush=True)
         if first:

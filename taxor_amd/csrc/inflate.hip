@@ -529,12 +529,13 @@ extern "C" int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in
     uint64_t total_in = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (chunks[i].stop_bit < chunks[i].start_bit || chunks[i].start_bit > in_bytes * 8) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode: chunk %u lies outside the input", i);
-        total_in += chunks[i].stop_bit - chunks[i].start_bit + 8;
+        total_in += chunks[i].weight + 8;
     }
-    const uint64_t spare = h->sym_cap - (uint64_t)n * (WIN + 256);
+    // (an eighth stays free behind the last chunk: where taxor_gpu_inflate_replace puts a chunk that outgrew its share)
+    const uint64_t spare = (h->sym_cap - (uint64_t)n * (WIN + 256)) / 8 * 7;
     uint64_t off = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t share = (uint64_t)((double)(chunks[i].stop_bit - chunks[i].start_bit + 8) / (double)total_in * (double)spare);
+        const uint64_t share = (uint64_t)((double)(chunks[i].weight + 8) / (double)total_in * (double)spare);
         h->chunks[i].start_bit = chunks[i].start_bit;
         h->chunks[i].stop_bit = chunks[i].stop_bit;
         h->chunks[i].sym_off = off;

@@ -780,6 +780,22 @@ private:
         c.crc = crc;
     }
 
+    // the window of the next chunk: the last WIN bytes of (window ++ this chunk), markers resolved
+    static void next_window_of(const std::vector<uint8_t> &window, const ChunkOut &co, std::vector<uint8_t> &nw)
+    {
+        using namespace pgz_detail;
+        const size_t n = co.n - WIN;
+        nw.resize(WIN);
+        for (size_t k = 0; k < WIN; ++k) {
+            const size_t pos = n + k;                          // index into (window ++ chunk), counted from the start of the window
+            if (pos < WIN) nw[k] = window[pos];
+            else {
+                const uint16_t v = co.sym[pos];
+                nw[k] = v < 256 ? (uint8_t)v : window[v - 256];
+            }
+        }
+    }
+
     // tie chunk i to its predecessor (mu_ held on entry and exit; released while a chunk is decoded again): its start must be the
     // predecessor's end.  Sets its window, computes the next one, queues the resolution.  Returns false if chunk i is not decoded yet.
     bool tie(std::unique_lock<std::mutex> &lk, size_t i)
@@ -808,20 +824,8 @@ private:
             text_ = text;
         } else
             c.window = next_window_;
-        // the window of the next chunk: the last WIN bytes of (window ++ this chunk), markers resolved
-        const size_t n = c.co.n - WIN;
-        std::vector<uint8_t> nw(WIN);
-        for (size_t k = 0; k < WIN; ++k) {
-            const size_t pos = n + k;                          // index into (window ++ chunk), counted from the start of the window
-            if (pos < WIN + n && pos >= WIN) {
-                const uint16_t v = c.co.sym[pos];
-                nw[k] = v < 256 ? (uint8_t)v : c.window[v - 256];
-            }
-        }
-        for (size_t k = 0; k < WIN; ++k) {
-            const size_t pos = n + k;
-            if (pos < WIN) nw[k] = c.window[pos];
-        }
+        std::vector<uint8_t> nw;
+        next_window_of(c.window, c.co, nw);
         next_window_.swap(nw);
         prev_end_ = c.co.end_bit;
         ++chunks_total;
@@ -885,10 +889,11 @@ private:
                 const uint64_t lo_byte = (lo_bit / 8) & ~3ull;
                 const uint64_t hi_byte = std::min<uint64_t>(size_, chunks_[b0 + k - 1].nominal_stop / 8 + 1 + dev_slack_);
                 const uint64_t base = lo_byte * 8;
-                req.assign(k, taxor_inflate_chunk{0, 0});
+                req.assign(k, taxor_inflate_chunk{0, 0, 0});
                 res.assign(k, taxor_inflate_result{});
                 for (size_t i = 0; i < k; ++i) {
                     const Chunk &c = chunks_[b0 + i];
+                    req[i].weight = c.nominal_stop - c.nominal_start;
                     if (c.found_start == ~0ull || c.found_start < base) continue;        // no start found: a slot that decodes nothing
                     req[i].start_bit = c.found_start - base;
                     req[i].stop_bit = std::max(c.found_start, c.nominal_stop) - base;
@@ -911,14 +916,16 @@ private:
                         ChunkOut co;
                         if (!decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr))
                             throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
-                        if (taxor_gpu_inflate_replace(dev_, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) != TAXOR_OK)
-                            throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+                        // its symbols go where the device's would be -- or, if the arena has no room for them (a chunk of zeros is a
+                        // thousand times its size), stay here and are resolved here, between two device runs
+                        const bool on_dev = taxor_gpu_inflate_replace(dev_, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) == TAXOR_OK;
                         c.co.start_bit = want;
                         c.co.end_bit = co.end_bit;
                         c.co.final_block = co.final_block;
                         c.co.n = co.n;
                         c.co.ok = true;
-                        give_back(co.sym);
+                        if (on_dev) give_back(co.sym);
+                        else { c.co.sym = std::move(co.sym); c.found_start = ~1ull; }         // (~1: resolved on the host)
                         ++chunks_host_fallback;
                         if (c.found_start != ~0ull) ++chunks_redecoded;
                     }
@@ -929,6 +936,7 @@ private:
                 outp.resize(count);
                 for (size_t i = 0; i < count; ++i) {
                     Chunk &c = chunks_[b0 + i];
+                    if (c.found_start == ~1ull) continue;              // resolved on the host below: resolve() makes its buffer
                     const size_t n = c.co.n - WIN;
                     {
                         std::lock_guard<std::mutex> pl(pool_mu_);
@@ -946,9 +954,23 @@ private:
                     c.out_len = n;
                     outp[i] = reinterpret_cast<uint8_t *>(c.out.data());
                 }
-                if (taxor_gpu_inflate_resolve(dev_, win.data(), 0, (uint32_t)count, outp.data(), win_next.data()) != TAXOR_OK)
-                    throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
-                win.swap(win_next);
+                for (size_t i = 0; i < count;) {
+                    if (chunks_[b0 + i].found_start == ~1ull) {
+                        Chunk &c = chunks_[b0 + i];
+                        c.window = win;
+                        next_window_of(c.window, c.co, win_next);
+                        resolve(c);                                   // (bytes + CRC; the CRC queue computes it once more: rare)
+                        win.swap(win_next);
+                        ++i;
+                        continue;
+                    }
+                    size_t j = i;
+                    while (j < count && chunks_[b0 + j].found_start != ~1ull) ++j;
+                    if (taxor_gpu_inflate_resolve(dev_, win.data(), (uint32_t)i, (uint32_t)(j - i), outp.data() + i, win_next.data()) != TAXOR_OK)
+                        throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+                    win.swap(win_next);
+                    i = j;
+                }
             } catch (const std::exception &ex) { err = ex.what(); }
             ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             lk.lock();
