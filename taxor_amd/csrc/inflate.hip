@@ -14,9 +14,11 @@
 // Second kernel pair: the windows are chained from chunk to chunk (one block, chunk after chunk -- 32 Ki symbols each), then every
 // symbol of every chunk is resolved to its byte in parallel.
 #include "../../include/taxor_gpu.h"
+#include "tuning.h"
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -56,23 +58,41 @@ enum : uint32_t { ST_OK = 0, ST_INVALID = 2, ST_OVERFLOW = 3, ST_INPUT_END = 4 }
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-__device__ __constant__ uint16_t c_lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__device__ __constant__ uint8_t c_lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__device__ __constant__ uint16_t c_dbase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__device__ __constant__ uint8_t c_dext[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __device__ __constant__ uint8_t c_clord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-// the input as 32-bit words (the buffer is 4-byte aligned and followed by zero padding); wave-uniform
+// the input as 32-bit words (the buffer is 16-byte aligned and followed by zero padding); wave-uniform.  The words come through a
+// window of IN_WORDS words in LDS that all lanes fill together (eight words each, one coalesced read of 2 KB): a word fetched from
+// memory by itself costs the wave a memory round trip for every four or five symbols
+constexpr uint32_t IN_WORDS = 512;
 struct Bits {
     const uint32_t *w;
-    uint64_t n_words;      // words that hold input; beyond them zeros are read
+    uint32_t *ring;        // LDS, IN_WORDS words
+    uint64_t n_words;      // words that hold input (a multiple of 4, the padding included); beyond them zeros are read
+    uint64_t ring_base, ring_end;
     uint64_t wp;           // next word to take
     uint64_t bb;
     int bc;
     uint32_t ahead;        // word wp, loaded ahead of its use
-    __device__ __forceinline__ uint32_t word(uint64_t i) const { return i < n_words ? uni(w[i]) : 0u; }
+    __device__ __forceinline__ uint32_t word(uint64_t i)
+    {
+        if (i >= n_words) return 0u;
+        if (i < ring_base || i >= ring_end) {
+            ring_base = i & ~3ull;
+            ring_end = ring_base + IN_WORDS < n_words ? ring_base + IN_WORDS : n_words;
+            const uint64_t mine = ring_base + threadIdx.x * 8u;
+            uint4 a = make_uint4(0, 0, 0, 0), b = a;
+            if (mine < n_words) a = *reinterpret_cast<const uint4 *>(w + mine);
+            if (mine + 4 < n_words) b = *reinterpret_cast<const uint4 *>(w + mine + 4);
+            __builtin_amdgcn_wave_barrier();
+            *reinterpret_cast<uint4 *>(ring + threadIdx.x * 8u) = a;
+            *reinterpret_cast<uint4 *>(ring + threadIdx.x * 8u + 4) = b;
+            __builtin_amdgcn_wave_barrier();
+        }
+        return uni(ring[i - ring_base]);
+    }
     __device__ __forceinline__ void seek(uint64_t bit)
     {
+        ring_base = ring_end = 0;
         wp = bit >> 5;
         bb = 0;
         bc = 0;
@@ -205,6 +225,7 @@ struct WaveLds {
     Code<7, 19> cl;
     uint8_t lens[32 + 320];
     uint16_t scratch[2 * 288];
+    __attribute__((aligned(16))) uint32_t in_ring[IN_WORDS];
 };
 
 // One wave per chunk: blocks from start_bit on until a block boundary at or behind stop_bit, or the member's final block
@@ -226,7 +247,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
     const uint64_t size_bits = in_bytes * 8;
     Bits B;
     B.w = in;
-    B.n_words = (in_bytes + 3) / 4;
+    B.ring = S.in_ring;
+    B.n_words = ((in_bytes + 15) / 16) * 4;          // (whole 16-byte pieces: the buffer is padded with zeros beyond in_bytes)
     B.seek(C.start_bit);
     uint32_t status = ST_OK, final_block = 0;
     uint64_t end_bit = C.start_bit;
@@ -236,6 +258,19 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
             if (lane < pend) out[n + lane] = (uint16_t)lit_buf;
             n += pend;
             pend = 0;
+        }
+    };
+    // A match of up to 64 symbols is not stored when it is decoded: its sources are loaded (one per lane), the wave goes on
+    // decoding, and the values are stored when the NEXT match has issued its loads -- a load from the 64 KB behind the write
+    // position is a memory round trip of a microsecond, and in sequence data nearly every symbol belongs to a short match
+    // (any six letters of four have occurred in the last 32 KiB).  A match whose source reaches into the pending one's
+    // destination makes it land first.
+    uint32_t p_len = 0, p_val = 0;
+    uint64_t p_dst = 0;
+    auto commit = [&]() {
+        if (p_len) {
+            if (lane < p_len) out[p_dst + lane] = (uint16_t)p_val;
+            p_len = 0;
         }
     };
 
@@ -261,6 +296,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
             const uint64_t src = B.bitpos() >> 3;
             if (src + len > in_bytes) { status = ST_INPUT_END; break; }
             flush();
+            commit();
             if (n + len > cap) { status = ST_OVERFLOW; break; }
             const uint8_t *sb = reinterpret_cast<const uint8_t *>(in) + src;
             for (uint32_t i = lane; i < len; i += 64) out[n + i] = sb[i];
@@ -360,8 +396,10 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                 s -= 257;
                 if (s >= 29) { status = ST_INVALID; break; }
                 B.refill();
-                const uint32_t len = c_lbase[s] + B.peek(c_lext[s]);
-                B.drop(c_lext[s]);
+                // (RFC 1951's length and distance tables, computed: a table in memory is a scalar load's latency per look)
+                const int lx = s < 8 || s == 28 ? 0 : (int)((s - 4) >> 2);
+                const uint32_t len = (s == 28 ? 258u : s < 8 ? 3u + s : 3u + ((4u + (s & 3u)) << lx)) + B.peek(lx);
+                B.drop(lx);
                 const uint32_t de = decode_sym(S.dist, B.bb);
                 const int dl = (int)(de & 0xFF);
                 if (!dl) { status = ST_INVALID; break; }
@@ -369,15 +407,28 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                 const uint32_t ds = de >> 8;
                 if (ds >= 30) { status = ST_INVALID; break; }
                 B.refill();
-                const uint32_t d = c_dbase[ds] + B.peek(c_dext[ds]);
-                B.drop(c_dext[ds]);
+                const int dx = ds < 4 ? 0 : (int)((ds - 2) >> 1);
+                const uint32_t d = (ds < 4 ? 1u + ds : 1u + ((2u + (ds & 1u)) << dx)) + B.peek(dx);
+                B.drop(dx);
                 flush();
                 if (d > n) { status = ST_INVALID; break; }
                 if (n + len > cap) { status = ST_OVERFLOW; break; }
                 if (B.bitpos() > size_bits) { status = ST_INPUT_END; break; }
                 // out[n + i] = out[n - d + (i mod d)]: every source lies in what is written already, so the lanes copy side by side
-                const uint16_t *srcp = out + (n - d);
-                for (uint32_t i = lane; i < len; i += 64) out[n + i] = srcp[d >= len ? i : i % d];
+                const uint64_t src0 = n - d, src1 = src0 + (d < len ? d : len);
+                if (p_len && src0 < p_dst + p_len && src1 > p_dst) commit();
+                const uint16_t *srcp = out + src0;
+                if (len <= 64) {
+                    uint32_t v = 0;
+                    if (lane < len) v = srcp[d >= len ? lane : lane % d];
+                    commit();                                     // (the previous match: its loads are long back)
+                    p_val = v;
+                    p_dst = n;
+                    p_len = len;
+                } else {
+                    commit();
+                    for (uint32_t i = lane; i < len; i += 64) out[n + i] = srcp[d >= len ? i : i % d];
+                }
                 n += len;
             }
             if (status != ST_OK) break;
@@ -386,6 +437,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
         if (bfinal) { final_block = 1; end_bit = B.bitpos(); break; }
     }
     if (status == ST_OK) {
+        commit();
         if (n + pend > cap) status = ST_OVERFLOW;
         else flush();
     }
@@ -542,13 +594,25 @@ extern "C" int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in
         h->chunks[i].sym_cap = (WIN + 128 + share) & ~3ull;
         off += h->chunks[i].sym_cap;
     }
+    static const bool trace = taxor::tune_env("TAXOR_INFLATE_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(h->d_in, in, in_bytes, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemsetAsync(h->d_in + in_bytes, 0, h->in_cap - in_bytes, h->st));
     HIP_TRY(hipMemcpyAsync(h->d_chunks, h->chunks.data(), sizeof(ChunkIn) * n, hipMemcpyHostToDevice, h->st));
+    if (trace) HIP_TRY(hipStreamSynchronize(h->st));
+    const auto t1 = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, h->st, reinterpret_cast<const uint32_t *>(h->d_in), in_bytes, h->d_chunks, h->d_res, h->d_sym, n);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->res.data(), h->d_res, sizeof(ChunkRes) * n, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
+    if (trace) {
+        const auto t2 = std::chrono::steady_clock::now();
+        uint64_t syms = 0;
+        for (uint32_t i = 0; i < n; ++i) syms += h->res[i].n_sym - WIN;
+        fprintf(stderr, "[inflate] batch of %u chunks, %.1f MB in: upload %.1f ms, k_inflate %.1f ms for %.1f M symbols = %.2f G symbols/s\n", n, in_bytes / 1e6,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), syms / 1e6,
+                syms / 1e9 / std::chrono::duration<double>(t2 - t1).count());
+    }
     for (uint32_t i = 0; i < n; ++i) {
         results[i].end_bit = h->res[i].end_bit;
         results[i].n_out = h->res[i].n_sym - WIN;
@@ -597,18 +661,25 @@ extern "C" int taxor_gpu_inflate_resolve(taxor_gpu_inflater *h, const uint8_t *w
         boff[i + 1] = boff[i] + ((h->res[first + i].n_sym - WIN + 7) & ~7ull);
     }
     if (boff[count] > h->out_cap) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_resolve: output larger than the inflater's buffer");
+    static const bool trace = taxor::tune_env("TAXOR_INFLATE_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(h->d_win, window_in, WIN, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemcpyAsync(h->d_boff, boff.data(), sizeof(uint64_t) * (count + 1), hipMemcpyHostToDevice, h->st));
     hipLaunchKernelGGL(k_chain_windows, dim3(1), dim3(1024), 0, h->st, h->d_chunks, h->d_res, h->d_sym, h->d_win, first, count);
     const uint32_t bpc = 32;
     hipLaunchKernelGGL(k_resolve, dim3(count * bpc), dim3(256), 0, h->st, h->d_chunks, h->d_res, h->d_sym, h->d_win, h->d_boff, h->d_out, first, count, bpc);
     HIP_TRY(hipGetLastError());
+    if (trace) HIP_TRY(hipStreamSynchronize(h->st));
+    const auto t1 = std::chrono::steady_clock::now();
     for (uint32_t i = 0; i < count; ++i) {
         const uint64_t nb = h->res[first + i].n_sym - WIN;
         if (nb) HIP_TRY(hipMemcpyAsync(out[i], h->d_out + boff[i], nb, hipMemcpyDeviceToHost, h->st));
     }
     if (window_out) HIP_TRY(hipMemcpyAsync(window_out, h->d_win + (size_t)count * WIN, WIN, hipMemcpyDeviceToHost, h->st));
     HIP_TRY(hipStreamSynchronize(h->st));
+    if (trace)
+        fprintf(stderr, "[inflate] %u chunks resolved: windows + symbols %.1f ms, %.1f MB to the host %.1f ms\n", count,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), boff[count] / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     return TAXOR_OK;
 }
 

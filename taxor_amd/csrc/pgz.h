@@ -38,6 +38,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -477,7 +478,8 @@ public:
     {
         shutdown();
 #ifdef TAXOR_PGZ_DEVICE
-        if (dev_) taxor_gpu_inflater_destroy(dev_);
+        for (auto *d : dev_)
+            if (d) taxor_gpu_inflater_destroy(d);
 #endif
         if (map_) munmap(const_cast<uint8_t *>(map_), size_);
     }
@@ -529,13 +531,18 @@ private:
         dev_slack_ = std::max<size_t>(chunk_bytes_, 1u << 20);
         const uint64_t in_cap = (uint64_t)dev_batch_ * chunk_bytes_ + dev_slack_ + 64;
         const uint64_t syms = (uint64_t)dev_batch_ * ((uint64_t)(ratio_cap * (double)chunk_bytes_) + pgz_detail::WIN + 256) + (uint64_t)(ratio_cap * (double)chunk_bytes_) * 2;
-        if (taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_) != TAXOR_OK) {
+        if (taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_[0]) != TAXOR_OK) {
             if (why) *why = taxor_gpu_last_error();
-            dev_ = nullptr;
+            dev_[0] = nullptr;
             return false;
         }
-        lookahead_ = std::max(lookahead_, 2 * dev_batch_ + 2);
-        th_.emplace_back([this] { device_driver(); });
+        n_dev_ = 1;
+        // a second one, so that a batch is decoded while its predecessor is tied and resolved (without it: one after the other)
+        if (n_total > dev_batch_ && taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_[1]) == TAXOR_OK) n_dev_ = 2;
+        else dev_[1] = nullptr;
+        lookahead_ = std::max(lookahead_, (size_t)(n_dev_ + 1) * dev_batch_ + 2);
+        th_.emplace_back([this] { device_decoder(); });
+        th_.emplace_back([this] { device_tier(); });
         return true;
     }
 public:
@@ -630,6 +637,12 @@ private:
             chunks_.back().nominal_stop = std::min(endb, b + (uint64_t)chunk_bytes_ * 8);
         }
         next_decode_ = 0;
+#ifdef TAXOR_PGZ_DEVICE
+        dec_next_ = 0;
+        for (auto &q : dev_q_) slot_free_[q->slot] = true;
+        dev_q_.clear();
+        ++member_gen_;
+#endif
         tied_ = 0;
         cur_ = 0;
         n_live_ = chunks_.size();
@@ -666,7 +679,7 @@ private:
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
 #ifdef TAXOR_PGZ_DEVICE
-                if (dev_) {
+                if (dev_[0]) {
                     const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
                     uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
                     for (size_t p = 0; p < c.out_len; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(c.out_len - p, 1u << 30));
@@ -686,7 +699,7 @@ private:
             c.state = 1;
             ++busy_;
 #ifdef TAXOR_PGZ_DEVICE
-            if (dev_) {       // only the block start; the decoding is the device's
+            if (dev_[0]) {       // only the block start; the decoding is the device's
                 const bool text = text_;
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
@@ -839,67 +852,108 @@ private:
     bool device_mode() const
     {
 #ifdef TAXOR_PGZ_DEVICE
-        return dev_ != nullptr;
+        return dev_[0] != nullptr;
 #else
         return false;
 #endif
     }
 
 #ifdef TAXOR_PGZ_DEVICE
-    // batches of consecutive chunks whose block starts are known -> device -> tied on the host -> resolved on the device -> CRC queue
-    void device_driver()
-    {
-        using namespace pgz_detail;
+    // Two stages, so that the device decodes one batch while the previous one is tied, resolved, copied out and CRC-checked:
+    //   device_decoder : consecutive chunks whose block starts are known -> upload + one wave per chunk -> queue (two inflaters taken in turn)
+    //   device_tier    : in order: every chunk must start where its predecessor ended (else: decoded here, its symbols put in the
+    //                    device's place) -> windows chained and symbols resolved on the device -> bytes to the host -> CRC queue
+    struct DevBatch {
+        size_t b0 = 0, k = 0;
+        uint64_t base = 0, gen = 0;
+        int slot = 0;
         std::vector<taxor_inflate_chunk> req;
         std::vector<taxor_inflate_result> res;
-        std::vector<uint8_t *> outp;
-        std::vector<uint8_t> win(WIN, 0), win_next(WIN, 0);
+        std::string err;
+    };
+
+    void device_decoder()
+    {
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
             size_t b0 = 0, k = 0;
+            int slot = -1;
             cv_done_.wait(lk, [&] {
-                if (stop_) return true;
-                b0 = tied_;
+                if (stop_ || !dev_error_.empty()) return true;
+                slot = -1;
+                for (int q = 0; q < n_dev_; ++q)
+                    if (slot_free_[(dev_turn_ + q) % n_dev_]) { slot = (dev_turn_ + q) % n_dev_; break; }
+                if (slot < 0) return false;
+                b0 = dec_next_;
                 if (b0 >= n_live_ || b0 >= cur_ + lookahead_) return false;
                 k = std::min(dev_batch_, n_live_ - b0);
                 if (b0 + k > cur_ + lookahead_) k = cur_ + lookahead_ - b0;
                 for (size_t i = 0; i < k; ++i)
-                    if (chunks_[b0 + i].state != 2) {
-                        // a batch need not be full when the stream's first chunks are waited for (the first batch: latency) -- but
-                        // never split at a chunk whose start is still being looked for unless something is ready in front of it
-                        k = i;
-                        break;
-                    }
-                return k >= std::min<size_t>(dev_batch_, n_live_ - b0) || (k > 0 && b0 == cur_);
+                    if (chunks_[b0 + i].state != 2) { k = i; break; }     // (a batch is a launch: never a partial one while more is coming)
+                return k > 0 && k >= std::min<size_t>({dev_batch_, n_live_ - b0, cur_ + lookahead_ - b0});
             });
+            if (stop_ || !dev_error_.empty()) return;
+            std::unique_ptr<DevBatch> B(new DevBatch);
+            B->b0 = b0;
+            B->k = k;
+            B->slot = slot;
+            B->gen = member_gen_;
+            slot_free_[slot] = false;
+            dev_turn_ = (slot + 1) % n_dev_;
+            dec_next_ = b0 + k;
+            ++busy_;
+            // the batch's input: from the byte of the first start to the last chunk's nominal end plus slack for its last block
+            uint64_t lo_bit = chunks_[b0].nominal_start;
+            for (size_t i = 0; i < k; ++i)
+                if (chunks_[b0 + i].found_start != ~0ull) lo_bit = std::min(lo_bit, chunks_[b0 + i].found_start);
+            const uint64_t lo_byte = (lo_bit / 8) & ~3ull;
+            const uint64_t hi_byte = std::min<uint64_t>(size_, chunks_[b0 + k - 1].nominal_stop / 8 + 1 + dev_slack_);
+            B->base = lo_byte * 8;
+            B->req.assign(k, taxor_inflate_chunk{0, 0, 0});
+            B->res.assign(k, taxor_inflate_result{});
+            for (size_t i = 0; i < k; ++i) {
+                const Chunk &c = chunks_[b0 + i];
+                B->req[i].weight = c.nominal_stop - c.nominal_start;
+                if (c.found_start == ~0ull || c.found_start < B->base) continue;        // no start found: a slot that decodes nothing
+                B->req[i].start_bit = c.found_start - B->base;
+                B->req[i].stop_bit = std::max(c.found_start, c.nominal_stop) - B->base;
+            }
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (taxor_gpu_inflate_decode(dev_[slot], map_ + lo_byte, hi_byte - lo_byte, B->req.data(), (uint32_t)k, B->res.data()) != TAXOR_OK)
+                B->err = std::string("gzip on the device: ") + taxor_gpu_last_error();
+            ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            lk.lock();
+            --busy_;
+            if (B->gen != member_gen_) slot_free_[slot] = true;        // the member ended in front of this batch: nobody wants it
+            else dev_q_.push_back(std::move(B));
+            cv_done_.notify_all();
+        }
+    }
+
+    void device_tier()
+    {
+        using namespace pgz_detail;
+        std::vector<uint8_t *> outp;
+        std::vector<uint8_t> win(WIN, 0), win_next(WIN, 0);
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_done_.wait(lk, [&] { return stop_ || !dev_q_.empty(); });
             if (stop_) return;
+            std::unique_ptr<DevBatch> B = std::move(dev_q_.front());
+            dev_q_.pop_front();
+            const size_t b0 = B->b0, k = B->k;
+            taxor_gpu_inflater *dev = dev_[B->slot];
             ++busy_;
             const uint64_t want0 = b0 == 0 ? (uint64_t)member_data_ * 8 : prev_end_;
             if (b0 == 0) std::fill(win.begin(), win.end(), 0);
             lk.unlock();
-            std::string err;
+            std::string err = B->err;
             size_t count = 0;
             const auto t0 = std::chrono::steady_clock::now();
-            try {
-                // the batch's input: from the byte of the first start (or of where the stream is) to the last chunk's nominal end plus
-                // slack for its last block
-                uint64_t lo_bit = want0;
-                for (size_t i = 0; i < k; ++i)
-                    if (chunks_[b0 + i].found_start != ~0ull) lo_bit = std::min(lo_bit, chunks_[b0 + i].found_start);
-                const uint64_t lo_byte = (lo_bit / 8) & ~3ull;
-                const uint64_t hi_byte = std::min<uint64_t>(size_, chunks_[b0 + k - 1].nominal_stop / 8 + 1 + dev_slack_);
-                const uint64_t base = lo_byte * 8;
-                req.assign(k, taxor_inflate_chunk{0, 0, 0});
-                res.assign(k, taxor_inflate_result{});
-                for (size_t i = 0; i < k; ++i) {
-                    const Chunk &c = chunks_[b0 + i];
-                    req[i].weight = c.nominal_stop - c.nominal_start;
-                    if (c.found_start == ~0ull || c.found_start < base) continue;        // no start found: a slot that decodes nothing
-                    req[i].start_bit = c.found_start - base;
-                    req[i].stop_bit = std::max(c.found_start, c.nominal_stop) - base;
-                }
-                if (taxor_gpu_inflate_decode(dev_, map_ + lo_byte, hi_byte - lo_byte, req.data(), (uint32_t)k, res.data()) != TAXOR_OK)
-                    throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
+            if (err.empty()) try {
+                const uint64_t base = B->base;
+                const std::vector<taxor_inflate_result> &res = B->res;
                 // tie: every chunk must start where its predecessor ended
                 uint64_t want = want0;
                 for (size_t i = 0; i < k; ++i) {
@@ -917,8 +971,11 @@ private:
                         if (!decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr))
                             throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
                         // its symbols go where the device's would be -- or, if the arena has no room for them (a chunk of zeros is a
-                        // thousand times its size), stay here and are resolved here, between two device runs
-                        const bool on_dev = taxor_gpu_inflate_replace(dev_, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) == TAXOR_OK;
+                        // thousand times its size) or the stream ran back behind the batch's input, stay here and are resolved here,
+                        // between two device runs
+                        const bool on_dev = co.end_bit >= base &&
+                                            taxor_gpu_inflate_replace(dev, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) == TAXOR_OK;
+                        if (c.found_start != ~0ull) ++chunks_redecoded;
                         c.co.start_bit = want;
                         c.co.end_bit = co.end_bit;
                         c.co.final_block = co.final_block;
@@ -927,7 +984,6 @@ private:
                         if (on_dev) give_back(co.sym);
                         else { c.co.sym = std::move(co.sym); c.found_start = ~1ull; }         // (~1: resolved on the host)
                         ++chunks_host_fallback;
-                        if (c.found_start != ~0ull) ++chunks_redecoded;
                     }
                     want = c.co.end_bit;
                     count = i + 1;
@@ -966,7 +1022,7 @@ private:
                     }
                     size_t j = i;
                     while (j < count && chunks_[b0 + j].found_start != ~1ull) ++j;
-                    if (taxor_gpu_inflate_resolve(dev_, win.data(), (uint32_t)i, (uint32_t)(j - i), outp.data() + i, win_next.data()) != TAXOR_OK)
+                    if (taxor_gpu_inflate_resolve(dev, win.data(), (uint32_t)i, (uint32_t)(j - i), outp.data() + i, win_next.data()) != TAXOR_OK)
                         throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
                     win.swap(win_next);
                     i = j;
@@ -975,6 +1031,7 @@ private:
             ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             lk.lock();
             --busy_;
+            slot_free_[B->slot] = true;
             if (!err.empty()) {
                 dev_error_ = err;
                 cv_done_.notify_all();
@@ -989,6 +1046,11 @@ private:
                 resolve_q_.push_back(b0 + i);
             }
             tied_ = b0 + count;
+            if (count < k) {                                           // the member ended inside this batch: what was decoded beyond is nobody's
+                for (auto &q : dev_q_) slot_free_[q->slot] = true;
+                dev_q_.clear();
+                ++member_gen_;
+            }
             cv_work_.notify_all();
             cv_done_.notify_all();
         }
@@ -1067,8 +1129,12 @@ private:
     size_t cur_pos_ = 0;
     std::string dev_error_;
 #ifdef TAXOR_PGZ_DEVICE
-    taxor_gpu_inflater *dev_ = nullptr;
-    size_t dev_batch_ = 512, dev_slack_ = 4u << 20;
+    taxor_gpu_inflater *dev_[2] = {nullptr, nullptr};
+    int n_dev_ = 0, dev_turn_ = 0;
+    bool slot_free_[2] = {true, true};
+    size_t dev_batch_ = 512, dev_slack_ = 4u << 20, dec_next_ = 0;
+    uint64_t member_gen_ = 0;
+    std::deque<std::unique_ptr<DevBatch>> dev_q_;
 #endif
 };
 
