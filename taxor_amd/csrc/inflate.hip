@@ -57,6 +57,11 @@ struct ChunkRes { uint64_t end_bit; uint64_t n_sym; uint32_t status, final_block
 enum : uint32_t { ST_OK = 0, ST_INVALID = 2, ST_OVERFLOW = 3, ST_INPUT_END = 4 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// Behind every statement that only some lanes execute.  The compiler's uniformity analysis marks the values merged at the join of a
+// lane-dependent branch as divergent, and a one-armed `if` joins in whatever block follows it -- often a loop latch where the
+// decoder's whole state is merged, which then leaves the scalar registers for good.  The (empty) wave barrier gives the `if` a join
+// block of its own.
+#define LANES_DONE __builtin_amdgcn_wave_barrier()
 
 __device__ __constant__ uint8_t c_clord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
@@ -64,6 +69,21 @@ __device__ __constant__ uint8_t c_clord[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5,
 // window of IN_WORDS words in LDS that all lanes fill together (eight words each, one coalesced read of 2 KB): a word fetched from
 // memory by itself costs the wave a memory round trip for every four or five symbols
 constexpr uint32_t IN_WORDS = 512;
+__shared__ __attribute__((aligned(16))) uint32_t s_in_ring[IN_WORDS];
+// (out of line, and with nothing but values for arguments: the decoder's loops are a few hundred instructions that many waves run
+// at different places -- what is rare must not sit in between -- and its state must stay in scalar registers, which a reference
+// handed to a function would end)
+__device__ __noinline__ void fill_ring(const uint32_t *w, uint64_t ring_base, uint64_t n_words)
+{
+    const uint64_t mine = ring_base + threadIdx.x * 8u;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (mine < n_words) a = *reinterpret_cast<const uint4 *>(w + mine);
+    if (mine + 4 < n_words) b = *reinterpret_cast<const uint4 *>(w + mine + 4);
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<uint4 *>(s_in_ring + threadIdx.x * 8u) = a;
+    *reinterpret_cast<uint4 *>(s_in_ring + threadIdx.x * 8u + 4) = b;
+    __builtin_amdgcn_wave_barrier();
+}
 struct Bits {
     const uint32_t *w;
     uint32_t *ring;        // LDS, IN_WORDS words
@@ -79,14 +99,7 @@ struct Bits {
         if (i < ring_base || i >= ring_end) {
             ring_base = i & ~3ull;
             ring_end = ring_base + IN_WORDS < n_words ? ring_base + IN_WORDS : n_words;
-            const uint64_t mine = ring_base + threadIdx.x * 8u;
-            uint4 a = make_uint4(0, 0, 0, 0), b = a;
-            if (mine < n_words) a = *reinterpret_cast<const uint4 *>(w + mine);
-            if (mine + 4 < n_words) b = *reinterpret_cast<const uint4 *>(w + mine + 4);
-            __builtin_amdgcn_wave_barrier();
-            *reinterpret_cast<uint4 *>(ring + threadIdx.x * 8u) = a;
-            *reinterpret_cast<uint4 *>(ring + threadIdx.x * 8u + 4) = b;
-            __builtin_amdgcn_wave_barrier();
+            fill_ring(w, ring_base, n_words);
         }
         return uni(ring[i - ring_base]);
     }
@@ -130,7 +143,7 @@ template <int PB, int MAXSYM> struct Code {
 
 // lens[0..n) in LDS -> the code; wave-uniform control flow, the table filled by all lanes.  Returns 0 complete, 1 the legal
 // incomplete cases (one code of one bit, or no code at all), -1 invalid -- as the host decoder's Huff::build (pgz.h).
-template <int PB, int MAXSYM> __device__ int build_code(Code<PB, MAXSYM> &c, const uint8_t *lens, int n, uint16_t *scratch /* 2 * MAXSYM */)
+template <int PB, int MAXSYM> __device__ __noinline__ int build_code(Code<PB, MAXSYM> &c, const uint8_t *lens, int n, uint16_t *scratch /* 2 * MAXSYM */)
 {
     const uint32_t lane = threadIdx.x;
     if (lane < 16) c.count[lane] = 0;
@@ -198,19 +211,16 @@ template <int PB, int MAXSYM> __device__ int build_code(Code<PB, MAXSYM> &c, con
     return left > 0 ? 1 : 0;
 }
 
-// the symbol at the bottom of `bb` -> (symbol << 8 | length), 0 if there is no such code; wave-uniform
-template <int PB, int MAXSYM> __device__ __forceinline__ uint32_t decode_sym(const Code<PB, MAXSYM> &c, uint64_t bb)
+// a code longer than the primary table's bits (or none): canonical decoding, bit by bit (puff's loop)
+__device__ __noinline__ uint32_t decode_long(const uint16_t *count_, const uint16_t *sorted_, uint64_t bb)
 {
-    const uint32_t e = uni(c.tab[(uint32_t)bb & ((1u << PB) - 1)]);
-    if (e) return e;
-    // a code longer than PB bits (or none): canonical decoding, bit by bit (puff's loop)
     uint32_t code = 0, first = 0, index = 0;
     uint64_t b = bb;
     for (int len = 1; len <= 15; ++len) {
         code |= (uint32_t)(b & 1);
         b >>= 1;
-        const uint32_t count = uni(c.count[len]);
-        if (code < first + count) return ((uint32_t)uni(c.sorted[index + (code - first)]) << 8) | (uint32_t)len;
+        const uint32_t count = uni(count_[len]);
+        if (code < first + count) return ((uint32_t)uni(sorted_[index + (code - first)]) << 8) | (uint32_t)len;
         index += count;
         first += count;
         first <<= 1;
@@ -219,13 +229,20 @@ template <int PB, int MAXSYM> __device__ __forceinline__ uint32_t decode_sym(con
     return 0;
 }
 
+// the symbol at the bottom of `bb` -> (symbol << 8 | length), 0 if there is no such code; wave-uniform
+template <int PB, int MAXSYM> __device__ __forceinline__ uint32_t decode_sym(const Code<PB, MAXSYM> &c, uint64_t bb)
+{
+    const uint32_t e = uni(c.tab[(uint32_t)bb & ((1u << PB) - 1)]);
+    if (e) return e;
+    return uni(decode_long(c.count, c.sorted, bb));
+}
+
 struct WaveLds {
     Code<LIT_PB, 288> lit;
     Code<DIST_PB, 32> dist;
     Code<7, 19> cl;
     uint8_t lens[32 + 320];
     uint16_t scratch[2 * 288];
-    __attribute__((aligned(16))) uint32_t in_ring[IN_WORDS];
 };
 
 // One wave per chunk: blocks from start_bit on until a block boundary at or behind stop_bit, or the member's final block
@@ -240,14 +257,16 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
     const ChunkIn C = chunks[ci];
     uint16_t *const out = sym_arena + C.sym_off;
     const uint64_t cap = C.sym_cap - 64;        // (up to 63 collected literals are put out without another look at the bound)
-    for (uint32_t w = lane; w < WIN; w += 64) out[w] = (uint16_t)(256 + w);
+    // (loops over lanes' elements count in wave-uniform steps: a loop whose exit depends on the lane makes the compiler treat the
+    // decoder's whole state as divergent -- vector registers and exec-mask branches instead of the scalar unit)
+    for (uint32_t w0 = 0; w0 < WIN; w0 += 64) out[w0 + lane] = (uint16_t)(256 + w0 + lane);
     uint64_t n = WIN;                   // symbols in memory
     uint32_t pend = 0;                  // literals collected in `lit_buf` (lane k holds the k-th), not yet in memory
     uint32_t lit_buf = 0;
     const uint64_t size_bits = in_bytes * 8;
     Bits B;
     B.w = in;
-    B.ring = S.in_ring;
+    B.ring = s_in_ring;
     B.n_words = ((in_bytes + 15) / 16) * 4;          // (whole 16-byte pieces: the buffer is padded with zeros beyond in_bytes)
     B.seek(C.start_bit);
     uint32_t status = ST_OK, final_block = 0;
@@ -256,6 +275,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
     auto flush = [&]() {
         if (pend) {
             if (lane < pend) out[n + lane] = (uint16_t)lit_buf;
+            LANES_DONE;
             n += pend;
             pend = 0;
         }
@@ -270,6 +290,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
     auto commit = [&]() {
         if (p_len) {
             if (lane < p_len) out[p_dst + lane] = (uint16_t)p_val;
+            LANES_DONE;
             p_len = 0;
         }
     };
@@ -299,18 +320,25 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
             commit();
             if (n + len > cap) { status = ST_OVERFLOW; break; }
             const uint8_t *sb = reinterpret_cast<const uint8_t *>(in) + src;
-            for (uint32_t i = lane; i < len; i += 64) out[n + i] = sb[i];
+            for (uint32_t i0 = 0; i0 < len; i0 += 64)
+                if (i0 + lane < len) out[n + i0 + lane] = sb[i0 + lane];
+                LANES_DONE;
             n += len;
             B.seek((src + len) * 8);
         } else {
             // ---- the block's two codes
             if (btype == 1) {
-                for (uint32_t i = lane; i < 288; i += 64) S.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+                for (uint32_t i0 = 0; i0 < 288; i0 += 64) {
+                    const uint32_t i = i0 + lane;
+                    if (i < 288) S.lens[i] = (uint8_t)(i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8);
+                    LANES_DONE;
+                }
                 __builtin_amdgcn_wave_barrier();
-                (void)build_code(S.lit, S.lens, 288, S.scratch);
+                (void)uni((uint32_t)build_code(S.lit, S.lens, 288, S.scratch));
                 if (lane < 32) S.lens[lane] = 5;
+                LANES_DONE;
                 __builtin_amdgcn_wave_barrier();
-                (void)build_code(S.dist, S.lens, 32, S.scratch);
+                (void)uni((uint32_t)build_code(S.dist, S.lens, 32, S.scratch));
             } else {
                 B.refill();
                 const uint32_t hlit = B.peek(5) + 257;
@@ -321,15 +349,17 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                 B.drop(4);
                 if (hlit > 286 || hdist > 30) { status = ST_INVALID; break; }
                 if (lane < 19) S.lens[lane] = 0;
+                LANES_DONE;
                 __builtin_amdgcn_wave_barrier();
                 for (uint32_t i = 0; i < hclen; ++i) {
                     B.refill();
                     const uint32_t v = B.peek(3);
                     B.drop(3);
                     if (lane == 0) S.lens[c_clord[i]] = (uint8_t)v;
+                    LANES_DONE;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (build_code(S.cl, S.lens, 19, S.scratch) < 0) { status = ST_INVALID; break; }
+                if ((int)uni((uint32_t)build_code(S.cl, S.lens, 19, S.scratch)) < 0) { status = ST_INVALID; break; }
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t total = hlit + hdist;
                 uint32_t k = 0, prev = 0;
@@ -343,6 +373,7 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                     const uint32_t s = e >> 8;
                     if (s < 16) {
                         if (lane == 0) S.lens[32 + k] = (uint8_t)s;
+                        LANES_DONE;
                         prev = s;
                         ++k;
                         continue;
@@ -362,16 +393,19 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                     }
                     if (k + rep > total) { bad = true; break; }
                     if (lane < rep) S.lens[32 + k + lane] = (uint8_t)val;
+                    LANES_DONE;
                     if (lane + 64 < rep) S.lens[32 + k + lane + 64] = (uint8_t)val;
+                    LANES_DONE;
                     if (lane + 128 < rep) S.lens[32 + k + lane + 128] = (uint8_t)val;
+                    LANES_DONE;
                     prev = val;
                     k += rep;
                 }
                 if (bad || B.bitpos() > size_bits) { status = bad ? ST_INVALID : ST_INPUT_END; break; }
                 __builtin_amdgcn_wave_barrier();
                 if (uni(S.lens[32 + 256]) == 0) { status = ST_INVALID; break; }
-                if (build_code(S.lit, S.lens + 32, (int)hlit, S.scratch) < 0) { status = ST_INVALID; break; }
-                if (build_code(S.dist, S.lens + 32 + hlit, (int)hdist, S.scratch) < 0) { status = ST_INVALID; break; }
+                if ((int)uni((uint32_t)build_code(S.lit, S.lens + 32, (int)hlit, S.scratch)) < 0) { status = ST_INVALID; break; }
+                if ((int)uni((uint32_t)build_code(S.dist, S.lens + 32 + hlit, (int)hdist, S.scratch)) < 0) { status = ST_INVALID; break; }
             }
             // ---- the block's symbols
             bool done = false;
@@ -421,13 +455,18 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
                 if (len <= 64) {
                     uint32_t v = 0;
                     if (lane < len) v = srcp[d >= len ? lane : lane % d];
+                    LANES_DONE;
                     commit();                                     // (the previous match: its loads are long back)
                     p_val = v;
                     p_dst = n;
                     p_len = len;
                 } else {
                     commit();
-                    for (uint32_t i = lane; i < len; i += 64) out[n + i] = srcp[d >= len ? i : i % d];
+                    for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+                        const uint32_t i = i0 + lane;
+                        if (i < len) out[n + i] = srcp[d >= len ? i : i % d];
+                        LANES_DONE;
+                    }
                 }
                 n += len;
             }
