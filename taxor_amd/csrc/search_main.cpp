@@ -356,7 +356,19 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         multi = allow_ranges && members.open(query, gz_threads);
         // one member (what `gzip reads.fastq` writes): inflated speculatively from the middle on all of this file's threads (pgz.h);
         // --sequential and small files keep the one zlib stream
-        if (!multi && allow_ranges && gz_threads > 1) single = pgz.open(query, gz_threads);
+        if (!multi && allow_ranges && gz_threads > 1) {
+            // TAXOR_CLI_GPU_INFLATE=1 (under TAXOR_TUNING): the chunks are decoded on the first search device (inflate.hip) -- half-MiB
+            // chunks, 2048 to a batch: a wave decodes ~5 M symbols a second, the device's rate is the number of chunks in flight
+            static const int dev_inflate = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE"); return e ? atoi(e) : 0; }();
+            static const double dev_chunk_mb = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE_CHUNK_MB"); return e ? atof(e) : 0.5; }();
+            static const int dev_batch = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE_BATCH"); return e ? atoi(e) : 2048; }();
+            std::string note;
+            if (dev_inflate && !cfg.gpus.empty())
+                single = pgz.open(query, gz_threads, (size_t)(dev_chunk_mb * 1048576.0), 8u << 20, cfg.gpus[0], (size_t)dev_batch, &note);
+            else
+                single = pgz.open(query, gz_threads);
+            if (!note.empty()) fprintf(stderr, "[taxor] gzip chunks are decoded on the host (%s)\n", note.c_str());
+        }
     } catch (const std::exception &ex) { die(ex.what()); }
     if (single) {
         // The inflated stream arrives in chunks of ~16 MB that change hands without a copy (ParallelGz::take).  This thread only CUTS:
