@@ -518,6 +518,9 @@ int taxor_gpu_inflater_create(int device, uint64_t max_in_bytes, uint32_t max_ch
 void taxor_gpu_inflater_destroy(taxor_gpu_inflater *h);
 int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n_chunks,
                              taxor_inflate_result *results);
+/* the same in two halves: _begin returns when the input is on its way and the kernel queued, _end waits for the results */
+int taxor_gpu_inflate_decode_begin(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n_chunks);
+int taxor_gpu_inflate_decode_end(taxor_gpu_inflater *h, taxor_inflate_result *results);
 int taxor_gpu_inflate_replace(taxor_gpu_inflater *h, uint32_t chunk, const uint16_t *symbols, uint64_t n_out, uint64_t end_bit, uint32_t final_block);
 int taxor_gpu_inflate_resolve(taxor_gpu_inflater *h, const uint8_t *window_in /* 32768 bytes */, uint32_t first, uint32_t count, uint8_t *const *out,
                               uint8_t *window_out /* 32768 bytes, may be NULL */);

@@ -563,6 +563,9 @@ struct taxor_gpu_inflater {
     // the batch in flight
     std::vector<ChunkIn> chunks;
     std::vector<ChunkRes> res;
+    ChunkRes *h_res = nullptr;      // page-locked: the results come back without the host waiting for them
+    bool in_flight = false;
+    std::chrono::steady_clock::time_point t_begin, t_launch;
     uint32_t n = 0;
     uint64_t in_bytes = 0;
 };
@@ -586,6 +589,7 @@ extern "C" int taxor_gpu_inflater_create(int device, uint64_t max_in_bytes, uint
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_win, (size_t)WIN * (max_chunks + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_boff, sizeof(uint64_t) * (max_chunks + 1));
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_out, h->out_cap);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_res, sizeof(ChunkRes) * max_chunks, hipHostMallocDefault);
     if (e != hipSuccess) {
         const std::string msg = hipGetErrorString(e);
         taxor_gpu_inflater_destroy(h);
@@ -602,19 +606,28 @@ extern "C" void taxor_gpu_inflater_destroy(taxor_gpu_inflater *h)
     if (h->st) { (void)hipStreamSynchronize(h->st); (void)hipStreamDestroy(h->st); }
     for (void *p : {(void *)h->d_in, (void *)h->d_sym, (void *)h->d_chunks, (void *)h->d_res, (void *)h->d_win, (void *)h->d_boff, (void *)h->d_out})
         if (p) (void)hipFree(p);
+    if (h->h_res) (void)hipHostFree(h->h_res);
     delete h;
 }
 
 extern "C" int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n,
                                         taxor_inflate_result *results)
 {
-    if (!h || !in || !chunks || !results) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode: null argument");
+    const int rc = taxor_gpu_inflate_decode_begin(h, in, in_bytes, chunks, n);
+    return rc != TAXOR_OK ? rc : taxor_gpu_inflate_decode_end(h, results);
+}
+
+extern "C" int taxor_gpu_inflate_decode_begin(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n)
+{
+    if (!h || !in || !chunks) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode: null argument");
+    // (a batch that was begun and never ended is abandoned: this one is queued behind it on the same stream)
     if (n > h->max_chunks || in_bytes + 64 > h->in_cap) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode: the batch is larger than the inflater was created for");
     HIP_TRY(hipSetDevice(h->device));
     h->n = n;
     h->in_bytes = in_bytes;
     h->chunks.resize(n);
     h->res.resize(n);
+    h->in_flight = true;
     if (!n) return TAXOR_OK;
     // the arena is shared out by the chunks' compressed lengths (a chunk's output is, to first order, its input times the file's ratio)
     uint64_t total_in = 0;
@@ -633,24 +646,35 @@ extern "C" int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in
         h->chunks[i].sym_cap = (WIN + 128 + share) & ~3ull;
         off += h->chunks[i].sym_cap;
     }
-    static const bool trace = taxor::tune_env("TAXOR_INFLATE_TRACE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
+    h->t_begin = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(h->d_in, in, in_bytes, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemsetAsync(h->d_in + in_bytes, 0, h->in_cap - in_bytes, h->st));
     HIP_TRY(hipMemcpyAsync(h->d_chunks, h->chunks.data(), sizeof(ChunkIn) * n, hipMemcpyHostToDevice, h->st));
-    if (trace) HIP_TRY(hipStreamSynchronize(h->st));
-    const auto t1 = std::chrono::steady_clock::now();
+    h->t_launch = std::chrono::steady_clock::now();
     hipLaunchKernelGGL(k_inflate, dim3(n), dim3(64), 0, h->st, reinterpret_cast<const uint32_t *>(h->d_in), in_bytes, h->d_chunks, h->d_res, h->d_sym, n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->res.data(), h->d_res, sizeof(ChunkRes) * n, hipMemcpyDeviceToHost, h->st));
+    HIP_TRY(hipMemcpyAsync(h->h_res, h->d_res, sizeof(ChunkRes) * n, hipMemcpyDeviceToHost, h->st));
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_inflate_decode_end(taxor_gpu_inflater *h, taxor_inflate_result *results)
+{
+    if (!h || !results) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode_end: null argument");
+    if (!h->in_flight) return fail(TAXOR_E_ARG, "taxor_gpu_inflate_decode_end: no batch was begun");
+    h->in_flight = false;
+    const uint32_t n = h->n;
+    if (!n) return TAXOR_OK;
+    HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->st));
+    memcpy(h->res.data(), h->h_res, sizeof(ChunkRes) * n);
+    static const bool trace = taxor::tune_env("TAXOR_INFLATE_TRACE") != nullptr;
     if (trace) {
         const auto t2 = std::chrono::steady_clock::now();
         uint64_t syms = 0;
         for (uint32_t i = 0; i < n; ++i) syms += h->res[i].n_sym - WIN;
-        fprintf(stderr, "[inflate] batch of %u chunks, %.1f MB in: upload %.1f ms, k_inflate %.1f ms for %.1f M symbols = %.2f G symbols/s\n", n, in_bytes / 1e6,
-                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), syms / 1e6,
-                syms / 1e9 / std::chrono::duration<double>(t2 - t1).count());
+        fprintf(stderr, "[inflate] batch of %u chunks, %.1f MB in: upload %.1f ms (host), launch to end %.1f ms for %.1f M symbols = %.2f G symbols/s\n", n, h->in_bytes / 1e6,
+                std::chrono::duration<double, std::milli>(h->t_launch - h->t_begin).count(), std::chrono::duration<double, std::milli>(t2 - h->t_launch).count(), syms / 1e6,
+                syms / 1e9 / std::chrono::duration<double>(t2 - h->t_launch).count());
     }
     for (uint32_t i = 0; i < n; ++i) {
         results[i].end_bit = h->res[i].end_bit;

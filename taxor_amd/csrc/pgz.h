@@ -920,7 +920,9 @@ private:
             }
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
-            if (taxor_gpu_inflate_decode(dev_[slot], map_ + lo_byte, hi_byte - lo_byte, B->req.data(), (uint32_t)k, B->res.data()) != TAXOR_OK)
+            // (only begun: the other inflater's batch may be decoding at this moment -- a batch is a wave per chunk, and the device has
+            // room for two batches' waves; device_tier ends it)
+            if (taxor_gpu_inflate_decode_begin(dev_[slot], map_ + lo_byte, hi_byte - lo_byte, B->req.data(), (uint32_t)k) != TAXOR_OK)
                 B->err = std::string("gzip on the device: ") + taxor_gpu_last_error();
             ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             lk.lock();
@@ -951,6 +953,7 @@ private:
             std::string err = B->err;
             size_t count = 0;
             const auto t0 = std::chrono::steady_clock::now();
+            if (err.empty() && taxor_gpu_inflate_decode_end(dev, B->res.data()) != TAXOR_OK) err = std::string("gzip on the device: ") + taxor_gpu_last_error();
             if (err.empty()) try {
                 const uint64_t base = B->base;
                 const std::vector<taxor_inflate_result> &res = B->res;

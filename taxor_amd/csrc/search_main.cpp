@@ -409,7 +409,8 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             std::condition_variable jcv_put, jcv_get;
             std::deque<Job> jobs;
             bool jdone = false;
-            const unsigned np = std::max(2u, gz_threads / 4);
+            static const unsigned np_env = [] { const char *e = tune_env("TAXOR_CLI_GZ_PARSERS"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 64 ? (unsigned)v : 0u; }();
+            const unsigned np = np_env ? np_env : std::max(2u, gz_threads / 4);
             std::vector<std::thread> parsers;
             for (unsigned t = 0; t < np; ++t)
                 parsers.emplace_back([&] {
