@@ -490,10 +490,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint32_t *__restrict__ in,
     }
 }
 
-// the windows, chunk after chunk: win[c + 1] = the last WIN bytes of (win[c] ++ chunk c resolved).  One block -- of four waves: the
-// other inflater's batch may hold eight of a CU's wave slots for a quarter of a second, and a block of sixteen waves would wait for
-// them to end (measured: 250 ms instead of 36 for a batch's windows and symbols).
-__global__ __launch_bounds__(256) void k_chain_windows(const ChunkIn *__restrict__ chunks, const ChunkRes *__restrict__ res,
+// the windows, chunk after chunk: win[c + 1] = the last WIN bytes of (win[c] ++ chunk c resolved).  One block.
+__global__ __launch_bounds__(1024) void k_chain_windows(const ChunkIn *__restrict__ chunks, const ChunkRes *__restrict__ res,
                                                        const uint16_t *__restrict__ sym_arena, uint8_t *__restrict__ win, uint32_t first, uint32_t count)
 {
     for (uint32_t c = first; c < first + count; ++c) {
@@ -730,7 +728,7 @@ extern "C" int taxor_gpu_inflate_resolve(taxor_gpu_inflater *h, const uint8_t *w
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(h->d_win, window_in, WIN, hipMemcpyHostToDevice, h->st));
     HIP_TRY(hipMemcpyAsync(h->d_boff, boff.data(), sizeof(uint64_t) * (count + 1), hipMemcpyHostToDevice, h->st));
-    hipLaunchKernelGGL(k_chain_windows, dim3(1), dim3(256), 0, h->st, h->d_chunks, h->d_res, h->d_sym, h->d_win, first, count);
+    hipLaunchKernelGGL(k_chain_windows, dim3(1), dim3(1024), 0, h->st, h->d_chunks, h->d_res, h->d_sym, h->d_win, first, count);
     const uint32_t bpc = 32;
     hipLaunchKernelGGL(k_resolve, dim3(count * bpc), dim3(256), 0, h->st, h->d_chunks, h->d_res, h->d_sym, h->d_win, h->d_boff, h->d_out, first, count, bpc);
     HIP_TRY(hipGetLastError());
