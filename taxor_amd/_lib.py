@@ -101,6 +101,14 @@ class IxfVariant(C.Structure):
 
 # every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+class InflateChunk(C.Structure):
+    _fields_ = [("start_bit", C.c_uint64), ("stop_bit", C.c_uint64), ("weight", C.c_uint64)]
+
+
+class InflateResult(C.Structure):
+    _fields_ = [("end_bit", C.c_uint64), ("n_out", C.c_uint64), ("status", C.c_uint32), ("final_block", C.c_uint32)]
+
+
 SIGNATURES = {
     "taxor_gpu_last_error": (C.c_char_p, []),
     "taxor_gpu_index_create": (C.c_int, [C.POINTER(HixfView), C.c_int, C.POINTER(_P)]),
@@ -143,6 +151,15 @@ SIGNATURES = {
     "taxor_gpu_gather_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(Results)]),
     "taxor_gpu_comm_info": (C.c_int, [_P, C.POINTER(CommStats)]),
     "taxor_gpu_comm_set_self_exchange": (C.c_int, [_P, C.c_int]),
+    # deflate chunks decoded on the device (inflate.hip; driven by the C++ reader, pgz.h)
+    "taxor_gpu_inflater_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
+    "taxor_gpu_inflater_destroy": (None, [_P]),
+    "taxor_gpu_inflate_decode": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(InflateChunk), C.c_uint32, C.POINTER(InflateResult)]),
+    "taxor_gpu_inflate_decode_begin": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(InflateChunk), C.c_uint32]),
+    "taxor_gpu_inflate_decode_end": (C.c_int, [_P, C.POINTER(InflateResult)]),
+    "taxor_gpu_inflate_replace": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
+    "taxor_gpu_inflate_resolve": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), _P]),
+    "taxor_gpu_inflate_symbols": (C.c_int, [_P, C.c_uint32, _P]),
     "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),

@@ -107,3 +107,40 @@ def test_truncated_and_corrupted_streams_never_give_wrong_bytes(tmp_path):
             assert out.read_bytes() == raw, pos
             outcomes["same"] += 1
     assert outcomes["error"] >= 20, outcomes
+
+
+def test_c_abi_one_chunk_equals_zlib():
+    """Straight through the C ABI: a raw deflate stream as ONE chunk from bit 0 -- symbols (no window markers: nothing lies before the
+    chunk) and resolved bytes equal what zlib inflates; a start in the middle of nowhere is reported as invalid, not decoded."""
+    import ctypes as C
+
+    from taxor_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    raw = fastq(rng, 300)
+    for level in (1, 6, 9):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(raw) + co.flush()
+        h = C.c_void_p()
+        assert L.taxor_gpu_inflater_create(0, len(comp) + 64, 4, 4 * (32768 + 256) + 3 * len(raw), C.byref(h)) == 0, L.taxor_gpu_last_error()
+        try:
+            buf = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
+            req = (_lib.InflateChunk * 2)()
+            req[0].start_bit, req[0].stop_bit, req[0].weight = 0, len(comp) * 8, len(comp) * 8
+            req[1].start_bit, req[1].stop_bit, req[1].weight = 12345, len(comp) * 8, 8          # not a block start
+            res = (_lib.InflateResult * 2)()
+            assert L.taxor_gpu_inflate_decode(h, buf, len(comp), req, 2, res) == 0, L.taxor_gpu_last_error()
+            assert res[0].status == 0 and res[0].final_block == 1 and res[0].n_out == len(raw), (res[0].status, res[0].n_out, len(raw))
+            assert res[0].end_bit <= len(comp) * 8 and res[0].end_bit > len(comp) * 8 - 8
+            assert res[1].status != 0
+            sym = np.empty(len(raw), np.uint16)
+            assert L.taxor_gpu_inflate_symbols(h, 0, sym.ctypes.data_as(C.c_void_p)) == 0
+            assert sym.max() < 256 and bytes(sym.astype(np.uint8)) == raw
+            out = np.empty(len(raw), np.uint8)
+            outs = (C.c_void_p * 1)(out.ctypes.data)
+            win_in = (C.c_uint8 * 32768)()
+            win_out = (C.c_uint8 * 32768)()
+            assert L.taxor_gpu_inflate_resolve(h, win_in, 0, 1, outs, win_out) == 0, L.taxor_gpu_last_error()
+            assert bytes(out) == raw and bytes(win_out) == raw[-32768:]
+        finally:
+            L.taxor_gpu_inflater_destroy(h)
