@@ -24,6 +24,8 @@
 #include <zlib.h>
 #if defined(__SSE2__)
 #include <emmintrin.h>
+#include <smmintrin.h>
+#include <wmmintrin.h>
 #endif
 
 #include <fcntl.h>
@@ -457,6 +459,73 @@ inline uint64_t find_block(const uint8_t *base, const uint8_t *end, uint64_t fro
     return ~0ull;
 }
 
+// CRC-32 (the gzip polynomial) of n bytes, continuing `crc` like zlib's crc32().  The image's zlib does ~2 GB/s per thread -- a sixth of
+// the reader's CPU time once the chunks are resolved; with carry-less multiplication (four 128-bit lanes folded per 64 bytes, then
+// 128 -> 64 -> 32 bits by Barrett reduction: the published folding scheme, constants for the reflected polynomial 0x1DB710641) it is a
+// memory pass.  Hosts without PCLMULQDQ, and what the folding leaves (under 64 bytes, and the bytes behind the last 16), go to zlib.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc32_fold_step(__m128i x, __m128i k, __m128i next)
+{
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x00), _mm_clmulepi64_si128(x, k, 0x11)), next);
+}
+__attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_fold(uint32_t crc, const uint8_t *p, size_t n)       // n >= 64, a multiple of 16; crc without the inversions
+{
+    const __m128i k12 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll);        // x^(512+64) mod P and x^512 mod P, bit-reflected
+    const __m128i k34 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);        // x^(128+64), x^128
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124ll);                       // x^64
+    const __m128i pm = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);          // mu, P
+    const __m128i lo32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    __m128i a = _mm_loadu_si128((const __m128i *)p), b = _mm_loadu_si128((const __m128i *)(p + 16));
+    __m128i c = _mm_loadu_si128((const __m128i *)(p + 32)), d = _mm_loadu_si128((const __m128i *)(p + 48));
+    a = _mm_xor_si128(a, _mm_cvtsi32_si128((int)crc));
+    p += 64;
+    n -= 64;
+    for (; n >= 64; n -= 64, p += 64) {
+        a = crc32_fold_step(a, k12, _mm_loadu_si128((const __m128i *)p));
+        b = crc32_fold_step(b, k12, _mm_loadu_si128((const __m128i *)(p + 16)));
+        c = crc32_fold_step(c, k12, _mm_loadu_si128((const __m128i *)(p + 32)));
+        d = crc32_fold_step(d, k12, _mm_loadu_si128((const __m128i *)(p + 48)));
+    }
+    a = crc32_fold_step(a, k34, b);
+    a = crc32_fold_step(a, k34, c);
+    a = crc32_fold_step(a, k34, d);
+    for (; n >= 16; n -= 16, p += 16) a = crc32_fold_step(a, k34, _mm_loadu_si128((const __m128i *)p));
+    // 128 -> 64 bits
+    __m128i t = _mm_clmulepi64_si128(a, k34, 0x10);
+    a = _mm_xor_si128(_mm_srli_si128(a, 8), t);
+    t = _mm_srli_si128(a, 4);
+    a = _mm_and_si128(a, lo32);
+    a = _mm_xor_si128(_mm_clmulepi64_si128(a, k5, 0x00), t);
+    // Barrett: 64 -> 32 bits
+    t = _mm_and_si128(a, lo32);
+    t = _mm_clmulepi64_si128(t, pm, 0x10);
+    t = _mm_and_si128(t, lo32);
+    t = _mm_clmulepi64_si128(t, pm, 0x00);
+    a = _mm_xor_si128(a, t);
+    return (uint32_t)_mm_extract_epi32(a, 1);
+}
+#endif
+
+inline uint32_t crc32_bytes(uint32_t crc, const uint8_t *p, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool fast = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (fast && n >= 64) {
+        const size_t m = n & ~(size_t)15;
+        crc = ~crc32_fold(~crc, p, m);
+        p += m;
+        n -= m;
+    }
+#endif
+    for (; n; ) {
+        const size_t k = std::min<size_t>(n, 1u << 30);
+        crc = (uint32_t)crc32(crc, p, (uInt)k);
+        p += k;
+        n -= k;
+    }
+    return crc;
+}
+
 // gzip member header at p: returns its length, 0 if there is none
 inline size_t gzip_header_len(const uint8_t *p, size_t n)
 {
@@ -681,9 +750,7 @@ private:
 #ifdef TAXOR_PGZ_DEVICE
                 if (dev_[0]) {
                     const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
-                    uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-                    for (size_t p = 0; p < c.out_len; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(c.out_len - p, 1u << 30));
-                    c.crc = crc;
+                    c.crc = pgz_detail::crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o, c.out_len);
                 } else
 #endif
                 resolve(c);
@@ -788,9 +855,7 @@ private:
             o[i] = v < 256 ? (uint8_t)v : w[v - 256];
         }
         give_back(c.co.sym);
-        uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t p = 0; p < n; p += (1u << 30)) crc = (uint32_t)crc32(crc, o + p, (uInt)std::min<size_t>(n - p, 1u << 30));
-        c.crc = crc;
+        c.crc = crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o, n);
     }
 
     // the window of the next chunk: the last WIN bytes of (window ++ this chunk), markers resolved
