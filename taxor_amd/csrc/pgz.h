@@ -159,6 +159,15 @@ template <int PB, int MAXSYM> struct Huff {
     }
     struct Span { uint32_t *b, *e; uint32_t *data() { return b; } uint32_t *begin() { return b; } uint32_t *end() { return e; } };
     Span primary() { return Span{tab, tab + (1 << PB)}; }
+    // every entry's symbol field rewritten by f (the decoder wants a length code's base and extra bits, not its number, in the entry:
+    // two dependent table reads less per match)
+    template <class F> void remap(F f)
+    {
+        for (uint32_t &e : tab)
+            if (e && !(e & 0x8000u)) e = (f(e >> 16) << 16) | (e & 0xFFFFu);
+        for (uint32_t &e : sub)
+            if (e) e = (f(e >> 16) << 16) | (e & 0xFFFFu);
+    }
     // entry for the bits at the bottom of `bb` (0 = no such code)
     inline uint32_t lookup(uint64_t bb) const
     {
@@ -175,10 +184,31 @@ static const uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6,
 static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct Codes {
-    Huff<10, 288> lit;
-    Huff<8, 32> dist;
+    Huff<10, 288> lit;      // symbol field: a literal (< 256), 256 = end of block, LEN_FLAG | extra bits << 9 | base for a length code, BAD_SYM for 286 / 287
+    Huff<8, 32> dist;       // symbol field: extra bits << 12 ... see pack_dist: base in the high bits; 0 = codes 30 / 31
     bool have_dist = true;
+    void pack();
 };
+constexpr uint32_t LEN_FLAG = 0x8000u, BAD_SYM = 0x4000u;
+inline void Codes::pack()
+{
+    lit.remap([](uint32_t s) -> uint32_t {
+        if (s <= 256) return s;
+        if (s >= 286) return BAD_SYM;
+        return LEN_FLAG | ((uint32_t)LEXT[s - 257] << 9) | LBASE[s - 257];
+    });
+    // distance: base 1 .. 24577 does not fit beside four bits of extra count in 16 bits; the entry's bits 8..14 are free (a code
+    // length is at most 15): extra count there, the base in the symbol field
+    for (int pass = 0; pass < 2; ++pass) {
+        auto fix = [](uint32_t &e) {
+            if (!e || (e & 0x8000u)) return;
+            const uint32_t s = e >> 16, l = e & 0xFFu;
+            e = s >= 30 ? l : (((uint32_t)DBASE[s]) << 16) | ((uint32_t)DEXT[s] << 8) | l;
+        };
+        if (pass == 0) for (uint32_t &e : dist.tab) fix(e);
+        else for (uint32_t &e : dist.sub) fix(e);
+    }
+}
 
 // the header of a dynamic block at the reader's position; strict = what a block START SEARCH demands beyond validity (complete
 // alphabets); false on anything a decoder must reject
@@ -236,6 +266,7 @@ inline bool read_dynamic_header(BitIn &in, Codes &c, bool strict)
     const int dr = c.dist.build(lens + hlit, (int)hdist);
     if (dr < 0) return false;
     c.have_dist = true;
+    c.pack();
     return !in.overrun();
 }
 
@@ -250,6 +281,7 @@ inline void fixed_codes(Codes &c)
     uint8_t d[32];                       // 32 five-bit codes; 30 and 31 never occur in valid data (rejected where they are decoded)
     for (int i = 0; i < 32; ++i) d[i] = 5;
     c.dist.build(d, 32);
+    c.pack();
 }
 
 // symbols of a chunk: grown by realloc, never value-initialised (a std::vector would zero 32 MB per chunk before it is written),
@@ -341,24 +373,35 @@ inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t 
             if (!l) return false;
             in.drop(l);
             if (sym == 256) { n_io = n; return !in.overrun() && !bad; }
-            sym -= 257;
-            if (sym >= 29) return false;
-            const uint32_t len = LBASE[sym] + in.peek(LEXT[sym]);
-            in.drop(LEXT[sym]);
+            if (sym & BAD_SYM) return false;
+            const int lx = (int)((sym >> 9) & 7);
+            const uint32_t len = (sym & 0x1FFu) + in.peek(lx);
+            in.drop(lx);
             const uint32_t de = c.dist.lookup(in.bb);
             const int dl = (int)(de & 0xFF);
             if (!dl) return false;
             in.drop(dl);
-            const uint32_t ds = de >> 16;
-            if (ds >= 30) return false;
-            const uint32_t d = DBASE[ds] + in.peek(DEXT[ds]);
-            in.drop(DEXT[ds]);
+            const uint32_t dbase = de >> 16;
+            if (!dbase) return false;                          // codes 30 and 31
+            const int dx = (int)((de >> 8) & 15);
+            const uint32_t d = dbase + in.peek(dx);
+            in.drop(dx);
             if (d > n) return false;                            // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid)
             if (in.overrun()) return false;
             uint16_t *o = o0 + n;
             const uint16_t *s = o - d;
-            if (d >= len) memcpy(o, s, (size_t)len * 2);
-            else for (uint32_t i = 0; i < len; ++i) o[i] = s[i];
+            if (d >= 8) {
+                // eight symbols (16 bytes) at a time, the last step running over the match's end into the slack every stretch keeps
+                // free (a call of memcpy with a run-time length costs more than the typical match of a sequence line is long)
+                uint16_t *const e = o + len;
+                do {
+                    __m128i v = _mm_loadu_si128((const __m128i *)s);
+                    _mm_storeu_si128((__m128i *)o, v);
+                    o += 8;
+                    s += 8;
+                } while (o < e);
+            } else
+                for (uint32_t i = 0; i < len; ++i) o[i] = s[i];
             n += len;
         }
         if (TEXT && bad) return false;
