@@ -370,7 +370,9 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             if (!note.empty()) fprintf(stderr, "[taxor] gzip chunks are decoded on the host (%s)\n", note.c_str());
         }
     } catch (const std::exception &ex) { die(ex.what()); }
-    if (single) {
+    if (single || multi) {
+        // (a multi-member file -- bgzip's 64-KB members, concatenated runs -- goes the same way, its members being the chunks)
+        auto take_chunk = [&](std::vector<char> &v) { return single ? pgz.take(v) : members.take(v); };
         // The inflated stream arrives in chunks of ~16 MB that change hands without a copy (ParallelGz::take).  This thread only CUTS:
         // it collects chunks up to ~64 MB, finds the last record start in the last one (the range reader's test: an '@' line whose
         // second successor starts with '+', or a '>' line), and hands everything before it -- whole records -- to a parser thread;
@@ -379,7 +381,9 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         // its lines) is parsed front to back on this thread instead.
         std::vector<char> first;
         bool have = false;
-        try { have = pgz.take(first); } catch (const std::exception &ex) { die(ex.what()); }
+        try {
+            while ((have = take_chunk(first)) && first.empty()) {}         // (empty members are legal)
+        } catch (const std::exception &ex) { die(ex.what()); }
         size_t i0 = 0;
         while (i0 < first.size() && (first[i0] == '\n' || first[i0] == '\r')) ++i0;
         char kind = have && i0 < first.size() ? first[i0] : 0;
@@ -397,12 +401,13 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         }
         if (have && kind && !cuttable && kind != '@' && kind != '>') die("query file is neither FASTA nor FASTQ");
         if (!have || !cuttable) {
-            rd.pgz = &pgz;                                   // front to back: the chunk already taken first, then the stream
+            if (single) rd.pgz = &pgz;                       // front to back: the chunk already taken first, then the stream
+            else rd.members = &members;
             rd.buf.swap(first);
             rd.pos = 0;
             rd.len = rd.buf.size();
             if (rd.buf.size() < (8u << 20)) rd.buf.resize(8u << 20);
-            pgz.switch_to_read();
+            if (single) pgz.switch_to_read();
         } else {
             struct Job { std::deque<std::vector<char>> parts; uint64_t seq = 0; size_t bytes = 0; };
             std::mutex jmu;
@@ -415,7 +420,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             for (unsigned t = 0; t < np; ++t)
                 parsers.emplace_back([&] {
                     fastx::FastxReader prd;
-                    prd.mem_recycle = [&pgz](std::vector<char> &&v) { pgz.recycle(std::move(v)); };
+                    if (single) prd.mem_recycle = [&pgz](std::vector<char> &&v) { pgz.recycle(std::move(v)); };
                     std::string pid;
                     size_t prev_records = 0, prev_id_bytes = 0;
                     for (;;) {
@@ -481,7 +486,8 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                         std::vector<char> &last = cur.parts.back();
                         const char *b = last.data(), *e = b + last.size();
                         const char *w = last.size() > (1u << 20) ? e - (1u << 20) : b;
-                        const char *p = w == b ? b : fastx::next_line(w, e);
+                        // (a part starts at a line start only if it is the job's first: jobs begin at record starts; a bgzip member begins anywhere)
+                        const char *p = w == b && cur.parts.size() == 1 ? b : fastx::next_line(w, e);
                         const char *cut = nullptr;
                         for (const char *r = fastx::resync(p, e, kind); r < e; r = fastx::resync(fastx::next_line(r, e), e, kind)) cut = r;
                         if (cut && (cut > b || cur.parts.size() > 1)) {
@@ -496,8 +502,8 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
                         }
                     }
                     std::vector<char> ck;
-                    if (!pgz.take(ck)) break;
-                    add(std::move(ck));
+                    if (!take_chunk(ck)) break;
+                    if (!ck.empty()) add(std::move(ck));
                 }
                 submit(std::move(cur));
             } catch (const std::exception &ex) { die(ex.what()); }
@@ -510,9 +516,6 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
             finish();
             return now() - t_begin;
         }
-    } else if (multi) {
-        rd.members = &members;
-        rd.buf.resize(8u << 20);
     } else if (!rd.open(query)) die("cannot open query file " + query);
     std::string id;
     bool more = true;
@@ -923,6 +926,7 @@ int main(int argc, char **argv)
             if (strcmp(argv[i], "--query-file") == 0 && i + 1 < argc) cfg.query_file = argv[++i];
             else if (strcmp(argv[i], "--threads") == 0 && i + 1 < argc) cfg.threads = (unsigned)atoi(argv[++i]);
             else if (strcmp(argv[i], "--batch-reads") == 0 && i + 1 < argc) cfg.batch_reads = strtoull(argv[++i], nullptr, 10);
+            else if (strcmp(argv[i], "--batch-bases") == 0 && i + 1 < argc) cfg.batch_bases = strtoull(argv[++i], nullptr, 10);      // (tests: small parser jobs)
             else if (strcmp(argv[i], "--sequential") == 0) allow_ranges = false;
         }
         if (cfg.threads == 0) cfg.threads = 1;

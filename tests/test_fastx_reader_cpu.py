@@ -197,6 +197,31 @@ def test_multi_member_gzip_is_inflated_in_parallel_and_in_order(tmp_path):
     assert cp.returncode != 0 or cp.stdout != "".join(f"{i}\t{n}\t{h:016x}\n" for i, n, h in want)
 
 
+def test_bgzip_like_members_through_the_cutter_and_the_parser_pool(tmp_path):
+    """Members of 64 KB and less (bgzip), boundaries anywhere -- inside lines, inside reads longer than a member -- quality lines that
+    start with '@' and '+': the members are the chunks the cutter collects into parser jobs (search_main.cpp), small jobs here so that
+    many cuts fall into parts that begin in the middle of a line."""
+    rng = np.random.default_rng(21)
+    recs = make_records(rng, 260, lo=1, hi=3000) + make_records(rng, 6, lo=90000, hi=150000) + make_records(rng, 200, lo=0, hi=9000)
+    recs = [(f"{i} n={j}", s) for j, (i, s) in enumerate(recs)]
+    plain = tmp_path / "reads.fastq"
+    write_fastq(plain, recs, rng)
+    raw = plain.read_bytes()
+    blob, pos = b"", 0
+    while pos < len(raw):
+        n = int(rng.choice([65280, 65280, 4096, 1, 30000]))
+        blob += gzip.compress(raw[pos:pos + n], compresslevel=int(rng.integers(1, 7)))
+        pos += n
+    p = tmp_path / "reads.bgzf.fastq.gz"
+    p.write_bytes(blob)
+    want = expected(recs)
+    for m in (("--threads", "8", "--batch-bases", "300000"), ("--threads", "3", "--batch-bases", "70000"), ("--threads", "4"), ("--sequential",)):
+        got, n_batches = run_reads(p, *m)
+        assert got == want, m
+        if "--batch-bases" in m:
+            assert n_batches > 5, (m, n_batches)
+
+
 def test_single_member_gzip_with_false_member_headers(tmp_path):
     """a one-member .gz whose (stored) data contains byte patterns that look like member headers: the speculative
     member search must not be fooled into a wrong split"""
