@@ -237,8 +237,8 @@ CpuMark cpu_mark()
     }
     return m;
 }
-// CPUs the process may use: the smaller of the affinity mask and the cgroup's quota (0 if unknown)
-double cpu_allowance()
+// CPUs the container's cgroup allows (cpu.max: quota / period); 0 if there is no quota
+double cpu_quota()
 {
     double q = 0;
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
@@ -247,6 +247,12 @@ double cpu_allowance()
         if (fscanf(f, "%63s %llu", a, &period) == 2 && strcmp(a, "max") != 0 && period) q = (double)strtoull(a, nullptr, 10) / (double)period;
         fclose(f);
     }
+    return q;
+}
+// CPUs the process may use: the smaller of the affinity mask and the cgroup's quota (0 if unknown)
+double cpu_allowance()
+{
+    const double q = cpu_quota();
     cpu_set_t set;
     CPU_ZERO(&set);
     const double aff = sched_getaffinity(0, sizeof set, &set) == 0 ? (double)CPU_COUNT(&set) : 0.0;
@@ -1032,10 +1038,12 @@ int main(int argc, char **argv)
     if (cfg.threads == 0) {
         // --threads not given.  The reference's default is one worker thread (taxor_search_configuration.hpp:17) -- there the
         // thread that classifies; here host threads only parse the query file and render text for the GPU, and one of them
-        // delivers 1-3 Gbp/s to a device that classifies 25.  Default: a sixteenth of the machine, between 4 and 16.  A
-        // --threads the user gives is obeyed as it is.
+        // delivers 1-3 Gbp/s to a device that classifies 25.  Default: a sixteenth of the machine, between 4 and 16 -- or what the
+        // container's CPU quota allows, if it has one (threads beyond it only make the cgroup stop all of them for the rest of each
+        // scheduler period).  A --threads the user gives is obeyed as it is.
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        cfg.threads = std::min(16u, std::max(4u, hw / 16u));
+        const double quota = cpu_quota();
+        cfg.threads = quota >= 1.0 ? std::min(16u, std::max(2u, (unsigned)quota)) : std::min(16u, std::max(4u, hw / 16u));
     }
 
     // ---- sanity checks (taxor_search.cpp:97-151) --------------------------------------------------------------
