@@ -183,7 +183,7 @@ private:
         if (!h) return;
         static thread_local ChunkOut co;
         const uint8_t *base = map_ + p, *end = base + avail;
-        const bool ok = decode_from(base, end, (uint64_t)h * 8, ~0ull, co, WIN + max_output, nullptr) && co.final_block;
+        const bool ok = decode_from(base, end, (uint64_t)h * 8, ~0ull, co, WIN + max_output, nullptr, 1 << 30, true) && co.final_block;
         if (ok) {
             const size_t n = co.n - WIN, t = (size_t)((co.end_bit + 7) / 8);         // the trailer behind the final block's last byte
             if (t + 8 <= size_ - p) {

@@ -324,7 +324,7 @@ struct TextSet {
 // max_out bounds the chunk (a trial decode of a candidate block start must not run away).  TEXT: every literal must be text (the
 // trial decode of a candidate block start); the check is a flag OR-ed per literal and looked at once per block, not a branch.
 template <bool TEXT>
-inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t &n_io, size_t max_out, const bool *text_ok)
+inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t &n_io, size_t max_out, const bool *text_ok, size_t floor = 0)
 {
     size_t n = n_io;
     uint32_t bad = 0;
@@ -386,7 +386,8 @@ inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t 
             const int dx = (int)((de >> 8) & 15);
             const uint32_t d = dbase + in.peek(dx);
             in.drop(dx);
-            if (d > n) return false;                            // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid)
+            if (d > n - floor) return false;                    // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid;
+                                                                //  floor = WIN: the stream STARTS here, nothing lies before it)
             if (in.overrun()) return false;
             uint16_t *o = o0 + n;
             const uint16_t *s = o - d;
@@ -419,12 +420,16 @@ struct ChunkOut {
 // blocks from start_bit on until a block boundary at or behind stop_bit (or the member's final block); text_ok != nullptr: every
 // literal must be text.  max_out bounds the output.
 inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_bit, uint64_t stop_bit, ChunkOut &co, size_t max_out, const bool *text_ok,
-                        int max_blocks = 1 << 30)
+                        int max_blocks = 1 << 30, bool stream_start = false)
 {
+    // stream_start: the deflate stream begins at start_bit (a gzip member): a reference behind it is invalid, and the window slots
+    // are left as they are (64 KB of markers written per 64-KB bgzip member would double the decoder's stores)
     BitIn in;
     in.seek(base, end, start_bit);
     if (co.sym.size() < WIN + (1u << 16)) co.sym.resize(WIN + (1u << 16));
-    for (uint32_t w = 0; w < WIN; ++w) co.sym[w] = (uint16_t)(256 + w);
+    const size_t floor = stream_start ? WIN : 0;
+    if (!stream_start)
+        for (uint32_t w = 0; w < WIN; ++w) co.sym[w] = (uint16_t)(256 + w);
     co.n = WIN;
     co.start_bit = start_bit;
     co.final_block = false;
@@ -465,7 +470,7 @@ inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_
         } else {
             if (btype == 1) fixed_codes(codes);
             else if (!read_dynamic_header(in, codes, false)) return false;
-            if (!(text_ok ? decode_block_symbols<true>(in, codes, co.sym, co.n, max_out, text_ok) : decode_block_symbols<false>(in, codes, co.sym, co.n, max_out, text_ok))) return false;
+            if (!(text_ok ? decode_block_symbols<true>(in, codes, co.sym, co.n, max_out, text_ok, floor) : decode_block_symbols<false>(in, codes, co.sym, co.n, max_out, text_ok, floor))) return false;
         }
         if (bfinal) { co.final_block = true; co.end_bit = in.bitpos(); co.ok = true; return true; }
     }
