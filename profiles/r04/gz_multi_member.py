@@ -51,12 +51,17 @@ def main():
             f.write(blob)
     print(f"bgzip-like file: {os.path.getsize(gz)/1e9:.2f} GB of {size/1e9:.2f} GB in members of 64 KB, {time.time()-t0:.0f} s", flush=True)
     env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "taxor_amd"))
+    extra_envs = [e for e in os.environ.get("GZM_ENVS", "").split(";") if e]          # e.g. "TAXOR_CLI_GZ_PARSERS=8;TAXOR_CLI_GZ_PARSERS=12": one more run each
     for rnd in range(2):
         for b in a.binaries:
             for th in a.threads.split(","):
                 t0 = time.time()
                 cp = subprocess.run([b, "reads", "--query-file", gz, "--threads", th], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
                 print(f"{os.path.basename(b)} --threads {th}: {cp.stderr.strip().splitlines()[-1]} -> {size/1e9/(time.time()-t0):.2f} GB/s of FASTQ (wall, printing included)", flush=True)
+                for ee in extra_envs:
+                    cp = subprocess.run([b, "reads", "--query-file", gz, "--threads", th], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                                        env=dict(env, TAXOR_TUNING="1", **dict([ee.split("=", 1)])))
+                    print(f"{os.path.basename(b)} --threads {th} {ee}: {cp.stderr.strip().splitlines()[-1]}", flush=True)
     subprocess.run(["rm", "-rf", tmp])
 
 

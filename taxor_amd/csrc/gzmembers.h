@@ -84,7 +84,13 @@ public:
             res_[0].state = 2;
             next_task_ = 1;
         }
-        window_ = std::max(4u, 2 * threads);
+        // (candidates in flight ahead of the chain.  bgzip's members are 64 KB: a window of two per thread had the consumer and the
+        // workers hand every member over one by one -- a lock, a wake-up of all workers and a wake-up of the consumer per member,
+        // 13 us each, which was the reader's rate)
+        {   // ... as many as ~1 GB of compressed members (their output is a few times that), never fewer than two per thread
+            const size_t avg = std::max<size_t>(1, size_ / std::max<size_t>(1, cand_.size()));
+            window_ = std::max<size_t>(std::max(4u, 2 * threads), std::min<size_t>(std::max(64u, 8 * threads), (1u << 30) / avg));
+        }
         for (unsigned t = 0; t < std::max(1u, threads); ++t) th_.emplace_back([this] { worker(); });
         return true;
     }
@@ -158,6 +164,7 @@ private:
                 res_[i].out.swap(r.out);
                 res_[i].end = r.end;
                 res_[i].state = r.state;
+                if (waiting_for_ != i) continue;               // (the consumer is woken for the member it waits for, not for every one)
             }
             cv_done_.notify_all();
         }
@@ -239,9 +246,14 @@ private:
         }
         const size_t i = (size_t)(it - cand_.begin());
         for (size_t j = chain_idx_; j < i; ++j) std::vector<char>().swap(res_[j].out);   // candidates the chain jumped over
+        const bool workers_wait = next_task_ >= chain_idx_ + window_;      // (they wait only with the window exhausted)
         chain_idx_ = i;
-        cv_work_.notify_all();
-        cv_done_.wait(lk, [&] { return res_[i].state >= 2; });
+        if (workers_wait) cv_work_.notify_all();
+        if (res_[i].state < 2) {
+            waiting_for_ = i;
+            cv_done_.wait(lk, [&] { return res_[i].state >= 2; });
+            waiting_for_ = SIZE_MAX;
+        }
         if (res_[i].state != 2) {
             // The chain has arrived here from a verified member's end, so this IS a member.  The speculative inflate may
             // have given up only because of its size caps (a genuine member beyond 256 MB compressed that also contains a
@@ -270,7 +282,7 @@ private:
     std::vector<std::thread> th_;
     std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;
-    size_t next_task_ = 0, chain_idx_ = 0, chain_off_ = 0, window_ = 8;
+    size_t next_task_ = 0, chain_idx_ = 0, chain_off_ = 0, window_ = 8, waiting_for_ = SIZE_MAX;
     size_t cur_ = SIZE_MAX, cur_pos_ = 0;
     bool stop_ = false, eof_ = false;
 };
