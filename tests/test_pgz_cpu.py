@@ -187,3 +187,17 @@ def test_cli_reader_takes_single_member_gzip_through_the_parallel_inflate(tmp_pa
     cp = subprocess.run([EXE, "inflate", "--query-file", str(gz), "--threads", "4", "--output-file", str(tmp_path / "o.fastq")], capture_output=True, text=True, timeout=600)
     assert cp.returncode == 0 and "verified" in cp.stdout, cp.stdout + cp.stderr
     assert (tmp_path / "o.fastq").read_bytes() == raw
+
+
+def test_crc32_by_carryless_multiplication_equals_zlib(tmp_path):
+    """pgz.h's crc32_bytes (PCLMULQDQ folding where the host has it, zlib otherwise) against zlib's crc32: 4000 random
+    (length, offset, start value) cases, a buffer in random pieces, plain and under ASan + UBSan."""
+    for name, flags in (("plain", []), ("asan", ["-fsanitize=address,undefined"])):
+        exe = tmp_path / f"crc_{name}"
+        cp = subprocess.run(["g++", "-std=c++17", "-O2", "-g", *flags, f"-I{CSRC}", os.path.join(SAN, "crc32_fold.cpp"), "-o", str(exe), "-lz", "-pthread"],
+                            capture_output=True, text=True)
+        if cp.returncode != 0 and "sanitize" in cp.stderr:
+            continue
+        assert cp.returncode == 0, cp.stderr
+        run_ = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+        assert run_.returncode == 0 and "bad 0" in run_.stdout and "runtime error" not in run_.stderr, run_.stdout + run_.stderr
