@@ -357,7 +357,9 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
     fastx::GzMembers members;
     fastx::ParallelGz pgz;
     bool multi = false, single = false;
-    const unsigned gz_threads = parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, 16u));
+    // (inflating threads: up to 32 of --threads -- or what the container's CPU quota allows: beyond it the cgroup only stops them all)
+    static const unsigned gz_cap = [] { const double q = cpu_quota(); return q >= 1.0 ? std::min(32u, std::max(2u, (unsigned)q)) : 32u; }();
+    const unsigned gz_threads = parse_threads ? parse_threads : std::max(1u, std::min(cfg.threads, gz_cap));
     try {
         multi = allow_ranges && members.open(query, gz_threads);
         // one member (what `gzip reads.fastq` writes): inflated speculatively from the middle on all of this file's threads (pgz.h);
