@@ -18,7 +18,7 @@ def build(force=False):
 
 class IxfView(C.Structure):
     _fields_ = [("bins", C.c_uint64), ("stride", C.c_uint64), ("seg_len", C.c_uint64), ("seed", C.c_uint64),
-                ("data", C.c_void_p), ("next_ixf", C.c_void_p), ("fname_idx", C.c_void_p)]
+                ("data", C.c_void_p), ("next_ixf", C.c_void_p), ("fname_idx", C.c_void_p), ("src_stride", C.c_uint64)]
 
 
 IXF_READ_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p)
@@ -32,7 +32,7 @@ class HixfView(C.Structure):
     _fields_ = [("n_ixf", C.c_uint64), ("ixf", C.POINTER(IxfView)), ("n_user_bins", C.c_uint64),
                 ("kmer_size", C.c_uint8), ("syncmer_size", C.c_uint8), ("t_syncmer", C.c_uint8),
                 ("use_syncmer", C.c_uint8), ("scaling", C.c_uint16), ("window_size", C.c_uint64), ("ixf_arith", C.c_uint32),
-                ("source", C.c_void_p)]
+                ("source", C.c_void_p), ("ixf_layout", C.c_uint32)]
 
 
 class ReadSegment(C.Structure):
@@ -44,7 +44,7 @@ class SearchParams(C.Structure):
                 ("time_kernels", C.c_uint32), ("model", C.c_uint32), ("error_rate", C.c_double), ("flags", C.c_uint32)]
 
 
-SEARCH_NO_PRUNE, SEARCH_GROUP_ALWAYS, SEARCH_NO_SMALL_PATH, SEARCH_SPLIT_ALWAYS = 1, 2, 4, 8
+SEARCH_NO_PRUNE, SEARCH_GROUP_ALWAYS, SEARCH_NO_SMALL_PATH, SEARCH_SPLIT_ALWAYS, SEARCH_FORCE_TREE_STALL = 1, 2, 4, 8, 16
 
 
 THR_PERCENTAGE, THR_SYNCMER, THR_KMER, THR_FRACMINHASH = 0, 1, 2, 3
@@ -62,7 +62,7 @@ class RunStats(C.Structure):
                 ("query_bytes", C.c_uint64), ("query_touched_bytes", C.c_uint64), ("query_launches", C.c_uint32), ("query_ms", C.c_float),
                 ("syncmer_ms", C.c_float), ("finalize_ms", C.c_float), ("total_ms", C.c_float),
                 ("level_ms", C.c_float * 8), ("level_requested_bytes", C.c_uint64 * 8), ("level_row_reads", C.c_uint64 * 8),
-                ("level_sparse_loads", C.c_uint64 * 8)]
+                ("level_sparse_loads", C.c_uint64 * 8), ("tree_stalls_recovered", C.c_uint32)]
 
 
 class CommStats(C.Structure):
@@ -90,16 +90,20 @@ class HixfMeta(C.Structure):
 class IxfSchema(C.Structure):
     _fields_ = [("n_before", C.c_uint32), ("n_after", C.c_uint32), ("idx_bins", C.c_int32), ("idx_stride", C.c_int32),
                 ("idx_seg_len", C.c_int32), ("idx_seed", C.c_int32), ("seg_len_is_rows", C.c_uint32),
-                ("default_seed", C.c_uint64)]
+                ("default_seed", C.c_uint64), ("layout", C.c_uint32)]
 
 
 class IxfVariant(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("seg_len", C.c_uint64), ("stride", C.c_uint64), ("key_hash", C.c_uint8),
                 ("seed_mode", C.c_uint8), ("rot", C.c_uint8), ("reduce", C.c_uint8), ("fp_mode", C.c_uint8),
-                ("layout", C.c_uint8), ("pad", C.c_uint8 * 2)]
+                ("pad", C.c_uint8), ("layout", C.c_uint16)]
 
 
-# every symbol include/taxor_gpu.h declares: name -> (restype, argtypes)
+# layout codes (taxor_amd/csrc/ixf_layout.h)
+LAYOUT_ROWS, LAYOUT_BIN_MAJOR, LAYOUT_BIT_SLICED = 0, 1, 2
+LAYOUT_POSITION_MAJOR, LAYOUT_PITCH_BINS, LAYOUT_PITCH_STORED = 0x100, 0x200, 0x400
+
+# every symbol include/taxor_gpu.h and include/taxor_gpu_tools.h declare: name -> (restype, argtypes)
 _P = C.c_void_p
 class InflateChunk(C.Structure):
     _fields_ = [("start_bit", C.c_uint64), ("stop_bit", C.c_uint64), ("weight", C.c_uint64)]
@@ -169,7 +173,11 @@ SIGNATURES = {
     "taxor_ixf_arith_decode": (None, [C.c_uint32, C.POINTER(IxfVariant)]),
     "taxor_ixf_build_bin_arith": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "taxor_ixf_variant_default": (None, [C.POINTER(IxfVariant), C.c_uint64, C.c_uint64, C.c_uint64]),
-    "taxor_gpu_ixf_variant_scan": (C.c_int, [_P, C.c_uint64, C.POINTER(IxfVariant), C.c_uint32, _P, _P, C.c_uint64, _P]),
+    "taxor_gpu_ixf_variant_scan": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_uint64, C.POINTER(IxfVariant), C.c_uint32, _P, _P, C.c_uint64, _P]),
+    "taxor_ixf_layout_parse": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint32)]),
+    "taxor_ixf_layout_describe": (C.c_uint64, [C.c_uint32, C.c_char_p, C.c_uint64]),
+    "taxor_hixf_set_layout": (C.c_int, [_P, C.c_uint32]),
+    "taxor_hixf_ixf_raw_bytes": (C.c_uint64, [_P, C.c_uint64]),
     "taxor_ixf_variant_describe": (C.c_uint64, [C.POINTER(IxfVariant), C.c_char_p, C.c_uint64]),
     "taxor_hixf_load": (C.c_int, [C.c_char_p, C.POINTER(_P)]),
     "taxor_ixf_schema_default": (None, [C.POINTER(IxfSchema)]),

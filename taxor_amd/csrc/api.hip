@@ -1,8 +1,9 @@
 // api.hip -- C ABI of libtaxor_gpu.so (include/taxor_gpu.h): index residency in HBM, the per-GPU searcher,
 // the batch pipeline (upload -> syncmers -> level-synchronous HIXF query -> DFS-ordered CSR) and the stage
 // entry points the parity tests use.  No CPU fallback exists: every compute entry point runs HIP kernels.
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
+#include "ixf_layout.h"
 #include "kernels.h"
 #include "tuning.h"
 
@@ -133,6 +134,7 @@ struct taxor_gpu_searcher {
     bool prune = true;   // taxor_gpu_search_params::flags & TAXOR_SEARCH_NO_PRUNE disables the threshold-aware pruning (A/B measurements)
     bool group_always = false;   // TAXOR_SEARCH_GROUP_ALWAYS: the queue grouping also for sub-batches of a few thousand reads
     bool split_always = false;   // TAXOR_SEARCH_SPLIT_ALWAYS: root items in column parts whatever the batch size (parity tests)
+    bool force_tree_stall = false; // TAXOR_SEARCH_FORCE_TREE_STALL: the one-launch traversal's watchdog fires at once (recovery-path test)
     bool small_path = true;      // !TAXOR_SEARCH_NO_SMALL_PATH: calls of up to a few thousand reads go through the lanes below
     size_t lds_query = 0;
 
@@ -253,8 +255,26 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 // progress(ctx, b): every byte of the slab below offset b is final (pieces complete out of order; b is the contiguous
 // prefix).  Used by the communicator to broadcast behind the upload.
 // ---------------------------------------------------------------------------------------------------------
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_upload_relayout(taxor_gpu_index *idx, const taxor_hixf_view *v);   // relayout.hip
+
+// the source's bytes are in the search layout (data[row * stride + bin] at the index's own strides): uploaded as they are
+static bool view_is_search_layout(const taxor_hixf_view *v)
+{
+    if (taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_ROWS || (v->ixf_layout & taxor::IXF_ROWS_POSITION_MAJOR)) return false;
+    for (uint64_t i = 0; i < v->n_ixf; ++i)
+        if (v->ixf[i].src_stride != 0 && v->ixf[i].src_stride != v->ixf[i].stride) return false;
+    return true;
+}
+
 static int index_upload(taxor_gpu_index *idx, const taxor_hixf_view *v, void (*progress)(void *, uint64_t), void *pctx)
 {
+    if (!view_is_search_layout(v)) {
+        // another writer's layout (ixf_layout.h): transposed on the device while it is uploaded (relayout.hip).  The slab is final
+        // only when the last chunk has landed (a bin-major chunk writes a column range of every row), so progress is one step
+        if (int rc = taxor_index_upload_relayout(idx, v)) return rc;
+        if (progress) progress(pctx, idx->slab_bytes);
+        return 0;
+    }
     struct Piece { uint64_t ixf, off, len, slab_end; };
     static const uint64_t piece_bytes = [] { const char *e = tune_env("TAXOR_UPLOAD_PIECE_MB"); const long m = e ? atol(e) : 0; return (uint64_t)(m > 0 ? m : 8) << 20; }();
     const uint64_t n = v->n_ixf;
@@ -409,6 +429,7 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
     if (v->use_syncmer && (k < 2 || k > 32 || s < 1 || s > 16 || s >= k || k - s + 1 > 32 || t < 1))
         return fail(TAXOR_E_ARG, "index_create: unsupported k=%d s=%d t=%d (need k<=32, s<=16, s<k, t>=1)", k, s, t);
     if (v->n_ixf >= (1u << 30)) return fail(TAXOR_E_ARG, "index_create: too many IXFs");
+    if (!taxor::ixf_layout_valid(v->ixf_layout)) return fail(TAXOR_E_ARG, "index_create: unknown fingerprint layout code %u", v->ixf_layout);
     HIP_TRY(hipSetDevice(device));
 
     auto idx = new taxor_gpu_index();
@@ -431,6 +452,11 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
             return fail(TAXOR_E_ARG, "index_create: IXF %llu malformed (bins=%llu stride=%llu seg_len=%llu)",
                         (unsigned long long)i, (unsigned long long)f.bins, (unsigned long long)f.stride,
                         (unsigned long long)f.seg_len);
+        }
+        if (f.src_stride != 0 && f.src_stride < f.bins && taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_BIT_SLICED) {
+            delete idx;
+            return fail(TAXOR_E_ARG, "index_create: IXF %llu: source pitch %llu below its %llu bins", (unsigned long long)i, (unsigned long long)f.src_stride,
+                        (unsigned long long)f.bins);
         }
         if (3 * f.seg_len >= (1ull << 32) || f.stride > (1u << 20)) {
             delete idx;
@@ -868,6 +894,7 @@ static int searcher_create_impl(taxor_gpu_index *idx, const taxor_gpu_search_par
     s->prune = !(prm->flags & TAXOR_SEARCH_NO_PRUNE);
     s->group_always = (prm->flags & TAXOR_SEARCH_GROUP_ALWAYS) != 0;
     s->split_always = (prm->flags & TAXOR_SEARCH_SPLIT_ALWAYS) != 0;
+    s->force_tree_stall = (prm->flags & TAXOR_SEARCH_FORCE_TREE_STALL) != 0;
     s->small_path = !(prm->flags & TAXOR_SEARCH_NO_SMALL_PATH);
     if (const char *e = tune_env("TAXOR_QUERY_PRUNE")) s->prune = atoi(e) != 0;
     if (const char *e = tune_env("TAXOR_FIRST_DIV")) { const int v = atoi(e); if (v >= 1 && v <= 64) s->first_div = (uint32_t)v; }
@@ -1203,9 +1230,11 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
     // root items in column parts (QueryArgs::parts): what the caller asks for (the small-batch lanes), or the widest valid
     // division when the searcher was created with TAXOR_SEARCH_SPLIT_ALWAYS; never for the raw per-IXF entry points
     if (root_parts == 0) root_parts = s->split_always ? idx->root_pmax : 1u;
-    if (d_counts_out || only_ixf >= 0 || root_parts > idx->root_pmax) root_parts = 1;
+    if (d_counts_out || only_ixf >= 0 || root_parts > idx->root_pmax || idx->root_pmax % root_parts != 0) root_parts = 1;   // (a count that does not
+                                                                                      // divide the widest division would leave the root's last columns out)
     q.parts = root_parts;
     for (uint32_t j = 0; j <= root_parts; ++j) q.part_cut[j] = idx->root_cut[j * (idx->root_pmax / root_parts)];
+    q.part_cut[root_parts] = idx->root_cut[idx->root_pmax];
     if (tree) {        // a lane's piece: the whole traversal in one launch (k_query_level<..., TREE>), children through the one queue d_q[0]
         q.level = 0;
         q.q_in = nullptr;
@@ -1214,8 +1243,10 @@ int run_query(taxor_gpu_searcher *s, const uint64_t *d_hashes, const uint64_t *d
         q.order0 = d_order;
         q.cursor_chunk = 1;
         q.xcd_slices = 0;
-        static const int polls_env = [] { const char *e = tune_env("TAXOR_TREE_POLLS"); return e ? atoi(e) : -1; }();
-        q.tree_polls = polls_env >= 0 ? (uint32_t)polls_env : 8u;
+        // the watchdog of a block that waits for its queue slot: ~2^22 polls of >= 0.5 us are seconds, far beyond any run of a piece
+        // of <= 1024 reads; TAXOR_SEARCH_FORCE_TREE_STALL (or TAXOR_TREE_POLLS=0) makes it fire at the first empty poll
+        const char *pe = tune_env("TAXOR_TREE_POLLS");
+        q.tree_polls = s->force_tree_stall ? 0u : pe ? (uint32_t)std::max(0, atoi(pe)) : (1u << 22);
         const uint64_t items0 = (uint64_t)n_reads * root_parts;
         // Blocks beyond the items a piece can have at one time only poll (the root's items, or a couple per read below it) -- and a
         // block that polls holds its place on a CU until ITS launch is complete, so a launch is also kept to half the chip: two
@@ -1863,7 +1894,10 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     uint32_t parts = 1;
     static const int parts_env = [] { const char *e = tune_env("TAXOR_SMALL_PARTS"); return e ? atoi(e) : 0; }();
     while (parts < idx->root_pmax && (uint64_t)n * parts * 2 <= (uint64_t)c->grid_query_short / 2) parts *= 2;
-    if (parts_env >= 1) parts = std::min<uint32_t>((uint32_t)parts_env, idx->root_pmax);
+    if (parts_env >= 1) {          // rounded down to a power of two: the divisions are halvings of the widest one (root_pmax)
+        parts = 1;
+        while (parts * 2 <= (uint32_t)parts_env && parts * 2 <= idx->root_pmax) parts *= 2;
+    }
     if (s->split_always) parts = idx->root_pmax;
     c->stats = taxor_gpu_run_stats{};
     // one launch for the whole traversal up to TREE_MAX reads; larger pieces keep the chip busy level by level, and from 4096 reads
@@ -1919,16 +1953,19 @@ int small_harvest_one(taxor_gpu_searcher *s)
     if (f & FLAG_ALPHABET) { L.fresh = true; return fail(TAXOR_E_ALPHABET, "a read contains a character outside the dna15 alphabet"); }
     if (f & FLAG_CAND_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "syncmer candidate capacity bound violated"); }
     if (f & FLAG_DEDUP_OVERFLOW) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "dedup scratch too small"); }
-    if (f & FLAG_TREE_STALL) { L.fresh = true; return fail(TAXOR_E_INTERNAL, "the one-launch traversal of a small batch stalled"); }
     const uint64_t *ro;
     const int64_t *ub;
     const uint32_t *cnt, *nh;
     uint64_t nt;
+    uint32_t tree_stalls = 0;
     taxor_gpu_results r{};
-    if (f & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TUPLE_OVERFLOW)) {
+    if (f & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TUPLE_OVERFLOW | FLAG_TREE_STALL)) {
         // the lane classifies the piece once more through the pipeline of large batches, which grows its buffers and reruns until
-        // everything fits (check_flags)
+        // everything fits (check_flags).  The same for a one-launch traversal whose watchdog fired (a block gave up waiting for
+        // its queue slot): that launch's hits are partial, the level-by-level pipeline has no spin-wait, and L.fresh has the lane's
+        // counters and queue cleared before its next piece -- a stall costs a rerun, never the batch
         L.fresh = true;
+        if (f & FLAG_TREE_STALL) ++tree_stalls;
         if (ensure_stream(&L.c->st_sync)) return TAXOR_E_HIP;        // (a lane has no second stream of its own; that pipeline wants one)
         if (int rc = taxor_gpu_search_batch(L.c, s->small_bases, s->small_offsets + pc.first, pc.n, &r)) return rc;
         ro = r.read_off; ub = r.user_bin; cnt = r.count; nh = r.n_hashes; nt = r.n_tuples;
@@ -1936,6 +1973,7 @@ int small_harvest_one(taxor_gpu_searcher *s)
         st.n_work_items += L.c->stats.n_work_items;
         st.query_bytes += L.c->stats.query_bytes;
         st.query_touched_bytes += L.c->stats.query_touched_bytes;
+        st.tree_stalls_recovered += tree_stalls;
     } else {
         ro = o.read_off; ub = o.ub; cnt = o.cnt; nh = o.nh; nt = o.status[1];
         st.n_hashes += o.status[2];

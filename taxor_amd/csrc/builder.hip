@@ -22,7 +22,7 @@
 // taxor_gpu_index_build_hixf builds a whole hierarchy bottom-up: the keys stay on the device, a merged bin's key set
 // is the sorted, duplicate-free union of everything in its child IXF (keyset.hip), and every IXF goes through the
 // same peeling.
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
 #include "kernels.h"
 #include "keyset.h"

@@ -14,7 +14,7 @@
 // TAXOR_COMM_HOST is the same interface with every transfer staged through host memory (each device's own PCIe link);
 // it is selectable for machines without a working RCCL and is what the parity tests compare the RCCL transport with.
 // A failure is an error return with a message -- a communicator never silently changes transport.
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #include "tuning.h"
 using taxor::tune_env;
 

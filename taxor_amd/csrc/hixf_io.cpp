@@ -17,7 +17,12 @@
 //     u64 bins | u64 technical_bins (= row stride) | u64 seg_len | u64 bin_words (= technical_bins/64) |
 //     u64 seed | u64 ftype (= 8 fingerprint bits) | vector<uint8_t> data (u64 len + len bytes)
 // with len == 3 * seg_len * technical_bins.
-#include "../../include/taxor_gpu.h"
+// How the bytes of `data` are laid out is un-vendored as well: ixf_layout.h lists the layouts a file may follow; the schema
+// carries the code (taxor_ixf_schema::layout), a loaded file starts at what its array lengths admit and `taxor pin` /
+// `taxor verify --variants` decide (taxor_hixf_set_layout).  Whatever it is, index creation transposes it into the search
+// layout on the device (relayout.hip); this file only does the bookkeeping and, for tests and export, the inverse on the host.
+#include "../../include/taxor_gpu_tools.h"
+#include "ixf_layout.h"
 #include "tuning.h"
 using taxor::tune_env;
 
@@ -84,6 +89,7 @@ struct taxor_hixf {
     size_t map_len = 0;
     int fd = -1;                                           // the file, kept open for the pread() source below
     std::vector<uint64_t> file_off;                        // file offset of every IXF's fingerprint array
+    std::vector<uint64_t> raw_len, stored_stride, stored_seg;  // its length; the record's stride / seg_len scalars (0 = not stored)
     taxor_ixf_source source{};                             // view.source: the bytes by pread(), never through the mapping
     std::vector<taxor_ixf_view> ixf;
     std::vector<std::vector<int64_t>> next_ixf, fname_idx; // copies (the file's i64 arrays may be unaligned)
@@ -220,6 +226,9 @@ std::string parse_ixfs(Cursor &c, const taxor_ixf_schema &sc, taxor_hixf *h, uin
                        std::vector<std::vector<uint64_t>> *scalars_out = nullptr, std::vector<uint64_t> *lens_out = nullptr)
 {
     h->ixf.assign(n_ixf, taxor_ixf_view{});
+    h->raw_len.assign(n_ixf, 0);
+    h->stored_stride.assign(n_ixf, 0);
+    h->stored_seg.assign(n_ixf, 0);
     const uint32_t ns = sc.n_before + sc.n_after;
     std::vector<uint64_t> sv(ns);
     for (uint64_t i = 0; i < n_ixf; ++i) {
@@ -233,38 +242,78 @@ std::string parse_ixfs(Cursor &c, const taxor_ixf_schema &sc, taxor_hixf *h, uin
         taxor_ixf_view &f = h->ixf[i];
         f.data = data;
         f.bins = sc.idx_bins >= 0 ? sv[sc.idx_bins] : 0;                 // 0: filled from next_ixf_id later
-        f.stride = sc.idx_stride >= 0 ? sv[sc.idx_stride] : 0;
-        f.seg_len = sc.idx_seg_len >= 0 ? sv[sc.idx_seg_len] : 0;
         f.seed = sc.idx_seed >= 0 ? sv[sc.idx_seed] : sc.default_seed;
+        h->raw_len[i] = len;
+        h->stored_stride[i] = sc.idx_stride >= 0 ? sv[sc.idx_stride] : 0;
+        h->stored_seg[i] = sc.idx_seg_len >= 0 ? (sc.seg_len_is_rows ? sv[sc.idx_seg_len] / 3 : sv[sc.idx_seg_len]) : 0;
+        if (sc.idx_seg_len >= 0 && h->stored_seg[i] == 0) return "IXF " + std::to_string(i) + ": stored segment length 0";
         if (scalars_out) scalars_out->push_back(sv);
         if (lens_out) lens_out->push_back(len);
-        // stash the length in next_ixf (pointer slot is unused until the tail is parsed): validated in finish_ixfs
-        f.next_ixf = reinterpret_cast<const int64_t *>(static_cast<uintptr_t>(len));
     }
+    return "";
+}
+
+// stride / seg_len / src_stride of IXF i under layout `code` from its array length, its bin count and the record's scalars; the
+// error text names what does not fit
+std::string apply_layout(taxor_hixf *h, size_t i, uint32_t code)
+{
+    taxor_ixf_view &f = h->ixf[i];
+    const uint64_t len = h->raw_len[i], bins = f.bins, S = ceil64(bins), stored = h->stored_stride[i];
+    const uint32_t kind = taxor::ixf_layout_kind(code), rule = code & taxor::IXF_PITCH_MASK;
+    uint64_t pitch = S;
+    if (kind != taxor::IXF_KIND_BIT_SLICED) {
+        pitch = rule == taxor::IXF_PITCH_BINS ? bins : rule == taxor::IXF_PITCH_STORED ? stored : S;
+        if (rule == taxor::IXF_PITCH_STORED && stored == 0) return "IXF " + std::to_string(i) + ": the layout takes its pitch from the record, which stores none";
+    }
+    if (pitch < bins || pitch == 0 || len % pitch != 0)
+        return "IXF " + std::to_string(i) + ": " + (kind == taxor::IXF_KIND_BIN_MAJOR ? "column count " : "row pitch ") + std::to_string(pitch) +
+               " inconsistent with " + std::to_string(bins) + " bins / " + std::to_string(len) + " fingerprint bytes";
+    const uint64_t rows = len / pitch;
+    const uint64_t seg = h->stored_seg[i] ? h->stored_seg[i] : rows / 3;
+    if (seg == 0 || seg > (1ull << 31) || 3 * seg != rows)
+        return "IXF " + std::to_string(i) + ": " + std::to_string(rows) + " rows are not 3 x segment length " + std::to_string(seg);
+    f.seg_len = seg;
+    // a row-interleaved source whose pitch is a legal stride is searched as it lies; everything else lands at ceil64(bins)
+    const bool as_is = kind == taxor::IXF_KIND_ROWS && !(code & taxor::IXF_ROWS_POSITION_MAJOR) && pitch % 64 == 0;
+    f.stride = as_is ? pitch : S;
+    f.src_stride = pitch;
     return "";
 }
 
 std::string finish_ixfs(const taxor_ixf_schema &sc, taxor_hixf *h)
 {
+    if (!taxor::ixf_layout_valid(sc.layout)) return "schema names an unknown fingerprint layout code " + std::to_string(sc.layout);
     for (size_t i = 0; i < h->ixf.size(); ++i) {
         taxor_ixf_view &f = h->ixf[i];
-        const uint64_t len = static_cast<uint64_t>(reinterpret_cast<uintptr_t>(f.next_ixf));
         const uint64_t bins = h->next_ixf[i].size();
         if (sc.idx_bins >= 0 && f.bins != bins)
             return "IXF " + std::to_string(i) + ": stored bin count " + std::to_string(f.bins) + " != next_ixf_id's " + std::to_string(bins);
         f.bins = bins;
-        if (sc.idx_stride < 0) f.stride = ceil64(bins);
-        if (f.stride < bins || f.stride % 64 != 0 || f.stride == 0 || len % f.stride != 0)
-            return "IXF " + std::to_string(i) + ": row stride " + std::to_string(f.stride) + " inconsistent with " + std::to_string(bins) +
-                   " bins / " + std::to_string(len) + " fingerprint bytes";
-        const uint64_t rows = len / f.stride;
-        if (sc.idx_seg_len < 0) f.seg_len = rows / 3;
-        else if (sc.seg_len_is_rows) f.seg_len = f.seg_len / 3;
-        if (f.seg_len == 0 || f.seg_len > (1ull << 31) || 3 * f.seg_len != rows)
-            return "IXF " + std::to_string(i) + ": " + std::to_string(rows) + " rows are not 3 x segment length " + std::to_string(f.seg_len);
         f.next_ixf = h->next_ixf[i].data();
         f.fname_idx = h->fname_idx[i].data();
     }
+    // the pitch rule: what the schema says; where it says nothing (0) the record's stride scalar if there is one, else bins padded
+    // to 64, else -- if no IXF's length fits that -- exactly bins
+    uint32_t code = sc.layout;
+    if ((code & taxor::IXF_PITCH_MASK) == 0 && taxor::ixf_layout_kind(code) != taxor::IXF_KIND_BIT_SLICED) {
+        std::vector<uint32_t> rules;
+        if (sc.idx_stride >= 0) rules.push_back(taxor::IXF_PITCH_STORED);
+        rules.push_back(taxor::IXF_PITCH_PADDED);
+        rules.push_back(taxor::IXF_PITCH_BINS);
+        std::string first_err;
+        for (uint32_t r : rules) {
+            std::string e;
+            for (size_t i = 0; i < h->ixf.size() && e.empty(); ++i) e = apply_layout(h, i, code | r);
+            if (e.empty()) { h->view.ixf_layout = code | r; return ""; }
+            if (first_err.empty()) first_err = e;
+        }
+        return first_err;
+    }
+    for (size_t i = 0; i < h->ixf.size(); ++i) {
+        const std::string e = apply_layout(h, i, code);
+        if (!e.empty()) return e;
+    }
+    h->view.ixf_layout = code;
     return "";
 }
 
@@ -364,7 +413,7 @@ int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bo
 extern "C" void taxor_ixf_schema_default(taxor_ixf_schema *out)
 {
     if (!out) return;
-    *out = taxor_ixf_schema{6, 0, 0, 1, 2, 4, 0, 13572355802537770549ull};
+    *out = taxor_ixf_schema{6, 0, 0, 1, 2, 4, 0, 13572355802537770549ull, 0};
 }
 
 extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *schema, taxor_hixf **out)
@@ -412,7 +461,7 @@ extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *r
     taxor_hixf tail;
     for (uint32_t total = 0; total <= 16 && !found; ++total)
         for (uint32_t na = 0; na <= std::min<uint32_t>(total, 4) && !found; ++na) {
-            taxor_ixf_schema t{total - na, na, -1, -1, -1, -1, 0, 13572355802537770549ull};
+            taxor_ixf_schema t{total - na, na, -1, -1, -1, -1, 0, 13572355802537770549ull, 0};
             Cursor c = c0;
             taxor_hixf trial;
             scal.clear();
@@ -446,11 +495,13 @@ extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *r
     auto bins_of = [&](uint64_t i) { return (uint64_t)tail.next_ixf[i].size(); };
     const std::vector<int> cb = all([&](uint64_t i, uint64_t v) { return v == bins_of(i); });
     if (!cb.empty()) sc.idx_bins = cb[0];
-    std::vector<int> cs = all([&](uint64_t i, uint64_t v) { return v >= bins_of(i) && v % 64 == 0 && v != 0 && lens[i] % v == 0 && v < bins_of(i) + 64; });
+    std::vector<int> cs = all([&](uint64_t i, uint64_t v) { return v >= bins_of(i) && v != 0 && lens[i] % v == 0 && v < bins_of(i) + 64; });
     for (int j : cs)
         if (j != sc.idx_bins) { sc.idx_stride = j; break; }
-    if (sc.idx_stride < 0 && !cs.empty()) sc.idx_stride = cs[0];
-    auto stride_of = [&](uint64_t i) { return sc.idx_stride >= 0 ? scal[i][sc.idx_stride] : ceil64(bins_of(i)); };
+    // without a stored pitch: bins padded to 64 where every array length admits it, else exactly bins
+    bool padded_fits = true;
+    for (uint64_t i = 0; i < n_ixf; ++i) padded_fits = padded_fits && lens[i] % ceil64(bins_of(i)) == 0 && (lens[i] / ceil64(bins_of(i))) % 3 == 0;
+    auto stride_of = [&](uint64_t i) { return sc.idx_stride >= 0 ? scal[i][sc.idx_stride] : padded_fits ? ceil64(bins_of(i)) : bins_of(i); };
     bool rows_ok = true;
     for (uint64_t i = 0; i < n_ixf; ++i) rows_ok = rows_ok && lens[i] % stride_of(i) == 0 && (lens[i] / stride_of(i)) % 3 == 0;
     const std::vector<int> cseg = all([&](uint64_t i, uint64_t v) { return 3 * v == lens[i] / stride_of(i); });
@@ -471,6 +522,16 @@ extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *r
                                                      : std::string("not stored (rows/3)")) + "\n";
     rep += "seed: " + (sc.idx_seed >= 0 ? "scalar " + std::to_string(sc.idx_seed) : std::string("not stored -> default 13572355802537770549 (xorfilter.hpp:153) -- VERIFY with a positive control")) + "\n";
     if (!rows_ok) rep += "WARNING: fingerprint bytes are not 3 x seg_len x stride under this reading; the fork's layout differs\n";
+    {   // which layouts the array lengths admit (the bytes themselves decide: `taxor verify --variants` / `taxor pin`)
+        bool unpadded_fits = true, any_unaligned = false;
+        for (uint64_t i = 0; i < n_ixf; ++i) {
+            unpadded_fits = unpadded_fits && lens[i] % bins_of(i) == 0 && (lens[i] / bins_of(i)) % 3 == 0;
+            any_unaligned = any_unaligned || bins_of(i) % 64 != 0;
+        }
+        rep += std::string("array lengths admit: ") + (padded_fits ? "pitch = bins padded to 64 (row-interleaved, bin-major or bit-sliced)" : "") +
+               (padded_fits && unpadded_fits && any_unaligned ? "; " : "") + (unpadded_fits && any_unaligned ? "pitch = exactly bins (row-interleaved or bin-major)" : "") +
+               (!any_unaligned ? " [every bin count is a multiple of 64: padded and unpadded coincide]" : "") + "\n";
+    }
     for (uint32_t j = 0; j < ns; ++j) {
         rep += "  scalar " + std::to_string(j) + " of IXF 0: " + std::to_string(scal[0][j]) + "\n";
     }
@@ -506,7 +567,7 @@ extern "C" void taxor_hixf_release_data(taxor_hixf *h)
     if (!h || !h->map) return;
     const uintptr_t base = (uintptr_t)h->map;
     for (size_t i = 0; i < h->ixf.size(); ++i) {
-        const uint64_t len = 3 * h->ixf[i].seg_len * h->ixf[i].stride;
+        const uint64_t len = h->raw_len[i];
         uintptr_t a = (base + h->file_off[i] + 4095) & ~(uintptr_t)4095, e = (base + h->file_off[i] + len) & ~(uintptr_t)4095;
         for (; a < e; a += (256ull << 20)) madvise((void *)a, std::min<uintptr_t>(256ull << 20, e - a), MADV_DONTNEED);
     }
@@ -525,6 +586,65 @@ extern "C" void taxor_hixf_set_arith(taxor_hixf *h, uint32_t arith)
     if (h) h->view.ixf_arith = arith;
 }
 
+extern "C" int taxor_hixf_set_layout(taxor_hixf *h, uint32_t layout)
+{
+    if (!h) return io_fail(TAXOR_E_ARG, "hixf_set_layout: null handle");
+    if (!taxor::ixf_layout_valid(layout)) return io_fail(TAXOR_E_ARG, "hixf_set_layout: unknown layout code " + std::to_string(layout));
+    std::vector<taxor_ixf_view> before = h->ixf;
+    for (size_t i = 0; i < h->ixf.size(); ++i) {
+        const std::string e = apply_layout(h, i, layout);
+        if (!e.empty()) {
+            h->ixf = before;
+            h->view.ixf = h->ixf.data();
+            return io_fail(TAXOR_E_ARG, "hixf_set_layout: " + e);
+        }
+    }
+    h->view.ixf_layout = layout;
+    return TAXOR_OK;
+}
+
+extern "C" uint64_t taxor_hixf_ixf_raw_bytes(const taxor_hixf *h, uint64_t ixf) { return h && ixf < h->raw_len.size() ? h->raw_len[ixf] : 0; }
+
+extern "C" int taxor_ixf_layout_parse(const char *spec, uint32_t *code)
+{
+    if (!spec || !code) return io_fail(TAXOR_E_ARG, "ixf_layout_parse: null argument");
+    uint32_t c = 0;
+    const std::string s(spec);
+    for (size_t a = 0; a <= s.size();) {
+        size_t b = s.find(',', a);
+        if (b == std::string::npos) b = s.size();
+        const std::string t = s.substr(a, b - a);
+        a = b + 1;
+        if (t.empty()) continue;
+        if (t == "interleaved") c = (c & ~taxor::IXF_KIND_MASK) | taxor::IXF_KIND_ROWS;
+        else if (t == "bin-major") c = (c & ~taxor::IXF_KIND_MASK) | taxor::IXF_KIND_BIN_MAJOR;
+        else if (t == "bit-sliced") c = (c & ~taxor::IXF_KIND_MASK) | taxor::IXF_KIND_BIT_SLICED;
+        else if (t == "padded") c = (c & ~taxor::IXF_PITCH_MASK) | taxor::IXF_PITCH_PADDED;
+        else if (t == "unpadded") c = (c & ~taxor::IXF_PITCH_MASK) | taxor::IXF_PITCH_BINS;
+        else if (t == "stored-pitch") c = (c & ~taxor::IXF_PITCH_MASK) | taxor::IXF_PITCH_STORED;
+        else if (t == "segment-major") c &= ~taxor::IXF_ROWS_POSITION_MAJOR;
+        else if (t == "position-major") c |= taxor::IXF_ROWS_POSITION_MAJOR;
+        else return io_fail(TAXOR_E_ARG, "ixf_layout_parse: unknown token '" + t + "' (interleaved | bin-major | bit-sliced, padded | unpadded | stored-pitch, segment-major | position-major)");
+    }
+    if (!taxor::ixf_layout_valid(c)) return io_fail(TAXOR_E_ARG, "ixf_layout_parse: '" + s + "' is not a layout (bit-sliced words have no pitch choice)");
+    *code = c;
+    return TAXOR_OK;
+}
+
+extern "C" uint64_t taxor_ixf_layout_describe(uint32_t code, char *buf, uint64_t cap)
+{
+    if (!buf || !cap) return 0;
+    static const char *kind[] = {"interleaved", "bin-major", "bit-sliced"};
+    const uint32_t k = taxor::ixf_layout_kind(code), rule = code & taxor::IXF_PITCH_MASK;
+    std::string t = k <= 2 ? kind[k] : "?";
+    if (k != taxor::IXF_KIND_BIT_SLICED) t += rule == taxor::IXF_PITCH_BINS ? ",unpadded" : rule == taxor::IXF_PITCH_STORED ? ",stored-pitch" : ",padded";
+    t += (code & taxor::IXF_ROWS_POSITION_MAJOR) ? ",position-major" : ",segment-major";
+    const size_t n = std::min<size_t>(t.size(), (size_t)cap - 1);
+    std::memcpy(buf, t.data(), n);
+    buf[n] = 0;
+    return n;
+}
+
 extern "C" const taxor_hixf_view *taxor_hixf_get_view(const taxor_hixf *h) { return h ? &h->view : nullptr; }
 extern "C" const taxor_hixf_meta *taxor_hixf_get_meta(const taxor_hixf *h) { return h ? &h->meta : nullptr; }
 
@@ -532,6 +652,11 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
                                        const taxor_ixf_schema *sc)
 {
     if (!path || !v || !m || !sc) return io_fail(TAXOR_E_ARG, "hixf_store: null argument");
+    if (!taxor::ixf_layout_valid(sc->layout)) return io_fail(TAXOR_E_ARG, "hixf_store: unknown layout code " + std::to_string(sc->layout));
+    for (uint64_t i = 0; i < v->n_ixf; ++i)
+        if (taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_ROWS || (v->ixf_layout & taxor::IXF_ROWS_POSITION_MAJOR) ||
+            (v->ixf[i].src_stride != 0 && v->ixf[i].src_stride != v->ixf[i].stride))
+            return io_fail(TAXOR_E_ARG, "hixf_store: the view's bytes must be in the search layout (data[row * stride + bin])");
     FILE *f = fopen(path, "wb");
     if (!f) return io_fail(TAXOR_E_IO, std::string("cannot create ") + path);
     Writer w{f};
@@ -565,26 +690,59 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
     w.put<uint64_t>(v->n_ixf);
     const uint32_t ns = sc->n_before + sc->n_after;
     std::vector<uint64_t> sv(ns);
+    const uint32_t code = sc->layout, kind = taxor::ixf_layout_kind(code), rule = code & taxor::IXF_PITCH_MASK;
     for (uint64_t i = 0; i < v->n_ixf; ++i) {
         const taxor_ixf_view &x = v->ixf[i];
         if (!x.data && !v->source) {
             fclose(f);
             return io_fail(TAXOR_E_ARG, "hixf_store: IXF without host data");
         }
+        // the file's pitch (row pitch / bin columns stored) under the schema's layout; the search layout's own is written as it lies
+        const uint64_t rows = 3 * x.seg_len;
+        const uint64_t pitch = kind == taxor::IXF_KIND_BIT_SLICED ? ceil64(x.bins) : rule == taxor::IXF_PITCH_BINS ? x.bins : rule == taxor::IXF_PITCH_STORED ? x.stride
+                               : (kind == taxor::IXF_KIND_ROWS ? x.stride : ceil64(x.bins));
+        const bool as_is = kind == taxor::IXF_KIND_ROWS && !(code & taxor::IXF_ROWS_POSITION_MAJOR) && pitch == x.stride;
         // scalars the schema does not name carry the other members such a class would hold
         const uint64_t filler[4] = {x.stride / 64, 8, x.bins ? (x.bins + 63) / 64 : 0, 3};
         uint32_t fi = 0;
         for (uint32_t j = 0; j < ns; ++j) {
             if ((int)j == sc->idx_bins) sv[j] = x.bins;
-            else if ((int)j == sc->idx_stride) sv[j] = x.stride;
+            else if ((int)j == sc->idx_stride) sv[j] = pitch;
             else if ((int)j == sc->idx_seg_len) sv[j] = sc->seg_len_is_rows ? 3 * x.seg_len : x.seg_len;
             else if ((int)j == sc->idx_seed) sv[j] = x.seed;
             else sv[j] = filler[fi++ % 4];
         }
         for (uint32_t j = 0; j < sc->n_before; ++j) w.put<uint64_t>(sv[j]);
-        const uint64_t len = 3 * x.seg_len * x.stride;
+        const uint64_t native_len = rows * x.stride, len = as_is ? native_len : taxor::ixf_src_bytes(code, rows, pitch, x.bins);
         w.put<uint64_t>(len);
-        if (v->source) {                                             // bytes that are not in host memory as a whole (e.g. an
+        if (!as_is) {
+            // another writer's layout: the inverse of what index creation does on the device (relayout.hip), on the host, one IXF
+            // in memory at a time -- tests of the re-layout and export; columns beyond `bins` are written as zeros
+            std::vector<uint8_t> native;
+            const uint8_t *src = x.data;
+            if (v->source) {
+                native.resize(native_len);
+                if (v->source->read(v->source->ctx, i, 0, native_len, native.data()) != 0) {
+                    fclose(f);
+                    return io_fail(TAXOR_E_IO, "hixf_store: the source failed to deliver IXF " + std::to_string(i));
+                }
+                src = native.data();
+            }
+            std::vector<uint8_t> out(len, 0);
+            const uint64_t groups = (x.bins + 63) / 64;
+            for (uint64_t r = 0; r < rows; ++r) {
+                const uint64_t rs = taxor::ixf_src_row(code, r, x.seg_len);
+                const uint8_t *row = src + r * x.stride;
+                if (kind == taxor::IXF_KIND_ROWS) std::memcpy(out.data() + rs * pitch, row, x.bins);
+                else if (kind == taxor::IXF_KIND_BIN_MAJOR)
+                    for (uint64_t b = 0; b < x.bins; ++b) out[b * rows + rs] = row[b];
+                else
+                    for (uint64_t b = 0; b < x.bins; ++b)
+                        for (uint32_t p2 = 0; p2 < 8; ++p2)
+                            if ((row[b] >> p2) & 1u) out[(rs * groups + b / 64) * 64 + p2 * 8 + ((b & 63) >> 3)] |= (uint8_t)(1u << (b & 7));
+            }
+            w.bytes(out.data(), len);
+        } else if (v->source) {                                      // bytes that are not in host memory as a whole (e.g. an
             std::vector<uint8_t> piece((size_t)std::min<uint64_t>(len, 64ull << 20));   // index resident on a GPU): piece by piece
             for (uint64_t o = 0; o < len && w.ok; o += piece.size()) {
                 const uint64_t n = std::min<uint64_t>(piece.size(), len - o);

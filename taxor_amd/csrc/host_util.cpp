@@ -1,6 +1,6 @@
 // host_util.cpp -- host-side scalars of the path and the tools the tests / bench need around it
 // (threshold ratio, classification filter, XOR-filter bin construction, synthetic reads).
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
 
 #include <cmath>

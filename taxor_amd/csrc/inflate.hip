@@ -13,7 +13,7 @@
 // device gives up on (a start that was not one, an output beyond its share of the arena) is decoded on the host and put in its place.
 // Second kernel pair: the windows are chained from chunk to chunk (one block, chunk after chunk -- 32 Ki symbols each), then every
 // symbol of every chunk is resolved to its byte in parallel.
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #include "tuning.h"
 
 #include <hip/hip_runtime.h>

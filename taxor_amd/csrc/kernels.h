@@ -37,7 +37,7 @@ enum : uint32_t {
     FLAG_HITS_OVERFLOW = 8u,  // hit buffer too small   -> host grows and reruns
     FLAG_TUPLE_OVERFLOW = 16u,// batch tuple arrays too small -> host grows and reruns
     FLAG_DEDUP_OVERFLOW = 32u,// dedup scratch too small (internal invariant)
-    FLAG_TREE_STALL = 64u     // the one-launch traversal of a small batch stopped waiting for work that never came (internal invariant)
+    FLAG_TREE_STALL = 64u     // the one-launch traversal of a small batch stopped waiting for work that never came -> host reruns the piece level by level
 };
 
 // counters block (one per searcher).  Hot words sit on their own 128-B lines: returning atomics on one line are
@@ -131,7 +131,8 @@ struct QueryArgs {
                               // boundaries where a bin run ends (part_cut, in 16-bin units), so a part sees whole runs and prunes,
                               // tallies and reports on its own -- small batches then fill the chip and finish sooner (api.hip)
     uint16_t part_cut[10];
-    uint32_t tree_polls;      // (unused)
+    uint32_t tree_polls;      // TREE launch: polls of an empty queue slot before the watchdog gives up (FLAG_TREE_STALL; the host then
+                              // classifies the piece level by level); 0 = at the first empty poll (test hook)
     uint32_t sort_units;      // 1 = the alive units of a sparse stage are put in ascending order, so that units sharing a 128-B line of a
                               // row are fetched by neighbouring lanes of one load instruction (one request to the memory side, not several)
     uint32_t dense_max_stride;// rows of at most this many bytes are counted densely to the end (a 16-B load of the sparse phase costs HBM

@@ -1224,7 +1224,8 @@ __device__ __forceinline__ void query_dense_range(const IxfDesc &D, const uint64
 // copies of one word, each polled by a sixty-fourth of the waiting blocks.  (Tried first: claiming entries by compare-and-swap
 // while cursor < reserved, idle blocks leaving -- a thousand blocks retrying a CAS on one word serialise into O(n^2) atomics,
 // milliseconds per launch.)  Consumers put ~0 back, so the queue is clean for the next launch.  A wait that outlives any
-// plausible run raises FLAG_TREE_STALL and leaves -- never a hung GPU.
+// plausible run raises FLAG_TREE_STALL, releases the other waiting blocks and leaves -- never a hung GPU, and the host classifies
+// the piece again level by level (api.hip, small_harvest_one).
 template <bool NT, int U, bool PROF = false, int BS = BLK, int QC = Q_CAP, bool TREE = false>
 __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
 {
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                         const uint32_t *done = &a.ctr->q_xcur[(blockIdx.x >> 3) & 7u][blockIdx.x & 7u].v;      // this block's copy of the "all done" word
                         unsigned long long e = ~0ull;
                         got = 3u;
-                        for (uint32_t spin = 0; spin < (1u << 22); ++spin) {
+                        for (uint32_t spin = 0; spin <= a.tree_polls; ++spin) {
                             if (k < a.q_cap) {
                                 e = __hip_atomic_load(&q64[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 if (e != ~0ull) { got = 1u; break; }
@@ -1326,7 +1327,13 @@ __global__ __launch_bounds__(BS) void k_query_level(const QueryArgs a)
                             if (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { got = 0u; break; }
                             __builtin_amdgcn_s_sleep(16);
                         }
-                        if (got == 3u) { atomicOr(&a.ctr->flags, FLAG_TREE_STALL); got = 0u; }
+                        if (got == 3u) {
+                            // the watchdog: the launch is abandoned as a whole (an entry that arrives in this slot later would never be
+                            // worked on), so everybody who waits is told to leave as well; the host reruns the piece level by level
+                            atomicOr(&a.ctr->flags, FLAG_TREE_STALL);
+                            for (uint32_t g = 0; g < 64u; ++g) __hip_atomic_store(&a.ctr->q_xcur[g >> 3][g & 7u].v, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            got = 0u;
+                        }
                         if (got == 1u) {
                             q64[k] = ~0ull;                                  // the slot is empty again for the next launch
                             ItemMeta m;
@@ -2120,7 +2127,7 @@ __global__ __launch_bounds__(1024) void k_finalize_small(const SmallFinalizeArgs
         off += c[j];
     }
     if (tid == 0) sRoff[n] = total;
-    const bool overflow = (flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW)) != 0u || total > a.tuple_cap;
+    const bool overflow = (flags & (FLAG_QUEUE_OVERFLOW | FLAG_HITS_OVERFLOW | FLAG_TREE_STALL)) != 0u || total > a.tuple_cap;     // (a stalled traversal's hits are partial)
     if (tid == 0) {
         a.h_status[0] = (uint64_t)flags | (total > a.tuple_cap ? (uint64_t)FLAG_TUPLE_OVERFLOW : 0ull);
         a.h_status[1] = total;

@@ -4,15 +4,17 @@
 // compare_tsv, variant_family, rank_variants).
 //
 //   taxor pin --index-file X.hixf --query-file R.fq --expect ref.tsv --out tests/golden/real_<name>.json
-//             [--ixf-arithmetic spec] [--error-rate e] [--percentage p] [--threads n] [--fixture-reads n] [--gpu id] [--name s]
+//             [--ixf-arithmetic spec] [--ixf-layout spec] [--error-rate e] [--percentage p] [--threads n] [--fixture-reads n] [--gpu id] [--name s]
 //
 // What it does, in order:
 //   1. probe     : the IXF record layout of the file (taxor_hixf_probe), loaded with what was found;
-//   2. variants  : which reading of the un-vendored IXF arithmetic the file follows -- the root IXF's raw bytes are probed under
-//                  the variant family of `taxor verify --variants`, with hash lists cut from the query reads the EXPECTED TSV
-//                  reports as the best matches (no genome file needed: the reference's own output says which reads are in the
-//                  index); skipped when --ixf-arithmetic names it;
-//   3. search    : `taxor search --ixf-arithmetic <that> --expect ref.tsv` as a child process, every read compared with the
+//   2. variants  : which reading of the un-vendored IXF the file follows -- arithmetic AND fingerprint layout: the root IXF's raw
+//                  bytes are probed under the variant family of `taxor verify --variants`, with hash lists cut from the query
+//                  reads the EXPECTED TSV reports as the best matches (no genome file needed: the reference's own output says
+//                  which reads are in the index); skipped when --ixf-arithmetic names the arithmetic (the layout is then what
+//                  --ixf-layout says, or what the loader settled on);
+//   3. search    : `taxor search --ixf-arithmetic <that> --ixf-layout <that> --expect ref.tsv` as a child process (a layout
+//                  other than the search layout is transposed on the device at load), every read compared with the
 //                  reference's lines (matched by id, a read's lines in DFS order);
 //   4. fixture   : schema, arithmetic code, the comparison's counts and, for a handful of reads, everything a test needs to
 //                  re-check the un-vendored boundaries WITHOUT the (hundreds of megabytes of) index: the read itself, the
@@ -74,7 +76,7 @@ static std::vector<std::string> split_tabs(const std::string &l)
 
 static int pin_command(int argc, char **argv)
 {
-    std::string index_file, query_file, expect_file, out_file, name, arith_given;
+    std::string index_file, query_file, expect_file, out_file, name, arith_given, layout_given;
     double error_rate = 0.04, percentage = -1.0;
     unsigned threads = 8;
     size_t fixture_reads = 8;
@@ -88,6 +90,7 @@ static int pin_command(int argc, char **argv)
         else if (k == "--out") out_file = val();
         else if (k == "--name") name = val();
         else if (k == "--ixf-arithmetic") arith_given = val();
+        else if (k == "--ixf-layout") layout_given = val();
         else if (k == "--error-rate") error_rate = atof(val().c_str());
         else if (k == "--percentage") percentage = atof(val().c_str());
         else if (k == "--threads") threads = (unsigned)atoi(val().c_str());
@@ -97,7 +100,7 @@ static int pin_command(int argc, char **argv)
     }
     if (index_file.empty() || query_file.empty() || expect_file.empty() || out_file.empty())
         die("usage: taxor pin --index-file <x.hixf> --query-file <reads.fq> --expect <reference.tsv> --out tests/golden/real_<name>.json\n"
-            "                 [--ixf-arithmetic kh=..,sm=..,rot=..,red=..,fp=..] [--error-rate e] [--percentage p] [--threads n] [--fixture-reads n]");
+            "                 [--ixf-arithmetic kh=..,sm=..,rot=..,red=..,fp=..] [--ixf-layout bin-major,unpadded,..] [--error-rate e] [--percentage p] [--threads n] [--fixture-reads n]");
     for (const auto &f : {index_file, query_file, expect_file})
         if (!file_exists(f)) die("taxor pin: no such file: " + f);
     if (threads < 1 || threads > 32) threads = 8;
@@ -201,19 +204,24 @@ static int pin_command(int argc, char **argv)
             fprintf(stderr, "[taxor pin] %zu of the %zu reads picked from the expected TSV were not found in the query file by id\n", wanted.size() - found, wanted.size());
     }
 
-    // ---- 2. the arithmetic the file follows -------------------------------------------------------------------------------
-    // a one-IXF index over the ROOT's bytes: every indexed genome is in one of its bins, and uploading the root alone keeps
-    // this step cheap for a 113 GB index
-    taxor_ixf_view root = view->ixf[0];
-    std::vector<int64_t> zero(root.bins, 0), iota(root.bins);
-    for (uint64_t b = 0; b < root.bins; ++b) iota[b] = (int64_t)b;
-    root.next_ixf = zero.data();
-    root.fname_idx = iota.data();
+    // ---- 2. the reading the file follows: arithmetic and fingerprint layout --------------------------------------------------
+    // hashing needs k / s / t only: a one-IXF dummy index carries them; the scan itself probes the ROOT's raw bytes (every indexed
+    // genome is in one of its bins), which keeps this step cheap for a 113 GB index
+    if (!layout_given.empty()) {
+        uint32_t lc = 0;
+        if (taxor_ixf_layout_parse(layout_given.c_str(), &lc) != TAXOR_OK || taxor_hixf_set_layout(h, lc) != TAXOR_OK) die(taxor_gpu_last_error());
+    }
+    const uint64_t root_raw = taxor_hixf_ixf_raw_bytes(h, 0);
+    std::vector<uint8_t> dz(3 * 16 * 64, 0);
+    std::vector<int64_t> zero(64, 0), iota(64);
+    for (uint64_t b = 0; b < 64; ++b) iota[b] = (int64_t)b;
+    taxor_ixf_view dummy{64, 64, 16, 1, dz.data(), zero.data(), iota.data(), 0};
     taxor_hixf_view rv = *view;
     rv.n_ixf = 1;
-    rv.ixf = &root;
-    rv.n_user_bins = root.bins;
-    rv.source = nullptr;                          // the root's bytes through the mapping (view->ixf[0].data)
+    rv.ixf = &dummy;
+    rv.n_user_bins = 64;
+    rv.source = nullptr;
+    rv.ixf_layout = 0;
     taxor_gpu_index *gi = nullptr;
     if (taxor_gpu_index_create(&rv, device, &gi) != TAXOR_OK) die(taxor_gpu_last_error());
     taxor_gpu_search_params prm{};
@@ -233,7 +241,11 @@ static int pin_command(int argc, char **argv)
     uint32_t arith = 0;
     std::string arith_source;
     taxor_ixf_variant chosen;
-    taxor_ixf_variant_default(&chosen, root.seed, root.seg_len, root.stride);
+    {
+        const taxor_ixf_view &root = view->ixf[0];
+        taxor_ixf_variant_default(&chosen, root.seed, root.seg_len, root.src_stride ? root.src_stride : root.stride);
+        chosen.layout = (uint16_t)view->ixf_layout;
+    }
     if (!arith_given.empty()) {
         if (!parse_arith_spec(arith_given, &arith)) die("--ixf-arithmetic: expected kh=..,sm=..,rot=..,red=..,fp=..");
         taxor_ixf_arith_decode(arith, &chosen);
@@ -243,32 +255,42 @@ static int pin_command(int argc, char **argv)
         for (const auto &s : scored)
             if (!wanted[s.id].seq.empty()) pos.push_back(&wanted[s.id]);
         if (pos.empty()) die("taxor pin: the expected TSV reports no classified read with >= 50 hashes that is also in the query file; name the reading with --ixf-arithmetic");
-        std::vector<uint64_t> hoff, hs;
+        std::vector<uint64_t> hoff, hs, s_off, s_hs;
         hashes_of(pos, hoff, hs);
-        std::vector<taxor_ixf_variant> vs = variant_family(view->ixf[0]);
+        cap_hash_lists(hoff.data(), hs.data(), pos.size(), 160, s_off, s_hs);
+        const taxor_ixf_view root = view->ixf[0];
+        std::vector<taxor_ixf_variant> vs = variant_family(root, root_raw, view->ixf_layout);
         std::vector<float> ratio(vs.size() * pos.size());
-        if (taxor_gpu_ixf_variant_scan(gi, 0, vs.data(), (uint32_t)vs.size(), hs.data(), hoff.data(), pos.size(), ratio.data()) != TAXOR_OK) die(taxor_gpu_last_error());
+        if (taxor_gpu_ixf_variant_scan(device, root.data, root_raw, root.bins, vs.data(), (uint32_t)vs.size(), s_hs.data(), s_off.data(), pos.size(), ratio.data()) != TAXOR_OK)
+            die(taxor_gpu_last_error());
         const auto rank = rank_variants(vs, ratio, pos.size());
-        printf("== variants: %zu readings of the root IXF probed with %zu reads the expected TSV reports at match ratios %.3f .. %.3f\n", vs.size(), pos.size(),
-               scored.back().ratio, scored.front().ratio);
+        printf("== variants: %zu readings of the root IXF's %llu raw bytes probed with %zu reads the expected TSV reports at match ratios %.3f .. %.3f\n", vs.size(),
+               (unsigned long long)root_raw, pos.size(), scored.back().ratio, scored.front().ratio);
         char desc[512];
         for (size_t i = 0; i < std::min<size_t>(3, rank.size()); ++i) {
             taxor_ixf_variant_describe(&vs[rank[i].second], desc, sizeof desc);
             printf("  %.4f  %s\n", rank[i].first, desc);
         }
         if (rank.empty() || rank[0].first < 0.35f)
-            die("taxor pin: no reading of the IXF arithmetic answers for the reads the reference classified (best median match ratio " +
+            die("taxor pin: no reading of the IXF answers for the reads the reference classified (best median match ratio " +
                 std::to_string(rank.empty() ? 0.0 : rank[0].first) + "): the key hash or the record layout is not what this library assumes -- see `taxor probe`");
         chosen = vs[rank[0].second];
-        if (chosen.layout != 0) die("taxor pin: the file stores its fingerprints bin-major; this build searches the interleaved layout only");
-        if (chosen.stride != root.stride || chosen.seg_len != root.seg_len || chosen.seed != root.seed)
-            die("taxor pin: the answering reading differs in seed / segment length / row stride from what the loader took from the file; `taxor probe` shows the record layout");
+        // every IXF of the file under the layout that answered (strides, segment lengths, pitches recomputed from the array lengths)
+        if (chosen.layout != view->ixf_layout && taxor_hixf_set_layout(h, chosen.layout) != TAXOR_OK) die(std::string("taxor pin: ") + taxor_gpu_last_error());
+        if (chosen.seg_len != view->ixf[0].seg_len || chosen.seed != view->ixf[0].seed)
+            die("taxor pin: the answering reading differs in seed / segment length from what the loader took from the file; `taxor probe` shows the record layout");
         arith = taxor_ixf_arith_code(&chosen);
         arith_source = "variant scan of the root IXF over " + std::to_string(pos.size()) + " reads of the expected TSV (median best-bin match ratio " +
                        std::to_string(rank[0].first) + ")";
     }
     const std::string spec = arith_spec(chosen);
+    const uint32_t layout = view->ixf_layout;
+    char layout_desc[128];
+    taxor_ixf_layout_describe(layout, layout_desc, sizeof layout_desc);
+    bool relayout = taxor::ixf_layout_kind(layout) != taxor::IXF_KIND_ROWS || (layout & taxor::IXF_ROWS_POSITION_MAJOR);
+    for (uint64_t i = 0; i < view->n_ixf && !relayout; ++i) relayout = view->ixf[i].src_stride != 0 && view->ixf[i].src_stride != view->ixf[i].stride;
     printf("== arithmetic: %s (code %u%s) -- %s\n", spec.c_str(), arith, arith == 0 ? ", this library's reading" : "", arith_source.c_str());
+    printf("== layout: %s (code %u)%s\n", layout_desc, layout, relayout ? " -- transposed into the search layout on the device at load" : " -- the search layout, uploaded as it lies");
 
     // ---- 4a. the fixture reads: hashes, probe rows, fingerprint bytes (host mapping of the file) -----------------------------
     std::vector<const PinRead *> fx;
@@ -302,6 +324,7 @@ static int pin_command(int argc, char **argv)
                                     "--threads", std::to_string(threads), "--error-rate", std::to_string(error_rate), "--gpu", std::to_string(device)};
         if (percentage >= 0.0) { av.push_back("--percentage"); av.push_back(std::to_string(percentage)); }
         if (arith != 0) { av.push_back("--ixf-arithmetic"); av.push_back(spec); }
+        if (relayout || !layout_given.empty()) { av.push_back("--ixf-layout"); av.push_back(layout_desc); }
         std::vector<char *> cav;
         for (auto &s : av) cav.push_back(&s[0]);
         cav.push_back(nullptr);
@@ -363,7 +386,8 @@ static int pin_command(int argc, char **argv)
           ", \"n_after\": " + std::to_string(schema.n_after) + ", \"idx_bins\": " + std::to_string(schema.idx_bins) + ", \"idx_stride\": " + std::to_string(schema.idx_stride) +
           ", \"idx_seg_len\": " + std::to_string(schema.idx_seg_len) + ", \"idx_seed\": " + std::to_string(schema.idx_seed) + ", \"seg_len_is_rows\": " +
           std::to_string(schema.seg_len_is_rows) + ", \"default_seed\": " + std::to_string((unsigned long long)schema.default_seed) + "},\n            \"ixf_arith\": " +
-          std::to_string(arith) + ", \"arith_spec\": \"" + spec + "\", \"arith_source\": \"" + json_escape(arith_source) + "\"},\n";
+          std::to_string(arith) + ", \"arith_spec\": \"" + spec + "\", \"arith_source\": \"" + json_escape(arith_source) + "\",\n            \"ixf_layout\": " +
+          std::to_string(layout) + ", \"layout_spec\": \"" + layout_desc + "\", \"relayout\": " + (relayout ? "true" : "false") + "},\n";
     js += "  \"search\": {\"error_rate\": " + std::to_string(error_rate) + ", \"percentage\": " + std::to_string(percentage) + "},\n";
     js += "  \"summary\": {\"reads_expected\": " + std::to_string(expect.size()) + ", \"reads_ours\": " + std::to_string((unsigned long long)n_ours) +
           ", \"identical\": " + std::to_string((unsigned long long)n_same) + ", \"differing_or_missing\": " + std::to_string((unsigned long long)bad) + "},\n";
@@ -417,7 +441,8 @@ static int pin_command(int argc, char **argv)
                 std::vector<uint8_t> bytes(3 * nh);
                 uint32_t count = 0;
                 for (size_t i = 0; i < nh; ++i) {
-                    for (int j = 0; j < 3; ++j) bytes[3 * i + j] = X.data[(uint64_t)rows[3 * i + j] * X.stride + bin];
+                    for (int j = 0; j < 3; ++j)          // read where the FILE keeps it (ixf_layout.h)
+                        bytes[3 * i + j] = taxor::ixf_src_fingerprint(X.data, layout, rows[3 * i + j], bin, X.seg_len, X.src_stride ? X.src_stride : X.stride, X.bins);
                     count += (uint8_t)(bytes[3 * i] ^ bytes[3 * i + 1] ^ bytes[3 * i + 2]) == fps[i];
                 }
                 js += std::string(bi ? ", " : "") + "{\"bin\": " + std::to_string((unsigned long long)bin) + ", \"expect_line\": " + std::to_string(tk.second[bi].second) +

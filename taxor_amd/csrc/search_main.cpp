@@ -2,11 +2,12 @@
 // reference's subcommand (src/main/taxor_search.cpp), with the chunk loop replaced by the C ABI
 // (include/taxor_gpu.h).  Host work here: argument parsing (:32-80), sanity checks (:97-151), FASTA/FASTQ(.gz)
 // reading (:181-184), batching (:315-326) and output (:268-311, :343).
-#include "../../include/taxor_gpu.h"
+#include "../../include/taxor_gpu_tools.h"
 #define TAXOR_PGZ_DEVICE 1      // pgz.h: the chunks of a single-member .gz may be decoded on a GPU (inflate.hip through the C ABI)
 #include "fastx.h"
 #include "tuning.h"
 #include "ixf_arith.h"
+#include "ixf_layout.h"
 using taxor::tune_env;
 extern char **environ;
 
@@ -154,6 +155,8 @@ struct Config {                              // taxor_search_configuration.hpp:8
     std::string expect_file;    // --expect: a TSV the reference wrote for the same reads and index, compared per read
     bool sequential = false;    // --sequential: one reader thread per file, no byte-range cutting (any legal FASTA/FASTQ)
     uint32_t ixf_arith = 0;     // --ixf-arithmetic: the reading of the un-vendored IXF arithmetic the index follows (0 = this library's)
+    bool layout_given = false;  // --ixf-layout: how the file stores each IXF's fingerprints (ixf_layout.h); transposed on the device at load
+    uint32_t ixf_layout = 0;
     uint64_t group_reads = 0;   // reads per GPU batch, made of queued chunks (0: 131072, or --batch-reads when that is given)
     std::string gather;         // several devices: "rccl" | "host" (taxor_gpu_comm transports) | "none" (independent workers, each
                                 // fetching its own results); empty = rccl when the devices are distinct, host when one repeats
@@ -206,6 +209,9 @@ void usage()
             "  --group-reads <n>        reads per GPU batch, made of whole chunks (default 131072; --batch-reads if that is given)\n"
             "  --ixf-arithmetic <spec>  search an index whose fingerprints follow another reading of the IXF arithmetic than this\n"
             "                           build's (the spec `taxor verify --variants` prints: kh=..,sm=..,rot=..,red=..,fp=..)\n"
+            "  --ixf-layout <spec>      search an index whose fingerprint vectors are laid out otherwise than data[row*stride + bin]\n"
+            "                           (the spec `taxor verify --variants` / `taxor pin` print, e.g. bin-major,unpadded,segment-major);\n"
+            "                           they are transposed on the device while the index is uploaded\n"
             "  --expect <tsv>           compare the output per read with a TSV the reference wrote for the same input (exit 3 if it differs)\n");
 }
 
@@ -670,40 +676,71 @@ std::string arith_spec(const taxor_ixf_variant &v)
            std::to_string(v.reduce) + ",fp=" + std::to_string(v.fp_mode);
 }
 
-// the readings of the un-vendored IXF arithmetic that `taxor verify --variants` and `taxor pin` probe a root IXF under: seed
-// (the file's, the prototype's fixed start seed, none) x row stride / segment length as stored or as implied by the array
-// length x key hash x seed entry x rotation step x range reduction x fingerprint fold x layout
-std::vector<taxor_ixf_variant> variant_family(const taxor_ixf_view &root)
+// the readings of the un-vendored IXF that `taxor verify --variants` and `taxor pin` probe a root IXF's RAW bytes under: seed (the
+// file's, the prototype's fixed start seed, none) x shape (layout kind x pitch x row order, each with the segment length the
+// array length implies and the one the loader took from the file) x key hash x seed entry x rotation step x range reduction x
+// fingerprint fold.  `loaded_layout` = the code the loader settled on (its pitch rule says whether root.src_stride is a stored
+// scalar).
+std::vector<taxor_ixf_variant> variant_family(const taxor_ixf_view &root, uint64_t raw_len, uint32_t loaded_layout)
 {
-    const uint64_t data_len = 3 * root.seg_len * root.stride;
     std::vector<uint64_t> seeds{root.seed};
     for (uint64_t sd : {13572355802537770549ull, 0ull})
         if (std::find(seeds.begin(), seeds.end(), sd) == seeds.end()) seeds.push_back(sd);
-    std::vector<std::pair<uint64_t, uint64_t>> shapes;          // (stride, seg_len)
-    for (uint64_t st : {root.stride, root.bins}) {
-        if (!st) continue;
-        for (uint64_t sg : {root.seg_len, data_len / st / 3}) {
-            if (!sg) continue;
-            if (std::find(shapes.begin(), shapes.end(), std::make_pair(st, sg)) == shapes.end()) shapes.push_back({st, sg});
+    const uint64_t S = (root.bins + 63) / 64 * 64;
+    struct Shape { uint32_t layout; uint64_t pitch, seg; };
+    std::vector<Shape> shapes;
+    auto add_shape = [&](uint32_t layout, uint64_t pitch) {
+        if (!pitch || pitch < root.bins || raw_len % pitch != 0) return;
+        for (uint64_t sg : {raw_len / pitch / 3, root.seg_len}) {
+            if (!sg || 3 * sg * pitch > raw_len) continue;
+            bool dup = false;
+            for (const Shape &sh : shapes) dup = dup || ((sh.layout & ~taxor::IXF_PITCH_MASK) == (layout & ~taxor::IXF_PITCH_MASK) && sh.pitch == pitch && sh.seg == sg);
+            if (!dup) shapes.push_back({layout, pitch, sg});
         }
+    };
+    for (uint32_t pm : {0u, (uint32_t)taxor::IXF_ROWS_POSITION_MAJOR}) {
+        for (uint32_t kind : {(uint32_t)taxor::IXF_KIND_ROWS, (uint32_t)taxor::IXF_KIND_BIN_MAJOR}) {
+            if ((loaded_layout & taxor::IXF_PITCH_MASK) == taxor::IXF_PITCH_STORED) add_shape(kind | pm | taxor::IXF_PITCH_STORED, root.src_stride ? root.src_stride : root.stride);
+            add_shape(kind | pm | taxor::IXF_PITCH_PADDED, S);
+            add_shape(kind | pm | taxor::IXF_PITCH_BINS, root.bins);
+        }
+        add_shape(taxor::IXF_KIND_BIT_SLICED | pm, S);
     }
     std::vector<taxor_ixf_variant> vs;
     for (uint64_t sd : seeds)
-        for (const auto &sh : shapes)
+        for (const Shape &sh : shapes)
             for (int kh = 0; kh < 4; ++kh)
                 for (int sm = 0; sm < 3; ++sm)
                     for (int rot : {21, 16, 32})
                         for (int red = 0; red < 3; ++red)
-                            for (int fp = 0; fp < 4; ++fp)
-                                for (int lay = 0; lay < 2; ++lay) {
-                                    if (sd == 0 && sm != 0) continue;        // without a seed the three seed modes coincide
-                                    taxor_ixf_variant v;
-                                    taxor_ixf_variant_default(&v, sd, sh.second, sh.first);
-                                    v.key_hash = (uint8_t)kh; v.seed_mode = (uint8_t)sm; v.rot = (uint8_t)rot;
-                                    v.reduce = (uint8_t)red; v.fp_mode = (uint8_t)fp; v.layout = (uint8_t)lay;
-                                    vs.push_back(v);
-                                }
+                            for (int fp = 0; fp < 4; ++fp) {
+                                if (sd == 0 && sm != 0) continue;        // without a seed the three seed modes coincide
+                                taxor_ixf_variant v;
+                                taxor_ixf_variant_default(&v, sd, sh.seg, sh.pitch);
+                                v.key_hash = (uint8_t)kh; v.seed_mode = (uint8_t)sm; v.rot = (uint8_t)rot;
+                                v.reduce = (uint8_t)red; v.fp_mode = (uint8_t)fp; v.layout = (uint16_t)sh.layout;
+                                vs.push_back(v);
+                            }
     return vs;
+}
+
+// hash lists for a variant scan: at most `cap` hashes per list (the score is a ratio; the scan's cost is lists x variants x bins x hashes)
+void cap_hash_lists(const uint64_t *hoff, const uint64_t *hs, uint64_t n_lists, uint64_t cap, std::vector<uint64_t> &off_out, std::vector<uint64_t> &hs_out)
+{
+    off_out.assign(1, 0);
+    hs_out.clear();
+    for (uint64_t l = 0; l < n_lists; ++l) {
+        const uint64_t n = std::min<uint64_t>(cap, hoff[l + 1] - hoff[l]);
+        hs_out.insert(hs_out.end(), hs + hoff[l], hs + hoff[l] + n);
+        off_out.push_back(hs_out.size());
+    }
+}
+
+// this library's own reading of the root as the loader took it: arithmetic code 0 in the search layout
+bool variant_is_native(const taxor_ixf_variant &v, const taxor_ixf_view &root)
+{
+    return taxor_ixf_arith_code(&v) == 0 && taxor::ixf_layout_kind(v.layout) == taxor::IXF_KIND_ROWS && !(v.layout & taxor::IXF_ROWS_POSITION_MAJOR) &&
+           v.stride == root.stride && v.seg_len == root.seg_len && v.seed == root.seed;
 }
 
 // (median best-bin match ratio over the hash lists, variant index), best first
@@ -764,7 +801,8 @@ int main(int argc, char **argv)
         uint64_t n_reads = 2000, read_len = 5000;
         int device = 0;
         bool scan_variants = false;
-        uint32_t verify_arith = 0;
+        uint32_t verify_arith = 0, verify_layout = 0;
+        bool layout_given = false;
         for (int i = 2; i < argc; ++i) {
             if (strcmp(argv[i], "--variants") == 0) { scan_variants = true; continue; }
             if (strcmp(argv[i], "--index-file") == 0 && i + 1 < argc) index_file = argv[++i];
@@ -775,12 +813,17 @@ int main(int argc, char **argv)
             else if (strcmp(argv[i], "--ixf-arithmetic") == 0 && i + 1 < argc) {
                 if (!parse_arith_spec(argv[++i], &verify_arith)) die("--ixf-arithmetic: expected kh=..,sm=..,rot=..,red=..,fp=..");
             }
+            else if (strcmp(argv[i], "--ixf-layout") == 0 && i + 1 < argc) {
+                if (taxor_ixf_layout_parse(argv[++i], &verify_layout) != TAXOR_OK) die(taxor_gpu_last_error());
+                layout_given = true;
+            }
         }
         if (index_file.empty() || genome_file.empty() || !file_exists(index_file) || !file_exists(genome_file) || !n_reads || !read_len)
             die("usage: taxor verify --index-file <x.hixf> --genome-file <fasta of a genome contained in the index> [--reads n] [--read-len l]");
         taxor_hixf *h = nullptr;
         if (taxor_hixf_load(index_file.c_str(), &h) != TAXOR_OK) die(taxor_gpu_last_error());
         taxor_hixf_set_arith(h, verify_arith);
+        if (layout_given && taxor_hixf_set_layout(h, verify_layout) != TAXOR_OK) die(taxor_gpu_last_error());
         const taxor_hixf_view *view = taxor_hixf_get_view(h);
         taxor_gpu_index *gi = nullptr;
         if (taxor_gpu_index_create(view, device, &gi) != TAXOR_OK) die(taxor_gpu_last_error());
@@ -843,33 +886,39 @@ int main(int argc, char **argv)
             const uint64_t *hoff = nullptr, *hs = nullptr;
             if (taxor_gpu_syncmers(sr, bases.data(), offsets.data(), n_lists, &hoff, &hs) != TAXOR_OK) die(taxor_gpu_last_error());
             const taxor_ixf_view &root = view->ixf[0];
-            std::vector<taxor_ixf_variant> vs = variant_family(root);
+            const uint64_t raw_len = taxor_hixf_ixf_raw_bytes(h, 0);
+            std::vector<taxor_ixf_variant> vs = variant_family(root, raw_len, view->ixf_layout);
+            std::vector<uint64_t> s_off, s_hs;
+            cap_hash_lists(hoff, hs, n_lists, 160, s_off, s_hs);
             std::vector<float> ratio(vs.size() * n_lists);
-            if (taxor_gpu_ixf_variant_scan(gi, 0, vs.data(), (uint32_t)vs.size(), hs, hoff, n_lists, ratio.data()) != TAXOR_OK) die(taxor_gpu_last_error());
+            if (taxor_gpu_ixf_variant_scan(device, root.data, raw_len, root.bins, vs.data(), (uint32_t)vs.size(), s_hs.data(), s_off.data(), n_lists, ratio.data()) != TAXOR_OK)
+                die(taxor_gpu_last_error());
             const std::vector<std::pair<float, size_t>> rank = rank_variants(vs, ratio, (size_t)n_lists);
-            printf("variant scan of the root IXF (%zu readings of the fingerprint array, %llu hash lists): median best-bin match ratio\n", vs.size(),
-                   (unsigned long long)n_lists);
+            printf("variant scan of the root IXF (%zu readings of its %llu raw fingerprint bytes, %llu hash lists): median best-bin match ratio\n", vs.size(),
+                   (unsigned long long)raw_len, (unsigned long long)n_lists);
             char desc[512];
-            taxor_ixf_variant mine;
-            taxor_ixf_variant_default(&mine, root.seed, root.seg_len, root.stride);   // this library's own reading (code 0)
             for (size_t i = 0; i < std::min<size_t>(5, rank.size()); ++i) {
                 const taxor_ixf_variant &v = vs[rank[i].second];
                 taxor_ixf_variant_describe(&v, desc, sizeof desc);
-                const bool is_mine = memcmp(&v, &mine, sizeof v) == 0;
-                printf("  %.4f  %s%s\n", rank[i].first, desc, is_mine ? "   [this library's reading, ixf_arith.h]" : "");
+                printf("  %.4f  %s%s\n", rank[i].first, desc, variant_is_native(v, root) ? "   [this library's reading, ixf_arith.h, in the search layout]" : "");
             }
             if (!rank.empty() && rank[0].first >= 0.9f) {
-                const bool is_mine = memcmp(&vs[rank[0].second], &mine, sizeof mine) == 0;
-                printf("%s\n", is_mine ? "the file follows this library's reading of the IXF arithmetic"
-                                       : "the file follows ANOTHER reading of the IXF arithmetic (first line)");
+                const taxor_ixf_variant &bv = vs[rank[0].second];
+                const bool is_mine = variant_is_native(bv, root);
+                printf("%s\n", is_mine ? "the file follows this library's reading of the IXF arithmetic, in the search layout"
+                                       : "the file follows ANOTHER reading of the IXF (first line)");
                 if (!is_mine) {
-                    const taxor_ixf_variant &bv = vs[rank[0].second];
-                    if (bv.layout != 0)
-                        printf("that reading stores the fingerprints bin-major (data[bin*rows + row]): this build searches the interleaved layout only\n");
-                    else if (bv.stride != root.stride || bv.seg_len != root.seg_len || bv.seed != root.seed)
-                        printf("that reading also differs in seed / segment length / row stride from what the loader took from the file: `taxor probe` shows the record layout\n");
+                    char ld[128];
+                    taxor_ixf_layout_describe(bv.layout, ld, sizeof ld);
+                    if (bv.seed != root.seed)
+                        printf("that reading also uses another seed than the loader took from the file: `taxor probe` shows the record layout\n");
                     else
-                        printf("search it with: taxor search --ixf-arithmetic %s ...\n", arith_spec(bv).c_str());
+                    {
+                        const bool as_it_lies = taxor::ixf_layout_kind(bv.layout) == taxor::IXF_KIND_ROWS && !(bv.layout & taxor::IXF_ROWS_POSITION_MAJOR) && bv.stride == root.stride &&
+                                                bv.seg_len == root.seg_len;
+                        printf("search it with: taxor search%s%s%s%s ...\n", taxor_ixf_arith_code(&bv) ? " --ixf-arithmetic " : "",
+                               taxor_ixf_arith_code(&bv) ? arith_spec(bv).c_str() : "", as_it_lies ? "" : " --ixf-layout ", as_it_lies ? "" : ld);
+                    }
                 }
             } else {
                 printf("no variant answers: the key hash (wyhash / minimiser value) or the genome is not what the index holds\n");
@@ -1029,6 +1078,11 @@ int main(int argc, char **argv)
             const std::string spec = val();
             if (!parse_arith_spec(spec, &cfg.ixf_arith)) die("Validation failed for option --ixf-arithmetic: expected kh=<0-3>,sm=<0-3>,rot=<1-63>,red=<0-2>,fp=<0-3> (as printed by `taxor verify --variants`), got " + spec);
         }
+        else if (k == "--ixf-layout") {
+            const std::string spec = val();
+            if (taxor_ixf_layout_parse(spec.c_str(), &cfg.ixf_layout) != TAXOR_OK) die(std::string("Validation failed for option --ixf-layout: ") + taxor_gpu_last_error());
+            cfg.layout_given = true;
+        }
         else if (k == "--gather") {
             cfg.gather = val();
             if (cfg.gather != "rccl" && cfg.gather != "host" && cfg.gather != "none") die("Validation failed for option --gather: Value not in {rccl, host, none}.");
@@ -1101,6 +1155,13 @@ int main(int argc, char **argv)
             fprintf(stderr, "[TAXOR SEARCH WARNING] %s is searched under --ixf-arithmetic %s, not under this build's own reading of the\n"
                             "  un-vendored IXF arithmetic: %s (seed, segment length and row stride per IXF from the file)\n", hixf_file.c_str(),
                     arith_spec(av).c_str(), desc);
+        }
+        if (cfg.layout_given) {
+            if (taxor_hixf_set_layout(h, cfg.ixf_layout) != TAXOR_OK) die(taxor_gpu_last_error());
+            char ld[128];
+            taxor_ixf_layout_describe(cfg.ixf_layout, ld, sizeof ld);
+            fprintf(stderr, "[TAXOR SEARCH WARNING] %s is read under --ixf-layout %s: its fingerprint vectors are transposed into the search layout on the device\n",
+                    hixf_file.c_str(), ld);
         }
         const taxor_hixf_view *view = taxor_hixf_get_view(h);
         if (taxor_hixf_get_meta(h)->foreign_schema)

@@ -1,14 +1,16 @@
-// verify.hip -- diagnosis aid for indexes this library did not write (SURVEY.md 8(f) #2, VERDICT r01 #8).
+// verify.hip -- diagnosis aid for indexes this library did not write (SURVEY.md 8(f) #2).
 //
-// The arithmetic of seqan3::interleaved_xor_filter<uint8_t> is un-vendored in the reference; the
-// product's reading of it lives in ixf_arith.h.  When `taxor verify` finds that an indexed genome does not answer, this
-// scan tells WHICH reading the file follows: the same raw fingerprint bytes of one IXF are probed under a family of
-// arithmetic variants (how the seed enters, which mixer, rotation step, range reduction, fingerprint fold, row stride,
-// segment length, row- or bin-major layout), each scored by the best-bin match ratio of hash lists taken from a genome
-// that IS in the index.  The right variant scores ~1.0, every other one sits at the 2^-8 false-positive floor.
-// Not on the search path; a plain kernel (one block per (hash list, variant), a thread per bin).
-#include "../../include/taxor_gpu.h"
+// Both the arithmetic of seqan3::interleaved_xor_filter<uint8_t> and the layout its serialiser gives the fingerprint vector are
+// un-vendored in the reference; the product's reading of the former lives in ixf_arith.h, the layouts a
+// file may follow in ixf_layout.h.  This scan tells WHICH reading a file follows: the RAW fingerprint bytes of one IXF, as the
+// file holds them, are probed under a family of variants (how the seed enters, which mixer, rotation step, range reduction,
+// fingerprint fold, segment length; row-interleaved at one of several pitches, bin-major, bit-sliced words, rows in segment- or
+// position-major order), each scored by the best-bin match ratio of hash lists taken from sequences that ARE in the index.  The
+// right variant scores ~1.0, every other one sits at the 2^-8 false-positive floor.  Not on the search path; a plain kernel
+// (one block per (hash list, variant), a thread per bin).
+#include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
+#include "ixf_layout.h"
 
 #include <hip/hip_runtime.h>
 
@@ -18,9 +20,6 @@
 #include <vector>
 
 extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const char *msg);
-extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_gpu_index *idx, uint64_t ixf, uint8_t **data,
-                                                                          uint64_t *stride, uint64_t *seg_len, uint64_t *bins,
-                                                                          int *device);
 
 namespace {
 
@@ -45,22 +44,19 @@ __global__ __launch_bounds__(256) void k_variant_scan(const uint8_t *__restrict_
     if (threadIdx.x == 0) sBest = 0;
     __syncthreads();
     const uint64_t rows = 3 * v.seg_len;
+    const uint32_t lay = v.layout;
+    // every byte a probe may touch lies inside the raw array?  (a variant whose shape does not fit the length scores 0)
+    const bool fits = ixf_src_bytes(lay, rows, v.stride, bins) <= data_len && (ixf_layout_kind(lay) == IXF_KIND_BIT_SLICED || v.stride >= bins);
     uint32_t best = 0;
-    for (uint32_t b = threadIdx.x; b < bins; b += 256) {
+    for (uint32_t b = threadIdx.x; fits && b < bins; b += 256) {
         uint32_t cnt = 0;
         for (uint64_t i = 0; i < n; ++i) {
             const uint32_t code = variant_code(v);
             const uint64_t h = ixf_key_hash_arith(hashes[h0 + i], v.seed, code);
             uint8_t x = ixf_fingerprint_arith(h, code);
-            bool ok = true;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const uint64_t r = ixf_row_arith(h, j, v.seg_len, code);
-                const uint64_t addr = v.layout == 0 ? r * v.stride + b : (uint64_t)b * rows + r;
-                if (addr >= data_len) { ok = false; break; }
-                x ^= data[addr];
-            }
-            cnt += (ok && x == 0) ? 1u : 0u;
+            for (int j = 0; j < 3; ++j) x ^= ixf_src_fingerprint(data, lay, ixf_row_arith(h, j, v.seg_len, code), b, v.seg_len, v.stride, bins);
+            cnt += x == 0 ? 1u : 0u;
         }
         best = max(best, cnt);
     }
@@ -77,37 +73,38 @@ int vfail(int code, const std::string &msg)
 
 } // namespace
 
-extern "C" int taxor_gpu_ixf_variant_scan(taxor_gpu_index *idx, uint64_t ixf, const taxor_ixf_variant *variants, uint32_t n_variants,
+extern "C" int taxor_gpu_ixf_variant_scan(int device, const uint8_t *raw, uint64_t raw_len, uint64_t bins, const taxor_ixf_variant *variants, uint32_t n_variants,
                                           const uint64_t *hashes, const uint64_t *hash_off, uint64_t n_lists, float *best_ratio)
 {
-    if (!idx || !variants || !n_variants || !hashes || !hash_off || !n_lists || !best_ratio)
+    if (!raw || !raw_len || !bins || !variants || !n_variants || !hashes || !hash_off || !n_lists || !best_ratio)
         return vfail(TAXOR_E_ARG, "ixf_variant_scan: null or empty argument");
-    uint8_t *data;
-    uint64_t stride, seg_len, bins;
-    int device;
-    if (taxor_index_ixf_info(idx, ixf, &data, &stride, &seg_len, &bins, &device) != 0) return vfail(TAXOR_E_ARG, "ixf_variant_scan: bad IXF id");
     for (uint32_t i = 0; i < n_variants; ++i)
-        if (variants[i].seg_len == 0 || variants[i].stride == 0) return vfail(TAXOR_E_ARG, "ixf_variant_scan: variant with zero segment length or stride");
-    if (n_lists > 65535 || n_variants > 65535) return vfail(TAXOR_E_ARG, "ixf_variant_scan: more than 65535 lists or variants");
-    const uint64_t data_len = 3 * seg_len * stride, nh = hash_off[n_lists];
+        if (variants[i].seg_len == 0 || variants[i].stride == 0 || !ixf_layout_valid(variants[i].layout))
+            return vfail(TAXOR_E_ARG, "ixf_variant_scan: variant with zero segment length or stride, or an unknown layout");
+    if (n_lists > 65535 || n_variants > 65535 || bins >= (1ull << 32)) return vfail(TAXOR_E_ARG, "ixf_variant_scan: more than 65535 lists or variants");
+    const uint64_t nh = hash_off[n_lists];
+    uint8_t *d_raw = nullptr;
     taxor_ixf_variant *d_v = nullptr;
     uint64_t *d_h = nullptr, *d_off = nullptr;
     float *d_out = nullptr;
     hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_raw, raw_len);
     if (e == hipSuccess) e = hipMalloc((void **)&d_v, n_variants * sizeof(taxor_ixf_variant));
     if (e == hipSuccess) e = hipMalloc((void **)&d_h, std::max<uint64_t>(nh, 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_off, (n_lists + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&d_out, (size_t)n_variants * n_lists * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_raw, raw, raw_len, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_v, variants, n_variants * sizeof(taxor_ixf_variant), hipMemcpyHostToDevice);
     if (e == hipSuccess && nh) e = hipMemcpy(d_h, hashes, nh * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_off, hash_off, (n_lists + 1) * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_variant_scan, dim3((uint32_t)n_lists, n_variants), dim3(256), 0, nullptr, data, data_len, (uint32_t)bins, d_v,
+        hipLaunchKernelGGL(k_variant_scan, dim3((uint32_t)n_lists, n_variants), dim3(256), 0, nullptr, d_raw, raw_len, (uint32_t)bins, d_v,
                            d_h, d_off, d_out, (uint32_t)n_lists);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipMemcpy(best_ratio, d_out, (size_t)n_variants * n_lists * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_raw);
     (void)hipFree(d_v);
     (void)hipFree(d_h);
     (void)hipFree(d_off);
@@ -145,9 +142,11 @@ extern "C" uint64_t taxor_ixf_variant_describe(const taxor_ixf_variant *v, char 
     static const char *seed_name[] = {"h(key + seed)", "h(key ^ seed)", "h(key) + seed", "h(key), seed unused"};
     static const char *red_name[] = {"(u32)rot * seg >> 32", "(u32)rot % seg", "mulhi64(rot, seg)"};
     static const char *fp_name[] = {"(u8)(h ^ h>>32)", "(u8)h", "(u8)(h>>56)", "(u8)(h>>32)"};
-    const int n = snprintf(buf, cap, "%s as %s, seed %llu, row_i = %s + i*seg with rot = rotl(h, %u*i), fingerprint %s, seg_len %llu, row stride %llu, %s",
+    static const char *lay_name[] = {"data[row*pitch + bin]", "data[bin*rows + row]", "bit-sliced 64-bin words"};
+    const uint32_t kind = ixf_layout_kind(v->layout);
+    const int n = snprintf(buf, cap, "%s as %s, seed %llu, row_i = %s + i*seg with rot = rotl(h, %u*i), fingerprint %s, seg_len %llu, %s %llu, %s%s",
                            hash_name[v->key_hash & 3], seed_name[v->seed_mode & 3], (unsigned long long)v->seed, red_name[v->reduce % 3],
-                           (unsigned)v->rot, fp_name[v->fp_mode & 3], (unsigned long long)v->seg_len, (unsigned long long)v->stride,
-                           v->layout == 0 ? "data[row*stride + bin]" : "data[bin*rows + row]");
+                           (unsigned)v->rot, fp_name[v->fp_mode & 3], (unsigned long long)v->seg_len, kind == IXF_KIND_BIN_MAJOR ? "columns" : "row pitch",
+                           (unsigned long long)v->stride, lay_name[kind <= 2 ? kind : 0], (v->layout & IXF_ROWS_POSITION_MAJOR) ? ", rows position-major" : "");
     return n < 0 ? 0 : (uint64_t)n;
 }

@@ -62,9 +62,22 @@ def default_schema():
     return sc
 
 
-def make_schema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows=0):
+def make_schema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows=0, layout=0):
     return _lib.IxfSchema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows,
-                          13572355802537770549)
+                          13572355802537770549, layout)
+
+
+def parse_layout(spec):
+    """"bin-major,unpadded,position-major" -> layout code (taxor_ixf_layout_parse)"""
+    c = C.c_uint32()
+    check(_lib.lib().taxor_ixf_layout_parse(spec.encode(), C.byref(c)))
+    return int(c.value)
+
+
+def describe_layout(code):
+    buf = C.create_string_buffer(128)
+    _lib.lib().taxor_ixf_layout_describe(int(code), buf, len(buf))
+    return buf.value.decode()
 
 
 def probe_hixf(path):
@@ -85,6 +98,15 @@ class HixfFile:
         else:
             check(_lib.lib().taxor_hixf_load_schema(str(path).encode(), C.byref(schema), C.byref(h)))
         self._h = h
+        self._read_view()
+
+    def set_layout(self, layout):
+        """the fingerprint layout `taxor verify --variants` / `taxor pin` found the file to follow (taxor_hixf_set_layout)"""
+        check(_lib.lib().taxor_hixf_set_layout(self._h, int(layout)))
+        self._read_view()
+
+    def _read_view(self):
+        h = self._h
         v = _lib.lib().taxor_hixf_get_view(h).contents
         m = _lib.lib().taxor_hixf_get_meta(h).contents
         self.k, self.s, self.t = v.kmer_size, v.syncmer_size, v.t_syncmer
@@ -92,15 +114,16 @@ class HixfFile:
         self.n_user_bins = int(v.n_user_bins)
         self.window_size = int(m.window_size)
         self.foreign_schema = bool(m.foreign_schema)
+        self.layout = int(v.ixf_layout)      # how the FILE lays each IXF's bytes out (ixf_layout.h); "data" below are those raw bytes
         self.ixfs = []
         for i in range(v.n_ixf):
             f = v.ixf[i]
-            n = 3 * f.seg_len * f.stride
+            n = int(_lib.lib().taxor_hixf_ixf_raw_bytes(h, i))
             data = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_uint8)), shape=(n,))
             nx = np.ctypeslib.as_array(C.cast(f.next_ixf, C.POINTER(C.c_int64)), shape=(f.bins,))
             fn = np.ctypeslib.as_array(C.cast(f.fname_idx, C.POINTER(C.c_int64)), shape=(f.bins,))
             self.ixfs.append(dict(bins=int(f.bins), stride=int(f.stride), seg_len=int(f.seg_len), seed=int(f.seed),
-                                  data=data, next_ixf=nx, fname_idx=fn))
+                                  data=data, next_ixf=nx, fname_idx=fn, src_stride=int(f.src_stride)))
         self.species = [dict(organism_name=m.species[i].organism_name.decode("utf-8", "replace"), accession_id=m.species[i].accession_id.decode("utf-8", "replace"),
                              taxid=m.species[i].taxid.decode("utf-8", "replace"), taxnames_string=m.species[i].taxnames_string.decode("utf-8", "replace"),
                              taxid_string=m.species[i].taxid_string.decode("utf-8", "replace"), user_bin=int(m.species[i].user_bin),

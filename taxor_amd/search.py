@@ -78,21 +78,58 @@ def _results(res: _lib.Results, copy=True) -> SearchResults:
     return SearchResults(ro, ub, ct, nh)
 
 
+def source_bytes(layout, f):
+    """bytes a source holds for IXF dict f under layout code `layout` (taxor_amd/csrc/ixf_layout.h ixf_src_bytes)"""
+    rows, kind = 3 * f["seg_len"], int(layout) & 0xFF
+    pitch = int(f.get("src_stride", 0)) or f["stride"]
+    if kind == _lib.LAYOUT_BIT_SLICED:
+        return rows * ((f["bins"] + 63) // 64) * 64
+    return rows * pitch
+
+
+def to_source_layout(f, layout):
+    """numpy restatement of ixf_layout.h, independent of the library: the bytes ANOTHER writer would store for IXF dict f (data in
+    the search layout data[row * stride + bin]) under `layout` -> (bytes, src_stride).  Test infrastructure for the re-layout."""
+    bins, stride, seg = f["bins"], f["stride"], f["seg_len"]
+    rows, kind, rule = 3 * seg, int(layout) & 0xFF, int(layout) & 0x600
+    D = np.asarray(f["data"], dtype=np.uint8).reshape(rows, stride)[:, :bins]
+    if layout & _lib.LAYOUT_POSITION_MAJOR:          # source row pos*3 + segment holds search row segment*seg_len + pos
+        D = D.reshape(3, seg, bins).transpose(1, 0, 2).reshape(rows, bins)
+    S = (bins + 63) // 64 * 64
+    pitch = S if kind == _lib.LAYOUT_BIT_SLICED else bins if rule == _lib.LAYOUT_PITCH_BINS else stride if rule == _lib.LAYOUT_PITCH_STORED else S
+    if kind == _lib.LAYOUT_ROWS:
+        out = np.zeros((rows, pitch), np.uint8)
+        out[:, :bins] = D
+    elif kind == _lib.LAYOUT_BIN_MAJOR:
+        out = np.zeros((pitch, rows), np.uint8)
+        out[:bins, :] = D.T
+    else:
+        P = np.zeros((rows, S), np.uint8)
+        P[:, :bins] = D
+        planes = (P[:, :, None] >> np.arange(8, dtype=np.uint8)[None, None, :]) & 1            # [row][bin][plane]
+        planes = planes.reshape(rows, S // 64, 64, 8).transpose(0, 1, 3, 2)                      # [row][group][plane][bin in group]
+        out = np.packbits(planes, axis=-1, bitorder="little")                                    # 8 bytes per plane word, little endian
+    return np.ascontiguousarray(out).reshape(-1), pitch
+
+
 class GpuIndex:
     """A HIXF resident in one GPU's HBM."""
 
-    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None, arith=0):
-        """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)}"""
+    def __init__(self, ixfs, n_user_bins, k=22, s=12, t=5, device=0, use_syncmer=True, scaling=1, window_size=None, arith=0, layout=0):
+        """ixfs: list of dicts {bins, stride, seg_len, seed, next_ixf, fname_idx, data (np.uint8 or None)[, src_stride]};
+        layout != 0 (_lib.LAYOUT_*): `data` holds the bytes as ANOTHER writer's file would (ixf_layout.h, pitch / column count in
+        src_stride); the library transposes them into the search layout on the device while uploading"""
         L = _lib.lib()
-        view, keep = self._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size)
+        view, keep = self._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size, layout)
         view.ixf_arith = int(arith)      # 0 = the library's reading of the IXF arithmetic; else arith_code(...)
+        view.ixf_layout = int(layout)
         h = C.c_void_p()
         check(L.taxor_gpu_index_create(C.byref(view), device, C.byref(h)))
         del keep                 # the library copied everything into HBM
         self._adopt(h, ixfs, n_user_bins, k, s, t, device, use_syncmer, window_size)
 
     @staticmethod
-    def _view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size):
+    def _view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size, layout=0):
         """taxor_hixf_view over numpy arrays (+ the arrays that must stay alive while the library reads it)"""
         keep = []
         arr = (_lib.IxfView * len(ixfs))()
@@ -103,10 +140,10 @@ class GpuIndex:
             d = f.get("data")
             if d is not None:
                 d = np.ascontiguousarray(d, dtype=np.uint8)
-                assert d.size == 3 * f["seg_len"] * f["stride"], "IXF data size mismatch"
+                assert d.size == source_bytes(layout, f), "IXF data size mismatch"
             keep += [nx, fn, d]
             arr[i] = _lib.IxfView(f["bins"], f["stride"], f["seg_len"], f["seed"],
-                                  d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data)
+                                  d.ctypes.data if d is not None else None, nx.ctypes.data, fn.ctypes.data, int(f.get("src_stride", 0)))
         ws = int(window_size) if window_size is not None else k
         keep.append(arr)
         return _lib.HixfView(len(ixfs), arr, n_user_bins, k, s, t, 1 if use_syncmer else 0, scaling, ws), keep
@@ -210,10 +247,12 @@ class Searcher:
     """One GPU-side agent: syncmers -> dedup -> threshold -> HIXF query -> per-read tuples."""
 
     def __init__(self, index: GpuIndex, error_rate=0.04, percentage=-1.0, ratio=None, sub_batch_reads=0,
-                 sub_batch_bases=0, time_kernels=False, prune=True, group_always=False, small_path=True, split_always=False):
+                 sub_batch_bases=0, time_kernels=False, prune=True, group_always=False, small_path=True, split_always=False,
+                 force_tree_stall=False):
         self.index = index
         flags = ((0 if prune else _lib.SEARCH_NO_PRUNE) | (_lib.SEARCH_GROUP_ALWAYS if group_always else 0)
-                 | (0 if small_path else _lib.SEARCH_NO_SMALL_PATH) | (_lib.SEARCH_SPLIT_ALWAYS if split_always else 0))
+                 | (0 if small_path else _lib.SEARCH_NO_SMALL_PATH) | (_lib.SEARCH_SPLIT_ALWAYS if split_always else 0)
+                 | (_lib.SEARCH_FORCE_TREE_STALL if force_tree_stall else 0))
         prm = _lib.SearchParams(0.0, sub_batch_reads, sub_batch_bases, 1 if time_kernels else 0, _lib.THR_PERCENTAGE, error_rate, flags)
         if ratio is not None:          # explicit (size_t)(n * ratio), whatever the index
             prm.ratio = float(ratio)

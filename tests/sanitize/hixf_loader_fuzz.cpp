@@ -1,7 +1,8 @@
 // AddressSanitizer / UBSan driver for the .hixf loader, the probe and the TSV formatter (host code only, no GPU):
 // usage: hixf_loader_fuzz <valid.hixf> <data_lo> <data_hi> <trials> <scratch file>
 // mutates the file (bit flips, huge integers, truncation, insertions, deletions outside [data_lo, data_hi)) and loads it.
-#include <taxor_gpu.h>
+#include <taxor_gpu_tools.h>
+#include <ixf_layout.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,7 +36,8 @@ int main(int argc, char **argv) {
             unsigned long long sum = 0;
             for (size_t i = 0; i < v->n_ixf; ++i) {   // touch every byte the view claims
                 const taxor_ixf_view &x = v->ixf[i];
-                size_t sz = 3 * x.seg_len * x.stride;
+                size_t sz = taxor_hixf_ixf_raw_bytes(h, i);
+                if (sz != taxor::ixf_src_bytes(v->ixf_layout, 3 * x.seg_len, x.src_stride ? x.src_stride : x.stride, x.bins)) return 5;
                 sum += x.data[0] + x.data[sz - 1];
                 for (size_t j = 0; j < x.bins; ++j) sum += x.next_ixf[j] + x.fname_idx[j];
             }
@@ -57,13 +59,25 @@ int main(int argc, char **argv) {
             if (v->source) {   // the pread() reader the index upload uses: first and last bytes of every IXF, and a request past its end
                 for (size_t i = 0; i < v->n_ixf; ++i) {
                     const taxor_ixf_view &x = v->ixf[i];
-                    const size_t sz = 3 * x.seg_len * x.stride;
+                    const size_t sz = taxor_hixf_ixf_raw_bytes(h, i);
                     unsigned char two[2] = {0, 0};
                     if (v->source->read(v->source->ctx, i, 0, 1, two) != 0 || v->source->read(v->source->ctx, i, sz - 1, 1, two + 1) != 0) return 4;
                     if (two[0] != x.data[0] || two[1] != x.data[sz - 1]) return 4;
                 }
                 unsigned char one;
                 (void)v->source->read(v->source->ctx, v->n_ixf, 0, 1, &one);
+            }
+            // every layout the scan can name: either refused, or every fingerprint it addresses lies inside the raw array
+            for (uint32_t code : {0x000u, 0x200u, 0x400u, 0x001u, 0x201u, 0x401u, 0x101u, 0x002u, 0x102u, 0x300u, 0x600u, 0x003u, 0x202u}) {
+                if (taxor_hixf_set_layout(h, code) != TAXOR_OK) continue;
+                const taxor_hixf_view *w = taxor_hixf_get_view(h);
+                for (size_t i = 0; i < w->n_ixf; ++i) {
+                    const taxor_ixf_view &x = w->ixf[i];
+                    const uint64_t pitch = x.src_stride ? x.src_stride : x.stride;
+                    if (taxor::ixf_src_bytes(code, 3 * x.seg_len, pitch, x.bins) != taxor_hixf_ixf_raw_bytes(h, i)) return 6;
+                    sum += taxor::ixf_src_fingerprint(x.data, code, 0, 0, x.seg_len, pitch, x.bins) +
+                           taxor::ixf_src_fingerprint(x.data, code, 3 * x.seg_len - 1, x.bins - 1, x.seg_len, pitch, x.bins);
+                }
             }
             taxor_hixf_release_data(h);
             taxor_ixf_schema sc; char rep[4096]; taxor_hixf_probe(argv[5], &sc, rep, sizeof rep);

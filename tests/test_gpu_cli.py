@@ -381,7 +381,7 @@ def test_cli_verify_variant_scan_names_a_foreign_arithmetic(tmp_path):
     assert cp.returncode == 2 and "FAIL" in cp.stdout, cp.stdout + cp.stderr
     assert "ANOTHER reading" in cp.stdout, cp.stdout
     first = [l for l in cp.stdout.splitlines() if l.startswith("  1.0000")][0]
-    assert "murmur64 as h(key ^ seed)" in first and "(u32)rot % seg" in first and "fingerprint (u8)h," in first and "data[row*stride + bin]" in first, first
+    assert "murmur64 as h(key ^ seed)" in first and "(u32)rot % seg" in first and "fingerprint (u8)h," in first and "data[row*pitch + bin]" in first, first
     assert f"seed {seed}" in first and "rotl(h, 21*i)" in first
     # ... and the reading it names is a run-time choice, not a rebuild: `taxor search --ixf-arithmetic <spec>`
     # classifies the foreign index, bit for bit like the oracle parametrised the same way; without it the index answers at the

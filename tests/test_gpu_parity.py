@@ -810,6 +810,31 @@ def test_small_call_overflow_falls_back_per_piece():
     sr.close(); idx.close()
 
 
+@pytest.mark.parametrize("n_reads", [40, 1018, 3000])
+def test_stalled_tree_launch_is_rerun_level_by_level(n_reads):
+    """the one-launch traversal of a small piece waits for queue entries with a watchdog; when it fires (forced here:
+    TAXOR_SEARCH_FORCE_TREE_STALL makes every block give up at its first empty poll) the piece is classified again through the
+    level-by-level pipeline -- identical tuples, counted in tree_stalls_recovered, and the lanes stay usable afterwards"""
+    g, go, lay, host = _family_like_index(53)
+    idx = GpuIndex(host, lay["n_user_bins"])
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    reads = _mixed_reads(g, go, n_reads, seed=n_reads + 1)
+    B, O = _cat(reads)
+    want = h.search_batch(np.frombuffer(orc.dna4_normalise(B.tobytes()), np.uint8), O, threads=8)
+    assert int(want[1][-1]) > 0
+    stalled, healthy = Searcher(idx, force_tree_stall=True), Searcher(idx)
+    for rep in range(3):
+        res = stalled.search_batch(B, O)
+        _compare(res, want, len(reads))
+        st = stalled.stats()
+        # pieces of up to 1024 reads take the one-launch traversal (api.hip small_enqueue); larger ones never wait on a queue
+        assert st["tree_stalls_recovered"] >= 1 or n_reads > 2048, st["tree_stalls_recovered"]
+        assert st["n_tuples"] == res.user_bin.size and st["n_hashes"] == int(res.n_hashes.sum())
+    _compare(healthy.search_batch(B, O), want, len(reads))
+    assert healthy.stats()["tree_stalls_recovered"] == 0
+    stalled.close(); healthy.close(); idx.close()
+
+
 @pytest.mark.parametrize("root_bins", [128, 200, 1024, 4096])
 def test_root_items_in_column_parts_equal_whole_rows(root_bins):
     """QueryArgs::parts forced on for a batch of any size (TAXOR_SEARCH_SPLIT_ALWAYS): a root work item cut into column ranges at

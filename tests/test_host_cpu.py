@@ -1,5 +1,5 @@
-"""CPU-side checks that need no GPU: the C-ABI library loads and exports every symbol include/taxor_gpu.h
-declares, and the host-side scalars / construction helpers agree with the oracle."""
+"""CPU-side checks that need no GPU: the C-ABI library loads and exports every symbol include/taxor_gpu.h and
+include/taxor_gpu_tools.h declare, and the host-side scalars / construction helpers agree with the oracle."""
 import os
 import re
 
@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "taxor_gpu.h")).read()
-    declared = set(re.findall(r"\b(taxor_[a-z0-9_]+)\s*\(", hdr))
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("taxor_gpu.h", "taxor_gpu_tools.h"))
+    declared = set(re.findall(r"\b(taxor_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)))
     declared -= {"taxor_status"}
     L = _lib.lib()
     for name in sorted(declared):
