@@ -34,6 +34,10 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                  --read-error), resident and host-fed, detail under "read_error_0.04".
   roofline.contract_frac / moved_frac : SURVEY 8(d)'s formula on the kernel that does all of that work (= unpruned.frac) and
                  the bytes the memory side moved (= traffic_frac_of_peak), beside `frac` (requested bytes of the pruned kernel).
+  layouts      : the headline's workload choices varied one at a time in the same invocation (N = 1): strand-mixed reads
+                 (frac_reverse 0.5, SURVEY 8(d) as written), chopper-shaped children (as wide as the root) and a 4096-bin root --
+                 value / frac / work per read for each, 3 timed steps, no PMC pass (moved_frac null); config.frac_reverse and
+                 config.layout_note say what the headline itself runs.
   TAXOR_BENCH_FORCE_DIST=1 : every N > 1 branch with one rank (RCCL process group, probe gather, collectives) -- tests.
   N > 1        : pcie_inclusive_per_rank -- rank 0's host-fed rate alone, then every rank's at once, and
                  host_fed_scaling = their sum / rank 0's solo rate (the resident `value` scales by construction);
@@ -97,6 +101,14 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("TAXOR_BENCH_WORKLOAD", "gtdb"), choices=sorted(WORKLOADS))
     ap.add_argument("--root-bins", type=int, default=0, help="root t_max (taxor_build.cpp:177-184: 64..4096); 0 = workload default")
+    ap.add_argument("--child-bins", type=int, default=0, help="bins of every IXF below the root; 0 = workload default.  The reference applies ONE t_max "
+                                                               "at every level (taxor_build.cpp:168-187,473): chopper-shaped = --child-bins equal to --root-bins")
+    ap.add_argument("--frac-reverse", type=float, default=0.0,
+                    help="fraction of the planted reads drawn from the reverse strand.  Default 0: with the reference's t = ceil((k-s+1)/2) in INTEGER "
+                         "division (taxor_build.cpp:509-510; 5 at k22/s12) open-syncmer selection is not strand-symmetric, a reverse-strand read shares "
+                         "no syncmers with a forward-indexed genome and stops at the root -- forward-only reads are the harder case.  SURVEY 8(d) says "
+                         "'strand uniformly': the `layouts` array of the line carries that leg (0.5)")
+    ap.add_argument("--no-layouts", action="store_true", help="skip the `layouts` legs (strand-mixed reads; chopper-shaped children; root 4096)")
     ap.add_argument("--reads", type=int, default=0, help="reads per step and GPU (0 = workload default)")
     ap.add_argument("--read-len", type=int, default=0)
     ap.add_argument("--genomes", type=int, default=0, help="planted genomes (0 = workload default)")
@@ -236,6 +248,8 @@ def build_workload(args, local_rank, rank, world):
     wl = dict(WORKLOADS[args.workload])
     if args.root_bins:
         wl["root_bins"] = args.root_bins
+    if getattr(args, "child_bins", 0):
+        wl["child_bins"] = args.child_bins
     n_reads = args.reads or wl["reads"]
     read_len = args.read_len or wl["read_len"]
     n_genomes = args.genomes or wl["genomes"]
@@ -316,7 +330,7 @@ def build_workload(args, local_rank, rank, world):
             origin = None
         else:
             bases, offs, origin = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
-                                                    seed=seed, threads=ncpu)
+                                                    seed=seed, threads=ncpu, frac_reverse=getattr(args, "frac_reverse", 0.0))
         if args.scaling == "strong" and world > 1:  # this rank's contiguous shard of the common batch
             lo_, hi_ = (lo, hi) if not args.len_mix else td.shard_range(offs.size - 1, rank, world)
             bases, offs = bases[int(offs[lo_]):int(offs[hi_])], offs[lo_:hi_ + 1] - offs[lo_]
@@ -751,6 +765,12 @@ def main():
                        "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "root_bins": wl["root_bins"],
                        "child_bins": wl["child_bins"], "depth": idx.depth, "reads_per_gpu": shard_reads[0], "read_len": read_len,
                        "distinct_batches": len(batches), "read_error": args.read_error, "search_error_rate": args.error_rate,
+                       "frac_reverse": args.frac_reverse, "frac_random": 0.1,
+                       "layout_note": (f"reads: forward strand {'only' if args.frac_reverse == 0 else f'{1 - args.frac_reverse:.2f}'} (reverse-strand reads share no "
+                                       "syncmers with the index at the reference's t = 5 and stop at the root: forward-only is the harder case); "
+                                       f"index: children {wl['child_bins']} bins under a {wl['root_bins']}-bin root (the reference's chopper layout applies one t_max "
+                                       "at every level, taxor_build.cpp:168-187,473).  `layouts` carries the same invocation's legs with strand-mixed reads, "
+                                       "chopper-shaped children and a 4096-bin root"),
                        "planted_genomes": info["n_genomes"], "family_size": info["fam_size"],
                        "sharding": "reads by rank, index replicated",
                        "hashes_per_read": round(acc["hashes"] / nr, 1),
@@ -799,13 +819,80 @@ def main():
             ncpu = len(full_affinity)
             hash_kw = dict(k=info["k"], s=info["s"], t=info["t"], window=info["window"]) if args.mode != "syncmer" else {}
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu, hash_kw)
+        if world == 1 and not dist_on and not args.no_layouts and args.mode == "syncmer" and not args.len_mix:
+            out["layouts"] = layout_legs(args, idx, info, searchers, timed, local_rank, out)
+            idx = None
         print(json.dumps(out), flush=True)
     for sr in searchers:
         sr.close()
-    idx.close()
+    if idx is not None:
+        idx.close()
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def layout_legs(args, idx, info, searchers, timed, local_rank, out):
+    """The headline's workload choices, varied one at a time in the SAME invocation (2 resident batches, 3 timed steps each, HIP-event
+    kernel time, no PMC pass): (a) strand-mixed reads on the headline index -- SURVEY 8(d) as written; (b) chopper-shaped index:
+    every IXF below the root as wide as the root (the reference applies one t_max at every level, taxor_build.cpp:168-187,473);
+    (c) a 4096-bin root (the largest t_max the reference offers, :177-184).  (b) and (c) build their own 113-GB-class index, so
+    the headline index is released first (closes `idx` and `searchers`)."""
+    from taxor_amd import Searcher, synth
+    n_reads, read_len, ncpu = info["n_reads"], info["read_len"], info["ncpu"]
+    legs = []
+
+    def measure(index, batches, label, what, extra):
+        pool = []
+        for bb, oo in batches:
+            s2 = Searcher(index, error_rate=args.error_rate, time_kernels=True)
+            s2.upload(bb, oo)
+            s2.run()
+            s2.sync()
+            pool.append(s2)
+        e, a = timed(pool, 3, 1)
+        q = a["q_ms"] * 1e-3
+        sparse = sum(a["lvl_sparse"])
+        leg = {"layout": label, "what": what, "value": round(a["all_bases"] / e / 1e6, 2), "unit": "Mbp/s", "steps": 3,
+               "frac": round(a["q_touched"] / q / 1e9 / HBM_PEAK_GBS, 4) if q > 0 else None,
+               "algorithmic_frac": round(a["q_bytes"] / q / 1e9 / HBM_PEAK_GBS, 4) if q > 0 else None,
+               "moved_frac": None, "sparse_loads_per_launch": round(sparse / max(1, a["launches"]), 1),
+               "hashes_per_read": round(a["hashes"] / max(1, a["reads"]), 1), "tuples_per_read": round(a["tuples"] / max(1, a["reads"]), 3),
+               "work_items_per_read": round(a["work"] / max(1, a["reads"]), 3)}
+        leg.update(extra)
+        for s2 in pool:
+            s2.close()
+        log(f"layout leg {label}: {leg['value']:.0f} Mbp/s, frac {leg['frac']}")
+        return leg
+
+    shape = {"root_bins": out["config"]["root_bins"], "child_bins": out["config"]["child_bins"], "index_bytes": out["config"]["index_bytes"],
+             "n_ixf": out["config"]["n_ixf"], "depth": out["config"]["depth"]}
+    # (a) the headline index, reads from both strands
+    both = []
+    for b in range(2):
+        bb, oo, _ = synth.synth_reads(info["genomes"], info["genome_off"], n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
+                                      seed=synth.DEFAULT_SEED + 55000 + b, threads=ncpu, frac_reverse=0.5)
+        both.append((np.ascontiguousarray(bb), np.ascontiguousarray(oo)))
+    legs.append(measure(idx, both, "strand_mixed", "headline index, planted reads from either strand with probability 0.5 (SURVEY 8(d) 'strand uniformly'); "
+                        "reverse-strand reads share no syncmers with the index and stop at the root", dict(shape, frac_reverse=0.5)))
+    del both
+    for sr in searchers:
+        sr.close()
+    del searchers[:]
+    idx.close()
+    # (b), (c): indexes of the same footprint in other shapes, each with its own forward-strand reads like the headline
+    for label, root_bins, child_bins, what in (
+            ("chopper_1024", out["config"]["root_bins"], out["config"]["root_bins"],
+             "children as wide as the root: one t_max at every level, as the reference's layout step applies it"),
+            ("root_4096", 4096, out["config"]["child_bins"], "t_max 4096 at the root (the largest the reference offers), the headline's children")):
+        a2 = argparse.Namespace(**vars(args))
+        a2.root_bins, a2.child_bins, a2.batches = root_bins, child_bins, 2
+        wl2, idx2, lay2, batches2, info2 = build_workload(a2, local_rank, 0, 1)
+        legs.append(measure(idx2, batches2, label, what, {"root_bins": wl2["root_bins"], "child_bins": wl2["child_bins"], "index_bytes": idx2.data_bytes,
+                                                          "n_ixf": idx2.n_ixf, "depth": idx2.depth, "frac_reverse": args.frac_reverse}))
+        idx2.close()
+        del lay2, batches2, info2
+    return legs
 
 
 def dropin_measurements(args, idx, batches, read_len, single=True):

@@ -51,7 +51,7 @@ with open(fq, "w") as f:
 print(f"index: {len(ixfs)} IXFs, {total / 1e9:.2f} GB of fingerprints (root {root_bins} bins x {3 * root_seg} rows, {n_children} children of {child_bins} bins)")
 R, B, S, PM, UNP = _lib.LAYOUT_ROWS, _lib.LAYOUT_BIN_MAJOR, _lib.LAYOUT_BIT_SLICED, _lib.LAYOUT_POSITION_MAJOR, _lib.LAYOUT_PITCH_BINS
 digests = {}
-for code in (0, R | PM, B, B | PM, S, S | PM):
+for code in (0, R | PM, B, S):
     sc = default_schema()
     sc.layout = code
     path = os.path.join(tmp, "x.hixf")

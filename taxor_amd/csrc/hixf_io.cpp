@@ -32,6 +32,8 @@ using taxor::tune_env;
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -730,17 +732,33 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
             }
             std::vector<uint8_t> out(len, 0);
             const uint64_t groups = (x.bins + 63) / 64;
-            for (uint64_t r = 0; r < rows; ++r) {
-                const uint64_t rs = taxor::ixf_src_row(code, r, x.seg_len);
-                const uint8_t *row = src + r * x.stride;
-                if (kind == taxor::IXF_KIND_ROWS) std::memcpy(out.data() + rs * pitch, row, x.bins);
-                else if (kind == taxor::IXF_KIND_BIN_MAJOR)
-                    for (uint64_t b = 0; b < x.bins; ++b) out[b * rows + rs] = row[b];
-                else
-                    for (uint64_t b = 0; b < x.bins; ++b)
-                        for (uint32_t p2 = 0; p2 < 8; ++p2)
-                            if ((row[b] >> p2) & 1u) out[(rs * groups + b / 64) * 64 + p2 * 8 + ((b & 63) >> 3)] |= (uint8_t)(1u << (b & 7));
-            }
+            // tiles of 64 rows, shared out over a few threads (every source row maps to bytes of its own: no two tiles write the same byte)
+            const uint64_t n_tiles = (rows + 63) / 64;
+            const unsigned T = (unsigned)std::min<uint64_t>(std::max(1u, std::min(16u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, len >> 22));
+            std::atomic<uint64_t> next{0};
+            auto work = [&] {
+                for (uint64_t t = next.fetch_add(1); t < n_tiles; t = next.fetch_add(1)) {
+                    const uint64_t ra = t * 64, rb = std::min(rows, ra + 64);
+                    if (kind == taxor::IXF_KIND_BIN_MAJOR) {
+                        for (uint64_t b = 0; b < x.bins; ++b)
+                            for (uint64_t r = ra; r < rb; ++r) out[b * rows + taxor::ixf_src_row(code, r, x.seg_len)] = src[r * x.stride + b];
+                        continue;
+                    }
+                    for (uint64_t r = ra; r < rb; ++r) {
+                        const uint64_t rs = taxor::ixf_src_row(code, r, x.seg_len);
+                        const uint8_t *row = src + r * x.stride;
+                        if (kind == taxor::IXF_KIND_ROWS) std::memcpy(out.data() + rs * pitch, row, x.bins);
+                        else
+                            for (uint64_t b = 0; b < x.bins; ++b)
+                                for (uint32_t p2 = 0; p2 < 8; ++p2)
+                                    if ((row[b] >> p2) & 1u) out[(rs * groups + b / 64) * 64 + p2 * 8 + ((b & 63) >> 3)] |= (uint8_t)(1u << (b & 7));
+                    }
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; ++t) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
             w.bytes(out.data(), len);
         } else if (v->source) {                                      // bytes that are not in host memory as a whole (e.g. an
             std::vector<uint8_t> piece((size_t)std::min<uint64_t>(len, 64ull << 20));   // index resident on a GPU): piece by piece

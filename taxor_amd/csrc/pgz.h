@@ -38,6 +38,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -420,15 +421,17 @@ struct ChunkOut {
 // blocks from start_bit on until a block boundary at or behind stop_bit (or the member's final block); text_ok != nullptr: every
 // literal must be text.  max_out bounds the output.
 inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_bit, uint64_t stop_bit, ChunkOut &co, size_t max_out, const bool *text_ok,
-                        int max_blocks = 1 << 30, bool stream_start = false)
+                        int max_blocks = 1 << 30, int stream_start = 0)
 {
-    // stream_start: the deflate stream begins at start_bit (a gzip member): a reference behind it is invalid, and the window slots
-    // are left as they are (64 KB of markers written per 64-KB bgzip member would double the decoder's stores)
+    // stream_start != 0: the deflate stream begins at start_bit (a gzip member): a reference behind it is invalid ("distance too far
+    // back", like zlib).  1: the window slots are left as they are (64 KB of markers written per 64-KB bgzip member would double
+    // the decoder's stores); 2: they are marked like any chunk's (the first chunk of a member that goes on: its successor's window
+    // is cut from this output, window slots included if the chunk is short)
     BitIn in;
     in.seek(base, end, start_bit);
     if (co.sym.size() < WIN + (1u << 16)) co.sym.resize(WIN + (1u << 16));
     const size_t floor = stream_start ? WIN : 0;
-    if (!stream_start)
+    if (stream_start != 1)
         for (uint32_t w = 0; w < WIN; ++w) co.sym[w] = (uint16_t)(256 + w);
     co.n = WIN;
     co.start_bit = start_bit;
@@ -700,14 +703,18 @@ public:
     {
         if (v.capacity() < (1u << 20)) return;
         std::lock_guard<std::mutex> lk(pool_mu_);
-        if (out_pool_.size() < 2 * (size_t)threads_ + 8) out_pool_.push_back(std::move(v));
+        size_t held = v.capacity();
+        for (const auto &q : out_pool_) held += q.capacity();
+        if (out_pool_.size() < 2 * (size_t)threads_ + 8 && held <= budget_ / 4) out_pool_.push_back(std::move(v));
     }
 
     // after take(): go on with read() (the caller has consumed what it took)
     void switch_to_read() { cur_pos_ = cur_out_ ? cur_out_->size() : 0; }
 
     // statistics for the diagnostic command
-    uint64_t chunks_total = 0, chunks_redecoded = 0, bytes_out = 0, members = 0;
+    uint64_t chunks_total = 0, chunks_redecoded = 0, bytes_out = 0, members = 0, trailing_garbage = 0;
+    // bytes of decoded-but-unread output the reader may hold (symbols and resolved bytes); set before open()
+    void set_memory_budget(size_t bytes) { budget_ = std::max<size_t>(bytes, 64u << 20); }
     std::atomic<uint64_t> ns_find{0}, ns_decode{0}, ns_resolve{0};     // summed over the worker threads
 
 private:
@@ -762,6 +769,7 @@ private:
 #endif
         tied_ = 0;
         cur_ = 0;
+        ratio_seen_ = 1.0;
         n_live_ = chunks_.size();
         member_crc_ = crc32(0L, Z_NULL, 0);
         member_len_ = 0;
@@ -786,7 +794,7 @@ private:
         static const TextSet ts;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || !resolve_q_.empty() || (next_decode_ < n_live_ && next_decode_ < cur_ + lookahead_); });
+            cv_work_.wait(lk, [&] { return stop_ || !resolve_q_.empty() || (next_decode_ < n_live_ && next_decode_ < cur_ + eff_lookahead()); });
             if (stop_) return;
             if (!resolve_q_.empty()) {
                 const size_t i = resolve_q_.front();
@@ -795,15 +803,19 @@ private:
                 ++busy_;
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
+                std::string what;               // an exception (std::bad_alloc of a huge chunk) must not leave a std::thread: next_chunk() rethrows it
+                try {
 #ifdef TAXOR_PGZ_DEVICE
-                if (dev_[0]) {
-                    const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
-                    c.crc = pgz_detail::crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o, c.out_len);
-                } else
+                    if (dev_[0]) {
+                        const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
+                        c.crc = pgz_detail::crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o, c.out_len);
+                    } else
 #endif
-                resolve(c);
+                    resolve(c);
+                } catch (const std::exception &ex) { what = std::string("gzip reader: ") + ex.what(); } catch (...) { what = "gzip reader: unknown exception"; }
                 ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
+                if (!what.empty() && dev_error_.empty()) dev_error_ = what;
                 --busy_;
                 c.state = 4;
                 cv_done_.notify_all();
@@ -818,9 +830,14 @@ private:
                 const bool text = text_;
                 lk.unlock();
                 const auto t0 = std::chrono::steady_clock::now();
-                const uint64_t s = i > 0 ? find_block(map_, map_ + size_, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr) : c.nominal_start;
+                uint64_t s = ~0ull;
+                std::string what;
+                try {
+                    s = i > 0 ? find_block(map_, map_ + size_, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr) : c.nominal_start;
+                } catch (const std::exception &ex) { what = std::string("gzip reader: ") + ex.what(); } catch (...) { what = "gzip reader: unknown exception"; }
                 ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 lk.lock();
+                if (!what.empty() && dev_error_.empty()) dev_error_ = what;
                 c.found_start = s;
                 --busy_;
                 c.state = 2;
@@ -833,18 +850,27 @@ private:
                 if (!pool_.empty()) { c.co.sym = std::move(pool_.back()); pool_.pop_back(); }
             }
             const bool text = text_;
+            const size_t spec_out = speculative_out();
             lk.unlock();
             const uint8_t *base = map_, *end = map_ + size_;
             uint64_t s = c.nominal_start;
             const auto t0 = std::chrono::steady_clock::now();
-            if (i > 0) s = find_block(base, end, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr);
-            const auto t1 = std::chrono::steady_clock::now();
+            auto t1 = t0;
             bool ok = false;
-            if (s != ~0ull) ok = decode_from(base, end, s, c.nominal_stop, c.co, WIN + max_chunk_out(), nullptr);      // (the start's first block was held to text by the search)
+            std::string what;
+            try {
+                if (i > 0) s = find_block(base, end, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr);
+                t1 = std::chrono::steady_clock::now();
+                // (the start's first block was held to text by the search.)  A member's first chunk starts the stream: a distance that
+                // reaches before it is invalid there, as in zlib.  The output is capped at what this member's ratio so far makes
+                // plausible: a chunk beyond it is decoded again, alone, when it is tied
+                if (s != ~0ull) ok = decode_from(base, end, s, c.nominal_stop, c.co, WIN + spec_out, nullptr, 1 << 30, i == 0 ? 2 : 0);
+            } catch (const std::exception &ex) { what = std::string("gzip reader: ") + ex.what(); } catch (...) { what = "gzip reader: unknown exception"; }
             ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
             ns_decode += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
             if (!ok) { c.co.ok = false; give_back(c.co.sym); }
             lk.lock();
+            if (!what.empty() && dev_error_.empty()) dev_error_ = what;
             --busy_;
             c.state = 2;
             cv_done_.notify_all();
@@ -853,11 +879,31 @@ private:
 
     size_t max_chunk_out() const { return (size_t)1032 * chunk_bytes_ + (1u << 20); }    // deflate expands at most ~1032:1
 
+    // Memory in flight is bounded by the member's own compression ratio (mu_ held).  A decoded chunk holds two bytes per output byte
+    // (symbols) until it is resolved, and deflate may expand 1032:1 -- thirty-odd chunks of a very repetitive (but valid) member
+    // would be tens of gigabytes.  So: chunks decoded ahead of the reader are limited to what fits `budget_` at the largest
+    // ratio seen so far in this member (at least one; before the first chunk is tied, one per thread), and a speculative decode
+    // is cut off at 8x that ratio (at least 32:1) -- such a chunk is decoded again, alone, when it is tied (tie(), up to 1032:1).
+    size_t eff_lookahead() const
+    {
+        if (device_mode()) return lookahead_;                       // (the device arena has a ratio cap of its own)
+        if (tied_ == 0) return std::min<size_t>(lookahead_, (size_t)threads_ + 1);
+        const double per_chunk = 3.0 * ratio_seen_ * (double)chunk_bytes_;      // symbols + resolved bytes
+        return (size_t)std::max(1.0, std::min((double)lookahead_, (double)budget_ / std::max(1.0, per_chunk)));
+    }
+    size_t speculative_out() const
+    {
+        const double r = std::min(1032.0, std::max(32.0, 8.0 * ratio_seen_));
+        return (size_t)(r * (double)chunk_bytes_) + (1u << 20);
+    }
+
     void give_back(pgz_detail::SymBuf &b)
     {
         if (!b.p) return;
         std::lock_guard<std::mutex> lk(pool_mu_);
-        if (pool_.size() < 4 * (size_t)threads_) pool_.push_back(std::move(b));
+        size_t held = b.cap * sizeof(uint16_t);
+        for (const auto &q : pool_) held += q.cap * sizeof(uint16_t);
+        if (pool_.size() < 4 * (size_t)threads_ && held <= budget_ / 4) pool_.push_back(std::move(b));     // (the pools are part of the budget)
         else b.release();
     }
 
@@ -934,11 +980,15 @@ private:
             // not where the stream says the chunk starts (or it failed): decode it from the right place -- nothing speculative
             lk.unlock();
             ChunkOut co;
-            const bool ok = decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr);
+            const bool ok = decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr, 1 << 30, i == 0 ? 2 : 0);
             lk.lock();
             if (!ok) throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
             c.co = std::move(co);
             ++chunks_redecoded;
+        }
+        {   // this member's compression ratio so far (eff_lookahead, speculative_out)
+            const uint64_t in_bits = c.co.end_bit > c.co.start_bit ? c.co.end_bit - c.co.start_bit : 1;
+            ratio_seen_ = std::max(ratio_seen_, (double)(c.co.n - WIN) * 8.0 / (double)std::max<uint64_t>(in_bits, 8 * 1024));
         }
         if (i == 0) {
             c.window.assign(WIN, 0);
@@ -1059,6 +1109,12 @@ private:
             dev_q_.pop_front();
             const size_t b0 = B->b0, k = B->k;
             taxor_gpu_inflater *dev = dev_[B->slot];
+            if (B->gen != member_gen_ || b0 >= n_live_) {                // decoded for a member that has ended since (or beyond its final block): nobody's
+                (void)taxor_gpu_inflate_decode_end(dev, B->res.data());
+                slot_free_[B->slot] = true;
+                cv_done_.notify_all();
+                continue;
+            }
             ++busy_;
             const uint64_t want0 = b0 == 0 ? (uint64_t)member_data_ * 8 : prev_end_;
             if (b0 == 0) std::fill(win.begin(), win.end(), 0);
@@ -1162,7 +1218,7 @@ private:
                 resolve_q_.push_back(b0 + i);
             }
             tied_ = b0 + count;
-            if (count < k) {                                           // the member ended inside this batch: what was decoded beyond is nobody's
+            if (count < k || (count > 0 && chunks_[b0 + count - 1].co.final_block)) {   // the member ended inside (or exactly at the end of) this batch: what was decoded beyond is nobody's
                 for (auto &q : dev_q_) slot_free_[q->slot] = true;
                 dev_q_.clear();
                 ++member_gen_;
@@ -1191,7 +1247,7 @@ private:
             if (device_mode()) cv_done_.notify_all();
         }
         for (;;) {
-            while (!device_mode() && tied_ < n_live_ && tied_ < cur_ + lookahead_ && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
+            while (!device_mode() && tied_ < n_live_ && tied_ < cur_ + std::max<size_t>(eff_lookahead(), 1) && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
                 if (!tie(lk, tied_)) break;
                 ++tied_;
             }
@@ -1208,6 +1264,13 @@ private:
                 size_t nx = t + 8;
                 while (nx < size_ && map_[nx] == 0) ++nx;        // zero padding behind a member is legal
                 if (nx >= size_) return false;
+                // bytes behind the last member that are no gzip header: gzip(1) says "trailing garbage ignored" and keeps what it
+                // decoded; every byte of the members has been delivered and checked by now, so this reader does the same
+                if (!pgz_detail::gzip_header_len(map_ + nx, size_ - nx)) {
+                    trailing_garbage = size_ - nx;
+                    fprintf(stderr, "[TAXOR SEARCH WARNING] gzip: %zu bytes of trailing garbage behind the last member ignored\n", size_ - nx);
+                    return false;
+                }
                 lk.unlock();
                 start_member(nx);                                // another member: the same way
                 lk.lock();
@@ -1227,6 +1290,8 @@ private:
     size_t size_ = 0, chunk_bytes_ = 4u << 20, member_data_ = 0;
     unsigned threads_ = 1;
     size_t lookahead_ = 4;
+    size_t budget_ = (size_t)4 << 30;
+    double ratio_seen_ = 1.0;              // largest output : input ratio of a tied chunk of the current member
     std::vector<std::thread> th_;
     std::mutex mu_;
     std::condition_variable cv_work_, cv_done_;

@@ -276,7 +276,17 @@ static int pin_command(int argc, char **argv)
                 std::to_string(rank.empty() ? 0.0 : rank[0].first) + "): the key hash or the record layout is not what this library assumes -- see `taxor probe`");
         chosen = vs[rank[0].second];
         // every IXF of the file under the layout that answered (strides, segment lengths, pitches recomputed from the array lengths)
-        if (chosen.layout != view->ixf_layout && taxor_hixf_set_layout(h, chosen.layout) != TAXOR_OK) die(std::string("taxor pin: ") + taxor_gpu_last_error());
+        if (chosen.layout != view->ixf_layout && taxor_hixf_set_layout(h, chosen.layout) != TAXOR_OK) {
+            // two pitch rules can give the ROOT the same pitch (64 k bins: padded == unpadded) while only one fits the other IXFs
+            const std::string first_err = taxor_gpu_last_error();
+            bool ok = false;
+            for (uint32_t rule : {(uint32_t)taxor::IXF_PITCH_PADDED, (uint32_t)taxor::IXF_PITCH_BINS, (uint32_t)taxor::IXF_PITCH_STORED}) {
+                const uint32_t alt = ((uint32_t)chosen.layout & ~(uint32_t)taxor::IXF_PITCH_MASK) | rule;
+                if (alt == chosen.layout || taxor::ixf_layout_kind(alt) == taxor::IXF_KIND_BIT_SLICED) continue;
+                if (taxor_hixf_set_layout(h, alt) == TAXOR_OK && (view->ixf[0].src_stride ? view->ixf[0].src_stride : view->ixf[0].stride) == chosen.stride) { chosen.layout = (uint16_t)alt; ok = true; break; }
+            }
+            if (!ok) die("taxor pin: " + first_err);
+        }
         if (chosen.seg_len != view->ixf[0].seg_len || chosen.seed != view->ixf[0].seed)
             die("taxor pin: the answering reading differs in seed / segment length from what the loader took from the file; `taxor probe` shows the record layout");
         arith = taxor_ixf_arith_code(&chosen);

@@ -20,6 +20,7 @@ extern char **environ;
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -698,11 +699,15 @@ std::vector<taxor_ixf_variant> variant_family(const taxor_ixf_view &root, uint64
             if (!dup) shapes.push_back({layout, pitch, sg});
         }
     };
+    // the pitch rule the loader settled on goes first: it fits EVERY IXF's array length (the loader checked), and where two rules
+    // give the root the same pitch (a root of 64 k bins: padded == unpadded) the first one added is the one the shape keeps
+    const uint32_t loaded_rule = loaded_layout & taxor::IXF_PITCH_MASK;
+    auto pitch_of = [&](uint32_t rule) { return rule == taxor::IXF_PITCH_BINS ? root.bins : rule == taxor::IXF_PITCH_STORED ? (root.src_stride ? root.src_stride : root.stride) : S; };
     for (uint32_t pm : {0u, (uint32_t)taxor::IXF_ROWS_POSITION_MAJOR}) {
         for (uint32_t kind : {(uint32_t)taxor::IXF_KIND_ROWS, (uint32_t)taxor::IXF_KIND_BIN_MAJOR}) {
-            if ((loaded_layout & taxor::IXF_PITCH_MASK) == taxor::IXF_PITCH_STORED) add_shape(kind | pm | taxor::IXF_PITCH_STORED, root.src_stride ? root.src_stride : root.stride);
-            add_shape(kind | pm | taxor::IXF_PITCH_PADDED, S);
-            add_shape(kind | pm | taxor::IXF_PITCH_BINS, root.bins);
+            add_shape(kind | pm | loaded_rule, pitch_of(loaded_rule));
+            for (uint32_t rule : {(uint32_t)taxor::IXF_PITCH_PADDED, (uint32_t)taxor::IXF_PITCH_BINS})
+                if (rule != loaded_rule) add_shape(kind | pm | rule, pitch_of(rule));
         }
         add_shape(taxor::IXF_KIND_BIT_SLICED | pm, S);
     }
@@ -1282,6 +1287,8 @@ int main(int argc, char **argv)
         struct Hold { std::unique_ptr<Batch> b; std::atomic<uint32_t> left{0}; };
         struct Piece { Hold *h = nullptr; uint32_t r0 = 0, r1 = 0; uint64_t ticket = 0; };
         BoundedQueue<Piece> q_piece(4 * formatters + 16);
+        // from here on the report goes to the file descriptor: the header line above was the last thing written through the FILE*
+        // (flushed now); nothing may use `out`'s stdio buffer again until the pieces are done, or it would land out of order
         fflush(out);
         const int out_fd = fileno(out);
         static const uint64_t piece_bytes = [] { const char *e = tune_env("TAXOR_CLI_PIECE_KB"); const int v = e ? atoi(e) : 0; return (uint64_t)(v >= 16 ? v : 1024) << 10; }();
@@ -1379,7 +1386,8 @@ int main(int argc, char **argv)
                         if (t_first_write == 0) t_first_write = w0;
                         for (uint64_t done = 0; done < need;) {
                             const ssize_t w = ::write(out_fd, text.data() + done, need - done);
-                            if (w <= 0) die("cannot write to " + cfg.report_file);
+                            if (w < 0 && errno == EINTR) continue;            // a signal (SIGSTOP / SIGCONT, a debugger) is not an I/O error
+                            if (w <= 0) die("cannot write to " + cfg.report_file + ": " + (w < 0 ? strerror(errno) : "write() returned 0"));
                             done += (uint64_t)w;
                         }
                         t_last_write = now();

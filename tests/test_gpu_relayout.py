@@ -42,7 +42,7 @@ def test_every_layout_lands_in_the_search_layout(code):
 def test_arrays_of_several_upload_chunks(code):
     """8 MiB pieces: a wide IXF of many row chunks / column groups, and a narrow one whose bin-major columns are cut into row strips"""
     rng = np.random.default_rng(100 + code)
-    for bins, seg in [(4096, 2999), (130, 30001)]:
+    for bins, seg in [(4096, 2999), (130, 50001)]:
         f = _random_ixf(rng, bins, seg)
         raw, pitch = to_source_layout(f, code)
         assert raw.size > (16 << 20)

@@ -24,8 +24,8 @@ def _build(tmp_path_factory, name, flags):
     exe = tmp_path_factory.mktemp("pgz") / name
     cp = subprocess.run(["g++", "-std=c++17", "-O2", "-g", "-fno-omit-frame-pointer", *flags, f"-I{CSRC}", os.path.join(SAN, "pgz_inflate.cpp"),
                          "-o", str(exe), "-lz", "-pthread"], capture_output=True, text=True)
-    if cp.returncode != 0 and "sanitize" in cp.stderr:
-        pytest.skip("sanitizer runtime not available: " + cp.stderr[:200])
+    if cp.returncode != 0 and " error: " not in cp.stderr and any(t in cp.stderr for t in ("cannot find -lasan", "cannot find -lubsan", "cannot find -ltsan", "libasan", "libtsan")):
+        pytest.skip("sanitizer runtime not available: " + cp.stderr[:200])          # (a compile error is a failure, not a skip)
     assert cp.returncode == 0, cp.stderr
     return exe
 
@@ -57,8 +57,9 @@ def fastq(rng, n_reads, lo=200, hi=6000, genome=None):
     return b"".join(out)
 
 
-def run(exe, path, threads=4, chunk=65536, out=None):
-    cp = subprocess.run([str(exe), str(path), str(threads), str(chunk)] + ([str(out)] if out else []), capture_output=True, text=True, timeout=900)
+def run(exe, path, threads=4, chunk=65536, out=None, budget_mb=None):
+    cp = subprocess.run([str(exe), str(path), str(threads), str(chunk)] + ([str(out)] if out else ["-"] if budget_mb else []) + ([str(budget_mb)] if budget_mb else []),
+                        capture_output=True, text=True, timeout=900)
     assert cp.returncode == 0, cp.stderr[-3000:]
     assert "ERROR: " not in cp.stderr and "runtime error" not in cp.stderr and "WARNING: ThreadSanitizer" not in cp.stderr, cp.stderr[-3000:]
     return cp.stdout.strip()
@@ -139,6 +140,57 @@ def test_truncated_and_corrupted_streams_never_give_wrong_bytes(tmp_path, exe_pl
         assert "mismatch" in run(exe_plain, p, chunk=65536)
 
 
+def _bits_to_bytes(bits):
+    out = bytearray((len(bits) + 7) // 8)
+    for i, b in enumerate(bits):
+        out[i >> 3] |= b << (i & 7)
+    return bytes(out)
+
+
+def test_reader_behaves_like_the_zlib_stream_reader_at_the_edges(tmp_path, exe_plain):
+    """bytes behind the last member that are no gzip header: gzip(1) ignores them with a warning and keeps what it decoded -- so does
+    this reader, after the members' CRCs have been checked; a match that reaches before the START of the stream is invalid deflate
+    data ("distance too far back" in zlib), not a zero window found out by the CRC at the end of the member"""
+    rng = np.random.default_rng(9)
+    raw = fastq(rng, 1200)
+    comp = gzip.compress(raw, 6)
+    for tail in (b"garbage behind the member", b"\x1f", bytes(rng.integers(1, 256, size=3000, dtype=np.uint8))):
+        p = tmp_path / "tail.gz"
+        p.write_bytes(comp + b"\0" * 7 + tail)
+        cp = subprocess.run([str(exe_plain), str(p), "4", "65536"], capture_output=True, text=True, timeout=300)
+        assert cp.returncode == 0 and cp.stdout.startswith(want(raw)) and f"trailing {len(tail)} " in cp.stdout, cp.stdout + cp.stderr
+        assert "trailing garbage behind the last member ignored" in cp.stderr
+    # fixed-Huffman block: BFINAL=1, BTYPE=01, length code 257 (len 3), distance code 0 (dist 1) as the very first symbol, end of block
+    bits = [1, 1, 0] + [0, 0, 0, 0, 0, 0, 1] + [0, 0, 0, 0, 0] + [0, 0, 0, 0, 0, 0, 0]
+    body = _bits_to_bytes(bits)
+    with pytest.raises(zlib.error):
+        zlib.decompress(body, -15)
+    p = tmp_path / "far.gz"
+    p.write_bytes(b"\x1f\x8b\x08\x00" + b"\0" * 6 + body + zlib.crc32(b"\0\0\0").to_bytes(4, "little") + (3).to_bytes(4, "little"))
+    got = run(exe_plain, p, chunk=32768)
+    assert got.startswith("error:") and "invalid deflate data" in got, got
+
+
+def test_memory_in_flight_follows_the_compression_ratio(tmp_path, exe_plain):
+    """a very repetitive (valid) member expands ~180:1 (deflate allows 1032:1): chunks decoded ahead of the reader are limited to what fits the budget at the
+    ratio seen so far, instead of 2 x threads + 2 chunks whatever they expand to (each holds two bytes per output byte until resolved)"""
+    line = b"@r\n" + b"ACGT" * 64 + b"\n+\n" + b"I" * 256 + b"\n"
+    raw = line * (400_000_000 // len(line))
+    comp = gzip.compress(raw, 6)
+    assert len(raw) / len(comp) > 100
+    p = tmp_path / "rep.gz"
+    p.write_bytes(comp)
+    del comp
+    chunk = 32768                                     # ~70 chunks of ~6 MB of output (12 MB of symbols) each
+    bounded = run(exe_plain, p, threads=16, chunk=chunk, budget_mb=64)
+    assert bounded.startswith(want(raw)), bounded[:200]
+    rss_bounded = int(bounded.split("maxrss_kb ")[1])
+    free = run(exe_plain, p, threads=16, chunk=chunk, budget_mb=65536)
+    assert free.startswith(want(raw))
+    rss_free = int(free.split("maxrss_kb ")[1])
+    assert rss_bounded < 300_000 and rss_bounded < rss_free * 0.6, (rss_bounded, rss_free)
+
+
 @pytest.mark.parametrize("which", ["asan", "tsan"])
 def test_under_sanitizers(tmp_path, which, request):
     exe = request.getfixturevalue("exe_" + which)
@@ -196,7 +248,7 @@ def test_crc32_by_carryless_multiplication_equals_zlib(tmp_path):
         exe = tmp_path / f"crc_{name}"
         cp = subprocess.run(["g++", "-std=c++17", "-O2", "-g", *flags, f"-I{CSRC}", os.path.join(SAN, "crc32_fold.cpp"), "-o", str(exe), "-lz", "-pthread"],
                             capture_output=True, text=True)
-        if cp.returncode != 0 and "sanitize" in cp.stderr:
+        if cp.returncode != 0 and " error: " not in cp.stderr and ("libasan" in cp.stderr or "cannot find -lasan" in cp.stderr):
             continue
         assert cp.returncode == 0, cp.stderr
         run_ = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
