@@ -294,6 +294,13 @@ def build_workload(args, local_rank, rank, world):
         need_root = max(sum(len(p) for p in planted[2:]) // max(1, min(n_children, len(planted) - 2)) * 2, biggest)
     root_max = max(root_max, need_root)
     child_max = max(child_max, biggest + 1024)
+    # every child must hold the largest planted genome in one bin; where wide children (chopper-shaped: --child-bins = --root-bins)
+    # would blow the footprint, there are fewer of them instead -- like a layout step that merges more user bins per child
+    min_child_rows = 1.23 * child_max + 32
+    fit = int(wl["total_bytes"] * (1 - wl["root_frac"]) / (min_child_rows * max(64, wl["child_bins"]))) - 1
+    if fit < n_children:
+        n_children = max(2 * spread, fit)
+        log(f"children of {wl['child_bins']} bins: {n_children} of them fit the {wl['total_bytes']/1e9:.0f} GB footprint")
     if fam_size > 1:
         lay = synth.make_family_layout(planted, family, root_bins=wl["root_bins"], child_bins=wl["child_bins"],
                                        n_children=n_children, spread=spread, root_max_elems=root_max,

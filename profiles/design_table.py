@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""DESIGN.md section 5's table from ONE bench.py line (the headline and the `layouts` legs of the same invocation).
+usage: python profiles/design_table.py profiles/r05/bench_gtdb.json [--write]     (--write: replace the block between the
+<!-- BENCH-TABLE --> markers of DESIGN.md)"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = sys.argv[1]
+j = json.loads([l for l in open(path) if l.startswith("{")][-1])
+c, r = j["config"], j["roofline"]
+lv = r.get("levels", [])
+gc = r.get("gather_ceiling", {})
+out = []
+out.append(f"Source: `{os.path.relpath(path, ROOT)}` — one `python bench.py` invocation ({j['steps']} steps, {j['warmup']} warm-up; the driver's own run is `BENCH_r05.json`).")
+out.append("")
+out.append("| leg (same invocation) | index | reads | Mbp/s | `frac` | other fractions | work per read |")
+out.append("|---|---|---|---|---|---|---|")
+un = r.get("unpruned") or {}
+out.append(f"| **headline `value`** (resident, {j['steps']} steps) | {c['index_bytes'] / 1e9:.0f} GB, root {c['root_bins']}, children {c['child_bins']}, depth {c['depth']} | "
+           f"{c['reads_per_gpu']} × {c['read_len'] // 1000} kb, error {c['read_error']}, forward strand | **{j['value']:,.0f}** ({j['ms_per_step']:.1f} ms/step) | **{r['frac']:.3f}** | "
+           f"contract {r.get('contract_frac')} (pruning off: {un.get('value_Mbp_s', 0):,.0f} Mbp/s), moved {r.get('moved_frac')}, line128 {r.get('requested_accounting', {}).get('frac_line128')} | "
+           f"{c['hashes_per_read']} hashes, {c['work_items_per_read']} items, {c['tuples_per_read']} tuples |")
+if "value_host_fed" in j:
+    p = j.get("pcie_inclusive") or {}
+    out.append(f"| host-fed (PCIe inside; never `value`) | same | ≥ {j.get('sustained', {}).get('reads', 0):,} reads through `taxor_gpu_search_batch` | {j['value_host_fed']:,.0f} sustained; {p.get('value', 0):,.0f} single pageable call | | | |")
+if "read_error_0.04" in j:
+    e = j["read_error_0.04"]
+    out.append(f"| read error 0.04 (BASELINE.md §3; the easier case) | same | same shape | {e['value']:,.0f} ({e.get('value_host_fed', 0):,.0f} host-fed) | {e.get('frac')} | | {e['work_items_per_read']} items, {e['tuples_per_read']} tuples |")
+for leg in j.get("layouts", []):
+    out.append(f"| `layouts`: {leg['layout']} — {leg['what'].split(':')[0].split(';')[0]} | {leg['index_bytes'] / 1e9:.0f} GB, root {leg['root_bins']}, children {leg['child_bins']}, depth {leg['depth']} | "
+               f"frac_reverse {leg['frac_reverse']} | {leg['value']:,.0f} | {leg['frac']} | algorithmic {leg['algorithmic_frac']}; no PMC pass | "
+               f"{leg['hashes_per_read']} hashes, {leg['work_items_per_read']} items, {leg['tuples_per_read']} tuples |")
+cb = j.get("cpu_baseline") or {}
+if cb:
+    out.append(f"| CPU baseline ({cb.get('kind')}, {cb.get('cores')} cores, reference's `do_parallel` scheduler) | same | {cb.get('sample', '')[:60]}… | {cb.get('value', 0):,.0f} | | GPU results bit-identical on the sample | |")
+out.append("")
+if lv:
+    out.append("Per level of the headline: " + "; ".join(
+        f"level {x['level']} {x['ms_per_step']} ms/step, {x['requested_GBps']:,.0f} GB/s requested ({x['frac']}), {x['row_reads_G_per_s']} G rows/s of {x['bytes_per_row_read']:.0f} B" for x in lv) + ".")
+if gc:
+    out.append(f"Gather ceilings of the same run (random whole rows, nothing else): root {gc['root']['GBps']:,.0f} GB/s"
+               + (f", children {gc['children']['GBps']:,.0f} GB/s" if "children" in gc else "") + ".")
+if r.get("traffic") is not None:
+    out.append(f"Memory side (live `rocprofv3 --pmc` passes in the same invocation): {r['traffic'] / 1e9:.2f} GB per launch = {r.get('traffic_GBps', 0):,.0f} GB/s "
+               f"({r.get('traffic_over_requested')} × requested, {r.get('traffic_over_line128')} × the 128-B lines touched); average launch {r['avg_launch_ms']} ms "
+               f"(rocprofv3 kernel trace of the same command: `profiles/r05/gtdb_kernel_stats.csv`).")
+text = "\n".join(out)
+print(text)
+if "--write" in sys.argv:
+    dp = os.path.join(ROOT, "DESIGN.md")
+    s = open(dp).read()
+    block = "<!-- BENCH-TABLE -->\n" + text + "\n<!-- /BENCH-TABLE -->"
+    if "<!-- /BENCH-TABLE -->" in s:
+        s = re.sub(r"<!-- BENCH-TABLE -->.*?<!-- /BENCH-TABLE -->", lambda m: block, s, flags=re.S)
+    else:
+        s = s.replace("<!-- BENCH-TABLE -->", block)
+    open(dp, "w").write(s)

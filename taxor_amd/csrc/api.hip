@@ -181,6 +181,8 @@ struct taxor_gpu_searcher {
         DBuf<uint8_t> d_in;                 // aoff | poff | hoff | rlen | hcap | order of the piece: ONE host-to-device copy
         void *h_in = nullptr;               // its page-locked source
         size_t h_in_cap = 0;
+        void *h_bases = nullptr;            // TAXOR_SMALL_STAGE=1 (experiment, profiles/r05/small_calls.txt): the piece's bases copied here by the
+        size_t h_bases_cap = 0;             // calling thread, so that their host-to-device copy is asynchronous
         void *h_out = nullptr, *d_out = nullptr;   // results in host memory the device writes: status | read_off | nh | ub | cnt
         uint32_t out_reads = 0, out_tuples = 0;    // capacities of that area
         bool fresh = true;                  // counters / hit counts not known to be zero: clear them before the next piece
@@ -938,6 +940,7 @@ extern "C" void taxor_gpu_searcher_destroy(taxor_gpu_searcher *s)
         if (L.copied) (void)hipEventDestroy(L.copied);
         L.d_in.release();
         if (L.h_in) (void)hipHostFree(L.h_in);
+        if (L.h_bases) (void)hipHostFree(L.h_bases);
         if (L.h_out) (void)hipHostFree(L.h_out);
     }
     s->lanes.clear();
@@ -1844,7 +1847,22 @@ int small_enqueue(taxor_gpu_searcher *s, uint32_t li, const char *bases, const u
     // by side and all arrive late; each waits for its predecessor's instead, so the pieces arrive -- and start -- one after the
     // other as from pageable memory (where the call itself blocks until the bytes are over)
     if (copy_after) HIP_TRY(hipStreamWaitEvent(st, copy_after, 0));
-    if (nb) HIP_TRY(hipMemcpyAsync(c->d_ascii.p, bases + a0, nb, hipMemcpyHostToDevice, st));
+    // (Experiment of round 5, off by default: TAXOR_SMALL_STAGE=1 has the CALLING thread memcpy the piece's bases into a page-locked
+    // buffer of the lane, so that no copy enters the runtime's blocking pageable path.  A single thread copies ~10 GB/s: the 10 MB of a
+    // 1024 x 10 kb call cost more than the runtime's pin-in-place copy saves -- measured in profiles/r05/small_calls.txt.)
+    static const bool stage_bases = [] { const char *e = tune_env("TAXOR_SMALL_STAGE"); return e && atoi(e) != 0; }();
+    const char *src = bases + a0;
+    if (stage_bases && nb) {
+        if (L.h_bases_cap < nb) {
+            if (L.h_bases) { HIP_TRY(hipStreamSynchronize(st)); (void)hipHostFree(L.h_bases); }
+            L.h_bases = nullptr;
+            L.h_bases_cap = round_up(nb + (nb >> 2), 1u << 20);
+            HIP_TRY(hipHostMalloc(&L.h_bases, L.h_bases_cap, hipHostMallocDefault));
+        }
+        memcpy(L.h_bases, src, nb);
+        src = (const char *)L.h_bases;
+    }
+    if (nb) HIP_TRY(hipMemcpyAsync(c->d_ascii.p, src, nb, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(L.copied, st));
     t_bases = us();
     const uint64_t *d_aoff = (const uint64_t *)(L.d_in.p + o_aoff), *d_poff = (const uint64_t *)(L.d_in.p + o_poff),

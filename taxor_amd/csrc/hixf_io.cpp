@@ -425,7 +425,14 @@ extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *
     if (schema->n_before > 32 || schema->n_after > 32 || schema->idx_bins >= ns || schema->idx_stride >= ns ||
         schema->idx_seg_len >= ns || schema->idx_seed >= ns)
         return io_fail(TAXOR_E_ARG, "hixf_load_schema: schema indices out of range");
-    return load_with(path, *schema, out, nullptr);
+    const int rc = load_with(path, *schema, out, nullptr);
+    if (rc == TAXOR_OK) {            // records framed otherwise than this library writes them: written by other software (or for a test of that)
+        taxor_ixf_schema own;
+        taxor_ixf_schema_default(&own);
+        (*out)->meta.foreign_schema = schema->n_before != own.n_before || schema->n_after != own.n_after || schema->idx_bins != own.idx_bins ||
+                                      schema->idx_stride != own.idx_stride || schema->idx_seg_len != own.idx_seg_len || schema->idx_seed != own.idx_seed;
+    }
+    return rc;
 }
 
 extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *report, uint64_t cap)
