@@ -395,9 +395,10 @@ class Comm:
 
     __del__ = close
 
-    def replicate_index(self, ixfs, n_user_bins, k=22, s=12, t=5, use_syncmer=True, scaling=1, window_size=None):
-        """-> [GpuIndex on devices[0], GpuIndex on devices[1], ...]"""
-        view, keep = GpuIndex._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size)
+    def replicate_index(self, ixfs, n_user_bins, k=22, s=12, t=5, use_syncmer=True, scaling=1, window_size=None, layout=0):
+        """-> [GpuIndex on devices[0], GpuIndex on devices[1], ...]; layout as in GpuIndex"""
+        view, keep = GpuIndex._view(ixfs, n_user_bins, k, s, t, use_syncmer, scaling, window_size, layout)
+        view.ixf_layout = int(layout)
         out = (C.c_void_p * len(self.devices))()
         check(_lib.lib().taxor_gpu_index_create_replicated(self._h, C.byref(view), out))
         del keep

@@ -74,7 +74,21 @@ def run_trial(seed, verbose=False):
         # no seed peels, so nobody could have written such an index either -- nothing to search, the trial is void
         return True, dict(seed=seed, arith=arith, void="this arithmetic code does not peel"), 0
     host = synth.materialize_host(lay)
-    idx = GpuIndex(host, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith)
+    # one trial in three: the index reaches the device in ANOTHER writer's fingerprint layout (taxor_amd/csrc/ixf_layout.h: foreign
+    # pitch, bin-major, bit-sliced words, rows position-major) and is transposed there while it is uploaded (relayout.hip) -- drawn
+    # from a generator of its own, the trial's other draws stay what they were
+    lrng = np.random.default_rng(seed ^ 0x1A707)
+    layout = 0
+    device_side = host
+    if lrng.random() < 0.34:
+        from taxor_amd.search import to_source_layout
+        kind = int(lrng.integers(0, 3))
+        layout = kind | (0x100 if lrng.random() < 0.5 else 0) | (0 if kind == 2 else int(lrng.choice([0, 0x200, 0x400])))
+        device_side = []
+        for f in host:
+            raw, pitch = to_source_layout(f, layout)
+            device_side.append(dict(f, data=raw, src_stride=pitch, stride=(f["bins"] + 63) // 64 * 64))
+    idx = GpuIndex(device_side, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith, layout=layout)
     h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
     n_syn = int(rng.integers(20, 200))
     bases, offs, origin = synth.synth_reads(g, go, n_syn, int(rng.integers(200, 4000)), error_rate=float(rng.choice([0.0, 0.01, 0.03, 0.08])),
@@ -96,7 +110,7 @@ def run_trial(seed, verbose=False):
     err = float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.2])) if syncmer else float(rng.choice([0.01, 0.04, 0.1, 0.3]))
     sub = int(rng.choice([0, 1, 7, 64]))
     cfg = dict(seed=seed, syncmer=syncmer, k=k, s=s, t=t, window=win, scaling=scaling, n_ixf=len(host), depth=lay["depth"],
-               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith)
+               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith, layout=layout)
     if verbose:
         print(cfg, flush=True)
     sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub, group_always=group_always,

@@ -85,6 +85,36 @@ def test_single_rank_communicator(transport):
     sr.close(); idx.close(); comm.close(); ref.close(); ref_idx.close()
 
 
+@pytest.mark.parametrize("transport", ["rccl", "host"])
+def test_replicas_of_an_index_in_a_foreign_fingerprint_layout(transport):
+    """the one PCIe upload of a replicated index goes through the same re-layout as a plain index creation (bin-major source,
+    unpadded columns, rows position-major): every replica holds the search layout's bytes and answers like the plain index"""
+    from taxor_amd.search import to_source_layout
+    host, nub, batches = _index_and_batches(1, seed=11)
+    layout = 0x301
+    foreign = []
+    for f in host:
+        raw, pitch = to_source_layout(f, layout)
+        foreign.append(dict(f, data=raw, src_stride=pitch))
+    ref_idx = GpuIndex(host, nub)
+    want = Searcher(ref_idx).search_batch(*batches[0])
+    comm = Comm([0] if transport == "rccl" else [0, 0], transport)
+    idxs = comm.replicate_index(foreign, nub, layout=layout)
+    for idx in idxs:
+        for i in range(len(host)):
+            assert np.array_equal(idx.download_ixf(i), ref_idx.download_ixf(i))
+    srs = [Searcher(i) for i in idxs]
+    for s in srs:
+        s.search_batch_begin(*batches[0])
+    got = comm.gather(srs)
+    assert _same(got, _concat([want] * len(srs))) and got.user_bin.size > 0
+    for s in srs:
+        s.close()
+    for i in idxs:
+        i.close()
+    comm.close(); ref_idx.close()
+
+
 def test_host_transport_three_replicas_one_round():
     """three replicas (the same device three times: only the host transport allows that), one batch each, an empty batch on the
     third searcher in the second round"""
