@@ -51,7 +51,8 @@ with open(fq, "w") as f:
 print(f"index: {len(ixfs)} IXFs, {total / 1e9:.2f} GB of fingerprints (root {root_bins} bins x {3 * root_seg} rows, {n_children} children of {child_bins} bins)")
 R, B, S, PM, UNP = _lib.LAYOUT_ROWS, _lib.LAYOUT_BIN_MAJOR, _lib.LAYOUT_BIT_SLICED, _lib.LAYOUT_POSITION_MAJOR, _lib.LAYOUT_PITCH_BINS
 digests = {}
-for code in (0, R | PM, B, S):
+codes = [int(x, 0) for x in os.environ["RELAYOUT_CODES"].split(",")] if os.environ.get("RELAYOUT_CODES") else [0, R | PM, B, S]
+for code in codes:
     sc = default_schema()
     sc.layout = code
     path = os.path.join(tmp, "x.hixf")
