@@ -889,7 +889,7 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
     idx.close()
     # (b), (c): indexes of the same footprint in other shapes, each with its own forward-strand reads like the headline
     for label, root_bins, child_bins, what in (
-            ("chopper_1024", out["config"]["root_bins"], out["config"]["root_bins"],
+            (f"chopper_{out['config']['root_bins']}", out["config"]["root_bins"], out["config"]["root_bins"],
              "children as wide as the root: one t_max at every level, as the reference's layout step applies it"),
             ("root_4096", 4096, out["config"]["child_bins"], "t_max 4096 at the root (the largest the reference offers), the headline's children")):
         a2 = argparse.Namespace(**vars(args))

@@ -32,6 +32,9 @@ def test_equals_syntax_reaches_the_same_validators(tmp_path):
             ([f"--index-file={missing}", "--percentage=-0.1"], "Value not in range [0,1]"),
             ([f"--index-file={missing}", "--threads"], "Missing value"),
             ([f"--query-file={fa}"], "required"),
+            ([f"--index-file={missing}", "--ixf-layout=sideways"], "Validation failed for option --ixf-layout"),
+            ([f"--index-file={missing}", "--ixf-layout", "bit-sliced,unpadded"], "not a layout"),
+            ([f"--index-file={missing}", "--ixf-layout=bin-major,unpadded,position-major"], "does not exist"),
             ([f"--index-file={missing}", "--frobnicate"], "Unknown option --frobnicate"),
             ([f"--index-file={missing}", "--frobnicate=3"], "Unknown option --frobnicate")):
         cp = run("--output-file", str(tmp_path / "o.tsv"), *args)

@@ -95,6 +95,28 @@ def test_rendezvous_failure_is_loud(tmp_path):
     assert "FATAL rank 1/2" in cp.stderr and not [l for l in cp.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_line_says_what_the_workload_is_and_carries_the_layout_legs():
+    """the line states the headline's strand mix and child width (config.frac_reverse, child_bins, layout_note) and measures, in the
+    same invocation, strand-mixed reads (SURVEY 8(d) as written), chopper-shaped children (as wide as the root: one t_max at every
+    level, taxor_build.cpp:168-187,473) and a 4096-bin root"""
+    cmd = [sys.executable, "bench.py", "--workload", "viral", "--reads", "8192", "--steps", "2", "--warmup", "1", "--batches", "2", "--traffic", "none",
+           "--no-ceiling", "--no-unpruned", "--no-e04", "--no-dropin", "--no-cpu-baseline"]
+    cp = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert cp.returncode == 0, cp.stderr[-3000:]
+    j = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][0])
+    c = j["config"]
+    assert c["frac_reverse"] == 0.0 and c["child_bins"] == 64 and "forward strand only" in c["layout_note"] and "one t_max" in c["layout_note"]
+    legs = {l["layout"]: l for l in j["layouts"]}
+    assert sorted(legs) == ["chopper_256", "root_4096", "strand_mixed"] or sorted(legs) == ["chopper_1024", "root_4096", "strand_mixed"], sorted(legs)
+    chop = [l for k, l in legs.items() if k.startswith("chopper")][0]
+    assert chop["child_bins"] == chop["root_bins"] == c["root_bins"] and legs["root_4096"]["root_bins"] == 4096
+    for l in legs.values():
+        assert l["value"] > 0 and 0 < l["frac"] <= 1.0 and l["moved_frac"] is None and l["steps"] == 3
+    # half of the planted reads come from the strand the index does not hold: they stop at the root
+    assert legs["strand_mixed"]["frac_reverse"] == 0.5 and legs["strand_mixed"]["tuples_per_read"] < 0.75 * c["tuples_per_read"]
+    assert legs["strand_mixed"]["index_bytes"] == c["index_bytes"] and abs(chop["index_bytes"] - c["index_bytes"]) < 0.35 * c["index_bytes"]
+
+
 @pytest.mark.parametrize("mode", ["kmer", "minimiser"])
 def test_bench_tracks_indexes_built_without_syncmers(mode, tmp_path):
     """bench.py --mode kmer|minimiser: the reference's default build mode gets the same line -- value, roofline
