@@ -827,7 +827,7 @@ def main():
             hash_kw = dict(k=info["k"], s=info["s"], t=info["t"], window=info["window"]) if args.mode != "syncmer" else {}
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu, hash_kw)
         if world == 1 and not dist_on and not args.no_layouts and args.mode == "syncmer" and not args.len_mix:
-            out["layouts"] = layout_legs(args, idx, info, searchers, timed, local_rank, out)
+            out["layouts"] = layout_legs(args, idx, info, searchers, timed, local_rank, out)     # (never raises: a leg that fails is reported as such)
             idx = None
         print(json.dumps(out), flush=True)
     for sr in searchers:
@@ -880,8 +880,12 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
         bb, oo, _ = synth.synth_reads(info["genomes"], info["genome_off"], n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
                                       seed=synth.DEFAULT_SEED + 55000 + b, threads=ncpu, frac_reverse=0.5)
         both.append((np.ascontiguousarray(bb), np.ascontiguousarray(oo)))
-    legs.append(measure(idx, both, "strand_mixed", "headline index, planted reads from either strand with probability 0.5 (SURVEY 8(d) 'strand uniformly'); "
-                        "reverse-strand reads share no syncmers with the index and stop at the root", dict(shape, frac_reverse=0.5)))
+    try:
+        legs.append(measure(idx, both, "strand_mixed", "headline index, planted reads from either strand with probability 0.5 (SURVEY 8(d) 'strand uniformly'); "
+                            "reverse-strand reads share no syncmers with the index and stop at the root", dict(shape, frac_reverse=0.5)))
+    except Exception as e:        # the legs are additions to the line: a failure in one must not cost the headline
+        legs.append({"layout": "strand_mixed", "error": f"{type(e).__name__}: {e}"})
+        log(f"layout leg strand_mixed failed: {type(e).__name__}: {e}")
     del both
     for sr in searchers:
         sr.close()
@@ -894,11 +898,17 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
             ("root_4096", 4096, out["config"]["child_bins"], "t_max 4096 at the root (the largest the reference offers), the headline's children")):
         a2 = argparse.Namespace(**vars(args))
         a2.root_bins, a2.child_bins, a2.batches = root_bins, child_bins, 2
-        wl2, idx2, lay2, batches2, info2 = build_workload(a2, local_rank, 0, 1)
-        legs.append(measure(idx2, batches2, label, what, {"root_bins": wl2["root_bins"], "child_bins": wl2["child_bins"], "index_bytes": idx2.data_bytes,
-                                                          "n_ixf": idx2.n_ixf, "depth": idx2.depth, "frac_reverse": args.frac_reverse}))
-        idx2.close()
-        del lay2, batches2, info2
+        idx2 = None
+        try:
+            wl2, idx2, lay2, batches2, info2 = build_workload(a2, local_rank, 0, 1)
+            legs.append(measure(idx2, batches2, label, what, {"root_bins": wl2["root_bins"], "child_bins": wl2["child_bins"], "index_bytes": idx2.data_bytes,
+                                                              "n_ixf": idx2.n_ixf, "depth": idx2.depth, "frac_reverse": args.frac_reverse}))
+            del lay2, batches2, info2
+        except Exception as e:
+            legs.append({"layout": label, "error": f"{type(e).__name__}: {e}"})
+            log(f"layout leg {label} failed: {type(e).__name__}: {e}")
+        if idx2 is not None:
+            idx2.close()
     return legs
 
 

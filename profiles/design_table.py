@@ -30,6 +30,9 @@ if "read_error_0.04" in j:
     e = j["read_error_0.04"]
     out.append(f"| read error 0.04 (BASELINE.md §3; the easier case) | same | same shape | {e['value']:,.0f} ({e.get('value_host_fed', 0):,.0f} host-fed) | {e.get('frac')} | | {e['work_items_per_read']} items, {e['tuples_per_read']} tuples |")
 for leg in j.get("layouts", []):
+    if "error" in leg:
+        out.append(f"| `layouts`: {leg['layout']} | (failed: {leg['error'][:80]}) | | | | | |")
+        continue
     out.append(f"| `layouts`: {leg['layout']} — {leg['what'].split(':')[0].split(';')[0]} | {leg['index_bytes'] / 1e9:.0f} GB, root {leg['root_bins']}, children {leg['child_bins']}, depth {leg['depth']} | "
                f"frac_reverse {leg['frac_reverse']} | {leg['value']:,.0f} | {leg['frac']} | algorithmic {leg['algorithmic_frac']}; no PMC pass | "
                f"{leg['hashes_per_read']} hashes, {leg['work_items_per_read']} items, {leg['tuples_per_read']} tuples |")
