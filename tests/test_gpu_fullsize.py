@@ -92,7 +92,7 @@ def test_viral_class_one_million_reads():
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] and configs[3] at full size: RefSeq-class (9.9 GB) and GTDB-class (113 GB) indexes resident
 # in HBM, 10 M synthetic 10 kb reads each (ten batches of 1 M, like the CLI feeds them), the workload bench.py measures
-# (families of related strains, read error 0.04).  Bit-exact oracle samples at the first / middle / last reads, pruning
+# (families of related strains, read error 0.02 -- bench.py's default --read-error; the search runs at --error-rate 0.04).  Bit-exact oracle samples at the first / middle / last reads, pruning
 # on/off equality over ALL reads, sub-batch invariance and idempotence, counter checksums, positive/negative controls.
 # ---------------------------------------------------------------------------------------------------------------------
 def _digest(res):
