@@ -196,6 +196,10 @@ typedef struct {
     uint32_t seg_len_is_rows;   /* 1: the idx_seg_len scalar holds rows = 3*seg_len */
     uint64_t default_seed;      /* 13572355802537770549 = the fixed start seed of src/main/xorfilter.hpp:153 */
     uint32_t layout;            /* how the fingerprint vector is laid out (taxor_hixf_view::ixf_layout); 0 = the search layout */
+    uint32_t len_unit;          /* what the vector's u64 length word counts: 0 / 1 bytes (cereal's std::vector<uint8_t>), 8 = 64-bit words
+                                   (std::vector<uint64_t>), 64 = BITS held in whole 64-bit words (an sdsl int_vector / bit_vector) */
+    uint32_t skip_before_len, skip_after_len; /* bytes between the scalars and the length word / between it and the data (an int_vector's
+                                   u8 width); the scalars themselves are u64 */
 } taxor_ixf_schema;
 /* this library's own schema: bins | technical_bins | seg_len | bin_words | seed | ftype | data, layout 0 */
 void taxor_ixf_schema_default(taxor_ixf_schema *out);

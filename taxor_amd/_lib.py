@@ -90,7 +90,8 @@ class HixfMeta(C.Structure):
 class IxfSchema(C.Structure):
     _fields_ = [("n_before", C.c_uint32), ("n_after", C.c_uint32), ("idx_bins", C.c_int32), ("idx_stride", C.c_int32),
                 ("idx_seg_len", C.c_int32), ("idx_seed", C.c_int32), ("seg_len_is_rows", C.c_uint32),
-                ("default_seed", C.c_uint64), ("layout", C.c_uint32)]
+                ("default_seed", C.c_uint64), ("layout", C.c_uint32), ("len_unit", C.c_uint32), ("skip_before_len", C.c_uint32),
+                ("skip_after_len", C.c_uint32)]
 
 
 class IxfVariant(C.Structure):

@@ -235,10 +235,17 @@ std::string parse_ixfs(Cursor &c, const taxor_ixf_schema &sc, taxor_hixf *h, uin
     std::vector<uint64_t> sv(ns);
     for (uint64_t i = 0; i < n_ixf; ++i) {
         for (uint32_t j = 0; j < sc.n_before; ++j) sv[j] = c.get<uint64_t>();
-        const uint64_t len = c.get<uint64_t>();
+        if (sc.skip_before_len) (void)c.bytes(sc.skip_before_len);
+        const uint64_t count = c.get<uint64_t>();
+        if (sc.skip_after_len) (void)c.bytes(sc.skip_after_len);
         if (!c.ok) return "truncated in IXF " + std::to_string(i);
-        const uint8_t *data = c.bytes(len);
-        if (!data) return "IXF " + std::to_string(i) + ": fingerprint vector of " + std::to_string(len) + " bytes runs past the end of the file";
+        // bytes the vector occupies in the file, and fingerprint bytes of them (bits in whole words: up to 7 bytes of padding)
+        if (count > (1ull << 60)) return "IXF " + std::to_string(i) + ": fingerprint vector length implausible";
+        const uint64_t in_file = sc.len_unit == 8 ? count * 8 : sc.len_unit == 64 ? (count + 63) / 64 * 8 : count;
+        const uint64_t len = sc.len_unit == 64 ? count / 8 : in_file;
+        if (sc.len_unit == 64 && count % 8 != 0) return "IXF " + std::to_string(i) + ": a length of " + std::to_string(count) + " bits is not whole fingerprints";
+        const uint8_t *data = c.bytes(in_file);
+        if (!data) return "IXF " + std::to_string(i) + ": fingerprint vector of " + std::to_string(in_file) + " bytes runs past the end of the file";
         for (uint32_t j = 0; j < sc.n_after; ++j) sv[sc.n_before + j] = c.get<uint64_t>();
         if (!c.ok) return "truncated after IXF " + std::to_string(i);
         taxor_ixf_view &f = h->ixf[i];
@@ -415,7 +422,7 @@ int load_with(const char *path, const taxor_ixf_schema &sc, taxor_hixf **out, bo
 extern "C" void taxor_ixf_schema_default(taxor_ixf_schema *out)
 {
     if (!out) return;
-    *out = taxor_ixf_schema{6, 0, 0, 1, 2, 4, 0, 13572355802537770549ull, 0};
+    *out = taxor_ixf_schema{6, 0, 0, 1, 2, 4, 0, 13572355802537770549ull, 0, 1, 0, 0};
 }
 
 extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *schema, taxor_hixf **out)
@@ -423,14 +430,16 @@ extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *
     if (!path || !schema || !out) return io_fail(TAXOR_E_ARG, "hixf_load_schema: null argument");
     const int ns = (int)(schema->n_before + schema->n_after);
     if (schema->n_before > 32 || schema->n_after > 32 || schema->idx_bins >= ns || schema->idx_stride >= ns ||
-        schema->idx_seg_len >= ns || schema->idx_seed >= ns)
+        schema->idx_seg_len >= ns || schema->idx_seed >= ns || (schema->len_unit > 1 && schema->len_unit != 8 && schema->len_unit != 64) ||
+        schema->skip_before_len > 8 || schema->skip_after_len > 8)
         return io_fail(TAXOR_E_ARG, "hixf_load_schema: schema indices out of range");
     const int rc = load_with(path, *schema, out, nullptr);
     if (rc == TAXOR_OK) {            // records framed otherwise than this library writes them: written by other software (or for a test of that)
         taxor_ixf_schema own;
         taxor_ixf_schema_default(&own);
         (*out)->meta.foreign_schema = schema->n_before != own.n_before || schema->n_after != own.n_after || schema->idx_bins != own.idx_bins ||
-                                      schema->idx_stride != own.idx_stride || schema->idx_seg_len != own.idx_seg_len || schema->idx_seed != own.idx_seed;
+                                      schema->idx_stride != own.idx_stride || schema->idx_seg_len != own.idx_seg_len || schema->idx_seed != own.idx_seed ||
+                                      (schema->len_unit > 1) || schema->skip_before_len || schema->skip_after_len;
     }
     return rc;
 }
@@ -468,9 +477,14 @@ extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *r
     std::vector<std::vector<uint64_t>> scal;
     std::vector<uint64_t> lens;
     taxor_hixf tail;
+    // framing of the vector itself, likeliest first: a byte count (cereal's std::vector<uint8_t>), 64-bit words, bits in whole
+    // words (sdsl), each also with one byte (an int_vector's width) before or behind the length word
+    struct VecFrame { uint32_t unit, before, after; };
+    static const VecFrame frames[] = {{1, 0, 0}, {8, 0, 0}, {64, 0, 0}, {64, 0, 1}, {64, 1, 0}, {1, 0, 1}, {1, 1, 0}, {8, 0, 1}, {8, 1, 0}};
+    for (const VecFrame &vf : frames)
     for (uint32_t total = 0; total <= 16 && !found; ++total)
         for (uint32_t na = 0; na <= std::min<uint32_t>(total, 4) && !found; ++na) {
-            taxor_ixf_schema t{total - na, na, -1, -1, -1, -1, 0, 13572355802537770549ull, 0};
+            taxor_ixf_schema t{total - na, na, -1, -1, -1, -1, 0, 13572355802537770549ull, 0, vf.unit, vf.before, vf.after};
             Cursor c = c0;
             taxor_hixf trial;
             scal.clear();
@@ -490,6 +504,9 @@ extern "C" int taxor_hixf_probe(const char *path, taxor_ixf_schema *out, char *r
         return io_fail(TAXOR_E_IO, std::string(path) + ": IXF record framing not recognised");
     }
     rep += "framing: " + std::to_string(sc.n_before) + " u64 scalars | fingerprint vector | " + std::to_string(sc.n_after) + " u64 scalars\n";
+    rep += std::string("vector: u64 length in ") + (sc.len_unit == 8 ? "64-bit words" : sc.len_unit == 64 ? "bits (whole 64-bit words stored)" : "bytes") +
+           (sc.skip_before_len ? ", " + std::to_string(sc.skip_before_len) + " byte(s) before the length word" : std::string()) +
+           (sc.skip_after_len ? ", " + std::to_string(sc.skip_after_len) + " byte(s) behind it" : std::string()) + "\n";
     // 2. which scalar is which
     const uint32_t ns = sc.n_before + sc.n_after;
     auto all = [&](auto pred) {
@@ -723,7 +740,17 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
         }
         for (uint32_t j = 0; j < sc->n_before; ++j) w.put<uint64_t>(sv[j]);
         const uint64_t native_len = rows * x.stride, len = as_is ? native_len : taxor::ixf_src_bytes(code, rows, pitch, x.bins);
-        w.put<uint64_t>(len);
+        {   // the vector's framing under the schema: length word in its unit, optional filler bytes around it, words padded with zeros
+            static const uint8_t filler8[8] = {8, 0, 0, 0, 0, 0, 0, 0};       // (an int_vector's width byte)
+            if (sc->skip_before_len) w.bytes(filler8, sc->skip_before_len);
+            w.put<uint64_t>(sc->len_unit == 8 ? (len + 7) / 8 : sc->len_unit == 64 ? len * 8 : len);
+            if (sc->skip_after_len) w.bytes(filler8, sc->skip_after_len);
+        }
+        const uint64_t word_pad = sc->len_unit == 8 || sc->len_unit == 64 ? (8 - len % 8) % 8 : 0;
+        if (sc->len_unit == 8 && len % 8 != 0) {
+            fclose(f);
+            return io_fail(TAXOR_E_ARG, "hixf_store: a vector of 64-bit words cannot hold " + std::to_string(len) + " fingerprint bytes");
+        }
         if (!as_is) {
             // another writer's layout: the inverse of what index creation does on the device (relayout.hip), on the host, one IXF
             // in memory at a time -- tests of the re-layout and export; columns beyond `bins` are written as zeros
@@ -779,6 +806,7 @@ extern "C" int taxor_hixf_store_schema(const char *path, const taxor_hixf_view *
             }
         } else
             w.bytes(x.data, len);
+        if (word_pad) { static const uint8_t z[8] = {0}; w.bytes(z, word_pad); }
         for (uint32_t j = 0; j < sc->n_after; ++j) w.put<uint64_t>(sv[sc->n_before + j]);
     }
     w.put<uint64_t>(v->n_ixf);

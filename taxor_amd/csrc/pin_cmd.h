@@ -395,7 +395,8 @@ static int pin_command(int argc, char **argv)
           ", \"foreign_schema\": " + (meta->foreign_schema ? "true" : "false") + ",\n            \"schema\": {\"n_before\": " + std::to_string(schema.n_before) +
           ", \"n_after\": " + std::to_string(schema.n_after) + ", \"idx_bins\": " + std::to_string(schema.idx_bins) + ", \"idx_stride\": " + std::to_string(schema.idx_stride) +
           ", \"idx_seg_len\": " + std::to_string(schema.idx_seg_len) + ", \"idx_seed\": " + std::to_string(schema.idx_seed) + ", \"seg_len_is_rows\": " +
-          std::to_string(schema.seg_len_is_rows) + ", \"default_seed\": " + std::to_string((unsigned long long)schema.default_seed) + "},\n            \"ixf_arith\": " +
+          std::to_string(schema.seg_len_is_rows) + ", \"default_seed\": " + std::to_string((unsigned long long)schema.default_seed) + ", \"len_unit\": " +
+          std::to_string(schema.len_unit) + ", \"skip_before_len\": " + std::to_string(schema.skip_before_len) + ", \"skip_after_len\": " + std::to_string(schema.skip_after_len) + "},\n            \"ixf_arith\": " +
           std::to_string(arith) + ", \"arith_spec\": \"" + spec + "\", \"arith_source\": \"" + json_escape(arith_source) + "\",\n            \"ixf_layout\": " +
           std::to_string(layout) + ", \"layout_spec\": \"" + layout_desc + "\", \"relayout\": " + (relayout ? "true" : "false") + "},\n";
     js += "  \"search\": {\"error_rate\": " + std::to_string(error_rate) + ", \"percentage\": " + std::to_string(percentage) + "},\n";

@@ -62,9 +62,11 @@ def default_schema():
     return sc
 
 
-def make_schema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows=0, layout=0):
+def make_schema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows=0, layout=0, len_unit=1, skip_before_len=0,
+                skip_after_len=0):
+    """len_unit: what the vector's length word counts (1 bytes, 8 64-bit words, 64 bits in whole words); skip_*: filler bytes around it"""
     return _lib.IxfSchema(n_before, n_after, idx_bins, idx_stride, idx_seg_len, idx_seed, seg_len_is_rows,
-                          13572355802537770549, layout)
+                          13572355802537770549, layout, len_unit, skip_before_len, skip_after_len)
 
 
 def parse_layout(spec):

@@ -137,3 +137,26 @@ def test_search_layout_files_are_untouched_by_the_layout_machinery(tmp_path):
     for a, b in zip(h.ixfs, host):
         assert a["stride"] == b["stride"] == a["src_stride"] and np.array_equal(a["data"], b["data"])
     h.close()
+
+
+@pytest.mark.parametrize("frame", [(8, 0, 0), (64, 0, 0), (64, 0, 1), (64, 1, 0), (1, 0, 1), (8, 1, 0)])
+def test_probe_finds_other_framings_of_the_fingerprint_vector(tmp_path, frame):
+    """the vector's length word need not count bytes: a std::vector<uint64_t> counts words, an sdsl int_vector counts BITS (stored in
+    whole 64-bit words, with a width byte next to the length) -- `taxor probe` tries those framings, and a plain load falls back to
+    what it finds; here with bare records and bit-sliced plane words, the shape such a class would most likely hold"""
+    unit, before, after = frame
+    lay, host, _ = odd_layout(12)
+    sp = make_species(lay)
+    sc = make_schema(2, 1, 0, -1, -1, 1, layout=S, len_unit=unit, skip_before_len=before, skip_after_len=after)
+    p = tmp_path / "framed.hixf"
+    store_hixf(p, host, lay["n_user_bins"], sp, schema=sc)
+    found, report = probe_hixf(p)
+    assert (found.n_before, found.n_after, found.len_unit, found.skip_before_len, found.skip_after_len) == (2, 1, unit, before, after), report
+    assert ("bits" in report) == (unit == 64) and ("64-bit words" in report) == (unit in (8, 64))
+    h = HixfFile(p)
+    assert h.foreign_schema
+    h.set_layout(S)
+    for a, b in zip(h.ixfs, host):
+        assert (a["bins"], a["seg_len"], a["seed"]) == (b["bins"], b["seg_len"], b["seed"])
+        assert np.array_equal(a["data"], to_source_layout(b, S)[0])
+    h.close()
