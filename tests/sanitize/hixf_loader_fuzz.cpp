@@ -17,6 +17,34 @@ int main(int argc, char **argv) {
     int trials = atoi(argv[4]);
     std::mt19937_64 rng(7);
     int ok = 0, err = 0;
+    {   // the writer's re-layout (threaded host transform) and the vector framings, round trip on the unmutated file: every fingerprint of
+        // every IXF read back through ixf_src_fingerprint must be the original's
+        taxor_hixf *h0 = nullptr;
+        if (taxor_hixf_load(argv[1], &h0) != TAXOR_OK) return 7;
+        const taxor_hixf_view *v0 = taxor_hixf_get_view(h0);
+        struct Case { uint32_t layout, unit, before, after; };
+        for (const Case &cs : {Case{0x201, 1, 0, 0}, Case{0x002, 64, 0, 1}, Case{0x300, 1, 1, 0}, Case{0x102, 8, 0, 0}, Case{0x001, 1, 0, 0}}) {
+            taxor_ixf_schema sc;
+            taxor_ixf_schema_default(&sc);
+            sc.layout = cs.layout; sc.len_unit = cs.unit; sc.skip_before_len = cs.before; sc.skip_after_len = cs.after;
+            taxor_hixf_view plain = *v0;
+            plain.source = nullptr;                       // bytes through the mapping
+            if (taxor_hixf_store_schema(argv[5], &plain, taxor_hixf_get_meta(h0), &sc) != TAXOR_OK) return 8;
+            taxor_hixf *h1 = nullptr;
+            if (taxor_hixf_load_schema(argv[5], &sc, &h1) != TAXOR_OK) return 9;
+            const taxor_hixf_view *v1 = taxor_hixf_get_view(h1);
+            if (v1->n_ixf != v0->n_ixf || (v1->ixf_layout & 0x1FF) != (cs.layout & 0x1FF)) return 10;
+            for (size_t i = 0; i < v0->n_ixf; ++i) {
+                const taxor_ixf_view &a = v0->ixf[i], &b = v1->ixf[i];
+                if (a.bins != b.bins || a.seg_len != b.seg_len || a.seed != b.seed) return 11;
+                for (uint64_t r = 0; r < 3 * a.seg_len; r += 1 + r % 7)
+                    for (uint64_t bin = 0; bin < a.bins; ++bin)
+                        if (a.data[r * a.stride + bin] != taxor::ixf_src_fingerprint(b.data, v1->ixf_layout, r, bin, b.seg_len, b.src_stride ? b.src_stride : b.stride, b.bins)) return 12;
+            }
+            taxor_hixf_free(h1);
+        }
+        taxor_hixf_free(h0);
+    }
     std::vector<long> meta; for (long i = 0; i < n; ++i) if (i < data_lo || i >= data_hi) meta.push_back(i);
     for (int t = 0; t < trials; ++t) {
         std::vector<unsigned char> b = raw;
