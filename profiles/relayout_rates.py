@@ -42,7 +42,10 @@ for c in range(n_children):
     ub += child_bins
 total = sum(f["data"].size for f in ixfs)
 species = [dict(organism_name=f"o{i}", accession_id=f"a{i}", taxid=str(i), taxnames_string="x", taxid_string="1", user_bin=i, seq_len=1) for i in range(0, ub, 97)]
-tmp = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+keep = os.environ.get("RELAYOUT_KEEP")          # keep the files (one per layout) and the reads in this directory for a profiler run
+if keep:
+    os.makedirs(keep, exist_ok=True)
+tmp = keep or tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 fq = os.path.join(tmp, "reads.fq")
 with open(fq, "w") as f:
     for i in range(2000):
@@ -55,9 +58,9 @@ codes = [int(x, 0) for x in os.environ["RELAYOUT_CODES"].split(",")] if os.envir
 for code in codes:
     sc = default_schema()
     sc.layout = code
-    path = os.path.join(tmp, "x.hixf")
-    store_hixf(path, ixfs, ub, species, schema=sc)
     spec = describe_layout(code)
+    path = os.path.join(tmp, spec.replace(",", "_") + ".hixf" if keep else "x.hixf")
+    store_hixf(path, ixfs, ub, species, schema=sc)
     for rep in range(2):
         out = os.path.join(tmp, "out.tsv")
         cmd = [os.path.join(ROOT, "taxor_amd", "taxor"), "search", "--index-file", path, "--query-file", fq, "--output-file", out, "--percentage", "0.02"]
@@ -68,6 +71,7 @@ for code in codes:
         line = [l for l in cp.stderr.splitlines() if l.startswith("[upload]")]
         digests[code] = hashlib.sha256(open(out, "rb").read()).hexdigest()[:16]
         print(f"{spec:45s} run {rep}: {line[-1] if line else '(no upload line)'}   tsv {digests[code]}")
-    os.remove(path)
+    if not keep:
+        os.remove(path)
 assert len(set(digests.values())) == 1, digests
 print("TSV identical under every layout")
