@@ -9,9 +9,10 @@ RELAYOUT_KEEP=/dev/shm/taxor_relayout_r05 RELAYOUT_CODES=0x100,0x001,0x002 pytho
 cd /tmp && export TMPDIR=/tmp
 for spec in interleaved,padded,position-major bin-major,padded,segment-major bit-sliced,segment-major; do
     f=/dev/shm/taxor_relayout_r05/$(echo $spec | tr ',' '_').hixf
-    rocprofv3 --kernel-trace --stats --output-format csv -d $O/$spec -o run -- $R/taxor_amd/taxor search --index-file $f --query-file /dev/shm/taxor_relayout_r05/reads.fq --output-file /dev/shm/taxor_relayout_r05/out.tsv --percentage 0.02 --ixf-layout $spec > /dev/null 2> $O/$spec.err
+    d=$O/$(echo $spec | tr ',' '_')
+    TAXOR_TUNING=1 TAXOR_CLI_CLEAN_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o run -- $R/taxor_amd/taxor search --index-file $f --query-file /dev/shm/taxor_relayout_r05/reads.fq --output-file /dev/shm/taxor_relayout_r05/out.tsv --percentage 0.02 --ixf-layout $spec > /dev/null 2> $d.err
     echo "== $spec"
-    find $O/$spec -name "*kernel_stats.csv" -exec grep -E "Name|k_rows_repitch|k_bin_major|k_bit_sliced" {} \;
+    find $d -name "*kernel_stats.csv" -exec grep -E "Name|k_rows_repitch|k_bin_major|k_bit_sliced" {} \;
 done
 rm -rf /dev/shm/taxor_relayout_r05
 find $O -type f -size +200k -delete

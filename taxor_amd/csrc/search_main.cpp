@@ -1710,5 +1710,6 @@ int main(int argc, char **argv)
     if (!cfg.expect_file.empty()) rc = compare_tsv(cfg.report_file, cfg.expect_file) ? 3 : 0;
     fflush(stdout);
     fflush(stderr);
+    if (tune_env("TAXOR_CLI_CLEAN_EXIT")) return rc;     // a profiler's exit hooks must run (rocprofv3 writes its files at exit)
     _exit(rc);  // everything is written and closed; skip the runtime's and the allocator's teardown
 }
