@@ -9,8 +9,9 @@
 //   k_rows_repitch   row-interleaved with another pitch (e.g. exactly `bins`), and / or rows in position-major order
 //   k_bin_major      data[bin * rows + row]: 128-bin x 128-row tiles through LDS, 128-B lines read and 128-B lines written
 //   k_bit_sliced     eight 64-bit plane words per (row, 64 bins): 8 x 8 bit transposes in registers
-// All are HBM-bound byte shuffles far above the PCIe rate that feeds them (rates: profiles/r05/relayout.txt); the search layout
-// itself never comes through here (api.hip index_upload copies it as it is).
+// One launch per 8-MiB chunk: 40-57 us each, 140-210 GB/s per stream -- far above the PCIe rate that feeds them and 13-19 % of the
+// load's wall time (profiles/r05/relayout_kernel_stats.txt; the load stays bound by pread + PCIe: 41 GB/s bin-major against 44 GB/s
+// for the search layout at 64 GB).  The search layout itself never comes through here (api.hip index_upload copies it as it is).
 #include "../../include/taxor_gpu_tools.h"
 #include "ixf_layout.h"
 #include "tuning.h"
