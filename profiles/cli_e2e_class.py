@@ -69,7 +69,15 @@ host = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=idx.
 species = [dict(organism_name=f"Organism {u}", accession_id=f"GCF_{u:09d}.1", taxid=str(1000 + u), taxnames_string=f"k__Bacteria;s__Organism {u}",
                 taxid_string=f"2;{1000 + u}", user_bin=u, seq_len=info["genome_len"]) for u in range(lay["n_user_bins"])]
 idx_path = os.path.join(tmp, f"{workload}.hixf")
-store_hixf(idx_path, host, lay["n_user_bins"], species, data_of=idx.download_ixf)
+# TAXOR_E2E_LAYOUT=bin-major,padded,segment-major: the file is written in ANOTHER writer's fingerprint layout (ixf_layout.h) and the CLI
+# reads it with --ixf-layout: the whole chain through the device re-layout at class scale (round 5)
+e2e_layout = os.environ.get("TAXOR_E2E_LAYOUT", "")
+schema = None
+if e2e_layout:
+    from taxor_amd.hixf_file import default_schema, parse_layout  # noqa: E402
+    schema = default_schema()
+    schema.layout = parse_layout(e2e_layout)
+store_hixf(idx_path, host, lay["n_user_bins"], species, data_of=idx.download_ixf, schema=schema)
 del host
 print(f"{workload}-class index read back from HBM and written: {os.path.getsize(idx_path)/1e9:.2f} GB, {time.time()-t0:.1f}s", flush=True)
 fq = os.path.join(tmp, "reads.fastq")
@@ -78,7 +86,7 @@ t0 = time.time()
 # expected text, and appended to the FASTQ.  Fixed-width ids make every record the same length, so a batch is one 2-D array.
 from taxor_amd import synth  # noqa: E402
 sr = Searcher(idx, error_rate=args.error_rate)
-hx = HixfFile(idx_path)
+hx = HixfFile(idx_path, schema=schema)          # (only its formatter is used here)
 g, go = info.get("genomes"), info.get("genome_off")
 expected_sizes, n_tuples, n_lines, kept = [], 0, 0, []
 want_path = os.path.join(tmp, "want.tsv")
@@ -167,6 +175,8 @@ runs = _r.split(";") if ";" in _r else _r.split(",")       # "16;16:--gpu-list:0
 for thr in runs:
     thr, *run_env = thr.split("@")                                      # "32@TAXOR_CLI_FILL_MS=5": tuning variables of this run only
     extra = ["--threads", thr.split(":")[0]] + thr.split(":")[1:]       # "16:--gpu-list:0,0" = extra arguments after the thread count
+    if e2e_layout:
+        extra += ["--ixf-layout", e2e_layout]
     if run_env:
         print("run with", " ".join(run_env))
     binary = next((kv[4:] for kv in run_env if kv.startswith("BIN=")), os.path.join(ROOT, "taxor_amd", "taxor"))     # "32@BIN=/path/taxor_old": A/B of two builds
