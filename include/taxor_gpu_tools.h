@@ -48,17 +48,46 @@ int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8
 /* GPU construction of the fingerprint columns of one IXF, in place (the reference builds on
  * the CPU: src/hixf/build/construct_ixf.cpp:50-165, add_bin_elements + reseed loop).  keys = the bins' key lists
  * concatenated (distinct within a bin), key_off[bins+1]; bins without keys keep their content.  All bins are peeled
- * in parallel rounds; if a bin does not peel the IXF is re-seeded and rebuilt, like the reference.  On success the
- * IXF carries *seed_out (also written into the resident index); *rounds_out = peeling rounds of the slowest chunk. */
+ * at once in synchronous rounds (taxor_amd/csrc/builder.hip); if a bin does not peel the IXF is re-seeded and rebuilt,
+ * like the reference.  On success the IXF carries *seed_out (also written into the resident index); *rounds_out =
+ * peeling rounds of the slowest chunk.  The columns are a function of (keys, seed) alone: two builds are byte-identical.
+ * Every key is looked up in the finished columns before the call returns.  The index must not be searched meanwhile. */
 int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
                               uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out);
 /* The whole hierarchy at once (the back end of hierarchical_build.cpp:27-236): key_off[total_bins + 1] indexes `keys`
  * per technical bin in the index's bin order (all bins of IXF 0, then IXF 1, ...); LEAF bins bring their keys
  * (distinct within a bin; a split user bin brings one part per technical bin), MERGED bins bring none -- their key set
- * is the union of everything in their child IXF, computed on the device (sort + unique), bottom-up.  Every IXF is
- * then constructed as by taxor_gpu_index_build_ixf (its seed may be redrawn).  Unions are limited to 2^32 keys. */
+ * is the union of everything in their child IXF, computed on the device (sort + unique), level by level from the leaves
+ * up; the IXFs of one level share peeling chunks.  An IXF that does not peel is redone under a redrawn seed, it alone.
+ * Unions are limited to 2^32 keys. */
 int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
                                uint32_t *rounds_out);
+/* The same two with the keys already ON THE INDEX'S DEVICE (keys_on_device != 0: `keys` is a device pointer; key_off
+ * stays a host array) and with the run's figures. */
+typedef struct taxor_build_stats {
+    uint64_t keys_inserted;   /* key insertions done (a key below a merged bin counts once per level it is inserted at) */
+    uint64_t scratch_bytes;   /* peeling scratch at its largest */
+    uint32_t rounds_max;      /* peeling rounds of the slowest chunk */
+    uint32_t reseeds;         /* IXFs redone under a new seed */
+    uint32_t chunks;          /* peeling chunks */
+    uint32_t reserved;
+    double seconds_peel;      /* count + seed scan + rounds */
+    double seconds_assign;    /* clearing, assignment in reverse, verification */
+    double seconds_union;     /* sort + unique of the merged bins' key sets */
+    double seconds_total;
+} taxor_build_stats;
+int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
+                                 const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);
+int taxor_gpu_index_build_hixf_ex(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off,
+                                  uint64_t seed0, taxor_build_stats *stats);
+/* Synthetic key sets for the build bench and tests: key i = a bijection of (i + salt) (distinct without a table);
+ * taxor_gpu_synth_keys writes keys first .. first + n - 1 to the DEVICE array d_out, taxor_synth_key is the same
+ * function on the host.  taxor_gpu_malloc / _free / _memcpy_to_host: plain device memory for such arrays. */
+uint64_t taxor_synth_key(uint64_t i, uint64_t salt);
+int taxor_gpu_synth_keys(int device, uint64_t *d_out, uint64_t first, uint64_t n, uint64_t salt);
+int taxor_gpu_malloc(int device, uint64_t bytes, void **out);
+void taxor_gpu_free(void *p);
+int taxor_gpu_memcpy_to_host(void *dst, const void *d_src, uint64_t bytes);
 
 /* ---- taxor_gpu_search_batch split into its three phases so that a caller can keep a batch resident in HBM
  * (upload once, run many times) and overlap transfers with compute:
@@ -231,41 +260,6 @@ int taxor_ixf_build_bin_arith(const uint64_t *keys, uint64_t n, uint64_t seed, u
 int taxor_synth_reads(const char *genomes, const uint64_t *genome_off, uint64_t n_genomes, uint64_t n_reads,
                       uint32_t read_len, double error_rate, double frac_random, double frac_reverse,
                       uint64_t seed, int threads, char *bases, uint64_t cap, uint64_t *offsets, int32_t *origin);
-
-/* ---- Deflate chunks decoded on the device (taxor_amd/csrc/inflate.hip): the reader of single-member .gz query files (the
- * reference reads .gz through seqan3's stream layer, one zlib stream on one thread, src/main/taxor_search.cpp:181-184).  The host
- * (taxor_amd/csrc/pgz.h) cuts the member's deflate stream into chunks, finds a block start in each, and hands a batch over:
- * every chunk is decoded from its start bit to the first block boundary at or behind its stop bit into 16-bit symbols -- a byte,
- * or 256 + w for "byte w of the 32 KiB before this chunk".  The host then checks that every chunk starts where its predecessor
- * ended; a chunk that does not, or that the device gave up on (status != 0), is decoded on the host and its symbols are put in
- * its place (taxor_gpu_inflate_replace).  taxor_gpu_inflate_resolve chains the 32-KiB windows from chunk to chunk, turns every
- * symbol into its byte and copies the bytes of chunk first + i to out[i].  Bits are counted from the first byte of `in`.  One
- * caller at a time per inflater. */
-typedef struct taxor_gpu_inflater taxor_gpu_inflater;
-typedef struct taxor_inflate_chunk {
-    uint64_t start_bit, stop_bit; /* start == stop: nothing to decode (the host will put the chunk's symbols in place) */
-    uint64_t weight;              /* compressed bits the chunk stands for: the arena is shared out by it */
-} taxor_inflate_chunk;
-typedef struct taxor_inflate_result {
-    uint64_t end_bit;     /* the block boundary the chunk ended at (>= stop_bit), or the end of the member's final block */
-    uint64_t n_out;       /* symbols = bytes of output */
-    uint32_t status;      /* 0 decoded; 2 invalid deflate data from this start; 3 more output than the chunk's share of the arena; 4 ran past the input */
-    uint32_t final_block; /* the member's last block ended this chunk */
-} taxor_inflate_result;
-/* max_symbols: 16-bit symbols the arena holds for one batch (every chunk needs 32768 + its output + 256) */
-int taxor_gpu_inflater_create(int device, uint64_t max_in_bytes, uint32_t max_chunks, uint64_t max_symbols, taxor_gpu_inflater **out);
-void taxor_gpu_inflater_destroy(taxor_gpu_inflater *h);
-int taxor_gpu_inflate_decode(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n_chunks,
-                             taxor_inflate_result *results);
-/* the same in two halves: _begin returns when the input is on its way and the kernel queued, _end waits for the results */
-int taxor_gpu_inflate_decode_begin(taxor_gpu_inflater *h, const uint8_t *in, uint64_t in_bytes, const taxor_inflate_chunk *chunks, uint32_t n_chunks);
-int taxor_gpu_inflate_decode_end(taxor_gpu_inflater *h, taxor_inflate_result *results);
-int taxor_gpu_inflate_replace(taxor_gpu_inflater *h, uint32_t chunk, const uint16_t *symbols, uint64_t n_out, uint64_t end_bit, uint32_t final_block);
-int taxor_gpu_inflate_resolve(taxor_gpu_inflater *h, const uint8_t *window_in /* 32768 bytes */, uint32_t first, uint32_t count, uint8_t *const *out,
-                              uint8_t *window_out /* 32768 bytes, may be NULL */);
-/* a decoded chunk's symbols, n_out of them (parity tests against the host decoder) */
-int taxor_gpu_inflate_symbols(taxor_gpu_inflater *h, uint32_t chunk, uint16_t *out);
-
 
 #ifdef __cplusplus
 }

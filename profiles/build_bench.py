@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""Throughput of the GPU hierarchical builder (taxor_gpu_index_build_hixf): root of merged bins over child IXFs of leaf
-bins with random keys.  usage: python profiles/build_bench.py [children] [bins_per_child] [keys_per_bin]"""
+"""Throughput of the GPU hierarchical builder (taxor_gpu_index_build_hixf_ex): a root of merged bins over child IXFs of leaf
+bins, every bin a real filter, keys synthetic and generated on the device (nothing crosses PCIe).
+
+usage: python profiles/build_bench.py [--children N] [--child-bins B] [--keys-per-bin K] [--json] [--check] [--cpu-keys N]
+Defaults are GTDB-class leaf sizes (bench.py's `gtdb` workload: 128-bin children of 422 k keys per bin).
+--check     every key of a sample of bins is looked up through the query kernel (own bin and the root's merged bin)
+--cpu-keys  the reference's own builder (src/main/xorfilter.hpp AddAll, compiled into oracle/_ref) on this many keys, one core"""
+import argparse
+import ctypes as C
+import json
 import os
 import sys
 import time
@@ -10,40 +18,89 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taxor_amd import GpuIndex, synth  # noqa: E402
 
-nc = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-cb = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-kpb = int(sys.argv[3]) if len(sys.argv) > 3 else 30000
-rng = np.random.default_rng(1)
-rb = max(64, nc)
-nx = np.zeros(rb, np.int64)
-fn = np.arange(rb, dtype=np.int64)
-nx[:nc] = np.arange(1, nc + 1)
-fn[:nc] = -1
-shapes = [dict(bins=rb, stride=(rb + 63) // 64 * 64, seg_len=synth.seg_len_for(cb * kpb), seed=1, next_ixf=nx, fname_idx=fn, data=None)]
-ub = rb
-for c in range(nc):
-    shapes.append(dict(bins=cb, stride=(cb + 63) // 64 * 64, seg_len=synth.seg_len_for(kpb), seed=2 + c,
-                       next_ixf=np.full(cb, c + 1, np.int64), fname_idx=np.arange(ub, ub + cb, dtype=np.int64), data=None))
-    ub += cb
-t0 = time.time()
-allk = rng.integers(1, 2**63, size=nc * cb * kpb, dtype=np.uint64)     # distinct with overwhelming probability
-leaf = {}
-p = 0
-for c in range(nc):
-    for b in range(cb):
-        leaf[(c + 1, b)] = allk[p:p + kpb]
-        p += kpb
-print(f"{allk.size/1e6:.1f} M leaf keys generated in {time.time()-t0:.1f} s", flush=True)
-idx = GpuIndex(shapes, ub)
-print(f"index shell: {idx.data_bytes/1e9:.2f} GB, {idx.n_ixf} IXFs", flush=True)
-t0 = time.time()
-rounds = idx.build_hixf(leaf, seed0=5)
-dt = time.time() - t0
-tot = allk.size * 2      # every key is inserted at its leaf and once more in the root's merged bin
-print(f"build_hixf: {dt:.2f} s wall (incl. host marshalling), {rounds} peeling rounds max, {tot/dt/1e6:.1f} M key insertions/s")
-# spot check through the query kernel: the keys of one leaf bin are all found there and in the root's merged bin
-from taxor_amd import Searcher  # noqa: E402
-sr = Searcher(idx, ratio=0.5)
-keys = leaf[(3, 5)]
-assert sr.ixf_bulk_count(3, keys)[5] == keys.size and sr.ixf_bulk_count(0, keys)[2] == keys.size
-print("spot check OK")
+
+def shapes_for(nc, cb, kpb):
+    """root: max(64, nc) bins, the first nc merged; children: cb leaf bins of kpb keys"""
+    rb = max(64, nc)
+    nx = np.zeros(rb, np.int64)
+    fn = np.arange(rb, dtype=np.int64)
+    nx[:nc] = np.arange(1, nc + 1)
+    fn[:nc] = -1
+    shapes = [dict(bins=rb, stride=(rb + 63) // 64 * 64, seg_len=synth.seg_len_for(cb * kpb), seed=1, next_ixf=nx, fname_idx=fn, data=None)]
+    ub = rb
+    for c in range(nc):
+        shapes.append(dict(bins=cb, stride=(cb + 63) // 64 * 64, seg_len=synth.seg_len_for(kpb), seed=2 + c,
+                           next_ixf=np.full(cb, c + 1, np.int64), fname_idx=np.arange(ub, ub + cb, dtype=np.int64), data=None))
+        ub += cb
+    counts = np.zeros(rb + nc * cb, dtype=np.uint64)
+    counts[rb:] = kpb
+    return shapes, ub, counts
+
+
+def cpu_reference(n_keys, salt):
+    """the reference's XorFilter<uint64_t, uint8_t>::AddAll on n_keys synthetic keys, one core -> insertions per second"""
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libtaxor_ref.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.ref_xor_build.restype = C.c_void_p
+    L.ref_xor_build.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ref_xor_free.argtypes = [C.c_void_p]
+    keys = synth.synth_keys_host(0, n_keys, salt)
+    seed, bl, al = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        h = L.ref_xor_build(keys.ctypes.data_as(C.c_void_p), n_keys, C.byref(seed), C.byref(bl), C.byref(al))
+        dt = time.perf_counter() - t0
+        assert h, "the reference's builder failed"
+        L.ref_xor_free(h)
+        best = dt if best is None else min(best, dt)
+    return dict(value=round(n_keys / best / 1e6, 3), unit="M key insertions/s", cores=1, kind="reference",
+                sample=f"xorfilter::XorFilter<uint64_t,uint8_t>::AddAll (src/main/xorfilter.hpp:142-334, oracle/_ref) on {n_keys} keys of one bin, best of 3")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--children", type=int, default=16)
+    ap.add_argument("--child-bins", type=int, default=128)
+    ap.add_argument("--keys-per-bin", type=int, default=422000)
+    ap.add_argument("--salt", type=int, default=20250523)
+    ap.add_argument("--json", action="store_true")
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--cpu-keys", type=int, default=0, help="at most ~213000: beyond it the prototype never returns (its deferred-block path is cut short by a debugging break, xorfilter.hpp:237-238, and its seed is fixed)")
+    ap.add_argument("--repeat", type=int, default=1)
+    a = ap.parse_args()
+    shapes, ub, counts = shapes_for(a.children, a.child_bins, a.keys_per_bin)
+    idx = GpuIndex(shapes, ub)
+    st = None
+    for _ in range(max(1, a.repeat)):
+        t0 = time.time()
+        st, off = idx.build_hixf_synth(counts, salt=a.salt, seed0=5)
+        wall = time.time() - t0
+    out = dict(index_bytes=idx.data_bytes, n_ixf=idx.n_ixf, leaf_keys=int(counts.sum()), wall_s=round(wall, 3), **{k: (round(v, 4) if isinstance(v, float) else v) for k, v in st.items()})
+    out["insertions_per_s"] = round(st["keys_inserted"] / st["seconds_total"], 1)
+    out["insertions_per_s_peel_assign"] = round(st["keys_inserted"] / max(1e-9, st["seconds_peel"] + st["seconds_assign"]), 1)
+    if a.check:
+        from taxor_amd import Searcher
+        sr = Searcher(idx, ratio=0.5)
+        rb = shapes[0]["bins"]
+        for c, b in ((1, 0), (a.children, a.child_bins - 1), (max(1, a.children // 2), a.child_bins // 2)):
+            g = rb + (c - 1) * a.child_bins + b
+            keys = synth.synth_keys_host(int(off[g]), int(off[g + 1] - off[g]), a.salt)
+            own, up = sr.ixf_bulk_count(c, keys), sr.ixf_bulk_count(0, keys)
+            assert own[b] == keys.size and up[c - 1] == keys.size, (c, b, int(own[b]), int(up[c - 1]), keys.size)
+        sr.close()
+        out["check"] = "3 bins: every key found in its bin and in the root's merged bin"
+    if a.cpu_keys:
+        out["cpu_baseline"] = cpu_reference(a.cpu_keys, a.salt)
+    idx.close()
+    if a.json:
+        print(json.dumps(out))
+    else:
+        for k, v in out.items():
+            print(f"{k:32s} {v}")
+
+
+if __name__ == "__main__":
+    main()

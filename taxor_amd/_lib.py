@@ -106,12 +106,10 @@ LAYOUT_POSITION_MAJOR, LAYOUT_PITCH_BINS, LAYOUT_PITCH_STORED = 0x100, 0x200, 0x
 
 # every symbol include/taxor_gpu.h and include/taxor_gpu_tools.h declare: name -> (restype, argtypes)
 _P = C.c_void_p
-class InflateChunk(C.Structure):
-    _fields_ = [("start_bit", C.c_uint64), ("stop_bit", C.c_uint64), ("weight", C.c_uint64)]
-
-
-class InflateResult(C.Structure):
-    _fields_ = [("end_bit", C.c_uint64), ("n_out", C.c_uint64), ("status", C.c_uint32), ("final_block", C.c_uint32)]
+class BuildStats(C.Structure):
+    _fields_ = [("keys_inserted", C.c_uint64), ("scratch_bytes", C.c_uint64), ("rounds_max", C.c_uint32), ("reseeds", C.c_uint32),
+                ("chunks", C.c_uint32), ("reserved", C.c_uint32), ("seconds_peel", C.c_double), ("seconds_assign", C.c_double),
+                ("seconds_union", C.c_double), ("seconds_total", C.c_double)]
 
 
 SIGNATURES = {
@@ -119,6 +117,13 @@ SIGNATURES = {
     "taxor_gpu_index_create": (C.c_int, [C.POINTER(HixfView), C.c_int, C.POINTER(_P)]),
     "taxor_gpu_index_destroy": (None, [_P]),
     "taxor_gpu_index_build_hixf": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "taxor_gpu_index_build_ixf_ex": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(BuildStats)]),
+    "taxor_gpu_index_build_hixf_ex": (C.c_int, [_P, _P, C.c_int, _P, C.c_uint64, C.POINTER(BuildStats)]),
+    "taxor_synth_key": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "taxor_gpu_synth_keys": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "taxor_gpu_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),
+    "taxor_gpu_free": (None, [_P]),
+    "taxor_gpu_memcpy_to_host": (C.c_int, [_P, _P, C.c_uint64]),
     "taxor_gpu_index_ixf_seed": (C.c_uint64, [_P, C.c_uint64]),
     "taxor_gpu_index_data_bytes": (C.c_uint64, [_P]),
     "taxor_gpu_gather_ceiling": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
@@ -157,14 +162,6 @@ SIGNATURES = {
     "taxor_gpu_comm_info": (C.c_int, [_P, C.POINTER(CommStats)]),
     "taxor_gpu_comm_set_self_exchange": (C.c_int, [_P, C.c_int]),
     # deflate chunks decoded on the device (inflate.hip; driven by the C++ reader, pgz.h)
-    "taxor_gpu_inflater_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, C.POINTER(_P)]),
-    "taxor_gpu_inflater_destroy": (None, [_P]),
-    "taxor_gpu_inflate_decode": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(InflateChunk), C.c_uint32, C.POINTER(InflateResult)]),
-    "taxor_gpu_inflate_decode_begin": (C.c_int, [_P, _P, C.c_uint64, C.POINTER(InflateChunk), C.c_uint32]),
-    "taxor_gpu_inflate_decode_end": (C.c_int, [_P, C.POINTER(InflateResult)]),
-    "taxor_gpu_inflate_replace": (C.c_int, [_P, C.c_uint32, _P, C.c_uint64, C.c_uint64, C.c_uint32]),
-    "taxor_gpu_inflate_resolve": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.POINTER(_P), _P]),
-    "taxor_gpu_inflate_symbols": (C.c_int, [_P, C.c_uint32, _P]),
     "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),

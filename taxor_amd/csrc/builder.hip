@@ -1,34 +1,50 @@
-// builder.hip -- GPU construction of the fingerprint columns of one IXF.
+// builder.hip -- GPU construction of IXF fingerprint columns, one IXF or a whole hierarchy.
 //
-// The reference builds an IXF on the CPU, bin by bin: add_bin_elements(bin, hashes) peels the 3-uniform hypergraph
-// of the bin's keys and assigns fingerprints in reverse peeling order; if any bin fails to peel the whole IXF is
-// cleared, re-seeded and rebuilt (src/hixf/build/construct_ixf.cpp:50-165; XOR-filter algorithm family of
-// src/main/xorfilter.hpp:142-334).  Bins are independent, so the GPU peels all bins of a chunk at once, in
-// synchronous rounds over a work list of rows that just became singletons:
+// The reference builds an IXF on the CPU, bin by bin: add_bin_elements(bin, hashes) peels the 3-uniform hypergraph of the
+// bin's keys and assigns fingerprints in reverse peeling order; if any bin fails to peel the whole IXF is cleared, re-seeded
+// and rebuilt (src/hixf/build/construct_ixf.cpp:50-165, reseed loop :100-108; XOR-filter algorithm family of
+// src/main/xorfilter.hpp:142-334; the hierarchy bottom-up, a merged bin holding everything below it:
+// src/hixf/build/hierarchical_build.cpp:27-236).  Bins are independent, so a CHUNK of bins -- of one IXF or of many IXFs of one
+// level -- is peeled at once.  What bounds this on MI355X is the rate of random read-modify-writes (18-27 G/s whatever their
+// scope, width or return use: profiles/r06/atomics_bench.txt), so the design spends as few of them per key as it can, and none
+// on a word that other lanes hit at the same time (a returning atomic on one address serialises at ~13 ns):
 //
-//   count   : per (bin,row) degree + XOR of incident keys                                   (k_build_count)
-//   seed    : rows with degree 1 -> work list, flagged as this round's snapshot singletons   (k_build_seed)
-//   round   : a key A reachable from a snapshot singleton is peeled by exactly one of them -- the smallest-index row
-//             of A that is flagged -- which logs (key,row), and removes A from its three rows; rows whose degree
-//             drops to 1 go to the next work list                                           (k_build_round)
-//   flag    : flags of the next list are set at the round boundary, never inside a round, so the ownership
-//             rule is evaluated on a stable snapshot                          (k_build_unflag, k_build_setflag)
-//   assign  : rounds in reverse; keys peeled in the same round never touch each other's singleton row, so a
-//             round is assigned in parallel: D[row] = fp ^ D[row'] ^ D[row'']                (k_build_assign)
+//   state   : ONE word per (bin,row) slot: degree in the low 8 bits, SUM of the incident keys' indices (position of the key in
+//             its bin) above it.  One atomic add inserts a key into a row, one atomic sub removes it; a slot of degree 1 holds
+//             the index of its only key.  32-bit words while every bin has < 2^24 keys, 64-bit words otherwise.
+//   count   : 3 adds per key                                                                                 (k_count)
+//   seed    : slots of degree 1 -> work list, one list append per BLOCK (entries collected in LDS)            (k_seed)
+//   round t : the list is append-only; round t is its entries [end[t], end[t+1]).  An entry's slot has degree 1 or 0
+//             (only decrements happen).  Degree 1: the slot names its key; the key is CLAIMED with one atomic-or on a bit per
+//             key (two singleton rows of one key in the same round: one wins), its index logged at the entry's position, and
+//             removed from its three rows; a row whose degree drops 2 -> 1 is appended for round t+1 (it can never be
+//             appended twice) and remembers t+1.  Appends: collected in LDS, one returning atomic per block and 1024 entries.
+//             The last block to finish a round (ticket counter) records where the list ends -- one launch per round, no
+//             launch in between, no flags to set or retire                                                    (k_round)
+//   stop    : rounds are enqueued 32 at a time, two batches ahead of the host, which looks at the recorded ends of a batch
+//             only when the next one is already queued: no device-to-host copy per round, the device never waits for the host.
+//             Launches behind the last round find an empty range and return.
+//   assign  : rounds in reverse.  A key peeled in round t is never incident to the singleton row of another key of round t
+//             (that row had degree 1 when the round began), so a round is assigned in parallel: D[free] = fp ^ D[r'] ^ D[r''].
+//             The FREE row is not the row that happened to win the claim but the lowest-segment row of the key that entered
+//             the list for round t: that set does not depend on any race, so the columns are a function of (keys, seed) alone
+//             -- two builds of one index are byte-identical.  Small rounds (the long plateau close to the peeling threshold) are
+//             assigned by ONE block that walks them with a barrier in between instead of a launch each        (k_assign*)
+//   verify  : every key is looked up in the finished columns (3 bytes per key); a mismatch is a bug and fails loudly.
 //
-// The fingerprints differ from a sequential peel (any peeling order yields a valid filter); every key of every bin
-// matches, which is what the tests check through the query kernels and the CPU oracle.
+// A bin that does not peel (its group's claimed count falls short) re-seeds ITS IXF only; the other IXFs of the chunk are
+// finished, the failed one goes into the next chunk with a redrawn seed, like construct_ixf.cpp:100-108.
 //
-// taxor_gpu_index_build_hixf builds a whole hierarchy bottom-up: the keys stay on the device, a merged bin's key set
-// is the sorted, duplicate-free union of everything in its child IXF (keyset.hip), and every IXF goes through the
-// same peeling.
+// taxor_gpu_index_build_hixf* builds a whole hierarchy level by level from the leaves up: the keys stay on the device, a merged
+// bin's key set is the sorted, duplicate-free union of everything in its child IXF (keyset.hip), all IXFs of a level share chunks.
 #include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
 #include "kernels.h"
 #include "keyset.h"
 
 #include <algorithm>
-#include <functional>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,146 +54,319 @@ extern "C" __attribute__((visibility("hidden"))) void taxor_set_last_error(const
 
 namespace {
 
-constexpr int BB = 256;
+constexpr int BB = 256;                    // threads per block
+constexpr uint32_t DEAD = 0xFFFFFFFFu;     // log entry: this list entry peeled nothing
+constexpr uint32_t MAX_ROUNDS = 16000;     // (the pushed-round marks are 16 bits; 0xFFFF = never listed)
+constexpr uint32_t KEYS_PER_BLOCK = 2048;  // k_count, k_verify
+constexpr uint32_t SLOTS_PER_BLOCK = 4096; // k_seed
+constexpr int ROUND_ITER = 4;              // list entries per thread and staging cycle in k_round
+constexpr uint32_t ROUND_BATCH = 32;       // rounds enqueued between two looks at the recorded list ends
+constexpr uint32_t TAIL_ENTRIES = 2048;    // rounds up to this size are assigned by the one-block walker
+constexpr int TAIL_THREADS = 1024;
+constexpr uint32_t SLICE_BLOCKS = 8192;    // blocks per launch of the key / slot sweeps (16 M keys, 32 M slots: ~2 ms each)
 
-struct BuildArgs {
-    const uint64_t *keys;      // keys of the chunk's bins, concatenated
-    const uint32_t *key_bin;   // chunk-local bin of every key
+// one technical bin to construct
+struct BinJob {
+    const uint64_t *keys;   // device: the bin's keys (distinct)
     uint64_t n_keys;
+    uint64_t key_base;      // keys of the chunk's jobs before this one
+    uint64_t slot_base;     // slots (3 * seg_len each) of the chunk's jobs before this one
+    uint8_t *data;          // fingerprint array of the job's IXF
+    uint64_t stride;
     uint64_t seed;
     uint32_t seg_len;
-    uint32_t arith;            // arithmetic code of the index (ixf_arith.h), 0 = this library's reading
-    uint64_t rows;             // 3 * seg_len
-    uint32_t *cnt;             // [chunk_bins * rows]
-    uint64_t *xr;              // [chunk_bins * rows]
-    uint8_t *single;           // snapshot flags [chunk_bins * rows]
-    uint64_t *wl[2];           // work lists of slots (bin * rows + row)
-    uint32_t *wl_n;            // [2]
-    uint64_t *st_key;          // peel log
-    uint64_t *st_slot;
-    uint32_t *st_n;            // entries logged so far
+    uint32_t arith;         // arithmetic code of the index (ixf_arith.h)
+    uint32_t bin;           // column
+    uint32_t group;         // the chunk's IXF this bin belongs to: seed and failure are per IXF
 };
 
-// chunk-local bin of every key: off[nb+1] are the chunk's bin boundaries inside its contiguous key range
-__global__ __launch_bounds__(BB) void k_build_key_bin(const uint64_t *off, uint32_t nb, uint64_t n_keys, uint32_t *key_bin)
+// control block of a chunk; hot words on lines of their own
+struct Ctl {
+    uint32_t list_n;
+    uint32_t pad0[31];
+    unsigned long long peeled;
+    unsigned long long pad1[15];
+    unsigned long long mismatches;
+    unsigned long long pad2[15];
+    uint32_t done[MAX_ROUNDS + 2];       // blocks that finished launch i (0 = seed scan, t + 1 = round t)
+    uint32_t round_end[MAX_ROUNDS + 2];  // round t = list entries [round_end[t], round_end[t + 1])
+};
+
+template <typename WT>
+struct Peel {
+    const BinJob *jobs;
+    uint32_t n_jobs;
+    uint64_t n_keys, n_slots;
+    WT *w;               // [n_slots] degree | index sum
+    uint64_t *list;      // [n_slots] job << 32 | row, append-only
+    uint32_t *log;       // [n_slots] index of the key peeled by list entry i, or DEAD
+    uint16_t *pushed;    // [n_slots] the round a slot was listed for, 0xFFFF = never
+    uint32_t *claim;     // one bit per key
+    const uint8_t *skip; // per group: 1 = not peeled under this seed, leave its columns alone (nullptr: none)
+    Ctl *ctl;
+};
+
+// last job whose first key (slot) is <= g, searched inside [lo, hi]
+template <bool BY_KEY>
+__device__ __forceinline__ uint32_t job_in(const BinJob *jobs, uint32_t lo, uint32_t hi, uint64_t g)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n_keys; i += (uint64_t)gridDim.x * BB) {
-        uint32_t lo = 0, hi = nb;                     // last bin whose start is <= i
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (off[mid] <= i) lo = mid; else hi = mid;
-        }
-        key_bin[i] = lo;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if ((BY_KEY ? jobs[mid].key_base : jobs[mid].slot_base) <= g) lo = mid; else hi = mid - 1;
     }
+    return lo;
 }
 
-__global__ __launch_bounds__(BB) void k_build_count(const BuildArgs a)
+template <typename WT>
+__device__ __forceinline__ WT w_delta(uint64_t idx) { return (WT)((WT)idx << 8) + (WT)1; }
+
+// (k_count, k_seed, k_verify are launched in slices of SLICE_BLOCKS blocks: block0 = first block of the slice)
+template <typename WT>
+__global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
 {
-    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < a.n_keys; i += (uint64_t)gridDim.x * BB) {
-        const uint64_t key = a.keys[i];
-        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
-        const uint64_t base = (uint64_t)a.key_bin[i] * a.rows;
+    __shared__ uint32_t jr[2];
+    const uint64_t g0 = (uint64_t)(block0 + blockIdx.x) * KEYS_PER_BLOCK;
+    const uint64_t g1 = min(g0 + (uint64_t)KEYS_PER_BLOCK, a.n_keys);
+    if (threadIdx.x == 0) {
+        jr[0] = job_in<true>(a.jobs, 0, a.n_jobs - 1, g0);
+        jr[1] = job_in<true>(a.jobs, jr[0], a.n_jobs - 1, g1 - 1);
+    }
+    __syncthreads();
+    for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
+        const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
+        const uint64_t k = g - J.key_base;
+        const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
+        const WT d = w_delta<WT>(k);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            atomicAdd(&a.cnt[base + p.row[j]], 1u);
-            atomicXor((unsigned long long *)&a.xr[base + p.row[j]], (unsigned long long)key);
-        }
+        for (int j = 0; j < 3; ++j) __hip_atomic_fetch_add(&a.w[J.slot_base + p.row[j]], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-__global__ __launch_bounds__(BB) void k_build_seed(const BuildArgs a, uint64_t n_slots)
+// entries of one wave into the block's LDS stage: one LDS atomic per wave
+__device__ __forceinline__ void stage_push(bool pred, uint64_t e, uint64_t *stage, uint32_t *stage_n)
 {
-    for (uint64_t s = (uint64_t)blockIdx.x * BB + threadIdx.x; s < n_slots; s += (uint64_t)gridDim.x * BB) {
-        if (a.cnt[s] == 1u) {
-            a.single[s] = 1;
-            a.wl[0][atomicAdd(&a.wl_n[0], 1u)] = s;
-        }
-    }
+    const uint64_t m = __ballot(pred);
+    if (m == 0) return;
+    const int lane = (int)__lane_id(), leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(stage_n, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    if (pred) stage[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = e;
 }
 
-// one peeling round over work list `cur`; pushes rows that drop to degree 1 onto the other list
-__global__ __launch_bounds__(BB) void k_build_round(const BuildArgs a, int cur)
+// the block's staged entries -> the list (one returning atomic), then the stage is empty again.  All threads.
+__device__ __forceinline__ void stage_flush(uint64_t *stage, uint32_t *stage_n, uint32_t *gbase, uint64_t *list, uint32_t *list_n)
 {
-    const uint32_t n = a.wl_n[cur];
-    for (uint32_t i = blockIdx.x * BB + threadIdx.x; i < n; i += gridDim.x * BB) {
-        const uint64_t slot = a.wl[cur][i];
-        // a snapshot singleton holds exactly one key; only that key's owner may modify the slot during this round,
-        // and it decrements the degree BEFORE it xors the key out, so degree==1 read after the key proves the key
-        // read is intact (the key itself may legitimately be 0: wyhash(poly-A k-mer) = 0)
-        if (__hip_atomic_load(&a.cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
-        __threadfence();
-        const uint64_t key = __hip_atomic_load(&a.xr[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        if (__hip_atomic_load(&a.cnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) continue;
-        const uint64_t bin = slot / a.rows;
-        const uint32_t row = (uint32_t)(slot - bin * a.rows);
-        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
-        const uint64_t base = bin * a.rows;
-        // ownership: smallest-index row of this key that is flagged in the snapshot
-        uint32_t owner = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t n = *stage_n;
+    if (threadIdx.x == 0 && n) *gbase = atomicAdd(list_n, n);
+    __syncthreads();
+    if (n) {
+        const uint32_t b = *gbase;
+        for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) list[b + k] = stage[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *stage_n = 0;
+    __syncthreads();
+}
+
+// the last block of launch `which` records where the list ends now: round_end[which + 1]
+__device__ __forceinline__ void finish_launch(Ctl *ctl, uint32_t which, uint32_t blocks_total)
+{
+    // (this thread's own list appends are returning atomics whose values it has used: they are complete before the ticket is
+    //  drawn, and every block's are before ITS ticket -- the block that draws the last ticket sees every append)
+    const uint32_t ticket = atomicAdd(&ctl->done[which], 1u);
+    if (ticket == blocks_total - 1) ctl->round_end[which + 1] = atomicAdd(&ctl->list_n, 0u);
+}
+
+template <typename WT>
+__global__ __launch_bounds__(BB) void k_seed(const Peel<WT> a, uint32_t block0, uint32_t blocks_total)
+{
+    __shared__ uint64_t stage[SLOTS_PER_BLOCK];
+    __shared__ uint32_t stage_n, gbase, jr[2];
+    const uint64_t s0 = (uint64_t)(block0 + blockIdx.x) * SLOTS_PER_BLOCK;
+    const uint64_t s1 = min(s0 + (uint64_t)SLOTS_PER_BLOCK, a.n_slots);
+    if (threadIdx.x == 0) {
+        stage_n = 0;
+        jr[0] = job_in<false>(a.jobs, 0, a.n_jobs - 1, s0);
+        jr[1] = job_in<false>(a.jobs, jr[0], a.n_jobs - 1, s1 - 1);
+    }
+    __syncthreads();
+    for (uint64_t s = s0 + threadIdx.x; s < s0 + SLOTS_PER_BLOCK; s += BB) {      // (uniform trip count: stage_push is a wave operation)
+        bool single = false;
+        uint64_t e = 0;
+        if (s < s1 && (a.w[s] & (WT)0xFF) == (WT)1) {
+            const uint32_t j = job_in<false>(a.jobs, jr[0], jr[1], s);
+            e = ((uint64_t)j << 32) | (uint64_t)(s - a.jobs[j].slot_base);
+            a.pushed[s] = 0;
+            single = true;
+        }
+        stage_push(single, e, stage, &stage_n);
+    }
+    stage_flush(stage, &stage_n, &gbase, a.list, &a.ctl->list_n);
+    if (threadIdx.x == 0) finish_launch(a.ctl, 0, blocks_total);
+}
+
+template <typename WT>
+__global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
+{
+    __shared__ uint64_t stage[2 * ROUND_ITER * BB];
+    __shared__ uint32_t stage_n, gbase, claimed_blk;
+    const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
+    if (threadIdx.x == 0) { stage_n = 0; claimed_blk = 0; }
+    __syncthreads();
+    uint32_t claimed = 0;
+    const uint32_t step = (uint32_t)ROUND_ITER * BB;
+    for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * step; base < hi; base += (uint64_t)gridDim.x * step) {
+#pragma unroll 1
+        for (int it = 0; it < ROUND_ITER; ++it) {
+            const uint64_t i = base + (uint64_t)it * BB + threadIdx.x;
+            bool push[3] = {false, false, false};
+            uint64_t ent[3] = {0, 0, 0};
+            if (i < hi) {
+                const uint64_t e = a.list[i];
+                const uint32_t job = (uint32_t)(e >> 32), row = (uint32_t)e;
+                const BinJob &J = a.jobs[job];
+                const WT w = __hip_atomic_load(&a.w[J.slot_base + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                uint32_t logged = DEAD;
+                const uint64_t k = (uint64_t)(w >> 8);
+                if ((w & (WT)0xFF) == (WT)1 && k < J.n_keys) {
+                    const uint64_t gk = J.key_base + k;
+                    const uint32_t bit = 1u << (gk & 31u);
+                    if (!(atomicOr(&a.claim[gk >> 5], bit) & bit)) {
+                        logged = (uint32_t)k;
+                        ++claimed;
+                        const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
+                        const WT d = w_delta<WT>(k);
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (a.single[base + p.row[j]]) owner = min(owner, p.row[j]);
-        if (owner != row) continue; // another singleton row of the same key peels it (or the slot is stale)
-        const uint32_t pos = atomicAdd(a.st_n, 1u);
-        a.st_key[pos] = key;
-        a.st_slot[pos] = slot;
+                        for (int j = 0; j < 3; ++j) {
+                            const uint64_t s = J.slot_base + p.row[j];
+                            const WT old = __hip_atomic_fetch_sub(&a.w[s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((old & (WT)0xFF) == (WT)2) {
+                                a.pushed[s] = (uint16_t)(t + 1);
+                                push[j] = true;
+                                ent[j] = ((uint64_t)job << 32) | p.row[j];
+                            }
+                        }
+                    }
+                }
+                a.log[i] = logged;
+            }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const uint64_t s2 = base + p.row[j];
-            const uint32_t c = atomicSub(&a.cnt[s2], 1u) - 1u;
-            __threadfence();
-            atomicXor((unsigned long long *)&a.xr[s2], (unsigned long long)key);
-            if (c == 1u) a.wl[cur ^ 1][atomicAdd(&a.wl_n[cur ^ 1], 1u)] = s2;
+            for (int j = 0; j < 3; ++j) stage_push(push[j], ent[j], stage, &stage_n);
         }
+        stage_flush(stage, &stage_n, &gbase, a.list, &a.ctl->list_n);
+    }
+    if (claimed) atomicAdd(&claimed_blk, claimed);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (claimed_blk) atomicAdd(&a.ctl->peeled, (unsigned long long)claimed_blk);
+        finish_launch(a.ctl, t + 1, gridDim.x);
     }
 }
 
-__global__ void k_build_reset(uint32_t *wl_n, int which) { wl_n[which] = 0; }
-
-// round boundary, two launches so that retiring the old flags finishes grid-wide before the new ones are set:
-// flags change only here, never inside a round, so the ownership rule sees a stable snapshot
-__global__ __launch_bounds__(BB) void k_build_unflag(const BuildArgs a, int done)
+// list entry i (peeled in round t): D[free row] = fp ^ D[other two rows]; the free row is the lowest-segment row of the key that
+// was listed for round t (the row that won the claim is one of them)
+template <typename WT>
+__device__ __forceinline__ void assign_entry(const Peel<WT> &a, uint64_t i, uint32_t t)
 {
-    const uint32_t nd = a.wl_n[done];
-    for (uint32_t i = blockIdx.x * BB + threadIdx.x; i < nd; i += gridDim.x * BB) a.single[a.wl[done][i]] = 0;
+    const uint32_t k = a.log[i];
+    if (k == DEAD) return;
+    const BinJob &J = a.jobs[(uint32_t)(a.list[i] >> 32)];
+    if (a.skip && a.skip[J.group]) return;
+    const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
+    int fr = 2;
+    if (a.pushed[J.slot_base + p.row[0]] == (uint16_t)t) fr = 0;
+    else if (a.pushed[J.slot_base + p.row[1]] == (uint16_t)t) fr = 1;
+    uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j != fr) v ^= J.data[(uint64_t)p.row[j] * J.stride + J.bin];
+    J.data[(uint64_t)p.row[fr] * J.stride + J.bin] = v;
 }
 
-__global__ __launch_bounds__(BB) void k_build_setflag(const BuildArgs a, int next)
+template <typename WT>
+__global__ __launch_bounds__(BB) void k_assign(const Peel<WT> a, uint32_t t)
 {
-    const uint32_t nn = a.wl_n[next];
-    for (uint32_t i = blockIdx.x * BB + threadIdx.x; i < nn; i += gridDim.x * BB) {
-        const uint64_t s = a.wl[next][i];
-        if (a.cnt[s] == 1u) a.single[s] = 1;
+    const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
+    for (uint64_t i = (uint64_t)lo + (uint64_t)blockIdx.x * BB + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * BB) assign_entry(a, i, t);
+}
+
+// rounds t_hi, t_hi - 1, ..., t_lo by ONE block (all of them small): a barrier between two rounds instead of a launch.  The block's
+// waves share one L1, and __syncthreads() orders its stores before the next round's loads.
+template <typename WT>
+__global__ __launch_bounds__(TAIL_THREADS) void k_assign_tail(const Peel<WT> a, uint32_t t_hi, uint32_t t_lo)
+{
+    for (uint32_t t = t_hi + 1; t-- > t_lo;) {
+        const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
+        for (uint64_t i = (uint64_t)lo + threadIdx.x; i < hi; i += TAIL_THREADS) assign_entry(a, i, t);
+        __syncthreads();
     }
 }
 
-// assign the log entries [lo, hi) of one round: D[row] = fp ^ D[other two rows]
-__global__ __launch_bounds__(BB) void k_build_assign(const BuildArgs a, uint8_t *data, uint64_t stride, const uint32_t *bin_ids,
-                                                     uint32_t lo, uint32_t hi)
+// every key against the finished columns
+template <typename WT>
+__global__ __launch_bounds__(BB) void k_verify(const Peel<WT> a, uint32_t block0)
 {
-    for (uint32_t i = lo + blockIdx.x * BB + threadIdx.x; i < hi; i += gridDim.x * BB) {
-        const uint64_t key = a.st_key[i], slot = a.st_slot[i];
-        const uint64_t cb = slot / a.rows;
-        const uint32_t row = (uint32_t)(slot - cb * a.rows);
-        const uint64_t bin = bin_ids[cb];
-        const ixf_probe p = ixf_probe_key_arith(key, a.seed, a.seg_len, a.arith);
+    __shared__ uint32_t jr[2], bad_blk;
+    const uint64_t g0 = (uint64_t)(block0 + blockIdx.x) * KEYS_PER_BLOCK;
+    const uint64_t g1 = min(g0 + (uint64_t)KEYS_PER_BLOCK, a.n_keys);
+    if (threadIdx.x == 0) {
+        bad_blk = 0;
+        jr[0] = job_in<true>(a.jobs, 0, a.n_jobs - 1, g0);
+        jr[1] = job_in<true>(a.jobs, jr[0], a.n_jobs - 1, g1 - 1);
+    }
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
+        const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
+        if (a.skip && a.skip[J.group]) continue;
+        const ixf_probe p = ixf_probe_key_arith(J.keys[g - J.key_base], J.seed, J.seg_len, J.arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            if (p.row[j] != row) v ^= data[(uint64_t)p.row[j] * stride + bin];
-        data[(uint64_t)row * stride + bin] = v;
+        for (int j = 0; j < 3; ++j) v ^= J.data[(uint64_t)p.row[j] * J.stride + J.bin];
+        bad += v != 0;
+    }
+    if (bad) atomicAdd(&bad_blk, bad);
+    __syncthreads();
+    if (threadIdx.x == 0 && bad_blk) atomicAdd(&a.ctl->mismatches, (unsigned long long)bad_blk);
+}
+
+// claimed keys per job (only looked at when a chunk fell short): one block per job
+__global__ __launch_bounds__(BB) void k_job_peeled(const BinJob *jobs, const uint32_t *claim, uint64_t *out)
+{
+    __shared__ unsigned long long tot;
+    const BinJob &J = jobs[blockIdx.x];
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    const uint64_t b0 = J.key_base, b1 = J.key_base + J.n_keys;
+    unsigned long long n = 0;
+    for (uint64_t wd = (b0 >> 5) + threadIdx.x; wd <= ((b1 - 1) >> 5); wd += BB) {
+        uint32_t v = claim[wd];
+        if (wd == (b0 >> 5)) v &= 0xFFFFFFFFu << (b0 & 31u);
+        if (wd == ((b1 - 1) >> 5) && (b1 & 31u)) v &= 0xFFFFFFFFu >> (32u - (uint32_t)(b1 & 31u));
+        n += (unsigned)__popc(v);
+    }
+    if (n) atomicAdd(&tot, n);
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+
+// columns of the jobs [j0, j0 + nj) of one IXF -> 0 (bins that are not built keep their content)
+__global__ __launch_bounds__(BB) void k_zero_columns(const BinJob *jobs, uint32_t j0, uint32_t nj, uint64_t rows)
+{
+    const uint64_t total = rows * nj;
+    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * BB) {
+        const uint64_t r = i / nj;
+        const BinJob &J = jobs[j0 + (uint32_t)(i - r * nj)];
+        J.data[r * J.stride + J.bin] = 0;
     }
 }
 
-__global__ __launch_bounds__(BB) void k_build_zero_columns(uint8_t *data, uint64_t stride, uint64_t rows, const uint32_t *bin_ids,
-                                                           uint32_t n_bins)
+// keys[i] = a bijection of (first + i): distinct 64-bit keys without a table (synthetic key sets of the build bench and tests)
+__global__ __launch_bounds__(BB) void k_synth_keys(uint64_t *out, uint64_t first, uint64_t n, uint64_t salt)
 {
-    const uint64_t total = rows * n_bins;
-    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * BB) {
-        const uint64_t r = i / n_bins;
-        data[r * stride + bin_ids[i - r * n_bins]] = 0;
-    }
+    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BB) out[i] = synth_key(first + i, salt);
 }
 
 int bfail(int code, const std::string &m)
@@ -186,11 +375,7 @@ int bfail(int code, const std::string &m)
     return code;
 }
 
-#define B_TRY(expr)                                                                                      \
-    do {                                                                                                 \
-        hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess) { cleanup(); return bfail(TAXOR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-    } while (0)
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 } // namespace
 
@@ -200,185 +385,496 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_ixf_info(taxor_
                                                                           int *device);
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_gpu_index *idx, uint64_t ixf, uint64_t seed);
 extern "C" __attribute__((visibility("hidden"))) uint32_t taxor_index_arith(const taxor_gpu_index *idx);
+extern "C" __attribute__((visibility("hidden"))) int taxor_index_tree(taxor_gpu_index *idx, uint64_t *n_ixf, const uint32_t **bin_base,
+                                                                      const uint32_t **binfo);
 
 namespace {
 
-// d_keys: the bins' key lists concatenated ON THE DEVICE (distinct within a bin); key_off[bins+1] on the host
-int build_ixf_device(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *d_all_keys, const uint64_t *key_off, uint64_t seed0,
-                     uint64_t *seed_out, uint32_t *rounds_out)
-{
-    const uint64_t *keys = d_all_keys;
-    uint8_t *data = nullptr;
-    uint64_t stride = 0, seg_len = 0, bins = 0;
+#define E_TRY(expr)                                                                                      \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return bfail(TAXOR_E_HIP, std::string("build: ") + #expr + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// The chunk engine: scratch for one chunk of bins, reused from chunk to chunk, on a stream of its own.
+struct Engine {
     int device = 0;
-    if (!idx || !key_off || taxor_index_ixf_info(idx, ixf, &data, &stride, &seg_len, &bins, &device))
-        return bfail(TAXOR_E_ARG, "build_ixf: bad index / IXF id");
-    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_ixf: hipSetDevice failed");
-    const uint64_t rows = 3 * seg_len;
-    // bins that have keys, largest first; chunks bounded by scratch (count+xor+flag+lists = 29 B per (bin,row))
-    std::vector<uint32_t> work;
-    uint64_t max_keys = 0;
-    for (uint64_t b = 0; b < bins; ++b) {
-        const uint64_t n = key_off[b + 1] - key_off[b];
-        if (key_off[b + 1] < key_off[b]) return bfail(TAXOR_E_ARG, "build_ixf: key_off not monotone");
-        if (n) work.push_back((uint32_t)b);
-        max_keys = std::max(max_keys, n);
-    }
-    if (seed_out) *seed_out = seed0;
-    if (rounds_out) *rounds_out = 0;
-    if (work.empty()) return TAXOR_OK;
-    if (!keys) return bfail(TAXOR_E_ARG, "build_ixf: null keys");
-    if (max_keys > rows) return bfail(TAXOR_E_ARG, "build_ixf: a bin holds more keys than the IXF has rows");
-    const uint64_t scratch_budget = 24ull << 30;
-    uint64_t chunk_bins = std::max<uint64_t>(1, std::min<uint64_t>(work.size(), scratch_budget / (29 * rows)));
-    if (chunk_bins * rows >= (1ull << 32)) chunk_bins = std::max<uint64_t>(1, ((1ull << 32) - 1) / rows); // work-list counters are u32
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    void *d_w = nullptr;
+    uint64_t *d_list = nullptr, *d_job_peeled = nullptr;
+    uint32_t *d_log = nullptr, *d_claim = nullptr;
+    uint16_t *d_pushed = nullptr;
+    uint8_t *d_skip = nullptr;
+    Ctl *d_ctl = nullptr;
+    BinJob *d_jobs = nullptr;
+    uint32_t *h_round_end = nullptr;                   // page-locked
+    unsigned long long *h_counts = nullptr;            // page-locked: peeled, mismatches
+    uint64_t cap_slots = 0, cap_keys = 0, cap_jobs = 0, w_bytes = 0, budget_bytes = 0;
+    taxor_build_stats stats{};
 
-    uint32_t *d_cnt = nullptr, *d_key_bin = nullptr, *d_ctr = nullptr, *d_bin_ids = nullptr;
-    uint64_t *d_xr = nullptr, *d_wl0 = nullptr, *d_wl1 = nullptr, *d_st_key = nullptr, *d_st_slot = nullptr, *d_off = nullptr;
-    uint8_t *d_single = nullptr;
-    auto cleanup = [&] {
-        for (void *p : {(void *)d_cnt, (void *)d_key_bin, (void *)d_ctr, (void *)d_bin_ids, (void *)d_xr, (void *)d_wl0, (void *)d_wl1,
-                        (void *)d_st_key, (void *)d_st_slot, (void *)d_single, (void *)d_off})
+    ~Engine() { release(); }
+
+    void release()
+    {
+        for (void *p : {(void *)d_w, (void *)d_list, (void *)d_job_peeled, (void *)d_log, (void *)d_claim, (void *)d_pushed, (void *)d_skip, (void *)d_ctl, (void *)d_jobs})
             if (p) (void)hipFree(p);
-    };
-    const uint64_t n_slots_max = chunk_bins * rows;
-    B_TRY(hipMalloc((void **)&d_cnt, n_slots_max * 4));
-    B_TRY(hipMalloc((void **)&d_xr, n_slots_max * 8));
-    B_TRY(hipMalloc((void **)&d_single, n_slots_max));
-    B_TRY(hipMalloc((void **)&d_wl0, n_slots_max * 8));
-    B_TRY(hipMalloc((void **)&d_wl1, n_slots_max * 8));
-    B_TRY(hipMalloc((void **)&d_ctr, 64));
-    B_TRY(hipMalloc((void **)&d_bin_ids, chunk_bins * 4));
-    B_TRY(hipMalloc((void **)&d_off, (chunk_bins + 1) * 8));
+        d_w = nullptr; d_list = nullptr; d_job_peeled = nullptr; d_log = nullptr; d_claim = nullptr; d_pushed = nullptr; d_skip = nullptr; d_ctl = nullptr; d_jobs = nullptr;
+        if (h_round_end) (void)hipHostFree(h_round_end);
+        if (h_counts) (void)hipHostFree(h_counts);
+        h_round_end = nullptr; h_counts = nullptr;
+        for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+        cap_slots = cap_keys = cap_jobs = w_bytes = 0;
+    }
 
-    uint64_t seed = seed0;
-    uint32_t max_rounds = 0;
-    for (int attempt = 0; attempt < 32; ++attempt) {
-        bool failed = false;
-        for (size_t c0 = 0; c0 < work.size() && !failed; c0 += chunk_bins) {
-            const size_t nb = std::min<size_t>(chunk_bins, work.size() - c0);
-            // bins are taken in bin order, and bins without keys have empty ranges: the chunk's keys are one contiguous
-            // range of the concatenated device array
-            const uint64_t k0 = key_off[work[c0]], nk = key_off[work[c0 + nb - 1] + 1] - k0;
-            const uint64_t *d_keys = keys + k0;
-            std::vector<uint64_t> hoff(nb + 1);
-            for (size_t i = 0; i < nb; ++i) hoff[i] = key_off[work[c0 + i]] - k0;
-            hoff[nb] = nk;
-            if (nk >= (1ull << 32)) { cleanup(); return bfail(TAXOR_E_ARG, "build_ixf: more than 2^32 keys in one chunk of bins"); }
-            if (d_key_bin) { (void)hipFree(d_key_bin); (void)hipFree(d_st_key); (void)hipFree(d_st_slot); d_key_bin = nullptr; d_st_key = nullptr; d_st_slot = nullptr; }
-            B_TRY(hipMalloc((void **)&d_key_bin, nk * 4));
-            B_TRY(hipMalloc((void **)&d_st_key, nk * 8));
-            B_TRY(hipMalloc((void **)&d_st_slot, nk * 8));
-            B_TRY(hipMemcpy(d_off, hoff.data(), (nb + 1) * 8, hipMemcpyHostToDevice));
-            hipLaunchKernelGGL(k_build_key_bin, dim3(2048), dim3(BB), 0, nullptr, d_off, (uint32_t)nb, nk, d_key_bin);
-            B_TRY(hipMemcpy(d_bin_ids, work.data() + c0, nb * 4, hipMemcpyHostToDevice));
-            const uint64_t n_slots = nb * rows;
-            B_TRY(hipMemset(d_cnt, 0, n_slots * 4));
-            B_TRY(hipMemset(d_xr, 0, n_slots * 8));
-            B_TRY(hipMemset(d_single, 0, n_slots));
-            B_TRY(hipMemset(d_ctr, 0, 64));
-            BuildArgs a{};
-            a.keys = d_keys;
-            a.key_bin = d_key_bin;
-            a.n_keys = nk;
-            a.seed = seed;
-            a.arith = taxor_index_arith(idx);
-            a.seg_len = (uint32_t)seg_len;
-            a.rows = rows;
-            a.cnt = d_cnt;
-            a.xr = d_xr;
-            a.single = d_single;
-            a.wl[0] = d_wl0;
-            a.wl[1] = d_wl1;
-            a.wl_n = d_ctr;          // [0], [1]
-            a.st_n = d_ctr + 2;
-            a.st_key = d_st_key;
-            a.st_slot = d_st_slot;
-            const int grid = 2048;
-            hipLaunchKernelGGL(k_build_count, dim3(grid), dim3(BB), 0, nullptr, a);
-            hipLaunchKernelGGL(k_build_seed, dim3(grid), dim3(BB), 0, nullptr, a, n_slots);
-            std::vector<uint32_t> round_end; // log size after each round
-            uint32_t h[3] = {0, 0, 0};
-            int cur = 0;
-            for (uint32_t round = 0; round < 4096; ++round) {
-                hipLaunchKernelGGL(k_build_round, dim3(grid), dim3(BB), 0, nullptr, a, cur);
-                hipLaunchKernelGGL(k_build_unflag, dim3(grid), dim3(BB), 0, nullptr, a, cur);
-                hipLaunchKernelGGL(k_build_setflag, dim3(grid), dim3(BB), 0, nullptr, a, cur ^ 1);
-                hipLaunchKernelGGL(k_build_reset, dim3(1), dim3(1), 0, nullptr, d_ctr, cur);
-                B_TRY(hipMemcpy(h, d_ctr, 12, hipMemcpyDeviceToHost)); // (the reset above zeroed h[cur])
-                round_end.push_back(h[2]);
-                cur ^= 1;
-                if (h[2] == nk || h[cur] == 0) break;
-            }
-            max_rounds = std::max<uint32_t>(max_rounds, (uint32_t)round_end.size());
-            if (h[2] != nk) { failed = true; break; } // not peelable under this seed (or duplicate keys in a bin)
-            hipLaunchKernelGGL(k_build_zero_columns, dim3(grid), dim3(BB), 0, nullptr, data, stride, rows, d_bin_ids, (uint32_t)nb);
-            for (size_t r = round_end.size(); r-- > 0;) {
-                const uint32_t lo = r ? round_end[r - 1] : 0u, hi = round_end[r];
-                if (hi > lo) {
-                    const int g2 = (int)std::min<uint32_t>(2048u, (hi - lo + BB - 1) / BB);
-                    hipLaunchKernelGGL(k_build_assign, dim3(g2), dim3(BB), 0, nullptr, a, data, stride, d_bin_ids, lo, hi);
+    int open(int dev)
+    {
+        device = dev;
+        E_TRY(hipSetDevice(device));
+        E_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (auto &e : ev) E_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        E_TRY(hipHostMalloc((void **)&h_round_end, (MAX_ROUNDS + 2) * sizeof(uint32_t), hipHostMallocDefault));
+        E_TRY(hipHostMalloc((void **)&h_counts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        E_TRY(hipMalloc((void **)&d_ctl, sizeof(Ctl)));
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
+        if (const char *e = getenv("TAXOR_BUILD_SCRATCH_MB")) fr = (size_t)strtoull(e, nullptr, 10) << 21;      // (tests: small chunks)
+        budget_bytes = std::min<uint64_t>((uint64_t)fr / 2, 40ull << 30);
+        return TAXOR_OK;
+    }
+
+    // scratch bytes a chunk of (slots, keys) needs: 18 (26 with 64-bit words) per slot + a bit per key
+    static uint64_t bytes_for(uint64_t slots, uint64_t keys, bool wide) { return slots * (wide ? 26u : 18u) + keys / 8 + 64; }
+
+    // slots a chunk may have: scratch within half of the memory that was free when the engine was opened, at most 40 GB, and
+    // fewer than 2^32 slots (list positions are 32 bits)
+    uint64_t slot_budget(bool wide) const { return std::min<uint64_t>(budget_bytes / (wide ? 26u : 18u), 0xFFFFFFF0ull); }
+
+    int ensure(uint64_t slots, uint64_t keys, uint64_t jobs, bool wide)
+    {
+        const uint64_t wb = slots * (wide ? 8 : 4);
+        if (wb > w_bytes) {
+            if (d_w) (void)hipFree(d_w);
+            d_w = nullptr;
+            w_bytes = 0;
+            if (hipMalloc(&d_w, wb) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build: no device memory for the peeling state");
+            w_bytes = wb;
+        }
+        if (slots > cap_slots) {
+            for (void *p : {(void *)d_list, (void *)d_log, (void *)d_pushed})
+                if (p) (void)hipFree(p);
+            d_list = nullptr; d_log = nullptr; d_pushed = nullptr;
+            cap_slots = 0;
+            if (hipMalloc((void **)&d_list, slots * 8) != hipSuccess || hipMalloc((void **)&d_log, slots * 4) != hipSuccess ||
+                hipMalloc((void **)&d_pushed, slots * 2) != hipSuccess)
+                return bfail(TAXOR_E_NOMEM, "build: no device memory for the peeling work list");
+            cap_slots = slots;
+        }
+        if (keys > cap_keys) {
+            if (d_claim) (void)hipFree(d_claim);
+            d_claim = nullptr;
+            cap_keys = 0;
+            if (hipMalloc((void **)&d_claim, (keys / 32 + 2) * 4) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build: no device memory for the claim bits");
+            cap_keys = keys;
+        }
+        if (jobs > cap_jobs) {
+            for (void *p : {(void *)d_jobs, (void *)d_job_peeled, (void *)d_skip})
+                if (p) (void)hipFree(p);
+            d_jobs = nullptr; d_job_peeled = nullptr; d_skip = nullptr;
+            cap_jobs = 0;
+            if (hipMalloc((void **)&d_jobs, jobs * sizeof(BinJob)) != hipSuccess || hipMalloc((void **)&d_job_peeled, jobs * 8) != hipSuccess ||
+                hipMalloc((void **)&d_skip, jobs) != hipSuccess)
+                return bfail(TAXOR_E_NOMEM, "build: no device memory for the bin table");
+            cap_jobs = jobs;
+        }
+        stats.scratch_bytes = std::max<uint64_t>(stats.scratch_bytes, w_bytes + cap_slots * 14 + cap_keys / 8 + cap_jobs * (sizeof(BinJob) + 9) + sizeof(Ctl));
+        return TAXOR_OK;
+    }
+
+    template <typename WT>
+    int run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, uint64_t n_keys, uint64_t n_slots,
+                  const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows);
+
+    // construct the columns of `jobs` (key_base / slot_base are filled in here; every job has keys; jobs of one group are
+    // adjacent).  group_ok[g] = 0: a bin of group g did not peel under its seed, its columns are untouched.
+    // group_full[g] = 1: the jobs of group g are all the bins of its IXF (the whole array may be cleared at once).
+    int run(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, const std::vector<uint8_t> &group_full)
+    {
+        group_ok.assign(n_groups, 1);
+        if (jobs.empty()) return TAXOR_OK;
+        uint64_t nk = 0, ns = 0;
+        bool wide = false;
+        std::vector<uint64_t> group_rows(n_groups, 0);
+        for (auto &j : jobs) {
+            j.key_base = nk;
+            j.slot_base = ns;
+            nk += j.n_keys;
+            ns += 3ull * j.seg_len;
+            wide |= j.n_keys >= (1ull << 24);
+            group_rows[j.group] = 3ull * j.seg_len;
+            if (j.n_keys > 3ull * j.seg_len) return bfail(TAXOR_E_ARG, "build: a bin holds more keys than its IXF has rows");
+            if (j.n_keys >= 0xFFFFFFFFull) return bfail(TAXOR_E_ARG, "build: more than 2^32 - 2 keys in one bin");
+        }
+        if (ns >= 0xFFFFFFF8ull || jobs.size() >= (1ull << 31)) return bfail(TAXOR_E_INTERNAL, "build: chunk too large");
+        E_TRY(hipSetDevice(device));
+        const int rc = ensure(ns, nk, jobs.size(), wide);
+        if (rc != TAXOR_OK) return rc;
+        ++stats.chunks;
+        return wide ? run_typed<uint64_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows)
+                    : run_typed<uint32_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows);
+    }
+};
+
+template <typename WT>
+int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, uint64_t n_keys, uint64_t n_slots,
+                      const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows)
+{
+    const double t0 = now_s();
+    Peel<WT> a{};
+    a.jobs = d_jobs;
+    a.n_jobs = (uint32_t)jobs.size();
+    a.n_keys = n_keys;
+    a.n_slots = n_slots;
+    a.w = (WT *)d_w;
+    a.list = d_list;
+    a.log = d_log;
+    a.pushed = d_pushed;
+    a.claim = d_claim;
+    a.skip = nullptr;
+    a.ctl = d_ctl;
+    E_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(BinJob), hipMemcpyHostToDevice, st));
+    E_TRY(hipMemsetAsync(d_w, 0, n_slots * sizeof(WT), st));
+    E_TRY(hipMemsetAsync(d_pushed, 0xFF, n_slots * 2, st));
+    E_TRY(hipMemsetAsync(d_claim, 0, (n_keys / 32 + 2) * 4, st));
+    E_TRY(hipMemsetAsync(d_ctl, 0, sizeof(Ctl), st));
+    const uint32_t grid_keys = (uint32_t)((n_keys + KEYS_PER_BLOCK - 1) / KEYS_PER_BLOCK);
+    for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_count<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
+    const uint32_t grid_slots = (uint32_t)((n_slots + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK);
+    for (uint32_t b = 0; b < grid_slots; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_seed<WT>), dim3(std::min(SLICE_BLOCKS, grid_slots - b)), dim3(BB), 0, st, a, b, grid_slots);
+    // rounds: two batches ahead of the host.  The grid follows the chunk's size (a small chunk's rounds are small)
+    // (every block draws one ticket from ONE counter at the end of a round, ~13 ns each: 1024 blocks = 4 per CU is the knee)
+    const uint32_t round_grid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(8, n_keys / (2 * ROUND_ITER * BB)));
+    uint32_t launched = 0, rounds = 0;      // rounds = index of the first empty round, once known
+    bool done = false;
+    int slot = 0;
+    uint32_t pending_lo[2] = {0, 0}, pending_hi[2] = {0, 0};
+    bool pending[2] = {false, false};
+    auto check = [&](int s) -> int {        // wait for batch s's copy, look for the first empty round in it
+        E_TRY(hipEventSynchronize(ev[s]));
+        pending[s] = false;
+        for (uint32_t t = pending_lo[s]; t < pending_hi[s] && !done; ++t)
+            if (h_round_end[t + 1] == h_round_end[t]) { rounds = t; done = true; }
+        return TAXOR_OK;
+    };
+    while (!done) {
+        if (launched >= MAX_ROUNDS) return bfail(TAXOR_E_INTERNAL, "build: peeling did not end within 16000 rounds");
+        const uint32_t lo = launched, hi = std::min(MAX_ROUNDS, launched + ROUND_BATCH);
+        for (uint32_t t = lo; t < hi; ++t) hipLaunchKernelGGL((k_round<WT>), dim3(round_grid), dim3(BB), 0, st, a, t);
+        launched = hi;
+        // the ends of rounds lo .. hi (round t's own end is written by the launch before it, hi's by the last one of this batch)
+        E_TRY(hipMemcpyAsync(h_round_end + lo, &d_ctl->round_end[lo], (hi - lo + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        E_TRY(hipEventRecord(ev[slot], st));
+        pending_lo[slot] = lo;
+        pending_hi[slot] = hi;
+        pending[slot] = true;
+        slot ^= 1;
+        if (pending[slot]) { const int rc = check(slot); if (rc != TAXOR_OK) return rc; }
+    }
+    for (int s = 0; s < 2; ++s)
+        if (pending[s]) E_TRY(hipEventSynchronize(ev[s]));                  // (launches behind the last round: empty, already queued)
+    E_TRY(hipMemcpyAsync(h_round_end, &d_ctl->round_end[0], (rounds + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    E_TRY(hipMemcpyAsync(&h_counts[0], &d_ctl->peeled, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    E_TRY(hipStreamSynchronize(st));
+    E_TRY(hipGetLastError());
+    stats.rounds_max = std::max(stats.rounds_max, rounds);
+    const double t1 = now_s();
+    stats.seconds_peel += t1 - t0;
+
+    // which IXFs fell short?
+    uint32_t n_failed = 0;
+    if (h_counts[0] != n_keys) {
+        hipLaunchKernelGGL(k_job_peeled, dim3((uint32_t)jobs.size()), dim3(BB), 0, st, d_jobs, d_claim, d_job_peeled);
+        std::vector<uint64_t> got(jobs.size());
+        E_TRY(hipMemcpyAsync(got.data(), d_job_peeled, jobs.size() * 8, hipMemcpyDeviceToHost, st));
+        E_TRY(hipStreamSynchronize(st));
+        for (size_t j = 0; j < jobs.size(); ++j)
+            if (got[j] != jobs[j].n_keys) group_ok[jobs[j].group] = 0;
+        for (uint32_t g = 0; g < n_groups; ++g) n_failed += !group_ok[g];
+        if (!n_failed) return bfail(TAXOR_E_INTERNAL, "build: claimed keys fall short but every bin is complete");
+        std::vector<uint8_t> skip(n_groups);
+        for (uint32_t g = 0; g < n_groups; ++g) skip[g] = !group_ok[g];
+        E_TRY(hipMemcpyAsync(d_skip, skip.data(), n_groups, hipMemcpyHostToDevice, st));
+        E_TRY(hipStreamSynchronize(st));                                     // (skip is a stack vector)
+        a.skip = d_skip;
+        stats.reseeds += n_failed;
+    }
+    if (n_failed < n_groups) {
+        // clear what is built: the whole array of an IXF all of whose bins are here, else column by column
+        for (size_t j0 = 0; j0 < jobs.size();) {
+            size_t j1 = j0;
+            while (j1 < jobs.size() && jobs[j1].group == jobs[j0].group) ++j1;
+            const uint32_t g = jobs[j0].group;
+            if (group_ok[g]) {
+                if (group_full[g]) E_TRY(hipMemsetAsync(jobs[j0].data, 0, group_rows[g] * jobs[j0].stride, st));
+                else {
+                    const uint64_t total = group_rows[g] * (j1 - j0);
+                    hipLaunchKernelGGL(k_zero_columns, dim3((uint32_t)std::min<uint64_t>(4096, (total + BB - 1) / BB)), dim3(BB), 0, st, d_jobs,
+                                       (uint32_t)j0, (uint32_t)(j1 - j0), group_rows[g]);
                 }
             }
-            B_TRY(hipGetLastError());
-            B_TRY(hipDeviceSynchronize());
+            j0 = j1;
         }
-        if (!failed) {
-            cleanup();
-            taxor_index_set_seed(idx, ixf, seed);
-            if (seed_out) *seed_out = seed;
-            if (rounds_out) *rounds_out = max_rounds;
-            return TAXOR_OK;
+        // rounds in reverse: runs of small rounds by the one-block walker, the others a launch each
+        for (uint32_t t = rounds; t-- > 0;) {
+            const uint32_t n = h_round_end[t + 1] - h_round_end[t];
+            if (n <= TAIL_ENTRIES) {
+                uint32_t t_lo = t;
+                while (t_lo > 0 && h_round_end[t_lo] - h_round_end[t_lo - 1] <= TAIL_ENTRIES) --t_lo;
+                hipLaunchKernelGGL((k_assign_tail<WT>), dim3(1), dim3(TAIL_THREADS), 0, st, a, t, t_lo);
+                t = t_lo;
+            } else
+                hipLaunchKernelGGL((k_assign<WT>), dim3((uint32_t)std::min<uint32_t>(2048, (n + BB - 1) / BB)), dim3(BB), 0, st, a, t);
         }
-        // re-seed and rebuild every bin of this IXF, like construct_ixf.cpp:100-108
-        seed = seed * 6364136223846793005ull + 1442695040888963407ull;
+        for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_verify<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
+        E_TRY(hipMemcpyAsync(&h_counts[1], &d_ctl->mismatches, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        E_TRY(hipStreamSynchronize(st));
+        E_TRY(hipGetLastError());
+        if (h_counts[1] != 0)
+            return bfail(TAXOR_E_INTERNAL, "build: " + std::to_string(h_counts[1]) + " keys do not match their own columns after construction");
     }
-    cleanup();
-    return bfail(TAXOR_E_INTERNAL, "build_ixf: no seed peeled every bin in 32 attempts (duplicate keys inside a bin?)");
+    for (const auto &j : jobs)
+        if (group_ok[j.group]) stats.keys_inserted += j.n_keys;
+    stats.seconds_assign += now_s() - t1;
+    return TAXOR_OK;
+}
+
+// one IXF to construct: where its bins' keys are
+struct IxfPlan {
+    uint64_t ixf = 0;
+    uint8_t *data = nullptr;
+    uint64_t stride = 0, seg_len = 0, bins = 0;
+    uint64_t seed = 0;
+    std::vector<const uint64_t *> keys;      // per bin (device)
+    std::vector<uint64_t> n;                 // per bin
+    uint64_t total = 0, max_bin = 0, n_with_keys = 0;
+    int attempts = 0;
+};
+
+uint64_t next_seed(uint64_t s) { return s * 6364136223846793005ull + 1442695040888963407ull; }
+
+// construct the IXFs of `plans` (one level of a hierarchy, or a single IXF): as many as fit go into one chunk; an IXF that
+// does not peel is redone with a redrawn seed; an IXF larger than a chunk is built from several chunks of its bins
+int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
+{
+    const uint32_t arith = taxor_index_arith(idx);
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < plans.size(); ++i)
+        if (plans[i].total) todo.push_back(i);
+    auto add_jobs = [&](const IxfPlan &p, uint32_t group, uint64_t b0, uint64_t b1, std::vector<BinJob> &jobs) {
+        for (uint64_t b = b0; b < b1; ++b) {
+            if (!p.n[b]) continue;
+            BinJob j{};
+            j.keys = p.keys[b];
+            j.n_keys = p.n[b];
+            j.data = p.data;
+            j.stride = p.stride;
+            j.seed = p.seed;
+            j.seg_len = (uint32_t)p.seg_len;
+            j.arith = arith;
+            j.bin = (uint32_t)b;
+            j.group = group;
+            jobs.push_back(j);
+        }
+    };
+    while (!todo.empty()) {
+        std::vector<BinJob> jobs;
+        std::vector<size_t> members;
+        std::vector<uint8_t> full, ok;
+        uint64_t slots = 0, keys = 0;
+        bool wide = false;
+        for (size_t q : todo) wide |= plans[q].max_bin >= (1ull << 24);
+        const uint64_t budget = eng.slot_budget(wide);
+        size_t taken = 0;
+        for (; taken < todo.size(); ++taken) {
+            const IxfPlan &p = plans[todo[taken]];
+            const uint64_t s = p.n_with_keys * 3 * p.seg_len;
+            if (!members.empty() && (slots + s > budget || keys + p.total >= (1ull << 32))) break;
+            if (members.empty() && (s > budget || p.total >= (1ull << 32))) break;          // larger than a chunk: below
+            add_jobs(p, (uint32_t)members.size(), 0, p.bins, jobs);
+            full.push_back(p.n_with_keys == p.bins);
+            members.push_back(todo[taken]);
+            slots += s;
+            keys += p.total;
+        }
+        if (members.empty()) {
+            // one IXF in several chunks of its bins; a bin that does not peel restarts the IXF under a new seed
+            IxfPlan &p = plans[todo[0]];
+            const uint64_t per_bin = 3 * p.seg_len;
+            if (per_bin > budget) return bfail(TAXOR_E_NOMEM, "build: one bin of IXF " + std::to_string(p.ixf) + " does not fit the peeling scratch");
+            bool built = false;
+            while (!built) {
+                built = true;
+                for (uint64_t b0 = 0; b0 < p.bins && built;) {
+                    uint64_t b1 = b0, s = 0, k = 0;
+                    while (b1 < p.bins && (p.n[b1] == 0 || (s + per_bin <= budget && k + p.n[b1] < (1ull << 32)))) {
+                        if (p.n[b1]) { s += per_bin; k += p.n[b1]; }
+                        ++b1;
+                    }
+                    jobs.clear();
+                    add_jobs(p, 0, b0, b1, jobs);
+                    full.assign(1, 0);
+                    const int rc = eng.run(jobs, 1, ok, full);
+                    if (rc != TAXOR_OK) return rc;
+                    if (!ok[0]) built = false;
+                    b0 = b1;
+                }
+                if (!built) {
+                    if (++p.attempts >= 32) return bfail(TAXOR_E_INTERNAL, "build: no seed peeled every bin of IXF " + std::to_string(p.ixf) + " in 32 attempts (duplicate keys inside a bin?)");
+                    p.seed = next_seed(p.seed);
+                }
+            }
+            taxor_index_set_seed(idx, p.ixf, p.seed);
+            todo.erase(todo.begin());
+            continue;
+        }
+        const int rc = eng.run(jobs, (uint32_t)members.size(), ok, full);
+        if (rc != TAXOR_OK) return rc;
+        std::vector<size_t> again;
+        for (size_t m = 0; m < members.size(); ++m) {
+            IxfPlan &p = plans[members[m]];
+            if (ok[m]) taxor_index_set_seed(idx, p.ixf, p.seed);
+            else {
+                if (++p.attempts >= 32) return bfail(TAXOR_E_INTERNAL, "build: no seed peeled every bin of IXF " + std::to_string(p.ixf) + " in 32 attempts (duplicate keys inside a bin?)");
+                p.seed = next_seed(p.seed);         // re-seed and rebuild every bin of this IXF, like construct_ixf.cpp:100-108
+                again.push_back(members[m]);
+            }
+        }
+        todo.erase(todo.begin(), todo.begin() + (long)taken);
+        todo.insert(todo.begin(), again.begin(), again.end());
+    }
+    return TAXOR_OK;
+}
+
+int plan_ixf(taxor_gpu_index *idx, uint64_t ixf, IxfPlan &p, int *device)
+{
+    if (taxor_index_ixf_info(idx, ixf, &p.data, &p.stride, &p.seg_len, &p.bins, device)) return bfail(TAXOR_E_ARG, "build: bad index / IXF id");
+    p.ixf = ixf;
+    p.keys.assign(p.bins, nullptr);
+    p.n.assign(p.bins, 0);
+    return TAXOR_OK;
+}
+
+void plan_totals(IxfPlan &p)
+{
+    p.total = p.max_bin = p.n_with_keys = 0;
+    for (uint64_t b = 0; b < p.bins; ++b) {
+        p.total += p.n[b];
+        p.max_bin = std::max(p.max_bin, p.n[b]);
+        p.n_with_keys += p.n[b] != 0;
+    }
 }
 
 } // namespace
 
+extern "C" uint64_t taxor_synth_key(uint64_t i, uint64_t salt) { return synth_key(i, salt); }
+
+extern "C" int taxor_gpu_synth_keys(int device, uint64_t *d_out, uint64_t first, uint64_t n, uint64_t salt)
+{
+    if (!d_out && n) return bfail(TAXOR_E_ARG, "synth_keys: null output");
+    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "synth_keys: hipSetDevice failed");
+    if (n) hipLaunchKernelGGL(k_synth_keys, dim3((uint32_t)std::min<uint64_t>(8192, (n + BB - 1) / BB)), dim3(BB), 0, nullptr, d_out, first, n, salt);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bfail(TAXOR_E_HIP, "synth_keys: kernel failed");
+    return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_malloc(int device, uint64_t bytes, void **out)
+{
+    if (!out) return bfail(TAXOR_E_ARG, "taxor_gpu_malloc: null output");
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "taxor_gpu_malloc: hipSetDevice failed");
+    if (hipMalloc(out, bytes ? bytes : 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "taxor_gpu_malloc: no device memory for " + std::to_string(bytes) + " bytes");
+    return TAXOR_OK;
+}
+
+extern "C" void taxor_gpu_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+
+extern "C" int taxor_gpu_memcpy_to_host(void *dst, const void *d_src, uint64_t bytes)
+{
+    return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TAXOR_OK : bfail(TAXOR_E_HIP, "taxor_gpu_memcpy_to_host failed");
+}
+
+// keys: the bins' key lists concatenated, on the host or (keys_on_device) on the index's device
+static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device, const uint64_t *key_off, uint64_t seed0,
+                          uint64_t *seed_out, uint32_t *rounds_out, taxor_build_stats *stats_out)
+{
+    std::vector<IxfPlan> plans(1);
+    int device = 0;
+    if (!idx || !key_off) return bfail(TAXOR_E_ARG, "build_ixf: bad index / IXF id");
+    int rc = plan_ixf(idx, ixf, plans[0], &device);
+    if (rc != TAXOR_OK) return rc;
+    IxfPlan &p = plans[0];
+    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_ixf: hipSetDevice failed");
+    for (uint64_t b = 0; b < p.bins; ++b)
+        if (key_off[b + 1] < key_off[b]) return bfail(TAXOR_E_ARG, "build_ixf: key_off not monotone");
+    const uint64_t total = key_off[p.bins] - key_off[0];
+    if (seed_out) *seed_out = seed0;
+    if (rounds_out) *rounds_out = 0;
+    if (stats_out) *stats_out = taxor_build_stats{};
+    if (!total) return TAXOR_OK;
+    if (!keys) return bfail(TAXOR_E_ARG, "build_ixf: null keys");
+    const double t0 = now_s();
+    uint64_t *d_own = nullptr;
+    const uint64_t *d_keys = keys + key_off[0];
+    if (!keys_on_device) {
+        if (hipMalloc((void **)&d_own, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_ixf: no device memory for the keys");
+        if (hipMemcpy(d_own, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_own);
+            return bfail(TAXOR_E_HIP, "build_ixf: key upload failed");
+        }
+        d_keys = d_own;
+    }
+    for (uint64_t b = 0; b < p.bins; ++b) {
+        p.keys[b] = d_keys + (key_off[b] - key_off[0]);
+        p.n[b] = key_off[b + 1] - key_off[b];
+    }
+    plan_totals(p);
+    p.seed = seed0;
+    Engine eng;
+    rc = eng.open(device);
+    if (rc == TAXOR_OK) rc = build_plans(eng, idx, plans);
+    if (d_own) (void)hipFree(d_own);
+    if (rc != TAXOR_OK) return rc;
+    eng.stats.seconds_total = now_s() - t0;
+    if (seed_out) *seed_out = p.seed;
+    if (rounds_out) *rounds_out = eng.stats.rounds_max;
+    if (stats_out) *stats_out = eng.stats;
+    return TAXOR_OK;
+}
+
 extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
                                          uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out)
 {
-    uint8_t *data = nullptr;
-    uint64_t stride = 0, seg_len = 0, bins = 0;
-    int device = 0;
-    if (!idx || !key_off || taxor_index_ixf_info(idx, ixf, &data, &stride, &seg_len, &bins, &device))
-        return bfail(TAXOR_E_ARG, "build_ixf: bad index / IXF id");
-    if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_ixf: hipSetDevice failed");
-    const uint64_t total = key_off[bins] - key_off[0];
-    if (total && !keys) return bfail(TAXOR_E_ARG, "build_ixf: null keys");
-    uint64_t *d_keys = nullptr;
-    if (total) {
-        if (hipMalloc((void **)&d_keys, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_ixf: no device memory for the keys");
-        if (hipMemcpy(d_keys, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d_keys);
-            return bfail(TAXOR_E_HIP, "build_ixf: key upload failed");
-        }
-    }
-    std::vector<uint64_t> off(bins + 1);
-    for (uint64_t b = 0; b <= bins; ++b) off[b] = key_off[b] - key_off[0];
-    const int rc = build_ixf_device(idx, ixf, d_keys, off.data(), seed0, seed_out, rounds_out);
-    if (d_keys) (void)hipFree(d_keys);
-    return rc;
+    return build_ixf_impl(idx, ixf, keys, 0, key_off, seed0, seed_out, rounds_out, nullptr);
 }
 
-// library-internal: tree of the resident index (api.hip)
-extern "C" __attribute__((visibility("hidden"))) int taxor_index_tree(taxor_gpu_index *idx, uint64_t *n_ixf, const uint32_t **bin_base,
-                                                                      const uint32_t **binfo);
-
-extern "C" int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
-                                          uint32_t *rounds_out)
+static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off, uint64_t seed0,
+                           uint32_t *rounds_out, taxor_build_stats *stats_out)
 {
     uint64_t n_ixf = 0;
     const uint32_t *bin_base = nullptr, *binfo = nullptr;
     if (!idx || !key_off || taxor_index_tree(idx, &n_ixf, &bin_base, &binfo)) return bfail(TAXOR_E_ARG, "build_hixf: bad index");
-    uint8_t *data = nullptr;
-    uint64_t stride = 0, seg_len = 0, bins = 0;
+    std::vector<IxfPlan> plan(n_ixf);
     int device = 0;
-    taxor_index_ixf_info(idx, 0, &data, &stride, &seg_len, &bins, &device);
+    for (uint64_t i = 0; i < n_ixf; ++i) {
+        const int rc = plan_ixf(idx, i, plan[i], &device);
+        if (rc != TAXOR_OK) return rc;
+        plan[i].seed = seed0 + 0x9E3779B97F4A7C15ull * i;
+    }
     if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "build_hixf: hipSetDevice failed");
     const uint64_t total_bins = bin_base[n_ixf];
     for (uint64_t g = 0; g < total_bins; ++g) {
@@ -388,66 +884,145 @@ extern "C" int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *
     }
     const uint64_t total = key_off[total_bins] - key_off[0];
     if (total && !keys) return bfail(TAXOR_E_ARG, "build_hixf: null keys");
-    uint64_t *d_leaf = nullptr;
-    if (total) {
-        if (hipMalloc((void **)&d_leaf, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys");
-        if (hipMemcpy(d_leaf, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d_leaf);
-            return bfail(TAXOR_E_HIP, "build_hixf: key upload failed");
+    if (rounds_out) *rounds_out = 0;
+    if (stats_out) *stats_out = taxor_build_stats{};
+    const double t0 = now_s();
+    // depth of every IXF (the root is IXF 0; children have larger ids than nothing in particular, so walk the tree)
+    std::vector<int> depth(n_ixf, -1);
+    std::vector<int64_t> parent(n_ixf, -1);
+    int max_depth = 0;
+    {
+        std::vector<uint64_t> stack{0};
+        depth[0] = 0;
+        while (!stack.empty()) {
+            const uint64_t i = stack.back();
+            stack.pop_back();
+            for (uint64_t b = 0; b < plan[i].bins; ++b) {
+                const uint32_t bi = binfo[bin_base[i] + b];
+                if (!(bi & BINFO_MERGED)) continue;
+                const uint64_t c = bi & 0x3FFFFFFFu;
+                if (c >= n_ixf || depth[c] >= 0) return bfail(TAXOR_E_ARG, "build_hixf: the hierarchy is not a tree");
+                depth[c] = depth[i] + 1;
+                parent[c] = (int64_t)i;
+                max_depth = std::max(max_depth, depth[c]);
+                stack.push_back(c);
+            }
         }
     }
-    uint32_t max_rounds = 0;
-    std::string err;
-    int err_code = TAXOR_OK;
-    struct DevKeys { uint64_t *p = nullptr; uint64_t n = 0; };
-    // post-order: children first; returns the union of everything below IXF i (not needed for the root)
-    std::function<bool(uint64_t, bool, DevKeys *)> build = [&](uint64_t i, bool want_union, DevKeys *out) -> bool {
-        taxor_index_ixf_info(idx, i, &data, &stride, &seg_len, &bins, &device);
-        const uint64_t nb = bins, g0 = bin_base[i];
-        std::vector<DevKeys> child(nb);
-        std::vector<uint64_t> off(nb + 1, 0);
-        bool ok = true;
-        for (uint64_t b = 0; b < nb && ok; ++b) {
-            if (binfo[g0 + b] & BINFO_MERGED) ok = build(binfo[g0 + b] & 0x3FFFFFFFu, true, &child[b]);
-            off[b + 1] = off[b] + ((binfo[g0 + b] & BINFO_MERGED) ? child[b].n : key_off[g0 + b + 1] - key_off[g0 + b]);
+    uint64_t *d_leaf = nullptr;
+    const uint64_t *d_keys = keys ? keys + key_off[0] : nullptr;
+    std::vector<uint64_t *> arenas;            // unions of one level each; freed when the level above is built
+    auto cleanup = [&] {
+        if (d_leaf) (void)hipFree(d_leaf);
+        for (auto *p : arenas)
+            if (p) (void)hipFree(p);
+    };
+    if (total && !keys_on_device) {
+        if (hipMalloc((void **)&d_leaf, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys");
+        if (hipMemcpy(d_leaf, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+            cleanup();
+            return bfail(TAXOR_E_HIP, "build_hixf: key upload failed");
         }
-        uint64_t *d_all = nullptr;
-        if (ok && off[nb]) {
-            if (hipMalloc((void **)&d_all, off[nb] * 8) != hipSuccess) { err = "build_hixf: no device memory for the keys of one IXF"; err_code = TAXOR_E_NOMEM; ok = false; }
-            for (uint64_t b = 0; b < nb && ok;) {              // runs of leaf bins are contiguous in the caller's array
-                if (binfo[g0 + b] & BINFO_MERGED) {
-                    if (child[b].n && hipMemcpyAsync(d_all + off[b], child[b].p, child[b].n * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) ok = false;
-                    ++b;
+        d_keys = d_leaf;
+    }
+    Engine eng;
+    int rc = eng.open(device);
+    if (rc != TAXOR_OK) { cleanup(); return rc; }
+    struct Union { const uint64_t *p = nullptr; uint64_t n = 0; };
+    std::vector<Union> uni(n_ixf);
+    SortScratch sorter;
+    for (int d = max_depth; d >= 0 && rc == TAXOR_OK; --d) {
+        std::vector<IxfPlan> level;
+        std::vector<uint64_t> ids;
+        uint64_t level_keys = 0, level_max = 0;
+        for (uint64_t i = 0; i < n_ixf; ++i) {
+            if (depth[i] != d) continue;
+            IxfPlan &p = plan[i];
+            for (uint64_t b = 0; b < p.bins; ++b) {
+                const uint64_t g = bin_base[i] + b;
+                if (binfo[g] & BINFO_MERGED) {
+                    const Union &u = uni[binfo[g] & 0x3FFFFFFFu];
+                    p.keys[b] = u.p;
+                    p.n[b] = u.n;
                 } else {
-                    uint64_t e = b;
-                    while (e < nb && !(binfo[g0 + e] & BINFO_MERGED)) ++e;
-                    const uint64_t n = off[e] - off[b];
-                    if (n && hipMemcpyAsync(d_all + off[b], d_leaf + (key_off[g0 + b] - key_off[0]), n * 8, hipMemcpyDeviceToDevice, nullptr) != hipSuccess) ok = false;
-                    b = e;
+                    p.keys[b] = d_keys ? d_keys + (key_off[g] - key_off[0]) : nullptr;
+                    p.n[b] = key_off[g + 1] - key_off[g];
                 }
             }
-            if (!ok && err.empty()) { err = "build_hixf: device copy failed"; err_code = TAXOR_E_HIP; }
-            if (ok && hipDeviceSynchronize() != hipSuccess) { err = "build_hixf: device copy failed"; err_code = TAXOR_E_HIP; ok = false; }
+            plan_totals(p);
+            level_keys += p.total;
+            level_max = std::max(level_max, p.total);
+            ids.push_back(i);
         }
-        for (auto &c : child)
-            if (c.p) (void)hipFree(c.p);
-        if (ok) {
-            uint64_t seed = 0;
-            uint32_t rounds = 0;
-            const int rc = build_ixf_device(idx, i, d_all, off.data(), seed0 + 0x9E3779B97F4A7C15ull * i, &seed, &rounds);
-            if (rc != TAXOR_OK) { err_code = rc; ok = false; }     // message already set
-            max_rounds = std::max(max_rounds, rounds);
+        for (uint64_t i : ids) level.push_back(plan[i]);
+        rc = build_plans(eng, idx, level);
+        if (rc != TAXOR_OK) break;
+        for (size_t q = 0; q < ids.size(); ++q) plan[ids[q]].seed = level[q].seed;
+        if (d == 0) break;
+        // what the level above inserts into its merged bins: the duplicate-free union of every IXF of this level
+        const double tu = now_s();
+        uint64_t *arena = nullptr, *concat = nullptr;
+        if (level_keys && hipMalloc((void **)&arena, level_keys * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
+        arenas.push_back(arena);
+        uint64_t used = 0;
+        for (uint64_t i : ids) {
+            IxfPlan &p = plan[i];
+            if (!p.total) continue;
+            if (p.total >= (1ull << 32)) { rc = bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 keys below one merged bin"); break; }
+            // the IXF's keys in one piece: its leaf bins are adjacent in the caller's array; with merged bins among them, gathered
+            const uint64_t *src = nullptr;
+            bool contiguous = true;
+            for (uint64_t b = 0; b < p.bins; ++b)
+                if (p.n[b] && (binfo[bin_base[i] + b] & BINFO_MERGED)) contiguous = false;
+            if (contiguous) src = d_keys + (key_off[bin_base[i]] - key_off[0]);
+            else {
+                if (!concat && hipMalloc((void **)&concat, level_max * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys of one IXF"); break; }
+                uint64_t o = 0;
+                for (uint64_t b = 0; b < p.bins; ++b) {
+                    if (p.n[b] && hipMemcpyAsync(concat + o, p.keys[b], p.n[b] * 8, hipMemcpyDeviceToDevice, eng.st) != hipSuccess) rc = bfail(TAXOR_E_HIP, "build_hixf: device copy failed");
+                    o += p.n[b];
+                }
+                if (rc != TAXOR_OK) break;
+                src = concat;
+            }
+            uint64_t n_out = 0;
+            const hipError_t e = sorter.sort_unique(src, p.total, arena + used, &n_out, eng.st);
+            if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
+            uni[i].p = arena + used;
+            uni[i].n = n_out;
+            used += n_out;
         }
-        if (ok && want_union && off[nb]) {
-            const hipError_t e = sort_unique_u64(d_all, off[nb], &out->p, &out->n, nullptr);
-            if (e != hipSuccess) { err = std::string("build_hixf: key union failed: ") + hipGetErrorString(e); err_code = TAXOR_E_HIP; ok = false; }
+        if (concat) (void)hipFree(concat);
+        // the unions of the level below are not needed any more
+        if (arenas.size() >= 2 && arenas[arenas.size() - 2]) {
+            (void)hipFree(arenas[arenas.size() - 2]);
+            arenas[arenas.size() - 2] = nullptr;
         }
-        if (d_all) (void)hipFree(d_all);
-        return ok;
-    };
-    const bool ok = build(0, false, nullptr);
-    if (d_leaf) (void)hipFree(d_leaf);
-    if (rounds_out) *rounds_out = max_rounds;
-    if (!ok) return err.empty() ? err_code : bfail(err_code, err);
+        eng.stats.seconds_union += now_s() - tu;
+    }
+    sorter.release();
+    cleanup();
+    if (rc != TAXOR_OK) return rc;
+    eng.stats.seconds_total = now_s() - t0;
+    if (rounds_out) *rounds_out = eng.stats.rounds_max;
+    if (stats_out) *stats_out = eng.stats;
     return TAXOR_OK;
+}
+
+extern "C" int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
+                                          uint32_t *rounds_out)
+{
+    return build_hixf_impl(idx, keys, 0, key_off, seed0, rounds_out, nullptr);
+}
+
+extern "C" int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device, const uint64_t *key_off,
+                                            uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats)
+{
+    return build_ixf_impl(idx, ixf, keys, keys_on_device, key_off, seed0, seed_out, nullptr, stats);
+}
+
+extern "C" int taxor_gpu_index_build_hixf_ex(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off, uint64_t seed0,
+                                             taxor_build_stats *stats)
+{
+    return build_hixf_impl(idx, keys, keys_on_device, key_off, seed0, nullptr, stats);
 }

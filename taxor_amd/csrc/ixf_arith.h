@@ -146,6 +146,16 @@ TAXOR_HD ixf_probe ixf_probe_key_arith(uint64_t key, uint64_t seed, uint32_t seg
     return p;
 }
 
+// key i of a synthetic key set: a bijection of (i + salt) (the splitmix64 finaliser), so that keys are distinct without a table --
+// build bench and tests regenerate them on the host instead of holding them
+TAXOR_HD uint64_t synth_key(uint64_t i, uint64_t salt)
+{
+    uint64_t z = i + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
 // rows per segment for a bin capacity of n keys: arrayLength = 32 + 1.23*n; blockLength = arrayLength/3
 inline uint64_t ixf_seg_len(uint64_t max_bin_elements) // xorfilter.hpp:67-68
 {

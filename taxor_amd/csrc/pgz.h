@@ -285,6 +285,27 @@ inline void fixed_codes(Codes &c)
     c.pack();
 }
 
+// Bytes the reader holds: symbol buffers (chunks being decoded, decoded, pooled, the per-thread trial buffers of the block search)
+// and the resolved output it still owns (chunks not yet consumed, the recycle pool).  `live` is what the memory budget is checked
+// against BEFORE another chunk is started (ParallelGz::may_start); `peak` is its high-water mark -- the number a test of the budget
+// asserts, the process's RSS being the allocator's business (sixteen threads' arenas keep what they freed).  One meter per
+// process: the diagnostic counts every reader that is open.
+struct MemMeter {
+    std::atomic<size_t> live{0}, peak{0};
+    void add(size_t n)
+    {
+        const size_t v = live.fetch_add(n, std::memory_order_relaxed) + n;
+        size_t p = peak.load(std::memory_order_relaxed);
+        while (v > p && !peak.compare_exchange_weak(p, v, std::memory_order_relaxed)) {}
+    }
+    void sub(size_t n) { live.fetch_sub(n, std::memory_order_relaxed); }
+};
+inline MemMeter &mem_meter()
+{
+    static MemMeter m;
+    return m;
+}
+
 // symbols of a chunk: grown by realloc, never value-initialised (a std::vector would zero 32 MB per chunk before it is written),
 // and handed back to a pool when the chunk has been resolved
 struct SymBuf {
@@ -294,8 +315,8 @@ struct SymBuf {
     SymBuf(const SymBuf &) = delete;
     SymBuf &operator=(const SymBuf &) = delete;
     SymBuf(SymBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
-    SymBuf &operator=(SymBuf &&o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
-    ~SymBuf() { free(p); }
+    SymBuf &operator=(SymBuf &&o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~SymBuf() { release(); }
     size_t size() const { return cap; }
     uint16_t *data() { return p; }
     const uint16_t *data() const { return p; }
@@ -306,11 +327,25 @@ struct SymBuf {
         if (n <= cap) return;
         uint16_t *q = (uint16_t *)realloc(p, n * sizeof(uint16_t));
         if (!q) throw std::bad_alloc();
+        mem_meter().add((n - cap) * sizeof(uint16_t));
         p = q;
         cap = n;
     }
-    void release() { free(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) mem_meter().sub(cap * sizeof(uint16_t));
+        free(p);
+        p = nullptr;
+        cap = 0;
+    }
 };
+
+// how a symbol buffer grows: by half (doubling would let a chunk hold 4 bytes per output byte where 2 are needed), at least 1 M
+// symbols, never beyond the caller's bound
+inline size_t sym_grow(size_t have, size_t need, size_t max_out)
+{
+    return std::min(max_out + 320, std::max<size_t>(std::max<size_t>(have + have / 2, 1u << 20), need));
+}
 
 struct TextSet {
     bool ok[256];
@@ -324,19 +359,23 @@ struct TextSet {
 // own symbols, so a reference behind the chunk's start copies markers like anything else.  Returns false on invalid data.
 // max_out bounds the chunk (a trial decode of a candidate block start must not run away).  TEXT: every literal must be text (the
 // trial decode of a candidate block start); the check is a flag OR-ed per literal and looked at once per block, not a branch.
-template <bool TEXT>
+// STORE = false: the block is only VALIDATED -- same accept / reject, same n, nothing written and `out` not touched (what a symbol
+// is never decides whether a block is valid: literals are checked as they are decoded, a match only has to stay inside what
+// has been produced).  The block search's trial decodes run this way: they used to keep up to 8 M symbols per thread.
+template <bool TEXT, bool STORE = true>
 inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t &n_io, size_t max_out, const bool *text_ok, size_t floor = 0)
 {
     size_t n = n_io;
     uint32_t bad = 0;
     for (;;) {
-        if (n + 320 > out.size()) {
+        if (STORE && n + 320 > out.size()) {
             if (n + 320 > max_out) return false;
-            out.resize(std::min(max_out + 320, std::max<size_t>(out.size() * 2, 1u << 20)));
+            out.resize(sym_grow(out.size(), n + 320, max_out));
         }
-        uint16_t *const o0 = out.data();
+        if (!STORE && n + 320 > max_out) return false;
+        uint16_t *const o0 = STORE ? out.data() : nullptr;
         // a stretch that cannot run out of room or of input: up to 64 rounds of (refill, up to three literals or one match)
-        size_t room = (out.size() - n - 320) / 264;
+        size_t room = STORE ? (out.size() - n - 320) / 264 : 64;
         if (room > 64) room = 64;
         if (in.p + 8 * (room + 1) > in.end) room = 0;           // near the end of the input: one careful round at a time
         size_t rounds = room ? room : 1;
@@ -349,21 +388,24 @@ inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t 
             if (sym < 256 && l) {
                 if (TEXT) bad |= (uint32_t)!text_ok[sym];
                 in.drop(l);
-                o0[n++] = (uint16_t)sym;
+                if (STORE) o0[n] = (uint16_t)sym;
+                ++n;
                 e = c.lit.lookup(in.bb);
                 l = (int)(e & 0xFF);
                 sym = e >> 16;
                 if (sym < 256 && l) {
                     if (TEXT) bad |= (uint32_t)!text_ok[sym];
                     in.drop(l);
-                    o0[n++] = (uint16_t)sym;
+                    if (STORE) o0[n] = (uint16_t)sym;
+                    ++n;
                     e = c.lit.lookup(in.bb);
                     l = (int)(e & 0xFF);
                     sym = e >> 16;
                     if (sym < 256 && l) {
                         if (TEXT) bad |= (uint32_t)!text_ok[sym];
                         in.drop(l);
-                        o0[n++] = (uint16_t)sym;
+                        if (STORE) o0[n] = (uint16_t)sym;
+                        ++n;
                         continue;
                     }
                 }
@@ -390,6 +432,7 @@ inline bool decode_block_symbols(BitIn &in, const Codes &c, SymBuf &out, size_t 
             if (d > n - floor) return false;                    // (n counts the WIN window slots too: farther back than 32 KiB + chunk is invalid;
                                                                 //  floor = WIN: the stream STARTS here, nothing lies before it)
             if (in.overrun()) return false;
+            if (!STORE) { n += len; continue; }
             uint16_t *o = o0 + n;
             const uint16_t *s = o - d;
             if (d >= 8) {
@@ -421,17 +464,18 @@ struct ChunkOut {
 // blocks from start_bit on until a block boundary at or behind stop_bit (or the member's final block); text_ok != nullptr: every
 // literal must be text.  max_out bounds the output.
 inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_bit, uint64_t stop_bit, ChunkOut &co, size_t max_out, const bool *text_ok,
-                        int max_blocks = 1 << 30, int stream_start = 0)
+                        int max_blocks = 1 << 30, int stream_start = 0, bool store = true)
 {
+    // store = false: validate only (decode_block_symbols<.., false>): co.sym is not touched, co.n / end_bit / final_block are set
     // stream_start != 0: the deflate stream begins at start_bit (a gzip member): a reference behind it is invalid ("distance too far
     // back", like zlib).  1: the window slots are left as they are (64 KB of markers written per 64-KB bgzip member would double
     // the decoder's stores); 2: they are marked like any chunk's (the first chunk of a member that goes on: its successor's window
     // is cut from this output, window slots included if the chunk is short)
     BitIn in;
     in.seek(base, end, start_bit);
-    if (co.sym.size() < WIN + (1u << 16)) co.sym.resize(WIN + (1u << 16));
+    if (store && co.sym.size() < WIN + (1u << 16)) co.sym.resize(WIN + (1u << 16));
     const size_t floor = stream_start ? WIN : 0;
-    if (stream_start != 1)
+    if (store && stream_start != 1)
         for (uint32_t w = 0; w < WIN; ++w) co.sym[w] = (uint16_t)(256 + w);
     co.n = WIN;
     co.start_bit = start_bit;
@@ -460,20 +504,22 @@ inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_
             if ((len ^ nlen) != 0xFFFFu) return false;
             const uint8_t *src = base + (in.bitpos() >> 3);
             if (src + len > end) return false;
-            if (co.n + len + 320 > co.sym.size()) {
-                if (co.n + len > max_out) return false;
-                co.sym.resize(std::min(max_out + 320, std::max<size_t>(co.sym.size() * 2, co.n + len + 320)));
-            }
+            if (co.n + len > max_out) return false;
+            if (store && co.n + len + 320 > co.sym.size()) co.sym.resize(sym_grow(co.sym.size(), co.n + len + 320, max_out));
             for (uint32_t i = 0; i < len; ++i) {
                 if (text_ok && !text_ok[src[i]]) return false;
-                co.sym[co.n + i] = src[i];
+                if (store) co.sym[co.n + i] = src[i];
             }
             co.n += len;
             in.seek(base, end, (uint64_t)(src + len - base) * 8);
         } else {
             if (btype == 1) fixed_codes(codes);
             else if (!read_dynamic_header(in, codes, false)) return false;
-            if (!(text_ok ? decode_block_symbols<true>(in, codes, co.sym, co.n, max_out, text_ok, floor) : decode_block_symbols<false>(in, codes, co.sym, co.n, max_out, text_ok, floor))) return false;
+            const bool good = store ? (text_ok ? decode_block_symbols<true>(in, codes, co.sym, co.n, max_out, text_ok, floor)
+                                               : decode_block_symbols<false>(in, codes, co.sym, co.n, max_out, text_ok, floor))
+                                    : (text_ok ? decode_block_symbols<true, false>(in, codes, co.sym, co.n, max_out, text_ok, floor)
+                                               : decode_block_symbols<false, false>(in, codes, co.sym, co.n, max_out, text_ok, floor));
+            if (!good) return false;
         }
         if (bfinal) { co.final_block = true; co.end_bit = in.bitpos(); co.ok = true; return true; }
     }
@@ -484,7 +530,7 @@ inline bool decode_from(const uint8_t *base, const uint8_t *end, uint64_t start_
 inline uint64_t find_block(const uint8_t *base, const uint8_t *end, uint64_t from_bit, uint64_t to_bit, const bool *text_ok)
 {
     static thread_local Codes codes;
-    static thread_local ChunkOut trial;
+    ChunkOut trial;                                        // (validated only: no symbols are kept)
     const uint64_t size_bits = (uint64_t)(end - base) * 8;
     if (to_bit + 64 > size_bits) to_bit = size_bits > 64 ? size_bits - 64 : 0;
     for (uint64_t b = from_bit; b < to_bit; ++b) {
@@ -497,7 +543,7 @@ inline uint64_t find_block(const uint8_t *base, const uint8_t *end, uint64_t fro
         in.seek(base, end, b + 3);
         if (!read_dynamic_header(in, codes, true)) continue;
         // the whole block must decode (at most 8 MiB of output) and be followed by something that can be a block header
-        if (!decode_from(base, end, b, ~0ull, trial, WIN + (8u << 20), text_ok, 1)) continue;
+        if (!decode_from(base, end, b, ~0ull, trial, WIN + (8u << 20), text_ok, 1, 0, false)) continue;
         if (trial.n == WIN) continue;
         const uint64_t e = trial.end_bit;
         if (e + 3 <= size_bits) {
@@ -597,19 +643,14 @@ public:
     ~ParallelGz()
     {
         shutdown();
-#ifdef TAXOR_PGZ_DEVICE
-        for (auto *d : dev_)
-            if (d) taxor_gpu_inflater_destroy(d);
-#endif
+        drop_outputs();
+        for (auto &v : out_pool_) pgz_detail::mem_meter().sub(v.capacity());
         if (map_) munmap(const_cast<uint8_t *>(map_), size_);
     }
 
     // true: `path` is a gzip file large enough to be worth the threads; inflating starts at once.  chunk_bytes = compressed bytes
     // per chunk (0: 4 MiB).
-    // device >= 0 (builds with TAXOR_PGZ_DEVICE): the chunks are decoded on that GPU, see open_device below; if it has no room the
-    // host path stays and *device_note says why.
-    bool open(const std::string &path, unsigned threads, size_t chunk_bytes = 0, size_t min_size = 8u << 20, int device = -1, size_t batch_chunks = 0,
-              std::string *device_note = nullptr)
+    bool open(const std::string &path, unsigned threads, size_t chunk_bytes = 0, size_t min_size = 8u << 20)
     {
         const int fd = ::open(path.c_str(), O_RDONLY);
         if (fd < 0) return false;
@@ -624,49 +665,11 @@ public:
         threads_ = std::max(1u, threads);
         chunk_bytes_ = chunk_bytes ? chunk_bytes : (4u << 20);
         lookahead_ = 2 * threads_ + 2;
-#ifdef TAXOR_PGZ_DEVICE
-        if (device >= 0) (void)open_device(device, batch_chunks, 6.0, device_note);
-#else
-        (void)device; (void)batch_chunks; (void)device_note;
-#endif
         start_member(0);
         for (unsigned t = 0; t < threads_; ++t) th_.emplace_back([this] { worker(); });
         return true;
     }
 
-#ifdef TAXOR_PGZ_DEVICE
-    // The chunks' decoding on a GPU (taxor_amd/csrc/inflate.hip through the C ABI): the host threads only look for the block starts
-    // and check the CRCs; a driver thread hands batches of consecutive chunks to the device (one wave per chunk), ties them on the
-    // host (a chunk that does not start where its predecessor ended, or that the device gave up on, is decoded here and put in its
-    // place), and has the device chain the windows and resolve the symbols.  Call right after open(); false (and the host path
-    // stays) if the device has no room.  batch_chunks: chunks per batch (0: 512); ratio_cap: output bytes per input byte the arena
-    // is sized for (chunks beyond it are decoded on the host).  Called by open() before any thread runs.
-    uint64_t chunks_device = 0, chunks_host_fallback = 0;
-    std::atomic<uint64_t> ns_device{0};
-private:
-    bool open_device(int device, size_t batch_chunks = 0, double ratio_cap = 6.0, std::string *why = nullptr)
-    {
-        const size_t n_total = (size_ + chunk_bytes_ - 1) / chunk_bytes_;
-        dev_batch_ = std::max<size_t>(1, std::min<size_t>(batch_chunks ? batch_chunks : 512, n_total));
-        dev_slack_ = std::max<size_t>(chunk_bytes_, 1u << 20);
-        const uint64_t in_cap = (uint64_t)dev_batch_ * chunk_bytes_ + dev_slack_ + 64;
-        const uint64_t syms = (uint64_t)dev_batch_ * ((uint64_t)(ratio_cap * (double)chunk_bytes_) + pgz_detail::WIN + 256) + (uint64_t)(ratio_cap * (double)chunk_bytes_) * 2;
-        if (taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_[0]) != TAXOR_OK) {
-            if (why) *why = taxor_gpu_last_error();
-            dev_[0] = nullptr;
-            return false;
-        }
-        n_dev_ = 1;
-        // a second one, so that a batch is decoded while its predecessor is tied and resolved (without it: one after the other)
-        if (n_total > dev_batch_ && taxor_gpu_inflater_create(device, in_cap, (uint32_t)dev_batch_, syms, &dev_[1]) == TAXOR_OK) n_dev_ = 2;
-        else dev_[1] = nullptr;
-        lookahead_ = std::max(lookahead_, (size_t)(n_dev_ + 1) * dev_batch_ + 2);
-        th_.emplace_back([this] { device_decoder(); });
-        th_.emplace_back([this] { device_tier(); });
-        return true;
-    }
-public:
-#endif
 
     // next bytes of the decompressed stream; 0 at the end.  Throws std::runtime_error on a corrupt stream.
     size_t read(char *dst, size_t n)
@@ -690,7 +693,9 @@ public:
     bool take(std::vector<char> &dst)
     {
         if (!next_chunk()) return false;
+        pgz_detail::mem_meter().sub(cur_out_->capacity());
         dst.swap(*cur_out_);
+        pgz_detail::mem_meter().add(cur_out_->capacity());      // (the caller's previous buffer: recycled or dropped when this chunk is retired)
         cur_pos_ = 0;
         cur_out_->clear();
         return true;
@@ -699,14 +704,13 @@ public:
     // a buffer that take() handed out, when the caller is done with it: the next chunk is resolved into it instead of into fresh
     // pages (a chunk's 16 MB from the allocator are mapped, faulted in and zeroed before the first byte is written -- on 32 threads
     // that is the allocator's lock and the kernel's, not memory bandwidth).  Any thread.
-    void recycle(std::vector<char> &&v)
-    {
-        if (v.capacity() < (1u << 20)) return;
-        std::lock_guard<std::mutex> lk(pool_mu_);
-        size_t held = v.capacity();
-        for (const auto &q : out_pool_) held += q.capacity();
-        if (out_pool_.size() < 2 * (size_t)threads_ + 8 && held <= budget_ / 4) out_pool_.push_back(std::move(v));
-    }
+    void recycle(std::vector<char> &&v) { pool_out(std::move(v), false); }
+
+    // bytes this process's readers hold right now / at most so far (symbols, resolved output not yet handed out, both pools):
+    // what set_memory_budget() bounds, up to one chunk (the one the consumer is waiting for is always decoded)
+    static size_t memory_in_flight() { return pgz_detail::mem_meter().live.load(); }
+    static size_t memory_high_water() { return pgz_detail::mem_meter().peak.load(); }
+    size_t largest_chunk_bytes() const { return largest_chunk_.load(); }      // symbols + output of the largest chunk so far
 
     // after take(): go on with read() (the caller has consumed what it took)
     void switch_to_read() { cur_pos_ = cur_out_ ? cur_out_->size() : 0; }
@@ -727,8 +731,16 @@ private:
         std::vector<char> out;
         size_t out_len = 0;                             // out.size() when it was resolved (the vector itself may have been taken)
         uint32_t crc = 0;
-        uint64_t found_start = ~0ull;                   // device mode: the block start the host found (state 2), ~0 if none
     };
+
+    // output buffers of chunks that will not be consumed (behind a member's final block, or at destruction) leave the meter
+    void drop_outputs()
+    {
+        for (auto &c : chunks_) {
+            pgz_detail::mem_meter().sub(c.out.capacity());
+            std::vector<char>().swap(c.out);
+        }
+    }
 
     void shutdown()
     {
@@ -751,6 +763,7 @@ private:
         std::unique_lock<std::mutex> lk(mu_);
         n_live_ = 0;                                           // no new decodes of the old member ...
         cv_done_.wait(lk, [&] { return busy_ == 0; });         // ... and none of them still running on its chunks
+        drop_outputs();
         chunks_.clear();
         resolve_q_.clear();
         member_data_ = off + h;
@@ -761,12 +774,6 @@ private:
             chunks_.back().nominal_stop = std::min(endb, b + (uint64_t)chunk_bytes_ * 8);
         }
         next_decode_ = 0;
-#ifdef TAXOR_PGZ_DEVICE
-        dec_next_ = 0;
-        for (auto &q : dev_q_) slot_free_[q->slot] = true;
-        dev_q_.clear();
-        ++member_gen_;
-#endif
         tied_ = 0;
         cur_ = 0;
         ratio_seen_ = 1.0;
@@ -774,15 +781,6 @@ private:
         member_crc_ = crc32(0L, Z_NULL, 0);
         member_len_ = 0;
         text_ = true;
-        if (device_mode()) {
-            // is it text?  (then candidate block starts must decode to text as well.)  The host path learns it from chunk 0's symbols
-            // when it ties them; here they never come to the host, so the member's first block is decoded for it now
-            static const TextSet ts;
-            ChunkOut trial;
-            if (decode_from(map_, map_ + size_, first, ~0ull, trial, WIN + (8u << 20), nullptr, 1))
-                for (size_t k = WIN; k < std::min<size_t>(trial.n, WIN + (1u << 16)); ++k)
-                    if (trial.sym[k] >= 256 || !ts.ok[trial.sym[k]]) { text_ = false; break; }
-        }
         ++members;
         cv_work_.notify_all();
         cv_done_.notify_all();
@@ -794,7 +792,7 @@ private:
         static const TextSet ts;
         std::unique_lock<std::mutex> lk(mu_);
         for (;;) {
-            cv_work_.wait(lk, [&] { return stop_ || !resolve_q_.empty() || (next_decode_ < n_live_ && next_decode_ < cur_ + eff_lookahead()); });
+            cv_work_.wait(lk, [&] { return stop_ || !resolve_q_.empty() || (next_decode_ < n_live_ && next_decode_ < cur_ + eff_lookahead() && may_start()); });
             if (stop_) return;
             if (!resolve_q_.empty()) {
                 const size_t i = resolve_q_.front();
@@ -805,12 +803,6 @@ private:
                 const auto t0 = std::chrono::steady_clock::now();
                 std::string what;               // an exception (std::bad_alloc of a huge chunk) must not leave a std::thread: next_chunk() rethrows it
                 try {
-#ifdef TAXOR_PGZ_DEVICE
-                    if (dev_[0]) {
-                        const uint8_t *o = reinterpret_cast<const uint8_t *>(c.out.data());
-                        c.crc = pgz_detail::crc32_bytes((uint32_t)crc32(0L, Z_NULL, 0), o, c.out_len);
-                    } else
-#endif
                     resolve(c);
                 } catch (const std::exception &ex) { what = std::string("gzip reader: ") + ex.what(); } catch (...) { what = "gzip reader: unknown exception"; }
                 ns_resolve += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -825,26 +817,7 @@ private:
             Chunk &c = chunks_[i];
             c.state = 1;
             ++busy_;
-#ifdef TAXOR_PGZ_DEVICE
-            if (dev_[0]) {       // only the block start; the decoding is the device's
-                const bool text = text_;
-                lk.unlock();
-                const auto t0 = std::chrono::steady_clock::now();
-                uint64_t s = ~0ull;
-                std::string what;
-                try {
-                    s = i > 0 ? find_block(map_, map_ + size_, c.nominal_start, c.nominal_stop, text ? ts.ok : nullptr) : c.nominal_start;
-                } catch (const std::exception &ex) { what = std::string("gzip reader: ") + ex.what(); } catch (...) { what = "gzip reader: unknown exception"; }
-                ns_find += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-                lk.lock();
-                if (!what.empty() && dev_error_.empty()) dev_error_ = what;
-                c.found_start = s;
-                --busy_;
-                c.state = 2;
-                cv_done_.notify_all();
-                continue;
-            }
-#endif
+            ++decoding_;
             {
                 std::lock_guard<std::mutex> pl(pool_mu_);
                 if (!pool_.empty()) { c.co.sym = std::move(pool_.back()); pool_.pop_back(); }
@@ -872,6 +845,7 @@ private:
             lk.lock();
             if (!what.empty() && dev_error_.empty()) dev_error_ = what;
             --busy_;
+            --decoding_;
             c.state = 2;
             cv_done_.notify_all();
         }
@@ -886,7 +860,6 @@ private:
     // is cut off at 8x that ratio (at least 32:1) -- such a chunk is decoded again, alone, when it is tied (tie(), up to 1032:1).
     size_t eff_lookahead() const
     {
-        if (device_mode()) return lookahead_;                       // (the device arena has a ratio cap of its own)
         if (tied_ == 0) return std::min<size_t>(lookahead_, (size_t)threads_ + 1);
         const double per_chunk = 3.0 * ratio_seen_ * (double)chunk_bytes_;      // symbols + resolved bytes
         return (size_t)std::max(1.0, std::min((double)lookahead_, (double)budget_ / std::max(1.0, per_chunk)));
@@ -897,14 +870,58 @@ private:
         return (size_t)(r * (double)chunk_bytes_) + (1u << 20);
     }
 
+    // The budget is checked against what is HELD (pgz_detail::mem_meter: every symbol buffer, every output buffer the reader owns,
+    // both pools), before a chunk is started: it may start if the held bytes plus what the chunks now being decoded may still
+    // grow to plus its own expected need stay inside the budget -- or if nothing else is in flight (the chunk the consumer waits
+    // for is always decoded, so the bound is budget + one chunk).  mu_ held.
+    // (a chunk's need: 2 B of symbols per output byte, grown by halves, + the resolved bytes; before the member's first chunk is tied
+    // its ratio is taken as 8:1 -- a speculative decode is cut off at 32:1 then, speculative_out)
+    // and never less than the largest chunk met so far: a chunk ends at the first block boundary behind its nominal end, and the
+    // blocks of very repetitive data are long)
+    size_t chunk_need() const
+    {
+        const size_t est = (size_t)(3.2 * (tied_ == 0 ? 8.0 : ratio_seen_) * (double)chunk_bytes_) + 2 * pgz_detail::WIN + (1u << 20);
+        return std::max(est, largest_chunk_.load(std::memory_order_relaxed));
+    }
+    bool may_start() const
+    {
+        if (next_decode_ <= cur_) return true;
+        const size_t need = chunk_need();
+        return pgz_detail::mem_meter().live.load(std::memory_order_relaxed) + (decoding_ + 1) * need <= budget_ + pooled_bytes();
+    }
+    size_t pooled_bytes() const          // buffers a starting chunk takes over instead of allocating (at most one of each kind)
+    {
+        std::lock_guard<std::mutex> lk(pool_mu_);
+        size_t a = 0, b = 0;
+        for (const auto &q : pool_) a = std::max(a, q.cap * sizeof(uint16_t));
+        for (const auto &q : out_pool_) b = std::max(b, q.capacity());
+        return a + b;
+    }
+
     void give_back(pgz_detail::SymBuf &b)
     {
         if (!b.p) return;
         std::lock_guard<std::mutex> lk(pool_mu_);
         size_t held = b.cap * sizeof(uint16_t);
         for (const auto &q : pool_) held += q.cap * sizeof(uint16_t);
-        if (pool_.size() < 4 * (size_t)threads_ && held <= budget_ / 4) pool_.push_back(std::move(b));     // (the pools are part of the budget)
+        if (pool_.size() < 4 * (size_t)threads_ && held <= budget_ / 8) pool_.push_back(std::move(b));     // (the pools are part of the budget)
         else b.release();
+    }
+
+    // an output buffer comes (back) to the pool or is dropped; counted: it is on the meter already (a chunk's own buffer)
+    void pool_out(std::vector<char> &&v, bool counted)
+    {
+        const size_t cap = v.capacity();
+        bool kept = false;
+        if (cap >= (1u << 20)) {
+            std::lock_guard<std::mutex> lk(pool_mu_);
+            size_t held = cap;
+            for (const auto &q : out_pool_) held += q.capacity();
+            if (out_pool_.size() < 2 * (size_t)threads_ + 8 && held <= budget_ / 8) { out_pool_.push_back(std::move(v)); kept = true; }
+        }
+        if (kept && !counted) pgz_detail::mem_meter().add(cap);
+        if (!kept && counted) pgz_detail::mem_meter().sub(cap);
+        if (!kept) std::vector<char>().swap(v);
     }
 
     void resolve(Chunk &c)
@@ -924,11 +941,18 @@ private:
             }
         }
         if (c.out.capacity() < n) {
+            pgz_detail::mem_meter().sub(c.out.capacity());
             std::vector<char>().swap(c.out);
-            c.out.reserve(n + n / 8);
+            c.out.reserve(n + n / 16);
+            pgz_detail::mem_meter().add(c.out.capacity());
         }
         c.out.resize(n);
         c.out_len = n;
+        {
+            const size_t mine = c.co.sym.cap * sizeof(uint16_t) + c.out.capacity();
+            size_t seen = largest_chunk_.load(std::memory_order_relaxed);
+            while (mine > seen && !largest_chunk_.compare_exchange_weak(seen, mine, std::memory_order_relaxed)) {}
+        }
         const uint16_t *s = c.co.sym.data() + WIN;
         const uint8_t *w = c.window.data();
         uint8_t *o = reinterpret_cast<uint8_t *>(c.out.data());
@@ -980,6 +1004,7 @@ private:
             // not where the stream says the chunk starts (or it failed): decode it from the right place -- nothing speculative
             lk.unlock();
             ChunkOut co;
+            co.sym = std::move(c.co.sym);                      // (what the speculative decode left is of no use: its buffer is)
             const bool ok = decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr, 1 << 30, i == 0 ? 2 : 0);
             lk.lock();
             if (!ok) throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
@@ -1012,222 +1037,6 @@ private:
         return true;
     }
 
-    bool device_mode() const
-    {
-#ifdef TAXOR_PGZ_DEVICE
-        return dev_[0] != nullptr;
-#else
-        return false;
-#endif
-    }
-
-#ifdef TAXOR_PGZ_DEVICE
-    // Two stages, so that the device decodes one batch while the previous one is tied, resolved, copied out and CRC-checked:
-    //   device_decoder : consecutive chunks whose block starts are known -> upload + one wave per chunk -> queue (two inflaters taken in turn)
-    //   device_tier    : in order: every chunk must start where its predecessor ended (else: decoded here, its symbols put in the
-    //                    device's place) -> windows chained and symbols resolved on the device -> bytes to the host -> CRC queue
-    struct DevBatch {
-        size_t b0 = 0, k = 0;
-        uint64_t base = 0, gen = 0;
-        int slot = 0;
-        std::vector<taxor_inflate_chunk> req;
-        std::vector<taxor_inflate_result> res;
-        std::string err;
-    };
-
-    void device_decoder()
-    {
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            size_t b0 = 0, k = 0;
-            int slot = -1;
-            cv_done_.wait(lk, [&] {
-                if (stop_ || !dev_error_.empty()) return true;
-                slot = -1;
-                for (int q = 0; q < n_dev_; ++q)
-                    if (slot_free_[(dev_turn_ + q) % n_dev_]) { slot = (dev_turn_ + q) % n_dev_; break; }
-                if (slot < 0) return false;
-                b0 = dec_next_;
-                if (b0 >= n_live_ || b0 >= cur_ + lookahead_) return false;
-                k = std::min(dev_batch_, n_live_ - b0);
-                if (b0 + k > cur_ + lookahead_) k = cur_ + lookahead_ - b0;
-                for (size_t i = 0; i < k; ++i)
-                    if (chunks_[b0 + i].state != 2) { k = i; break; }     // (a batch is a launch: never a partial one while more is coming)
-                return k > 0 && k >= std::min<size_t>({dev_batch_, n_live_ - b0, cur_ + lookahead_ - b0});
-            });
-            if (stop_ || !dev_error_.empty()) return;
-            std::unique_ptr<DevBatch> B(new DevBatch);
-            B->b0 = b0;
-            B->k = k;
-            B->slot = slot;
-            B->gen = member_gen_;
-            slot_free_[slot] = false;
-            dev_turn_ = (slot + 1) % n_dev_;
-            dec_next_ = b0 + k;
-            ++busy_;
-            // the batch's input: from the byte of the first start to the last chunk's nominal end plus slack for its last block
-            uint64_t lo_bit = chunks_[b0].nominal_start;
-            for (size_t i = 0; i < k; ++i)
-                if (chunks_[b0 + i].found_start != ~0ull) lo_bit = std::min(lo_bit, chunks_[b0 + i].found_start);
-            const uint64_t lo_byte = (lo_bit / 8) & ~3ull;
-            const uint64_t hi_byte = std::min<uint64_t>(size_, chunks_[b0 + k - 1].nominal_stop / 8 + 1 + dev_slack_);
-            B->base = lo_byte * 8;
-            B->req.assign(k, taxor_inflate_chunk{0, 0, 0});
-            B->res.assign(k, taxor_inflate_result{});
-            for (size_t i = 0; i < k; ++i) {
-                const Chunk &c = chunks_[b0 + i];
-                B->req[i].weight = c.nominal_stop - c.nominal_start;
-                if (c.found_start == ~0ull || c.found_start < B->base) continue;        // no start found: a slot that decodes nothing
-                B->req[i].start_bit = c.found_start - B->base;
-                B->req[i].stop_bit = std::max(c.found_start, c.nominal_stop) - B->base;
-            }
-            lk.unlock();
-            const auto t0 = std::chrono::steady_clock::now();
-            // (only begun: the other inflater's batch may be decoding at this moment -- a batch is a wave per chunk, and the device has
-            // room for two batches' waves; device_tier ends it)
-            if (taxor_gpu_inflate_decode_begin(dev_[slot], map_ + lo_byte, hi_byte - lo_byte, B->req.data(), (uint32_t)k) != TAXOR_OK)
-                B->err = std::string("gzip on the device: ") + taxor_gpu_last_error();
-            ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            lk.lock();
-            --busy_;
-            if (B->gen != member_gen_) slot_free_[slot] = true;        // the member ended in front of this batch: nobody wants it
-            else dev_q_.push_back(std::move(B));
-            cv_done_.notify_all();
-        }
-    }
-
-    void device_tier()
-    {
-        using namespace pgz_detail;
-        std::vector<uint8_t *> outp;
-        std::vector<uint8_t> win(WIN, 0), win_next(WIN, 0);
-        std::unique_lock<std::mutex> lk(mu_);
-        for (;;) {
-            cv_done_.wait(lk, [&] { return stop_ || !dev_q_.empty(); });
-            if (stop_) return;
-            std::unique_ptr<DevBatch> B = std::move(dev_q_.front());
-            dev_q_.pop_front();
-            const size_t b0 = B->b0, k = B->k;
-            taxor_gpu_inflater *dev = dev_[B->slot];
-            if (B->gen != member_gen_ || b0 >= n_live_) {                // decoded for a member that has ended since (or beyond its final block): nobody's
-                (void)taxor_gpu_inflate_decode_end(dev, B->res.data());
-                slot_free_[B->slot] = true;
-                cv_done_.notify_all();
-                continue;
-            }
-            ++busy_;
-            const uint64_t want0 = b0 == 0 ? (uint64_t)member_data_ * 8 : prev_end_;
-            if (b0 == 0) std::fill(win.begin(), win.end(), 0);
-            lk.unlock();
-            std::string err = B->err;
-            size_t count = 0;
-            const auto t0 = std::chrono::steady_clock::now();
-            if (err.empty() && taxor_gpu_inflate_decode_end(dev, B->res.data()) != TAXOR_OK) err = std::string("gzip on the device: ") + taxor_gpu_last_error();
-            if (err.empty()) try {
-                const uint64_t base = B->base;
-                const std::vector<taxor_inflate_result> &res = B->res;
-                // tie: every chunk must start where its predecessor ended
-                uint64_t want = want0;
-                for (size_t i = 0; i < k; ++i) {
-                    Chunk &c = chunks_[b0 + i];
-                    const bool usable = c.found_start != ~0ull && c.found_start >= base && res[i].status == 0 && c.found_start == want;
-                    if (usable) {
-                        c.co.start_bit = want;
-                        c.co.end_bit = res[i].end_bit + base;
-                        c.co.final_block = res[i].final_block != 0;
-                        c.co.n = WIN + (size_t)res[i].n_out;
-                        c.co.ok = true;
-                        ++chunks_device;
-                    } else {
-                        ChunkOut co;
-                        if (!decode_from(map_, map_ + size_, want, std::max(want, c.nominal_stop), co, WIN + max_chunk_out() * 2, nullptr))
-                            throw std::runtime_error("gzip: invalid deflate data near byte " + std::to_string(want / 8));
-                        // its symbols go where the device's would be -- or, if the arena has no room for them (a chunk of zeros is a
-                        // thousand times its size) or the stream ran back behind the batch's input, stay here and are resolved here,
-                        // between two device runs
-                        const bool on_dev = co.end_bit >= base &&
-                                            taxor_gpu_inflate_replace(dev, (uint32_t)i, co.sym.data() + WIN, co.n - WIN, co.end_bit - base, co.final_block ? 1 : 0) == TAXOR_OK;
-                        if (c.found_start != ~0ull) ++chunks_redecoded;
-                        c.co.start_bit = want;
-                        c.co.end_bit = co.end_bit;
-                        c.co.final_block = co.final_block;
-                        c.co.n = co.n;
-                        c.co.ok = true;
-                        if (on_dev) give_back(co.sym);
-                        else { c.co.sym = std::move(co.sym); c.found_start = ~1ull; }         // (~1: resolved on the host)
-                        ++chunks_host_fallback;
-                    }
-                    want = c.co.end_bit;
-                    count = i + 1;
-                    if (c.co.final_block) break;
-                }
-                outp.resize(count);
-                for (size_t i = 0; i < count; ++i) {
-                    Chunk &c = chunks_[b0 + i];
-                    if (c.found_start == ~1ull) continue;              // resolved on the host below: resolve() makes its buffer
-                    const size_t n = c.co.n - WIN;
-                    {
-                        std::lock_guard<std::mutex> pl(pool_mu_);
-                        if (!out_pool_.empty()) {
-                            size_t best = 0;
-                            for (size_t q = 1; q < out_pool_.size(); ++q)
-                                if (out_pool_[q].capacity() > out_pool_[best].capacity()) best = q;
-                            c.out.swap(out_pool_[best]);
-                            out_pool_[best].swap(out_pool_.back());
-                            out_pool_.pop_back();
-                        }
-                    }
-                    if (c.out.capacity() < n) { std::vector<char>().swap(c.out); c.out.reserve(n + n / 8); }
-                    c.out.resize(n);
-                    c.out_len = n;
-                    outp[i] = reinterpret_cast<uint8_t *>(c.out.data());
-                }
-                for (size_t i = 0; i < count;) {
-                    if (chunks_[b0 + i].found_start == ~1ull) {
-                        Chunk &c = chunks_[b0 + i];
-                        c.window = win;
-                        next_window_of(c.window, c.co, win_next);
-                        resolve(c);                                   // (bytes + CRC; the CRC queue computes it once more: rare)
-                        win.swap(win_next);
-                        ++i;
-                        continue;
-                    }
-                    size_t j = i;
-                    while (j < count && chunks_[b0 + j].found_start != ~1ull) ++j;
-                    if (taxor_gpu_inflate_resolve(dev, win.data(), (uint32_t)i, (uint32_t)(j - i), outp.data() + i, win_next.data()) != TAXOR_OK)
-                        throw std::runtime_error(std::string("gzip on the device: ") + taxor_gpu_last_error());
-                    win.swap(win_next);
-                    i = j;
-                }
-            } catch (const std::exception &ex) { err = ex.what(); }
-            ns_device += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            lk.lock();
-            --busy_;
-            slot_free_[B->slot] = true;
-            if (!err.empty()) {
-                dev_error_ = err;
-                cv_done_.notify_all();
-                return;
-            }
-            for (size_t i = 0; i < count; ++i) {
-                Chunk &c = chunks_[b0 + i];
-                prev_end_ = c.co.end_bit;
-                ++chunks_total;
-                if (c.co.final_block) n_live_ = b0 + i + 1;
-                c.state = 3;
-                resolve_q_.push_back(b0 + i);
-            }
-            tied_ = b0 + count;
-            if (count < k || (count > 0 && chunks_[b0 + count - 1].co.final_block)) {   // the member ended inside (or exactly at the end of) this batch: what was decoded beyond is nobody's
-                for (auto &q : dev_q_) slot_free_[q->slot] = true;
-                dev_q_.clear();
-                ++member_gen_;
-            }
-            cv_work_.notify_all();
-            cv_done_.notify_all();
-        }
-    }
-#endif
 
     // make the next chunk's bytes current; false at the end of the file
     bool next_chunk()
@@ -1238,16 +1047,15 @@ private:
             member_crc_ = (uint32_t)crc32_combine(member_crc_, c.crc, (z_off_t)c.out_len);
             member_len_ += c.out_len;
             bytes_out += c.out_len;
-            recycle(std::move(c.out));                          // (read(): consumed; take(): an empty vector, dropped)
+            pool_out(std::move(c.out), true);                   // (read(): consumed; take(): the caller's previous buffer)
             std::vector<char>().swap(c.out);
             c.state = 5;
             cur_out_ = nullptr;
             ++cur_;
             cv_work_.notify_all();
-            if (device_mode()) cv_done_.notify_all();
         }
         for (;;) {
-            while (!device_mode() && tied_ < n_live_ && tied_ < cur_ + std::max<size_t>(eff_lookahead(), 1) && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
+            while (tied_ < n_live_ && tied_ < cur_ + std::max<size_t>(eff_lookahead(), 1) && chunks_[tied_].state >= 2 && chunks_[tied_].state < 3) {
                 if (!tie(lk, tied_)) break;
                 ++tied_;
             }
@@ -1299,8 +1107,9 @@ private:
     std::deque<size_t> resolve_q_;
     std::vector<pgz_detail::SymBuf> pool_;
     std::vector<std::vector<char>> out_pool_;
-    std::mutex pool_mu_;
-    size_t next_decode_ = 0, tied_ = 0, cur_ = 0, n_live_ = 0, busy_ = 0;
+    mutable std::mutex pool_mu_;
+    std::atomic<size_t> largest_chunk_{0};
+    size_t next_decode_ = 0, tied_ = 0, cur_ = 0, n_live_ = 0, busy_ = 0, decoding_ = 0;
     uint64_t prev_end_ = 0;
     std::vector<uint8_t> next_window_;
     uint32_t member_crc_ = 0;
@@ -1309,14 +1118,6 @@ private:
     std::vector<char> *cur_out_ = nullptr;
     size_t cur_pos_ = 0;
     std::string dev_error_;
-#ifdef TAXOR_PGZ_DEVICE
-    taxor_gpu_inflater *dev_[2] = {nullptr, nullptr};
-    int n_dev_ = 0, dev_turn_ = 0;
-    bool slot_free_[2] = {true, true};
-    size_t dev_batch_ = 512, dev_slack_ = 4u << 20, dec_next_ = 0;
-    uint64_t member_gen_ = 0;
-    std::deque<std::unique_ptr<DevBatch>> dev_q_;
-#endif
 };
 
 } // namespace fastx

@@ -3,7 +3,6 @@
 // (include/taxor_gpu.h).  Host work here: argument parsing (:32-80), sanity checks (:97-151), FASTA/FASTQ(.gz)
 // reading (:181-184), batching (:315-326) and output (:268-311, :343).
 #include "../../include/taxor_gpu_tools.h"
-#define TAXOR_PGZ_DEVICE 1      // pgz.h: the chunks of a single-member .gz may be decoded on a GPU (inflate.hip through the C ABI)
 #include "fastx.h"
 #include "tuning.h"
 #include "ixf_arith.h"
@@ -372,17 +371,7 @@ double produce_batches(const std::string &query, const Config &cfg, bool allow_r
         // one member (what `gzip reads.fastq` writes): inflated speculatively from the middle on all of this file's threads (pgz.h);
         // --sequential and small files keep the one zlib stream
         if (!multi && allow_ranges && gz_threads > 1) {
-            // TAXOR_CLI_GPU_INFLATE=1 (under TAXOR_TUNING): the chunks are decoded on the first search device (inflate.hip) -- half-MiB
-            // chunks, 2048 to a batch: a wave decodes ~5 M symbols a second, the device's rate is the number of chunks in flight
-            static const int dev_inflate = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE"); return e ? atoi(e) : 0; }();
-            static const double dev_chunk_mb = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE_CHUNK_MB"); return e ? atof(e) : 0.5; }();
-            static const int dev_batch = [] { const char *e = tune_env("TAXOR_CLI_GPU_INFLATE_BATCH"); return e ? atoi(e) : 2048; }();
-            std::string note;
-            if (dev_inflate && !cfg.gpus.empty())
-                single = pgz.open(query, gz_threads, (size_t)(dev_chunk_mb * 1048576.0), 8u << 20, cfg.gpus[0], (size_t)dev_batch, &note);
-            else
-                single = pgz.open(query, gz_threads);
-            if (!note.empty()) fprintf(stderr, "[taxor] gzip chunks are decoded on the host (%s)\n", note.c_str());
+            single = pgz.open(query, gz_threads);
         }
     } catch (const std::exception &ex) { die(ex.what()); }
     if (single || multi) {
@@ -939,22 +928,17 @@ int main(int argc, char **argv)
         // decompresses (to a file, or nowhere) and reports the rate, the output's CRC-32 and how many chunks had to be decoded twice
         std::string in, out_path;
         unsigned threads = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
-        size_t chunk = 0, batch = 0;
-        int gpu = -1;
+        size_t chunk = 0;
         for (int i = 2; i < argc; ++i) {
             if (strcmp(argv[i], "--query-file") == 0 && i + 1 < argc) in = argv[++i];
             else if (strcmp(argv[i], "--threads") == 0 && i + 1 < argc) threads = (unsigned)atoi(argv[++i]);
             else if (strcmp(argv[i], "--chunk-mb") == 0 && i + 1 < argc) chunk = (size_t)(atof(argv[++i]) * 1048576.0);
-            else if (strcmp(argv[i], "--gpu") == 0 && i + 1 < argc) gpu = atoi(argv[++i]);                 // decode the chunks on this device
-            else if (strcmp(argv[i], "--batch-chunks") == 0 && i + 1 < argc) batch = (size_t)atoi(argv[++i]);
             else if (strcmp(argv[i], "--output-file") == 0 && i + 1 < argc) out_path = argv[++i];
         }
         if (in.empty() || !file_exists(in)) die("usage: taxor inflate --query-file <x.gz> [--threads n] [--chunk-mb m] [--output-file out]");
         fastx::ParallelGz g;
         const double t0 = now();
-        std::string note;
-        if (!g.open(in, threads, chunk, 0, gpu, batch, &note)) die(in + " is not a gzip file");
-        if (!note.empty()) fprintf(stderr, "device decoding not available (%s): decoding on the host\n", note.c_str());
+        if (!g.open(in, threads, chunk, 0)) die(in + " is not a gzip file");
         FILE *of = out_path.empty() ? nullptr : fopen(out_path.c_str(), "wb");
         if (!out_path.empty() && !of) die("cannot write " + out_path);
         std::vector<char> buf;
@@ -974,10 +958,7 @@ int main(int argc, char **argv)
         printf("%llu bytes in %.3f s = %.2f GB/s on %u threads; %llu member(s), %llu chunks, %llu decoded again from a corrected start; CRC-32 and length of every member verified\n",
                (unsigned long long)total, dt, total / 1e9 / dt, threads, (unsigned long long)g.members, (unsigned long long)g.chunks_total, (unsigned long long)g.chunks_redecoded);
         printf("worker seconds: block search %.3f, decode %.3f, marker resolution + CRC %.3f\n", g.ns_find / 1e9, g.ns_decode / 1e9, g.ns_resolve / 1e9);
-        if (gpu >= 0)
-            printf("device: %llu chunks decoded on GPU %d, %llu on the host (no block start found, a start that was none, or more output than the arena's share); "
-                   "%.3f s of the driver thread inside batches (upload, decode, tie, resolve, download)\n",
-                   (unsigned long long)g.chunks_device, gpu, (unsigned long long)g.chunks_host_fallback, g.ns_device / 1e9);
+        printf("memory held by the reader at most: %.1f MB (largest chunk %.1f MB)\n", fastx::ParallelGz::memory_high_water() / 1048576.0, g.largest_chunk_bytes() / 1048576.0);
         return 0;
     }
     if (argc > 1 && strcmp(argv[1], "pin") == 0) return pin_command(argc, argv);   // published .hixf + reference TSV -> committed parity fixture

@@ -231,6 +231,27 @@ class GpuIndex:
         check(_lib.lib().taxor_gpu_index_build_hixf(self._h, _p(keys) if keys.size else None, _p(off), int(seed0), C.byref(rounds)))
         return int(rounds.value)
 
+    def build_hixf_synth(self, bin_counts, salt=1, seed0=1):
+        """GPU construction of the whole hierarchy from SYNTHETIC keys generated on the device: technical bin g (index bin
+        order: all bins of IXF 0, then IXF 1, ...) receives the keys synth_key(i, salt) for i in [off[g], off[g+1]), off =
+        cumulative bin_counts (merged bins: 0).  Nothing crosses PCIe; a checker regenerates the keys with
+        synth.synth_keys_host.  Returns the run's figures (taxor_build_stats) as a dict."""
+        L = _lib.lib()
+        cnt = np.ascontiguousarray(bin_counts, dtype=np.uint64)
+        assert cnt.size == sum(b for b, _, _ in self.shapes)
+        off = np.zeros(cnt.size + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=off[1:])
+        total = int(off[-1])
+        d_keys = C.c_void_p()
+        check(L.taxor_gpu_malloc(self.device, total * 8, C.byref(d_keys)))
+        try:
+            check(L.taxor_gpu_synth_keys(self.device, d_keys, 0, total, int(salt)))
+            st = _lib.BuildStats()
+            check(L.taxor_gpu_index_build_hixf_ex(self._h, d_keys, 1, _p(off), int(seed0), C.byref(st)))
+        finally:
+            L.taxor_gpu_free(d_keys)
+        return {k: getattr(st, k) for k, _ in _lib.BuildStats._fields_ if k != "reserved"}, off
+
     def ixf_seed(self, ixf):
         return int(_lib.lib().taxor_gpu_index_ixf_seed(self._h, ixf))
 

@@ -43,6 +43,16 @@ def synth_reads(genomes, genome_off, n_reads, read_len, error_rate=0.04, frac_ra
     return bases, offs, origin
 
 
+def synth_keys_host(first, n, salt):
+    """keys first .. first+n-1 of the synthetic key set (ixf_arith.h synth_key: the splitmix64 finaliser of i + salt), as the
+    device generates them for GpuIndex.build_hixf_synth"""
+    with np.errstate(over="ignore"):
+        z = np.arange(first, first + n, dtype=np.uint64) + np.uint64(salt & (2**64 - 1))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
 def seg_len_for(max_bin_elements):
     return int(_lib.lib().taxor_ixf_seg_len(int(max_bin_elements)))
 

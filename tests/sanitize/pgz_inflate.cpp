@@ -1,5 +1,6 @@
 // pgz_inflate.cpp -- the parallel single-member gzip reader (taxor_amd/csrc/pgz.h) under AddressSanitizer / UBSan / ThreadSanitizer:
-//   pgz_inflate <file.gz> <threads> <chunk bytes> [out|-] [memory budget MB]   decompress, print "bytes <n> crc <hex> ... maxrss_kb <n>" or "error: <what>"
+//   pgz_inflate <file.gz> <threads> <chunk bytes> [out|-] [memory budget MB]   decompress, print "bytes <n> crc <hex> ... maxrss_kb <n> inflight_peak_kb <n>
+//   largest_chunk_kb <n>" or "error: <what>"
 #include "pgz.h"
 
 #include <cstdio>
@@ -32,8 +33,9 @@ int main(int argc, char **argv)
                 if (strncmp(line, "VmHWM:", 6) == 0) hwm = atol(line + 6);
             fclose(st);
         }
-        printf("bytes %llu crc %08x chunks %llu redecoded %llu members %llu trailing %llu maxrss_kb %ld\n", (unsigned long long)total, crc, (unsigned long long)g.chunks_total,
-               (unsigned long long)g.chunks_redecoded, (unsigned long long)g.members, (unsigned long long)g.trailing_garbage, hwm);
+        printf("bytes %llu crc %08x chunks %llu redecoded %llu members %llu trailing %llu maxrss_kb %ld inflight_peak_kb %zu largest_chunk_kb %zu\n", (unsigned long long)total, crc,
+               (unsigned long long)g.chunks_total, (unsigned long long)g.chunks_redecoded, (unsigned long long)g.members, (unsigned long long)g.trailing_garbage, hwm,
+               fastx::ParallelGz::memory_high_water() >> 10, g.largest_chunk_bytes() >> 10);
     } catch (const std::exception &e) { printf("error: %s\n", e.what()); }
     return 0;
 }

@@ -171,9 +171,13 @@ def test_reader_behaves_like_the_zlib_stream_reader_at_the_edges(tmp_path, exe_p
     assert got.startswith("error:") and "invalid deflate data" in got, got
 
 
-def test_memory_in_flight_follows_the_compression_ratio(tmp_path, exe_plain):
-    """a very repetitive (valid) member expands ~180:1 (deflate allows 1032:1): chunks decoded ahead of the reader are limited to what fits the budget at the
-    ratio seen so far, instead of 2 x threads + 2 chunks whatever they expand to (each holds two bytes per output byte until resolved)"""
+@pytest.mark.parametrize("which", ["plain", "asan"])
+def test_memory_in_flight_follows_the_compression_ratio(tmp_path, which, request):
+    """a very repetitive (valid) member expands ~180:1 (deflate allows 1032:1): what the reader HOLDS -- symbol buffers (two bytes per
+    output byte until resolved), resolved output not yet handed out, both pools; its own meter, pgz_detail::MemMeter -- stays within
+    the budget plus one chunk (the chunk the consumer waits for is always decoded), instead of 2 x threads + 2 chunks whatever they
+    expand to.  The process's RSS is the allocator's business (sixteen threads' arenas keep what they freed) and only printed."""
+    exe_plain = request.getfixturevalue("exe_" + which)
     line = b"@r\n" + b"ACGT" * 64 + b"\n+\n" + b"I" * 256 + b"\n"
     raw = line * (400_000_000 // len(line))
     comp = gzip.compress(raw, 6)
@@ -182,13 +186,22 @@ def test_memory_in_flight_follows_the_compression_ratio(tmp_path, exe_plain):
     p.write_bytes(comp)
     del comp
     chunk = 32768                                     # ~70 chunks of ~6 MB of output (12 MB of symbols) each
-    bounded = run(exe_plain, p, threads=16, chunk=chunk, budget_mb=64)
+
+    def fields(out):
+        w = out.split()
+        return {k: int(w[w.index(k) + 1]) for k in ("maxrss_kb", "inflight_peak_kb", "largest_chunk_kb")}
+
+    budget_mb = 64
+    bounded = run(exe_plain, p, threads=16, chunk=chunk, budget_mb=budget_mb)
     assert bounded.startswith(want(raw)), bounded[:200]
-    rss_bounded = int(bounded.split("maxrss_kb ")[1])
+    b = fields(bounded)
     free = run(exe_plain, p, threads=16, chunk=chunk, budget_mb=65536)
     assert free.startswith(want(raw))
-    rss_free = int(free.split("maxrss_kb ")[1])
-    assert rss_bounded < 300_000 and rss_bounded < rss_free * 0.6, (rss_bounded, rss_free)
+    f = fields(free)
+    print(f"budget {budget_mb} MB: held at most {b['inflight_peak_kb'] >> 10} MB (largest chunk {b['largest_chunk_kb'] >> 10} MB), RSS {b['maxrss_kb'] >> 10} MB; "
+          f"no budget: held {f['inflight_peak_kb'] >> 10} MB, RSS {f['maxrss_kb'] >> 10} MB")
+    assert b["inflight_peak_kb"] <= budget_mb * 1024 + b["largest_chunk_kb"], (b, f)
+    assert b["inflight_peak_kb"] < 0.5 * f["inflight_peak_kb"], (b, f)
 
 
 @pytest.mark.parametrize("which", ["asan", "tsan"])
