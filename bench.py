@@ -124,10 +124,17 @@ def parse_args(argv=None):
     ap.add_argument("--error-rate", type=float, default=0.04, help="taxor search --error-rate")
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate through")
     ap.add_argument("--scaling", default="weak", choices=("weak", "strong"))
-    ap.add_argument("--mode", default="syncmer", choices=("syncmer", "kmer", "minimiser"),
+    ap.add_argument("--mode", default="syncmer", choices=("syncmer", "kmer", "minimiser", "build"),
                     help="hashing of the index: syncmer = k22/s12 open syncmers (the BASELINE configs); kmer = an index built WITHOUT "
                          "--use-syncmer, the reference's default build mode (every canonical 20-mer, k-mer threshold model); minimiser = "
-                         "the same with window 32 (FracMinHash model).  kmer / minimiser run on the viral-class footprint with 5-kb reads")
+                         "the same with window 32 (FracMinHash model).  kmer / minimiser run on the viral-class footprint with 5-kb reads.  "
+                         "build = GPU construction of a hierarchy (SURVEY 8(f) #3): a step is one whole build, the line carries key insertions/s")
+    ap.add_argument("--build-children", type=int, default=48, help="--mode build: child IXFs under the root")
+    ap.add_argument("--build-child-bins", type=int, default=128)
+    ap.add_argument("--build-keys-per-bin", type=int, default=422000, help="--mode build: keys per leaf bin (default: the leaf size of the gtdb workload)")
+    ap.add_argument("--build-cpu-keys", type=int, default=200000,
+                    help="--mode build: keys the reference's own builder (xorfilter.hpp AddAll) is timed on; beyond ~213 000 it never returns "
+                         "(its deferred-block path is cut short by a debugging `break`, xorfilter.hpp:237-238, and its seed is fixed)")
     ap.add_argument("--len-mix", default="", help="'ont': skewed read lengths 1-100 kb (same total bases) instead of a fixed length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-buffer (PCIe-inclusive) measurements")
@@ -393,8 +400,116 @@ def build_workload_no_syncmer(args, local_rank, rank, world):
                                        origins=origins, genomes=g, genome_off=go, k=k, s=0, t=0, window=w)
 
 
+def build_cpu_reference(n_keys, salt):
+    """cpu_baseline of --mode build: the REFERENCE's own xorfilter::XorFilter<uint64_t, uint8_t>::AddAll (src/main/xorfilter.hpp:142-334,
+    compiled where it lies into oracle/_ref) on n_keys synthetic keys of one bin, one core, best of 3"""
+    import ctypes as C
+    from taxor_amd import synth
+    so = os.path.join(ROOT, "oracle", "_ref", "libtaxor_ref.so")
+    if not os.path.exists(so):
+        return None
+    L = C.CDLL(so)
+    L.ref_xor_build.restype = C.c_void_p
+    L.ref_xor_build.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.ref_xor_free.argtypes = [C.c_void_p]
+    keys = synth.synth_keys_host(0, n_keys, salt)
+    seed, bl, al = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        h = L.ref_xor_build(keys.ctypes.data_as(C.c_void_p), n_keys, C.byref(seed), C.byref(bl), C.byref(al))
+        dt = time.perf_counter() - t0
+        if not h:
+            return None
+        L.ref_xor_free(h)
+        best = dt if best is None else min(best, dt)
+    return {"value": round(n_keys / best, 1), "unit": "key insertions/s", "cores": 1, "kind": "reference",
+            "sample": f"xorfilter::XorFilter<uint64_t,uint8_t>::AddAll (src/main/xorfilter.hpp:142-334, oracle/_ref) on {n_keys} synthetic keys of one "
+                      "bin, best of 3; one filter at a time on one core is how the reference builds (construct_ixf.cpp:80-130)"}
+
+
+# algorithmic bytes one key insertion moves in builder.hip (32-bit state words; DESIGN.md section 4 derives the sum):
+#   key 8 B x 4 (count, round, assign, verify) + state word: 3 adds + 3 subs (4 B read + 4 B write each) + 1 load + the seed scan
+#   over 1.23 slots + claim bit (4 + 4) + list entry 8 B written and read for 1.12 listed rows + log 4 + 4 + round marks 2 B written
+#   per listed row, 3 x 2 B read + fingerprints: 2 read + 1 written + 3 verified + 1.23 cleared
+BUILD_BYTES_PER_INSERTION = 32 + 48 + 4 + 1.23 * 4 + 8 + 1.12 * 16 + 8 + 1.12 * 2 + 6 + 6 + 1.23
+BUILD_RMW_PER_INSERTION = 7          # 3 adds, 1 claim, 3 subs
+RMW_CEILING_G_PER_S = 27.1           # random 4-B atomics on a <= 256 MB set, any scope, returning or not (profiles/r06/atomics_bench.txt)
+
+
+def build_mode(args):
+    """bench.py --mode build: GPU construction of a two-level hierarchy in which every bin is a real filter.
+    A step = one whole build (leaf IXFs, key unions, root) from keys resident in HBM; value = key insertions/s."""
+    import torch  # noqa: F401  (first: its HIP runtime is the one the process uses)
+    from taxor_amd import GpuIndex, Searcher, synth
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    nc, cb, kpb = args.build_children, args.build_child_bins, args.build_keys_per_bin
+    shapes, ub, counts = synth.full_hierarchy_shapes(nc, cb, kpb)
+    salt = synth.DEFAULT_SEED
+    idx = GpuIndex(shapes, ub)
+    steps, warmup = max(1, args.steps), max(0, args.warmup)
+    sts = []
+    for i in range(warmup + steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st, off = idx.build_hixf_synth(counts, salt=salt, seed0=5 + i)
+        torch.cuda.synchronize()
+        st["wall_s"] = time.perf_counter() - t0
+        if i >= warmup:
+            sts.append(st)
+        log(f"build {i}: {st['keys_inserted'] / st['seconds_total'] / 1e9:.3f} G insertions/s ({st['seconds_total']:.3f} s; peel {st['seconds_peel']:.3f}, "
+            f"assign+verify {st['seconds_assign']:.3f}, unions {st['seconds_union']:.3f}; {st['chunks']} chunks, {st['rounds_max']} rounds, {st['reseeds']} reseeds)")
+    ins = sum(s_["keys_inserted"] for s_ in sts)
+    secs = sum(s_["seconds_total"] for s_ in sts)
+    wall = sum(s_["wall_s"] for s_ in sts)
+    value = ins / secs
+    # spot check through the query kernel against the oracle's answer for the same keys (the full check is tests/test_gpu_build_fullsize.py)
+    sr = Searcher(idx, ratio=0.5)
+    rb = shapes[0]["bins"]
+    for c, b in ((1, 0), (nc, cb - 1)):
+        g = rb + (c - 1) * cb + b
+        keys = synth.synth_keys_host(int(off[g]), int(off[g + 1] - off[g]), salt)
+        own, up = sr.ixf_bulk_count(c, keys), sr.ixf_bulk_count(0, keys)
+        if own[b] != keys.size or up[c - 1] != keys.size:
+            raise SystemExit("PARITY FAILURE: a built bin does not hold its keys")
+    sr.close()
+    kern_s = sum(s_["seconds_peel"] + s_["seconds_assign"] for s_ in sts)
+    achieved = BUILD_BYTES_PER_INSERTION * ins / kern_s / 1e9
+    out = {"metric": "key insertions/s (GPU IXF/HIXF construction, SURVEY 8(f) #3)", "value": round(value, 1), "unit": "key insertions/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(secs / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u64 keys -> u8 fingerprints", "data": "synthetic",
+           "config": {"workload": f"hierarchy of {idx.n_ixf} IXFs, {idx.data_bytes / 1e9:.2f} GB: {nc} children x {cb} leaf bins x {kpb} keys (GTDB-class leaf size) under a root "
+                                  f"of {nc} merged bins of {cb * kpb} keys; every bin built; {ins // steps} insertions per step",
+                      "timed_region": "keys resident in HBM (generated on the device): count -> seed scan -> peeling rounds -> clear -> assignment in reverse -> "
+                                      "verification of every key, for every chunk of bins; duplicate-free union of each child's keys for the root (a hash set in HBM); scratch allocation inside; "
+                                      "the index shell's allocation outside",
+                      "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "children": nc, "child_bins": cb, "keys_per_bin": kpb,
+                      "insertions_per_step": ins // steps, "chunks_per_step": sts[-1]["chunks"], "rounds_max": max(s_["rounds_max"] for s_ in sts),
+                      "reseeds": sum(s_["reseeds"] for s_ in sts), "scratch_bytes": max(s_["scratch_bytes"] for s_ in sts)},
+           "stage_s_per_step": {"peel": round(sum(s_["seconds_peel"] for s_ in sts) / steps, 4), "assign_verify": round(sum(s_["seconds_assign"] for s_ in sts) / steps, 4),
+                                "unions": round(sum(s_["seconds_union"] for s_ in sts) / steps, 4), "total": round(secs / steps, 4), "wall": round(wall / steps, 4)},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "k_count + k_round + k_assign + k_verify (builder.hip)",
+                        "algorithmic_bytes_per_insertion": round(BUILD_BYTES_PER_INSERTION, 1),
+                        "note": "achieved = algorithmic bytes per insertion x insertions / (peel + assign + verify time).  The builder is NOT bound by HBM bytes: "
+                                "every one of its accesses is a random 1-8-byte access, and what the chip limits is their NUMBER -- see `rmw`",
+                        "rmw": {"per_insertion": BUILD_RMW_PER_INSERTION, "achieved_G_per_s": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9, 2),
+                                "ceiling_G_per_s": RMW_CEILING_G_PER_S, "frac": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9 / RMW_CEILING_G_PER_S, 4),
+                                "note": "random atomic read-modify-writes per second against the chip's measured rate for them (profiles/r06/atomics_bench.txt: 27 G/s "
+                                        "up to 256 MB, 18-20 G/s beyond, whatever the scope, width or use of the return value); the builder also does ~11 random loads "
+                                        "and stores per insertion (54 G/s ceiling), so 7 RMW / 27 G/s + 11 / 54 G/s = 0.46 ns per insertion is the floor of this design: "
+                                        "2.2 G insertions/s"}}}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = build_cpu_reference(args.build_cpu_keys, salt)
+    idx.close()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
+    if args.mode == "build":
+        return build_mode(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -486,6 +601,7 @@ def main():
 
     from taxor_amd import distributed as td
     gathered = {}
+    comm_acc = {"ms": 0.0, "n": 0, "bytes": 0, "sent": 0}
 
     def gather_results(sr):
         """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
@@ -501,7 +617,21 @@ def main():
                          nh.data_ptr() if nr else None)
         if backend != "nccl":
             ro, ub, ct, nh = ro.cpu(), ub.cpu(), ct.cpu(), nh.cpu()
+        # HIP events around the exchange on the stream torch's collectives are ordered against (device tensors); wall clock for gloo
+        if backend == "nccl":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t_g = time.perf_counter()
         gathered["last"] = td.gather_csr(ro, ub, ct, nh, dst=0)
+        if backend == "nccl":
+            e1.record()
+            e1.synchronize()
+            comm_acc["ms"] += e0.elapsed_time(e1)
+        else:
+            comm_acc["ms"] += (time.perf_counter() - t_g) * 1e3
+        comm_acc["n"] += 1
+        comm_acc["bytes"] += td.last_gather["bytes_received"]
+        comm_acc["sent"] += sum(x.numel() * x.element_size() for x in (ro, ub, ct, nh))
 
     def step(i, pool):
         sr = pool[i % len(pool)]
@@ -519,8 +649,12 @@ def main():
         t0 = time.perf_counter()
         acc = dict(q_ms=0.0, q_bytes=0.0, q_touched=0.0, launches=0, bases=0, sync_ms=0.0, query_ms=0.0, fin_ms=0.0, total_ms=0.0,
                    hashes=0, tuples=0, work=0, reads=0, alg=0, lvl_ms=[0.0] * 8, lvl_bytes=[0] * 8, lvl_rows=[0] * 8, lvl_sparse=[0] * 8)
+        comm_acc.update(ms=0.0, n=0, bytes=0, sent=0)
+        acc["local_s"] = 0.0
         for i in range(steps):
+            t_s = time.perf_counter()
             sr = step(warmup + i, pool)
+            acc["local_s"] += time.perf_counter() - t_s
             st = sr.stats()
             acc["q_ms"] += st["query_ms"]
             acc["q_bytes"] += st["query_bytes"]
@@ -545,11 +679,20 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist_on:
-            tt = torch.tensor([elapsed, float(acc["bases"])], dtype=torch.float64,
-                              device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+            dev_t = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
+            tt = torch.tensor([elapsed, float(acc["bases"])], dtype=torch.float64, device=dev_t)
             dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
             dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)
             elapsed, acc["all_bases"] = float(tt[0].item()), float(tt[1].item())
+            mine_t = torch.tensor([acc["local_s"] / max(1, steps) * 1e3, comm_acc["ms"] / max(1, comm_acc["n"]), float(comm_acc["sent"]) / max(1, comm_acc["n"])],
+                                  dtype=torch.float64, device=dev_t)
+            all_t = [torch.zeros_like(mine_t) for _ in range(dist.get_world_size())]
+            dist.all_gather(all_t, mine_t)
+            acc["per_rank_ms"] = [float(v[0]) for v in all_t]
+            acc["per_rank_gather_ms"] = [float(v[1]) for v in all_t]
+            acc["per_rank_sent_bytes"] = [float(v[2]) for v in all_t]
+            acc["gather_bytes_received"] = comm_acc["bytes"] / max(1, comm_acc["n"])
+            acc["gather_sizes"] = list(td.last_gather["sizes"])
         else:
             acc["all_bases"] = float(acc["bases"])
         return elapsed, acc
@@ -569,6 +712,47 @@ def main():
             d_off, d_ub, d_cnt, d_nh = r_.read_off, r_.user_bin, r_.count, r_.n_hashes
         np.savez(args.dump_results, read_off=d_off.astype(np.int64), user_bin=d_ub.astype(np.int64), count=d_cnt.astype(np.int64),
                  n_hashes=d_nh.astype(np.int64))
+
+    # N > 1 (or the forced one-rank group): the same invocation also runs three STRONG-scaling steps -- one common batch, rank r
+    # classifies its contiguous shard, the shards are gathered -- and rank 0 classifies the whole batch alone: the gathered CSR must
+    # be the single-rank CSR, bit for bit.  That holds only if every rank's replica of the index is the same (the builder is
+    # deterministic) and every rank's tuples arrived in rank order.
+    strong_leg = None
+    if dist_on and args.mode == "syncmer" and not args.len_mix and not args.pmc_child:
+        import hashlib
+        from taxor_amd import synth as synth_s
+
+        def digest(ro, ub, ct, nh):
+            h_ = hashlib.sha256()
+            for x in (ro, ub, ct, nh):
+                h_.update(np.ascontiguousarray(np.asarray(x).astype(np.int64)).tobytes())
+            return h_.hexdigest()
+
+        wsz = dist.get_world_size()
+        cb_, co_, _ = synth_s.synth_reads(info["genomes"], info["genome_off"], n_reads, read_len, error_rate=args.read_error, frac_random=0.1,
+                                          seed=synth_s.DEFAULT_SEED + 424242, threads=ncpu)
+        lo_, hi_ = td.shard_range(n_reads, rank, wsz)
+        s_sh = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
+        s_sh.upload(np.ascontiguousarray(cb_[int(co_[lo_]):int(co_[hi_])]), np.ascontiguousarray(co_[lo_:hi_ + 1] - co_[lo_]))
+        s_sh.run()
+        s_sh.sync()
+        e_s, a_s = timed([s_sh], 3, 1)
+        s_sh.close()
+        if rank == 0:
+            g_ = [x.cpu().numpy() for x in gathered["last"]]
+            s_full = Searcher(idx, error_rate=args.error_rate)
+            r_full = s_full.search_batch(np.ascontiguousarray(cb_), np.ascontiguousarray(co_))
+            d_g, d_1 = digest(*g_), digest(r_full.read_off, r_full.user_bin, r_full.count, r_full.n_hashes)
+            s_full.close()
+            strong_leg = {"scaling": "strong", "steps": 3, "reads": int(n_reads), "value": round(a_s["all_bases"] / e_s / 1e6, 2), "unit": "Mbp/s",
+                          "ms_per_step": round(e_s / 3 * 1e3, 3), "tuples": int(g_[1].size), "digest_gathered": d_g, "digest_single_rank": d_1, "equal": d_g == d_1,
+                          "note": "one common batch, rank r classifies reads [r*n/N, (r+1)*n/N), gathered on rank 0; digest = sha256 over read_off, user_bin, "
+                                  "count, n_hashes; digest_single_rank = rank 0 classifying the whole batch alone in the same process"}
+            if d_g != d_1:
+                print(json.dumps({"PARITY FAILURE": "the gathered strong-scaling CSR differs from the single-rank result", "strong_leg": strong_leg}), file=sys.stderr, flush=True)
+                os._exit(14)
+        del cb_, co_
+        dist.barrier()
 
     # N > 1: the drop-in call with HOST buffers on every rank at the same time -- the ranks share the host's memory
     # bandwidth and PCIe root complexes, which is where a sharded run is won or lost (the resident-batch `value` is not)
@@ -769,6 +953,8 @@ def main():
                                     f"{'every canonical k-mer, k-mer threshold model' if args.mode == 'kmer' else 'window minimisers, FracMinHash threshold model'}) "
                                     f"{idx.data_bytes/1e9:.2f} GB in HBM, root {wl['root_bins']} bins, {shard_reads[0]} reads x {int(read_len)} bp/GPU/step"),
                        "mode": args.mode,
+                       "timed_region": "resident 2-bit batches: syncmers -> query -> CSR (+ gather on rank 0 at N > 1); H2D, dna4 pack (a1) and the D2H of the "
+                                       "CSR outside -- see value_host_fed for the PCIe-inclusive rate",
                        "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "root_bins": wl["root_bins"],
                        "child_bins": wl["child_bins"], "depth": idx.depth, "reads_per_gpu": shard_reads[0], "read_len": read_len,
                        "distinct_batches": len(batches), "read_error": args.read_error, "search_error_rate": args.error_rate,
@@ -805,6 +991,24 @@ def main():
                 _, sus04 = dropin_measurements(a04, idx, e04["_batches"], read_len, single=False)
                 e04["value_host_fed"] = sus04["value"]
                 e04["host_fed_reads"] = sus04["reads"]
+        if dist_on:
+            sizes = acc.get("gather_sizes", [])
+            prm = acc.get("per_rank_ms", [])
+            out["comm"] = {"backend": "nccl (RCCL)" if backend == "nccl" else backend,
+                           "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                           "world": dist.get_world_size(),
+                           "ranks_in_last_gather": [p_ for p_, (n_, _t) in enumerate(sizes) if n_ > 0],
+                           "reads_tuples_per_rank_last_gather": [[int(n_), int(t_)] for n_, t_ in sizes],
+                           "gather_bytes_per_step": round(acc.get("gather_bytes_received", 0.0), 1),
+                           "gather_ms_per_step": round(acc.get("per_rank_gather_ms", [0.0])[0], 4),
+                           "sent_bytes_per_rank_per_step": [round(v, 1) for v in acc.get("per_rank_sent_bytes", [])],
+                           "ms_per_step_per_rank": {"min": round(min(prm), 3) if prm else None, "max": round(max(prm), 3) if prm else None,
+                                                    "rank0": round(prm[0], 3) if prm else None, "all": [round(v, 3) for v in prm]},
+                           "strong_leg": strong_leg,
+                           "note": "written from what the exchange moved, not from WORLD_SIZE: ranks_in_last_gather = peers whose reads arrived in the last gathered "
+                                   "CSR; gather_bytes_per_step = payload bytes rank 0 received from its peers (0 with one rank); gather_ms_per_step = HIP events "
+                                   "around gather_csr on rank 0 (export of the four device arrays excluded); ms_per_step_per_rank = each rank's own clock around "
+                                   "its steps (run + sync + gather), without the barriers that bracket `value`"}
         if per_rank is not None:
             out["pcie_inclusive_per_rank"] = per_rank
             out["sustained_sum_Mbp_s"] = per_rank["sustained_sum_Mbp_s"]
@@ -827,6 +1031,15 @@ def main():
             hash_kw = dict(k=info["k"], s=info["s"], t=info["t"], window=info["window"]) if args.mode != "syncmer" else {}
             out["cpu_baseline"] = cpu_baseline(args, idx, lay, res, batches[(args.warmup + args.steps - 1) % len(batches)], read_len, ncpu, hash_kw)
         if world == 1 and not dist_on and not args.no_layouts and args.mode == "syncmer" and not args.len_mix:
+            # the legs build more 113-GB-class indexes: should one of them take the process down (a host out-of-memory kill cannot be caught),
+            # the headline measured so far is on disk already
+            side = os.environ.get("TAXOR_BENCH_SIDE_FILE", os.path.join(ROOT, "gpurun_out", "bench_headline_before_legs.json"))
+            try:
+                os.makedirs(os.path.dirname(side), exist_ok=True)
+                with open(side, "w") as fh:
+                    fh.write(json.dumps(out) + "\n")
+            except OSError:
+                pass
             out["layouts"] = layout_legs(args, idx, info, searchers, timed, local_rank, out)     # (never raises: a leg that fails is reported as such)
             idx = None
         print(json.dumps(out), flush=True)
@@ -851,13 +1064,18 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
 
     def measure(index, batches, label, what, extra):
         pool = []
-        for bb, oo in batches:
-            s2 = Searcher(index, error_rate=args.error_rate, time_kernels=True)
-            s2.upload(bb, oo)
-            s2.run()
-            s2.sync()
-            pool.append(s2)
-        e, a = timed(pool, 3, 1)
+        try:
+            for bb, oo in batches:
+                s2 = Searcher(index, error_rate=args.error_rate, time_kernels=True)
+                pool.append(s2)
+                s2.upload(bb, oo)
+                s2.run()
+                s2.sync()
+            e, a = timed(pool, 3, 1)
+        except BaseException:
+            for s2 in pool:          # searchers go before their index, also when a leg fails
+                s2.close()
+            raise
         q = a["q_ms"] * 1e-3
         sparse = sum(a["lvl_sparse"])
         leg = {"layout": label, "what": what, "value": round(a["all_bases"] / e / 1e6, 2), "unit": "Mbp/s", "steps": 3,
@@ -909,7 +1127,73 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
             log(f"layout leg {label} failed: {type(e).__name__}: {e}")
         if idx2 is not None:
             idx2.close()
+    # (d) every bin a real filter: the headline's SHAPE at a size whose keys fit HBM, against its twin with random-filled decoys
+    try:
+        legs.append(exact_fill_leg(args, measure, local_rank, ncpu))
+    except Exception as e:
+        legs.append({"layout": "exact_fill", "error": f"{type(e).__name__}: {e}"})
+        log(f"layout leg exact_fill failed: {type(e).__name__}: {e}")
     return legs
+
+
+EXACT_FILL_KEYS = {"gtdb": 4.5e9, "refseq": 1.5e9, "viral": 1.5e8, "tiny": 2e6}
+
+
+def exact_fill_leg(args, measure, local_rank, ncpu):
+    """`layouts` leg exact_fill: an index of the headline's shape -- root and child widths, number of children, the
+    depth-3 chain, the planted families -- in which EVERY bin is a real XOR filter built by taxor_gpu_index_build_hixf_ex (decoy
+    leaf bins filled to 90 % of capacity with synthetic keys, merged bins holding the union of their child), searched with the same reads
+    as its twin whose decoy bins are seeded random bytes (what the headline index is made of).  The keys of a 113-GB index
+    (7e10) do not fit one GPU next to it, so both twins are smaller: leaf bins of ~35 k keys instead of 422 k."""
+    from taxor_amd import GpuIndex, Searcher, synth
+    wl = dict(WORKLOADS[args.workload])
+    root_bins = args.root_bins or wl["root_bins"]
+    child_bins = args.child_bins or wl["child_bins"]
+    n_children = min(wl["n_children"], root_bins - 8)
+    fam_size = max(2, min(args.family_size, wl["genomes"]))
+    n_genomes = (wl["genomes"] // fam_size) * fam_size
+    read_len = args.read_len or wl["read_len"]
+    n_reads = args.reads or wl["reads"]
+    k, s_, t = 22, 12, 5
+    cap = int(EXACT_FILL_KEYS[args.workload] / ((n_children + 1) * child_bins))
+    genome_len = max(4 * read_len, int(cap * 11.0))                    # ~1 syncmer per 11.5 bases: the largest genome just fits a leaf bin
+    t0 = time.time()
+    g, go, family = synth.family_genomes(n_genomes // fam_size, fam_size, genome_len, seed=synth.DEFAULT_SEED + 7)
+    dummy = GpuIndex([dict(bins=64, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(64, np.int64), fname_idx=np.arange(64), data=np.zeros(3 * 16 * 64, np.uint8))],
+                     64, k, s_, t, device=local_rank)
+    hs = Searcher(dummy, ratio=0.5)
+    hoff, hashes = hs.seq_to_syncmers(g, go)
+    hs.close()
+    dummy.close()
+    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(n_genomes)]
+    child_cap = max(len(p) for p in planted) + 64
+    lay = synth.make_family_layout(planted, family, root_bins=root_bins, child_bins=child_bins, n_children=n_children, spread=4,
+                                   root_max_elems=child_bins * child_cap, child_max_elems=child_cap, seed=synth.DEFAULT_SEED, build="gpu")
+    batches = []
+    for b in range(2):
+        bb, oo, _ = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1, seed=synth.DEFAULT_SEED + 91000 + b, threads=ncpu)
+        batches.append((np.ascontiguousarray(bb), np.ascontiguousarray(oo)))
+    idx_e, st = synth.exact_fill_index(lay, device=local_rank)
+    log(f"exact-fill index: {idx_e.data_bytes/1e9:.2f} GB, {idx_e.n_ixf} IXFs, {st['keys_inserted']/1e9:.2f} G insertions in {st['seconds_total']:.2f} s "
+        f"({st['keys_inserted']/st['seconds_total']/1e9:.2f} G/s), {time.time()-t0:.1f}s")
+    shape = {"root_bins": root_bins, "child_bins": child_bins, "index_bytes": idx_e.data_bytes, "n_ixf": idx_e.n_ixf, "depth": idx_e.depth, "frac_reverse": 0.0,
+             "leaf_capacity_keys": child_cap}
+    try:
+        leg = measure(idx_e, batches, "exact_fill", "the headline's shape with EVERY bin a real filter (decoy leaf bins filled to 90 % of capacity with synthetic keys, merged "
+                      "bins = union of their child, all constructed on the GPU), smaller than the headline because 7e10 keys do not fit next to a 113-GB index", shape)
+    finally:
+        idx_e.close()
+    leg["build"] = {"insertions": int(st["keys_inserted"]), "seconds": round(st["seconds_total"], 3), "insertions_per_s": round(st["keys_inserted"] / st["seconds_total"], 1),
+                    "chunks": int(st["chunks"]), "rounds_max": int(st["rounds_max"]), "reseeds": int(st["reseeds"])}
+    idx_r = synth.device_index(lay, k, s_, t, device=local_rank)        # the twin: same shape and planted columns, decoy bins of seeded random bytes
+    try:
+        twin = measure(idx_r, batches, "exact_fill_twin", "the same layout with random-filled decoy bins, like the headline index", dict(shape, index_bytes=idx_r.data_bytes))
+    finally:
+        idx_r.close()
+    leg["random_fill_twin"] = {kk: twin[kk] for kk in ("value", "frac", "algorithmic_frac", "tuples_per_read", "work_items_per_read", "hashes_per_read")}
+    leg["value_over_random_fill_twin"] = round(leg["value"] / twin["value"], 4)
+    leg["within_3_percent"] = bool(abs(leg["value"] / twin["value"] - 1.0) < 0.03)
+    return leg
 
 
 def dropin_measurements(args, idx, batches, read_len, single=True):

@@ -57,7 +57,7 @@ int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t
 /* The whole hierarchy at once (the back end of hierarchical_build.cpp:27-236): key_off[total_bins + 1] indexes `keys`
  * per technical bin in the index's bin order (all bins of IXF 0, then IXF 1, ...); LEAF bins bring their keys
  * (distinct within a bin; a split user bin brings one part per technical bin), MERGED bins bring none -- their key set
- * is the union of everything in their child IXF, computed on the device (sort + unique), level by level from the leaves
+ * is the union of everything in their child IXF, computed on the device (a hash set in HBM), level by level from the leaves
  * up; the IXFs of one level share peeling chunks.  An IXF that does not peel is redone under a redrawn seed, it alone.
  * Unions are limited to 2^32 keys. */
 int taxor_gpu_index_build_hixf(taxor_gpu_index *idx, const uint64_t *keys, const uint64_t *key_off, uint64_t seed0,
@@ -73,7 +73,7 @@ typedef struct taxor_build_stats {
     uint32_t reserved;
     double seconds_peel;      /* count + seed scan + rounds */
     double seconds_assign;    /* clearing, assignment in reverse, verification */
-    double seconds_union;     /* sort + unique of the merged bins' key sets */
+    double seconds_union;     /* duplicate-free unions of the merged bins' key sets */
     double seconds_total;
 } taxor_build_stats;
 int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
@@ -82,12 +82,13 @@ int taxor_gpu_index_build_hixf_ex(taxor_gpu_index *idx, const uint64_t *keys, in
                                   uint64_t seed0, taxor_build_stats *stats);
 /* Synthetic key sets for the build bench and tests: key i = a bijection of (i + salt) (distinct without a table);
  * taxor_gpu_synth_keys writes keys first .. first + n - 1 to the DEVICE array d_out, taxor_synth_key is the same
- * function on the host.  taxor_gpu_malloc / _free / _memcpy_to_host: plain device memory for such arrays. */
+ * function on the host.  taxor_gpu_malloc / _free / _memcpy_to_host / _from_host: plain device memory for such arrays. */
 uint64_t taxor_synth_key(uint64_t i, uint64_t salt);
 int taxor_gpu_synth_keys(int device, uint64_t *d_out, uint64_t first, uint64_t n, uint64_t salt);
 int taxor_gpu_malloc(int device, uint64_t bytes, void **out);
 void taxor_gpu_free(void *p);
 int taxor_gpu_memcpy_to_host(void *dst, const void *d_src, uint64_t bytes);
+int taxor_gpu_memcpy_from_host(void *d_dst, const void *src, uint64_t bytes);
 
 /* ---- taxor_gpu_search_batch split into its three phases so that a caller can keep a batch resident in HBM
  * (upload once, run many times) and overlap transfers with compute:

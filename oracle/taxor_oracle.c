@@ -434,6 +434,65 @@ void orc_ixf_bulk_count(const orc_ixf *f, const uint64_t *hashes, size_t n, uint
     }
 }
 
+/* Checker of BUILT filters (the GPU builder's full-size test): the synthetic keys first .. first + n - 1 (a bijection of i + salt,
+ * the splitmix64 finaliser -- the same function the device generates them with, taxor_amd/csrc/ixf_arith.h synth_key) against
+ * filter f.  Every key is looked up in column `bin` with orc_ixf_bulk_count's rule (fp == D[h0][bin]^D[h1][bin]^D[h2][bin]); the
+ * return value is the number found there -- n when no key is missing.  Every sample_step-th key (sample_step > 0) also goes
+ * through orc_ixf_bulk_count itself, over all bins: counts[bins] accumulates (the caller zeroes it), *sampled the keys that did. */
+static uint64_t orc_synth_key(uint64_t i, uint64_t salt)
+{
+    uint64_t z = i + salt;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void orc_synth_keys(uint64_t first, uint64_t n, uint64_t salt, uint64_t *out)
+{
+    for (uint64_t i = 0; i < n; ++i) out[i] = orc_synth_key(first + i, salt);
+}
+
+uint64_t orc_ixf_synth_keys_found(const orc_ixf *f, uint64_t bin, uint64_t first, uint64_t n, uint64_t salt, uint64_t sample_step,
+                                  uint64_t *counts, uint64_t *sampled)
+{
+    uint64_t found = 0, n_sampled = 0;
+#pragma omp parallel reduction(+ : found, n_sampled)
+    {
+        uint32_t *mine = counts ? (uint32_t *)calloc(f->bins ? f->bins : 1, sizeof(uint32_t)) : NULL;
+        uint32_t *one = counts ? (uint32_t *)malloc((f->bins ? f->bins : 1) * sizeof(uint32_t)) : NULL;
+        /* (a 4096-bin root is tens of GB: three cache misses per key.  Keys go in groups of 32 -- probes first, with a prefetch of the
+         *  three bytes each, then the comparisons -- so that the misses overlap; the rule applied is the one above) */
+#pragma omp for schedule(static)
+        for (uint64_t g = 0; g < (n + 31) / 32; ++g) {
+            uint64_t keys[32], rows[32][3];
+            uint8_t fps[32];
+            const uint64_t i0 = g * 32, m = n - i0 < 32 ? n - i0 : 32;
+            for (uint64_t q = 0; q < m; ++q) {
+                keys[q] = orc_synth_key(first + i0 + q, salt);
+                orc_ixf_probe(f, keys[q], rows[q], &fps[q]);
+                for (int r = 0; r < 3; ++r) __builtin_prefetch(f->data + rows[q][r] * f->stride + bin, 0, 0);
+            }
+            for (uint64_t q = 0; q < m; ++q) {
+                const uint8_t v = (uint8_t)(f->data[rows[q][0] * f->stride + bin] ^ f->data[rows[q][1] * f->stride + bin] ^ f->data[rows[q][2] * f->stride + bin]);
+                found += (uint64_t)(v == fps[q]);
+                if (counts && sample_step && (i0 + q) % sample_step == 0) {
+                    orc_ixf_bulk_count(f, &keys[q], 1, one);
+                    for (uint64_t j = 0; j < f->bins; ++j) mine[j] += one[j];
+                    ++n_sampled;
+                }
+            }
+        }
+        if (counts) {
+#pragma omp critical
+            for (uint64_t j = 0; j < f->bins; ++j) counts[j] += mine[j];
+        }
+        free(mine);
+        free(one);
+    }
+    if (sampled) *sampled += n_sampled;
+    return found;
+}
+
 /* =============================================================================================== */
 /* hierarchical IXF traversal -- hierarchical_interleaved_xor_filter.hpp:303-340                   */
 /* =============================================================================================== */

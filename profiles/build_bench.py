@@ -19,24 +19,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from taxor_amd import GpuIndex, synth  # noqa: E402
 
 
-def shapes_for(nc, cb, kpb):
-    """root: max(64, nc) bins, the first nc merged; children: cb leaf bins of kpb keys"""
-    rb = max(64, nc)
-    nx = np.zeros(rb, np.int64)
-    fn = np.arange(rb, dtype=np.int64)
-    nx[:nc] = np.arange(1, nc + 1)
-    fn[:nc] = -1
-    shapes = [dict(bins=rb, stride=(rb + 63) // 64 * 64, seg_len=synth.seg_len_for(cb * kpb), seed=1, next_ixf=nx, fname_idx=fn, data=None)]
-    ub = rb
-    for c in range(nc):
-        shapes.append(dict(bins=cb, stride=(cb + 63) // 64 * 64, seg_len=synth.seg_len_for(kpb), seed=2 + c,
-                           next_ixf=np.full(cb, c + 1, np.int64), fname_idx=np.arange(ub, ub + cb, dtype=np.int64), data=None))
-        ub += cb
-    counts = np.zeros(rb + nc * cb, dtype=np.uint64)
-    counts[rb:] = kpb
-    return shapes, ub, counts
-
-
 def cpu_reference(n_keys, salt):
     """the reference's XorFilter<uint64_t, uint8_t>::AddAll on n_keys synthetic keys, one core -> insertions per second"""
     so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libtaxor_ref.so")
@@ -71,7 +53,7 @@ def main():
     ap.add_argument("--cpu-keys", type=int, default=0, help="at most ~213000: beyond it the prototype never returns (its deferred-block path is cut short by a debugging break, xorfilter.hpp:237-238, and its seed is fixed)")
     ap.add_argument("--repeat", type=int, default=1)
     a = ap.parse_args()
-    shapes, ub, counts = shapes_for(a.children, a.child_bins, a.keys_per_bin)
+    shapes, ub, counts = synth.full_hierarchy_shapes(a.children, a.child_bins, a.keys_per_bin)
     idx = GpuIndex(shapes, ub)
     st = None
     for _ in range(max(1, a.repeat)):

@@ -124,6 +124,7 @@ SIGNATURES = {
     "taxor_gpu_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),
     "taxor_gpu_free": (None, [_P]),
     "taxor_gpu_memcpy_to_host": (C.c_int, [_P, _P, C.c_uint64]),
+    "taxor_gpu_memcpy_from_host": (C.c_int, [_P, _P, C.c_uint64]),
     "taxor_gpu_index_ixf_seed": (C.c_uint64, [_P, C.c_uint64]),
     "taxor_gpu_index_data_bytes": (C.c_uint64, [_P]),
     "taxor_gpu_gather_ceiling": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -14,29 +14,31 @@
 //             the index of its only key.  32-bit words while every bin has < 2^24 keys, 64-bit words otherwise.
 //   count   : 3 adds per key                                                                                 (k_count)
 //   seed    : slots of degree 1 -> work list, one list append per BLOCK (entries collected in LDS)            (k_seed)
-//   round t : the list is append-only; round t is its entries [end[t], end[t+1]).  An entry's slot has degree 1 or 0
-//             (only decrements happen).  Degree 1: the slot names its key; the key is CLAIMED with one atomic-or on a bit per
-//             key (two singleton rows of one key in the same round: one wins), its index logged at the entry's position, and
-//             removed from its three rows; a row whose degree drops 2 -> 1 is appended for round t+1 (it can never be
-//             appended twice) and remembers t+1.  Appends: collected in LDS, one returning atomic per block and 1024 entries.
-//             The last block to finish a round (ticket counter) records where the list ends -- one launch per round, no
-//             launch in between, no flags to set or retire                                                    (k_round)
+//   round t : the list is append-only; round t is its entries [end[t], end[t+1]), and every listed slot remembers the round it
+//             was listed for (16 bits per slot).  A listed slot has degree 1 or 0 (only decrements happen).  Degree 1: the slot
+//             names its key.  A key with several singleton rows in one round is peeled by the LOWEST-SEGMENT one of them: the
+//             others see that a lower row of the key carries this round's mark and stand back -- no claim, no atomic, and the
+//             choice does not depend on any race.  The peeling row logs the key's index at its list position and removes the
+//             key from its OTHER two rows (its own slot is never looked at again); a row whose degree drops 2 -> 1 is appended
+//             for round t+1 (it can never be appended twice).  Two read-modify-writes per key.  Appends: collected in LDS, one
+//             returning atomic per block and 1024 entries.  The last block to finish a round (ticket counter) records where
+//             the list ends -- one launch per round, no launch in between, no flags to set or retire             (k_round)
 //   stop    : rounds are enqueued 32 at a time, two batches ahead of the host, which looks at the recorded ends of a batch
 //             only when the next one is already queued: no device-to-host copy per round, the device never waits for the host.
 //             Launches behind the last round find an empty range and return.
 //   assign  : rounds in reverse.  A key peeled in round t is never incident to the singleton row of another key of round t
-//             (that row had degree 1 when the round began), so a round is assigned in parallel: D[free] = fp ^ D[r'] ^ D[r''].
-//             The FREE row is not the row that happened to win the claim but the lowest-segment row of the key that entered
-//             the list for round t: that set does not depend on any race, so the columns are a function of (keys, seed) alone
-//             -- two builds of one index are byte-identical.  Small rounds (the long plateau close to the peeling threshold) are
-//             assigned by ONE block that walks them with a barrier in between instead of a launch each        (k_assign*)
+//             (that row had degree 1 when the round began), so a round is assigned in parallel: D[free] = fp ^ D[r'] ^ D[r''],
+//             free = the row that peeled the key.  Which rows are listed for which round, and therefore which row peels which
+//             key, is a function of (keys, seed) alone -- two builds of one index are byte-identical.  Small rounds (the long
+//             plateau close to the peeling threshold) are assigned by ONE block that walks them with a barrier in between
+//             instead of a launch each                                                                          (k_assign*)
 //   verify  : every key is looked up in the finished columns (3 bytes per key); a mismatch is a bug and fails loudly.
 //
-// A bin that does not peel (its group's claimed count falls short) re-seeds ITS IXF only; the other IXFs of the chunk are
+// A bin that does not peel (its logged keys fall short) re-seeds ITS IXF only; the other IXFs of the chunk are
 // finished, the failed one goes into the next chunk with a redrawn seed, like construct_ixf.cpp:100-108.
 //
 // taxor_gpu_index_build_hixf* builds a whole hierarchy level by level from the leaves up: the keys stay on the device, a merged
-// bin's key set is the sorted, duplicate-free union of everything in its child IXF (keyset.hip), all IXFs of a level share chunks.
+// bin's key set is the duplicate-free union of everything in its child IXF (keyset.hip: a hash set in HBM), all IXFs of a level share chunks.
 #include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
 #include "kernels.h"
@@ -46,6 +48,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace taxor;
@@ -101,7 +104,6 @@ struct Peel {
     uint64_t *list;      // [n_slots] job << 32 | row, append-only
     uint32_t *log;       // [n_slots] index of the key peeled by list entry i, or DEAD
     uint16_t *pushed;    // [n_slots] the round a slot was listed for, 0xFFFF = never
-    uint32_t *claim;     // one bit per key
     const uint8_t *skip; // per group: 1 = not peeled under this seed, leave its columns alone (nullptr: none)
     Ctl *ctl;
 };
@@ -116,6 +118,12 @@ __device__ __forceinline__ uint32_t job_in(const BinJob *jobs, uint32_t lo, uint
     }
     return lo;
 }
+
+// The key and fingerprint pointers come out of a BinJob in memory, so the compiler cannot infer their address space and would emit
+// flat loads / stores: cast to global.
+__device__ __forceinline__ uint64_t ldg64(const uint64_t *p) { return *(const uint64_t __attribute__((address_space(1))) *)(uintptr_t)p; }
+__device__ __forceinline__ uint8_t ldg8(const uint8_t *p) { return *(const uint8_t __attribute__((address_space(1))) *)(uintptr_t)p; }
+__device__ __forceinline__ void stg8(uint8_t *p, uint8_t v) { *(uint8_t __attribute__((address_space(1))) *)(uintptr_t)p = v; }
 
 template <typename WT>
 __device__ __forceinline__ WT w_delta(uint64_t idx) { return (WT)((WT)idx << 8) + (WT)1; }
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
     for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         const uint64_t k = g - J.key_base;
-        const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
+        const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
         const WT d = w_delta<WT>(k);
 #pragma unroll
         for (int j = 0; j < 3; ++j) __hip_atomic_fetch_add(&a.w[J.slot_base + p.row[j]], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -231,15 +239,19 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
                 uint32_t logged = DEAD;
                 const uint64_t k = (uint64_t)(w >> 8);
                 if ((w & (WT)0xFF) == (WT)1 && k < J.n_keys) {
-                    const uint64_t gk = J.key_base + k;
-                    const uint32_t bit = 1u << (gk & 31u);
-                    if (!(atomicOr(&a.claim[gk >> 5], bit) & bit)) {
+                    const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
+                    // the key's lowest-segment row that is listed for this round peels it; this row, unless a lower one carries the mark
+                    const int own = row == p.row[0] ? 0 : row == p.row[1] ? 1 : 2;
+                    bool mine = true;
+                    if (own >= 1 && a.pushed[J.slot_base + p.row[0]] == (uint16_t)t) mine = false;
+                    if (own == 2 && mine && a.pushed[J.slot_base + p.row[1]] == (uint16_t)t) mine = false;
+                    if (mine) {
                         logged = (uint32_t)k;
                         ++claimed;
-                        const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
                         const WT d = w_delta<WT>(k);
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
+                            if (j == own) continue;                 // (this slot is listed once, here, and holds no other key: never read again)
                             const uint64_t s = J.slot_base + p.row[j];
                             const WT old = __hip_atomic_fetch_sub(&a.w[s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if ((old & (WT)0xFF) == (WT)2) {
@@ -265,31 +277,30 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
     }
 }
 
-// list entry i (peeled in round t): D[free row] = fp ^ D[other two rows]; the free row is the lowest-segment row of the key that
-// was listed for round t (the row that won the claim is one of them)
+// list entry i: D[free row] = fp ^ D[other two rows]; the free row is the row that peeled the key, the entry's own
 template <typename WT>
-__device__ __forceinline__ void assign_entry(const Peel<WT> &a, uint64_t i, uint32_t t)
+__device__ __forceinline__ void assign_entry(const Peel<WT> &a, uint64_t i)
 {
     const uint32_t k = a.log[i];
     if (k == DEAD) return;
-    const BinJob &J = a.jobs[(uint32_t)(a.list[i] >> 32)];
+    const uint64_t e = a.list[i];
+    const BinJob &J = a.jobs[(uint32_t)(e >> 32)];
     if (a.skip && a.skip[J.group]) return;
-    const ixf_probe p = ixf_probe_key_arith(J.keys[k], J.seed, J.seg_len, J.arith);
-    int fr = 2;
-    if (a.pushed[J.slot_base + p.row[0]] == (uint16_t)t) fr = 0;
-    else if (a.pushed[J.slot_base + p.row[1]] == (uint16_t)t) fr = 1;
+    const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
+    const uint32_t row = (uint32_t)e;
+    const int fr = row == p.row[0] ? 0 : row == p.row[1] ? 1 : 2;
     uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-        if (j != fr) v ^= J.data[(uint64_t)p.row[j] * J.stride + J.bin];
-    J.data[(uint64_t)p.row[fr] * J.stride + J.bin] = v;
+        if (j != fr) v ^= ldg8(J.data + ((uint64_t)p.row[j] * J.stride + J.bin));
+    stg8(J.data + ((uint64_t)p.row[fr] * J.stride + J.bin), v);
 }
 
 template <typename WT>
 __global__ __launch_bounds__(BB) void k_assign(const Peel<WT> a, uint32_t t)
 {
     const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
-    for (uint64_t i = (uint64_t)lo + (uint64_t)blockIdx.x * BB + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * BB) assign_entry(a, i, t);
+    for (uint64_t i = (uint64_t)lo + (uint64_t)blockIdx.x * BB + threadIdx.x; i < hi; i += (uint64_t)gridDim.x * BB) assign_entry(a, i);
 }
 
 // rounds t_hi, t_hi - 1, ..., t_lo by ONE block (all of them small): a barrier between two rounds instead of a launch.  The block's
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_assign_tail(const Peel<WT> a, 
 {
     for (uint32_t t = t_hi + 1; t-- > t_lo;) {
         const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
-        for (uint64_t i = (uint64_t)lo + threadIdx.x; i < hi; i += TAIL_THREADS) assign_entry(a, i, t);
+        for (uint64_t i = (uint64_t)lo + threadIdx.x; i < hi; i += TAIL_THREADS) assign_entry(a, i);
         __syncthreads();
     }
 }
@@ -321,10 +332,10 @@ __global__ __launch_bounds__(BB) void k_verify(const Peel<WT> a, uint32_t block0
     for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         if (a.skip && a.skip[J.group]) continue;
-        const ixf_probe p = ixf_probe_key_arith(J.keys[g - J.key_base], J.seed, J.seg_len, J.arith);
+        const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + (g - J.key_base)), J.seed, J.seg_len, J.arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) v ^= J.data[(uint64_t)p.row[j] * J.stride + J.bin];
+        for (int j = 0; j < 3; ++j) v ^= ldg8(J.data + ((uint64_t)p.row[j] * J.stride + J.bin));
         bad += v != 0;
     }
     if (bad) atomicAdd(&bad_blk, bad);
@@ -332,24 +343,11 @@ __global__ __launch_bounds__(BB) void k_verify(const Peel<WT> a, uint32_t block0
     if (threadIdx.x == 0 && bad_blk) atomicAdd(&a.ctl->mismatches, (unsigned long long)bad_blk);
 }
 
-// claimed keys per job (only looked at when a chunk fell short): one block per job
-__global__ __launch_bounds__(BB) void k_job_peeled(const BinJob *jobs, const uint32_t *claim, uint64_t *out)
+// peeled keys per job, from the log (only looked at when a chunk fell short)
+__global__ __launch_bounds__(BB) void k_job_peeled(const uint64_t *list, const uint32_t *log, uint32_t n_list, unsigned long long *out)
 {
-    __shared__ unsigned long long tot;
-    const BinJob &J = jobs[blockIdx.x];
-    if (threadIdx.x == 0) tot = 0;
-    __syncthreads();
-    const uint64_t b0 = J.key_base, b1 = J.key_base + J.n_keys;
-    unsigned long long n = 0;
-    for (uint64_t wd = (b0 >> 5) + threadIdx.x; wd <= ((b1 - 1) >> 5); wd += BB) {
-        uint32_t v = claim[wd];
-        if (wd == (b0 >> 5)) v &= 0xFFFFFFFFu << (b0 & 31u);
-        if (wd == ((b1 - 1) >> 5) && (b1 & 31u)) v &= 0xFFFFFFFFu >> (32u - (uint32_t)(b1 & 31u));
-        n += (unsigned)__popc(v);
-    }
-    if (n) atomicAdd(&tot, n);
-    __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = tot;
+    for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < n_list; i += (uint64_t)gridDim.x * BB)
+        if (log[i] != DEAD) atomicAdd(&out[(uint32_t)(list[i] >> 32)], 1ull);
 }
 
 // columns of the jobs [j0, j0 + nj) of one IXF -> 0 (bins that are not built keep their content)
@@ -359,7 +357,7 @@ __global__ __launch_bounds__(BB) void k_zero_columns(const BinJob *jobs, uint32_
     for (uint64_t i = (uint64_t)blockIdx.x * BB + threadIdx.x; i < total; i += (uint64_t)gridDim.x * BB) {
         const uint64_t r = i / nj;
         const BinJob &J = jobs[j0 + (uint32_t)(i - r * nj)];
-        J.data[r * J.stride + J.bin] = 0;
+        stg8(J.data + (r * J.stride + J.bin), 0);
     }
 }
 
@@ -403,30 +401,30 @@ struct Engine {
     hipEvent_t ev[2] = {nullptr, nullptr};
     void *d_w = nullptr;
     uint64_t *d_list = nullptr, *d_job_peeled = nullptr;
-    uint32_t *d_log = nullptr, *d_claim = nullptr;
+    uint32_t *d_log = nullptr;
     uint16_t *d_pushed = nullptr;
     uint8_t *d_skip = nullptr;
     Ctl *d_ctl = nullptr;
     BinJob *d_jobs = nullptr;
     uint32_t *h_round_end = nullptr;                   // page-locked
     unsigned long long *h_counts = nullptr;            // page-locked: peeled, mismatches
-    uint64_t cap_slots = 0, cap_keys = 0, cap_jobs = 0, w_bytes = 0, budget_bytes = 0;
+    uint64_t cap_slots = 0, cap_jobs = 0, w_bytes = 0, budget_bytes = 0, free_half = 0;
     taxor_build_stats stats{};
 
     ~Engine() { release(); }
 
     void release()
     {
-        for (void *p : {(void *)d_w, (void *)d_list, (void *)d_job_peeled, (void *)d_log, (void *)d_claim, (void *)d_pushed, (void *)d_skip, (void *)d_ctl, (void *)d_jobs})
+        for (void *p : {(void *)d_w, (void *)d_list, (void *)d_job_peeled, (void *)d_log, (void *)d_pushed, (void *)d_skip, (void *)d_ctl, (void *)d_jobs})
             if (p) (void)hipFree(p);
-        d_w = nullptr; d_list = nullptr; d_job_peeled = nullptr; d_log = nullptr; d_claim = nullptr; d_pushed = nullptr; d_skip = nullptr; d_ctl = nullptr; d_jobs = nullptr;
+        d_w = nullptr; d_list = nullptr; d_job_peeled = nullptr; d_log = nullptr; d_pushed = nullptr; d_skip = nullptr; d_ctl = nullptr; d_jobs = nullptr;
         if (h_round_end) (void)hipHostFree(h_round_end);
         if (h_counts) (void)hipHostFree(h_counts);
         h_round_end = nullptr; h_counts = nullptr;
         for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (st) (void)hipStreamDestroy(st);
         st = nullptr;
-        cap_slots = cap_keys = cap_jobs = w_bytes = 0;
+        cap_slots = cap_jobs = w_bytes = 0;
     }
 
     int open(int dev)
@@ -440,19 +438,26 @@ struct Engine {
         E_TRY(hipMalloc((void **)&d_ctl, sizeof(Ctl)));
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
-        if (const char *e = getenv("TAXOR_BUILD_SCRATCH_MB")) fr = (size_t)strtoull(e, nullptr, 10) << 21;      // (tests: small chunks)
-        budget_bytes = std::min<uint64_t>((uint64_t)fr / 2, 40ull << 30);
+        free_half = (uint64_t)fr / 2;
+        budget_bytes = std::min<uint64_t>(free_half, 3ull << 30);
+        if (const char *e = getenv("TAXOR_BUILD_SCRATCH_MB")) budget_bytes = std::min<uint64_t>(free_half, strtoull(e, nullptr, 10) << 20);   // (tests, sweeps)
         return TAXOR_OK;
     }
 
-    // scratch bytes a chunk of (slots, keys) needs: 18 (26 with 64-bit words) per slot + a bit per key
-    static uint64_t bytes_for(uint64_t slots, uint64_t keys, bool wide) { return slots * (wide ? 26u : 18u) + keys / 8 + 64; }
+    // scratch bytes a chunk of `slots` needs: 18 per slot (26 with 64-bit words): state word, list entry, log entry, round mark
+    static uint64_t bytes_for(uint64_t slots, bool wide) { return slots * (wide ? 26u : 18u) + 64; }
 
-    // slots a chunk may have: scratch within half of the memory that was free when the engine was opened, at most 40 GB, and
-    // fewer than 2^32 slots (list positions are 32 bits)
+    // Slots a chunk may have.  Chunk size hardly matters for the rate (2.4 GB of scratch: 1.80 G insertions/s, 23 GB: 1.95,
+    // profiles/r06/build_chunk_sweep.txt) but decides how long a launch runs and how much memory a build takes next to a resident
+    // index: 3 GB by default (the largest launch, a chunk's first round, stays under 2 ms), more only when ONE bin needs more,
+    // never beyond half of what was free when the engine was opened; fewer than 2^32 slots (list positions are 32 bits).
     uint64_t slot_budget(bool wide) const { return std::min<uint64_t>(budget_bytes / (wide ? 26u : 18u), 0xFFFFFFF0ull); }
+    void fit_bin(uint64_t slots_of_one_bin, bool wide)
+    {
+        budget_bytes = std::min<uint64_t>(free_half, std::max<uint64_t>(budget_bytes, bytes_for(slots_of_one_bin, wide)));
+    }
 
-    int ensure(uint64_t slots, uint64_t keys, uint64_t jobs, bool wide)
+    int ensure(uint64_t slots, uint64_t jobs, bool wide)
     {
         const uint64_t wb = slots * (wide ? 8 : 4);
         if (wb > w_bytes) {
@@ -472,13 +477,6 @@ struct Engine {
                 return bfail(TAXOR_E_NOMEM, "build: no device memory for the peeling work list");
             cap_slots = slots;
         }
-        if (keys > cap_keys) {
-            if (d_claim) (void)hipFree(d_claim);
-            d_claim = nullptr;
-            cap_keys = 0;
-            if (hipMalloc((void **)&d_claim, (keys / 32 + 2) * 4) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build: no device memory for the claim bits");
-            cap_keys = keys;
-        }
         if (jobs > cap_jobs) {
             for (void *p : {(void *)d_jobs, (void *)d_job_peeled, (void *)d_skip})
                 if (p) (void)hipFree(p);
@@ -489,7 +487,7 @@ struct Engine {
                 return bfail(TAXOR_E_NOMEM, "build: no device memory for the bin table");
             cap_jobs = jobs;
         }
-        stats.scratch_bytes = std::max<uint64_t>(stats.scratch_bytes, w_bytes + cap_slots * 14 + cap_keys / 8 + cap_jobs * (sizeof(BinJob) + 9) + sizeof(Ctl));
+        stats.scratch_bytes = std::max<uint64_t>(stats.scratch_bytes, w_bytes + cap_slots * 14 + cap_jobs * (sizeof(BinJob) + 9) + sizeof(Ctl));
         return TAXOR_OK;
     }
 
@@ -519,7 +517,7 @@ struct Engine {
         }
         if (ns >= 0xFFFFFFF8ull || jobs.size() >= (1ull << 31)) return bfail(TAXOR_E_INTERNAL, "build: chunk too large");
         E_TRY(hipSetDevice(device));
-        const int rc = ensure(ns, nk, jobs.size(), wide);
+        const int rc = ensure(ns, jobs.size(), wide);
         if (rc != TAXOR_OK) return rc;
         ++stats.chunks;
         return wide ? run_typed<uint64_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows)
@@ -541,13 +539,11 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     a.list = d_list;
     a.log = d_log;
     a.pushed = d_pushed;
-    a.claim = d_claim;
     a.skip = nullptr;
     a.ctl = d_ctl;
     E_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(BinJob), hipMemcpyHostToDevice, st));
     E_TRY(hipMemsetAsync(d_w, 0, n_slots * sizeof(WT), st));
     E_TRY(hipMemsetAsync(d_pushed, 0xFF, n_slots * 2, st));
-    E_TRY(hipMemsetAsync(d_claim, 0, (n_keys / 32 + 2) * 4, st));
     E_TRY(hipMemsetAsync(d_ctl, 0, sizeof(Ctl), st));
     const uint32_t grid_keys = (uint32_t)((n_keys + KEYS_PER_BLOCK - 1) / KEYS_PER_BLOCK);
     for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_count<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
@@ -595,14 +591,15 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     // which IXFs fell short?
     uint32_t n_failed = 0;
     if (h_counts[0] != n_keys) {
-        hipLaunchKernelGGL(k_job_peeled, dim3((uint32_t)jobs.size()), dim3(BB), 0, st, d_jobs, d_claim, d_job_peeled);
+        E_TRY(hipMemsetAsync(d_job_peeled, 0, jobs.size() * 8, st));
+        hipLaunchKernelGGL(k_job_peeled, dim3(1024), dim3(BB), 0, st, d_list, d_log, h_round_end[rounds], (unsigned long long *)d_job_peeled);
         std::vector<uint64_t> got(jobs.size());
         E_TRY(hipMemcpyAsync(got.data(), d_job_peeled, jobs.size() * 8, hipMemcpyDeviceToHost, st));
         E_TRY(hipStreamSynchronize(st));
         for (size_t j = 0; j < jobs.size(); ++j)
             if (got[j] != jobs[j].n_keys) group_ok[jobs[j].group] = 0;
         for (uint32_t g = 0; g < n_groups; ++g) n_failed += !group_ok[g];
-        if (!n_failed) return bfail(TAXOR_E_INTERNAL, "build: claimed keys fall short but every bin is complete");
+        if (!n_failed) return bfail(TAXOR_E_INTERNAL, "build: peeled keys fall short but every bin is complete");
         std::vector<uint8_t> skip(n_groups);
         for (uint32_t g = 0; g < n_groups; ++g) skip[g] = !group_ok[g];
         E_TRY(hipMemcpyAsync(d_skip, skip.data(), n_groups, hipMemcpyHostToDevice, st));
@@ -688,6 +685,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             jobs.push_back(j);
         }
     };
+    for (size_t q : todo) eng.fit_bin(3 * plans[q].seg_len, plans[q].max_bin >= (1ull << 24));
     while (!todo.empty()) {
         std::vector<BinJob> jobs;
         std::vector<size_t> members;
@@ -801,6 +799,11 @@ extern "C" int taxor_gpu_malloc(int device, uint64_t bytes, void **out)
 extern "C" void taxor_gpu_free(void *p)
 {
     if (p) (void)hipFree(p);
+}
+
+extern "C" int taxor_gpu_memcpy_from_host(void *d_dst, const void *src, uint64_t bytes)
+{
+    return hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? TAXOR_OK : bfail(TAXOR_E_HIP, "taxor_gpu_memcpy_from_host failed");
 }
 
 extern "C" int taxor_gpu_memcpy_to_host(void *dst, const void *d_src, uint64_t bytes)
@@ -930,7 +933,7 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
     if (rc != TAXOR_OK) { cleanup(); return rc; }
     struct Union { const uint64_t *p = nullptr; uint64_t n = 0; };
     std::vector<Union> uni(n_ixf);
-    SortScratch sorter;
+    KeyUnion unioner;
     for (int d = max_depth; d >= 0 && rc == TAXOR_OK; --d) {
         std::vector<IxfPlan> level;
         std::vector<uint64_t> ids;
@@ -955,20 +958,31 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
             ids.push_back(i);
         }
         for (uint64_t i : ids) level.push_back(plan[i]);
+        // the arena the unions of this level go to: tens of GB at class scale, and hipMalloc of that much is half a second of
+        // page-table work on the host -- done by a thread of its own while the level's bins are peeled
+        uint64_t *arena = nullptr;
+        hipError_t arena_err = hipSuccess;
+        std::thread arena_thread;
+        if (d > 0 && level_keys)
+            arena_thread = std::thread([&arena, &arena_err, level_keys, device] {
+                arena_err = hipSetDevice(device);
+                if (arena_err == hipSuccess) arena_err = hipMalloc((void **)&arena, level_keys * 8);
+            });
         rc = build_plans(eng, idx, level);
+        if (arena_thread.joinable()) arena_thread.join();
+        arenas.push_back(arena);
         if (rc != TAXOR_OK) break;
         for (size_t q = 0; q < ids.size(); ++q) plan[ids[q]].seed = level[q].seed;
         if (d == 0) break;
         // what the level above inserts into its merged bins: the duplicate-free union of every IXF of this level
         const double tu = now_s();
-        uint64_t *arena = nullptr, *concat = nullptr;
-        if (level_keys && hipMalloc((void **)&arena, level_keys * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
-        arenas.push_back(arena);
+        uint64_t *concat = nullptr;
+        if (level_keys && (arena_err != hipSuccess || !arena)) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
         uint64_t used = 0;
         for (uint64_t i : ids) {
             IxfPlan &p = plan[i];
             if (!p.total) continue;
-            if (p.total >= (1ull << 32)) { rc = bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 keys below one merged bin"); break; }
+            if (p.total >= 0xFFFFFFFFull) { rc = bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 - 2 keys below one merged bin"); break; }
             // the IXF's keys in one piece: its leaf bins are adjacent in the caller's array; with merged bins among them, gathered
             const uint64_t *src = nullptr;
             bool contiguous = true;
@@ -986,7 +1000,7 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
                 src = concat;
             }
             uint64_t n_out = 0;
-            const hipError_t e = sorter.sort_unique(src, p.total, arena + used, &n_out, eng.st);
+            const hipError_t e = unioner.unique(src, p.total, arena + used, &n_out, eng.st);
             if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
             uni[i].p = arena + used;
             uni[i].n = n_out;
@@ -1000,7 +1014,7 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         }
         eng.stats.seconds_union += now_s() - tu;
     }
-    sorter.release();
+    unioner.release();
     cleanup();
     if (rc != TAXOR_OK) return rc;
     eng.stats.seconds_total = now_s() - t0;

@@ -501,7 +501,16 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
                 n_dist = tot;
             }
         } else if (n_sel > 0) {
-            auto cand_at = [&](uint32_t i) -> uint64_t { return i < (uint32_t)SY_LDS_CAND ? sCand[i] : cand[i]; };
+            // (two loads in two address spaces, each under its own branch: `c ? sCand[i] : cand[i]` lets the compiler select between
+            //  the ADDRESSES, and a pointer that may be LDS or global is a flat one -- flat_load ties up lgkmcnt as well as vmcnt)
+            typedef const uint64_t __attribute__((address_space(1))) *gcand_t;
+            const gcand_t gcand = (gcand_t)(uintptr_t)cand;
+            auto cand_at = [&](uint32_t i) -> uint64_t {
+                uint64_t v;
+                if (i < (uint32_t)SY_LDS_CAND) v = sCand[i];
+                else v = gcand[i];
+                return v;
+            };
             uint32_t *const sDupBits = sV;                               // the s-mer tile is dead by now: 1 bit per candidate
             static_assert((uint32_t)(SY_C * SY_RS) * 32u == SYNC_LDS_DEDUP_MAX, "dup-bit capacity");
             const bool in_lds = n_sel <= SYNC_LDS_DEDUP_MAX;
@@ -562,12 +571,13 @@ template <int FW, bool PROF = false> __global__ __launch_bounds__(BLK) void k_sy
                 // longer than ~750 kb: per-block table in global memory (one pass)
                 uint32_t ts = 64;
                 while (ts < 2u * n_sel) ts <<= 1;
-                uint32_t *tab = a.gtab + (size_t)blockIdx.x * a.gtab_stride;
+                // (always the global table: an LDS stand-in for the overflow case would make `tab` a flat pointer)
+                typedef uint32_t __attribute__((address_space(1))) *gtab_t;
+                uint32_t *const tab = (uint32_t *)(gtab_t)(uintptr_t)(a.gtab + (size_t)blockIdx.x * a.gtab_stride);
                 if (ts > a.gtab_stride) {
                     if (tid == 0) atomicOr(&a.ctr->flags, FLAG_DEDUP_OVERFLOW);
                     n_sel = 0;
-                    ts = 64;
-                    tab = sTab;
+                    ts = 0;
                 }
                 const uint32_t mask = ts - 1u;
                 for (uint32_t i = tid; i < ts; i += BLK) tab[i] = 0xFFFFFFFFu;

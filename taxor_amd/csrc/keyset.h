@@ -1,4 +1,4 @@
-// keyset.h -- sorted, duplicate-free copy of a device array of 64-bit keys (hierarchical build, see keyset.hip)
+// keyset.h -- duplicate-free copy of a device array of 64-bit keys (hierarchical build, see keyset.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -6,18 +6,16 @@
 
 namespace taxor {
 
-// Scratch of the union step, kept from one IXF to the next (a hipMalloc / hipFree pair per IXF costs more than sorting a small one).
-struct SortScratch {
-    uint64_t *sorted = nullptr;
-    size_t *d_count = nullptr;
-    size_t *h_count = nullptr;     // page-locked
-    void *tmp = nullptr;
-    uint64_t cap = 0;
-    size_t tmp_bytes = 0;
-    ~SortScratch() { release(); }
+// Scratch of the union step, kept from one IXF to the next (a hipMalloc / hipFree pair per IXF costs more than the union of a small one).
+struct KeyUnion {
+    uint64_t *table = nullptr;             // open-addressing set, 1.5 .. 3 slots per input key
+    uint64_t table_entries = 0;
+    unsigned long long *d_ctl = nullptr;   // [0] keys written, [1] the input held the empty marker itself
+    unsigned long long *h_ctl = nullptr;   // page-locked
+    ~KeyUnion() { release(); }
     void release();
-    // d_out (room for n keys) receives the sorted distinct keys of d_in[0, n), *n_out their number; n < 2^32.  Waits for `st`.
-    hipError_t sort_unique(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *n_out, hipStream_t st);
+    // d_out (room for n keys) receives the distinct keys of d_in[0, n) in no particular order, *n_out their number.  Waits for `st`.
+    hipError_t unique(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *n_out, hipStream_t st);
 };
 
 }

@@ -16,6 +16,11 @@ def shard_range(n_reads, rank, world):
     return lo, min(lo + per, n_reads)
 
 
+# what the last gather_csr on this rank moved (dst only): per-rank (reads, tuples) as announced AND received, payload bytes that
+# arrived from peers -- bench.py's `comm` object is written from this, not from WORLD_SIZE
+last_gather = {"sizes": [], "bytes_received": 0}
+
+
 def gather_csr(read_off, user_bin, count, n_hashes, dst=0):
     """Gather every rank's CSR results on `dst`.  Inputs are 1-D torch tensors on the rank's device:
     read_off int64[n+1] (rank-local offsets), user_bin int64[t], count int32[t], n_hashes int32[n].
@@ -29,6 +34,7 @@ def gather_csr(read_off, user_bin, count, n_hashes, dst=0):
     all_sizes = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(all_sizes, sizes)
     if world == 1:
+        last_gather["sizes"], last_gather["bytes_received"] = [(n, t)], 0
         return read_off, user_bin, count, n_hashes
     mine = [read_off.contiguous(), user_bin.contiguous(), count.contiguous(), n_hashes.contiguous()]
     if rank != dst:
@@ -50,6 +56,8 @@ def gather_csr(read_off, user_bin, count, n_hashes, dst=0):
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    last_gather["sizes"] = [(int(parts[p][3].numel()), int(parts[p][1].numel())) for p in range(world)]
+    last_gather["bytes_received"] = sum(b.numel() * b.element_size() for p in range(world) if p != dst for b in parts[p])
     offs, base = [torch.zeros(1, dtype=torch.int64, device=dev)], 0
     for p in range(world):
         ro = parts[p][0]

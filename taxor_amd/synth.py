@@ -53,6 +53,97 @@ def synth_keys_host(first, n, salt):
         return z ^ (z >> np.uint64(31))
 
 
+def full_hierarchy_shapes(n_children, child_bins, keys_per_bin, slack=1.0):
+    """Shapes of a two-level hierarchy in which every bin is meant to be built (build bench, full-size build test): a root of
+    max(64, n_children) bins, the first n_children merged, over children of child_bins leaf bins with keys_per_bin keys each.
+    slack > 1: the IXFs are sized for slack x the keys their bins get (bins of a few ten thousand keys filled to exactly
+    1/1.23 of their rows fail to peel too often for a hundred of them to succeed under one seed, see exact_fill_index).
+    Returns (shapes for GpuIndex, n_user_bins, keys per technical bin in index bin order)."""
+    rb = max(64, n_children)
+    nx = np.zeros(rb, np.int64)
+    fn = np.arange(rb, dtype=np.int64)
+    nx[:n_children] = np.arange(1, n_children + 1)
+    fn[:n_children] = -1
+    shapes = [dict(bins=rb, stride=_stride(rb), seg_len=seg_len_for(int(child_bins * keys_per_bin * slack)), seed=1, next_ixf=nx, fname_idx=fn, data=None)]
+    ub = rb
+    for c in range(n_children):
+        shapes.append(dict(bins=child_bins, stride=_stride(child_bins), seg_len=seg_len_for(int(keys_per_bin * slack)), seed=2 + c,
+                           next_ixf=np.full(child_bins, c + 1, np.int64), fname_idx=np.arange(ub, ub + child_bins, dtype=np.int64), data=None))
+        ub += child_bins
+    counts = np.zeros(rb + n_children * child_bins, dtype=np.uint64)
+    counts[rb:] = keys_per_bin
+    return shapes, ub, counts
+
+
+def capacity_of(seg_len):
+    """keys a bin of an IXF with this segment length is sized for: the largest n with seg_len_for(n) <= seg_len"""
+    n = int((3 * seg_len - 32) / 1.23)
+    while seg_len_for(n + 1) <= seg_len:
+        n += 1
+    while n > 0 and seg_len_for(n) > seg_len:
+        n -= 1
+    return n
+
+
+def exact_fill_index(layout, salt=DEFAULT_SEED, k=22, s=12, t=5, device=0, seed0=7, fill_frac=0.9):
+    """An index of the layout's shape in which EVERY bin is a real filter: planted leaf bins hold their genomes' hashes, every
+    other leaf bin is filled with synthetic keys (synth_key(running index, salt), generated on the device) to fill_frac of its
+    IXF's capacity, merged bins receive the union of their child -- all of it constructed by taxor_gpu_index_build_hixf_ex.
+    fill_frac < 1: an IXF's capacity is that of its LARGEST bin, the others are smaller in any real index; and a bin of a few
+    ten thousand keys filled to exactly 1/1.23 of its rows fails to peel under a given seed every so often (the margin to the
+    peeling threshold, 0.7 %, is about its own finite-size fluctuation), which a hundred such bins under ONE seed -- the
+    reference's rule, construct_ixf.cpp:100-108 -- practically never survive.  The layout must come from make_layout /
+    make_family_layout(build="gpu").  Returns (index, build figures)."""
+    from .search import GpuIndex
+    L = _lib.lib()
+    fs = layout["ixfs"]
+    idx = GpuIndex([dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], next_ixf=f["next_ixf"],
+                         fname_idx=f["fname_idx"], data=None) for f in fs], layout["n_user_bins"], k, s, t, device)
+    # how many synthetic keys a decoy leaf bin of IXF i gets: its IXF's capacity -- unless the IXF hangs below a merged bin, whose
+    # capacity P bounds the UNION of everything in the IXF: decoys * fill + planted + merged bins * capacity <= P
+    parent_cap = [None] * len(fs)
+    for i, f in enumerate(fs):
+        for b in range(f["bins"]):
+            if f["fname_idx"][b] < 0:
+                parent_cap[int(f["next_ixf"][b])] = capacity_of(f["seg_len"])
+    counts, planted = [], []            # per technical bin in index order; planted: (global bin, keys)
+    for i, f in enumerate(fs):
+        cap = capacity_of(f["seg_len"])
+        leaf = [b for b in range(f["bins"]) if f["fname_idx"][b] >= 0]
+        n_merged = f["bins"] - len(leaf)
+        own = sum(len(f["key_sets"][b]) for b in leaf if b in f["key_sets"])
+        decoys = sum(1 for b in leaf if b not in f["key_sets"])
+        fill = max(1, int(cap * fill_frac))
+        if parent_cap[i] is not None and decoys:
+            fill = max(1, min(fill, (parent_cap[i] - own - n_merged * cap) // decoys))
+        for b in range(f["bins"]):
+            if f["fname_idx"][b] < 0:                      # merged: its keys come from its child
+                counts.append(0)
+            elif b in f["key_sets"]:
+                planted.append((len(counts), f["key_sets"][b]))
+                counts.append(len(f["key_sets"][b]))
+            else:
+                counts.append(fill)
+    off = np.zeros(len(counts) + 1, dtype=np.uint64)
+    np.cumsum(np.array(counts, dtype=np.uint64), out=off[1:])
+    total = int(off[-1])
+    d_keys = C.c_void_p()
+    _lib.check(L.taxor_gpu_malloc(device, total * 8, C.byref(d_keys)))
+    try:
+        # decoys: one sweep over everything (the planted ranges are overwritten below), so that every synthetic key is distinct
+        _lib.check(L.taxor_gpu_synth_keys(device, d_keys, 0, total, int(salt)))
+        for g, keys in planted:
+            kk = np.ascontiguousarray(keys, dtype=np.uint64)
+            _lib.check(L.taxor_gpu_memcpy_from_host(C.c_void_p(d_keys.value + int(off[g]) * 8), _p(kk), kk.size * 8))
+        st = _lib.BuildStats()
+        _lib.check(L.taxor_gpu_index_build_hixf_ex(idx._h, d_keys, 1, _p(off), int(seed0), C.byref(st)))
+    finally:
+        L.taxor_gpu_free(d_keys)
+    for i, f in enumerate(fs):
+        f["seed"] = idx.ixf_seed(i)
+    return idx, {kk: getattr(st, kk) for kk, _ in _lib.BuildStats._fields_ if kk != "reserved"}
+
+
 def seg_len_for(max_bin_elements):
     return int(_lib.lib().taxor_ixf_seg_len(int(max_bin_elements)))
 

@@ -240,3 +240,88 @@ def test_arithmetic_code_through_builder_query_and_oracle(kh, sm, rot, red, fp):
             assert np.array_equal(ub, wub) and np.array_equal(ct, wct), (b, thr)
     sr.close()
     idx.close()
+
+
+def test_two_builds_are_byte_identical():
+    """which of a key's singleton rows wins the claim is a race; the free row that is ASSIGNED is the lowest-segment row listed for the
+    key's round, so the columns are a function of (keys, seed) alone -- ranks that each build their replica of an index hold the
+    same bytes (bench.py's strong-scaling digest rests on this)"""
+    rng = np.random.default_rng(12)
+    keys = {b: np.unique(rng.integers(0, 2**64 - 1, size=n, dtype=np.uint64)) for b, n in {0: 300000, 1: 290000, 7: 5, 63: 120000}.items()}
+    got = []
+    for _ in range(3):
+        ixf, idx = _empty_index(64, 300000, seed=3)
+        seed, rounds = idx.build_ixf(0, keys, seed0=99)
+        got.append((seed, idx.download_ixf(0)))
+        idx.close()
+    assert got[0][0] == got[1][0] == got[2][0]
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][1], got[2][1])
+
+
+def test_bins_of_more_than_16M_keys_use_64_bit_state_words():
+    """a bin of >= 2^24 keys (a merged bin high in a large hierarchy): the degree | index-sum words are 64 bits wide"""
+    n = (1 << 24) + 12345
+    keys = synth.synth_keys_host(0, n, 5)
+    bins = 3
+    ixf, idx = _empty_index(bins, n)
+    seed, rounds = idx.build_ixf(0, {1: keys, 2: keys[:1000]}, seed0=4)
+    after = idx.download_ixf(0)
+    h = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]])
+    found, _ = h.synth_keys_found(0, 1, 0, n, 5)
+    assert found == n
+    found, _ = h.synth_keys_found(0, 2, 0, 1000, 5)
+    assert found == 1000
+    found, _ = h.synth_keys_found(0, 2, 1000, 200000, 5)                  # non-members of bin 2
+    assert abs(found / 200000 - 1 / 256) < 0.001
+    idx.close()
+
+
+def test_ixf_larger_than_the_scratch_is_built_in_chunks_of_its_bins(monkeypatch):
+    """TAXOR_BUILD_SCRATCH_MB=1: the budget is raised to what ONE bin needs, so this IXF of 150 bins goes through the engine a few bins
+    at a time; the hierarchy above it is built from its union as usual"""
+    monkeypatch.setenv("TAXOR_BUILD_SCRATCH_MB", "1")
+    nc, cb, kpb = 3, 150, 20000
+    shapes, ub, counts = synth.full_hierarchy_shapes(nc, cb, kpb, slack=1.1)
+    idx = GpuIndex(shapes, ub)
+    st, off = idx.build_hixf_synth(counts, salt=77, seed0=3)
+    assert st["chunks"] > 30 and st["keys_inserted"] == 2 * nc * cb * kpb and st["scratch_bytes"] < 100 << 20        # (one root bin of 3.3 M keys is what sets the size)
+    host = [dict(s, seed=idx.ixf_seed(i), data=idx.download_ixf(i)) for i, s in enumerate(shapes)]
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    rb = shapes[0]["bins"]
+    for c in range(1, nc + 1):
+        for b in range(cb):
+            g = rb + (c - 1) * cb + b
+            assert h.synth_keys_found(c, b, int(off[g]), kpb, 77)[0] == kpb
+            assert h.synth_keys_found(0, c - 1, int(off[g]), kpb, 77)[0] == kpb
+    idx.close()
+
+
+def test_many_small_ixfs_share_chunks_and_only_a_failed_ixf_is_reseeded():
+    """400 child IXFs of 4 bins with 40 keys each: one chunk holds all of them (one launch sequence for 400 IXFs); tiny
+    hypergraphs fail to peel now and then -- such an IXF alone is redone under a redrawn seed, every key is found in the end, and
+    the duplicate keys shared by neighbouring bins are merged in the unions"""
+    nc, cb, kpb = 400, 4, 40
+    shapes, ub, counts = synth.full_hierarchy_shapes(nc, cb, kpb, slack=2.0)     # (a roomy root: its 400 small bins must all peel under ONE seed)
+    for f in shapes[1:]:
+        f["seg_len"] = 22                       # 66 rows for 40 keys, without the +32 slack: a bin peels under 88 % of the seeds, four under 60 %
+    idx = GpuIndex(shapes, ub)
+    rng = np.random.default_rng(8)
+    leaf = {}
+    for c in range(1, nc + 1):
+        shared = rng.integers(1, 2**63, size=8, dtype=np.uint64)                    # the same 8 keys in every bin of a child
+        for b in range(cb):
+            leaf[(c, b)] = np.unique(np.concatenate([shared, rng.integers(1, 2**63, size=kpb - 8, dtype=np.uint64)]))
+    rounds = idx.build_hixf(leaf, seed0=21)
+    seeds = [idx.ixf_seed(i) for i in range(1, nc + 1)]
+    redrawn = sum(1 for i, sd in enumerate(seeds) if sd != (21 + 0x9E3779B97F4A7C15 * (i + 1)) % 2**64)
+    print(f"\n{redrawn} of {nc} IXFs were redone under a redrawn seed")
+    assert 0 < redrawn < nc, redrawn                                                 # some failed and were redone, not all
+    sr = Searcher(idx, ratio=0.5)
+    for c in (1, 17, nc):
+        allk = np.unique(np.concatenate([leaf[(c, b)] for b in range(cb)]))
+        assert allk.size == cb * (kpb - 8) + 8
+        assert sr.ixf_bulk_count(0, allk)[c - 1] == allk.size
+        for b in (0, 1, cb - 1):
+            assert sr.ixf_bulk_count(c, leaf[(c, b)])[b] == leaf[(c, b)].size
+    sr.close()
+    idx.close()

@@ -124,11 +124,13 @@ def _full_size_class(workload, min_index_bytes, max_index_bytes):
     assert info["fam_size"] == 16 and lay["depth"] == 3 and lay["split_runs"] > 8
 
     host = None
-    checks = []           # (batch, lo, hi) oracle samples: first, middle and last reads of the 10 M
-    S = 1500
-    checks.append((0, 0, S))
-    checks.append((n_batches // 2, reads_per_batch // 2, reads_per_batch // 2 + S))
-    checks.append((n_batches - 1, reads_per_batch - S, reads_per_batch))
+    # oracle samples: 5 000 consecutive reads out of EVERY batch (50 000 in all, at a different place in each batch; the first
+    # reads of the first batch and the last reads of the last one among them)
+    S = 5000
+    checks = []           # (batch, lo, hi)
+    for b_ in range(n_batches):
+        lo_ = 0 if b_ == 0 else reads_per_batch - S if b_ == n_batches - 1 else (b_ * 97003) % (reads_per_batch - S)
+        checks.append((b_, lo_, lo_ + S))
 
     sr = Searcher(idx, error_rate=args.error_rate, time_kernels=True)
     dense = Searcher(idx, error_rate=args.error_rate, sub_batch_reads=65536, prune=False)
@@ -179,6 +181,11 @@ def _full_size_class(workload, min_index_bytes, max_index_bytes):
                 a, e = int(res.read_off[lo]), int(res.read_off[hi])
                 samples[(cb, lo)] = (bases[int(offs[lo]):int(offs[hi])].copy(), offs[lo:hi + 1] - offs[lo], res.n_hashes[lo:hi].copy(),
                                      res.read_off[lo:hi + 1] - res.read_off[lo], res.user_bin[a:e].copy(), res.count[a:e].copy())
+    # the `layouts` leg strand_mixed of bench.py: planted reads from either strand (a reverse-strand read stops at the root)
+    mb, mo, m_origin = synth.synth_reads(info["genomes"], info["genome_off"], S, read_len, error_rate=args.read_error, frac_random=0.1,
+                                         seed=synth.DEFAULT_SEED + 55000, threads=os.cpu_count() or 8, frac_reverse=0.5)
+    mres = sr.search_batch(mb, mo)
+    samples[("strand_mixed", 0)] = (mb, mo, mres.n_hashes.copy(), mres.read_off.copy(), mres.user_bin.copy(), mres.count.copy())
     sr.close()
     dense.close()
     assert total_reads == n_batches * reads_per_batch
@@ -197,14 +204,57 @@ def _full_size_class(workload, min_index_bytes, max_index_bytes):
         data = idx.download_ixf(i) if i in needed else np.empty(nbytes, dtype=np.uint8)    # untouched virtual memory
         host.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], data=data))
     h = orc.Hixf(host, [f["next_ixf"] for f in lay["ixfs"]], [f["fname_idx"] for f in lay["ixfs"]])
-    assert len(samples) == len(set((c[0], c[1]) for c in checks))
+    assert len(samples) == len(set((c[0], c[1]) for c in checks)) + 1
+    import time
+    t0 = time.time()
+    sched = "reference" if orc.ref_lib() is not None else "openmp"          # the reference's own do_parallel where oracle/_ref is present
+    n_checked = t_checked = 0
     for key, (sb, so, g_nh, g_off, g_ub, g_cnt) in samples.items():
-        nh, off, ub, cnt, _ = h.search_batch(sb, so, err=args.error_rate, threads=min(64, os.cpu_count() or 8))
+        nh, off, ub, cnt, _ = h.search_batch(sb, so, err=args.error_rate, threads=min(32, os.cpu_count() or 8), scheduler=sched)
         assert np.array_equal(g_nh, nh), key
         assert np.array_equal(g_off, off), key
         assert np.array_equal(g_ub, ub) and np.array_equal(g_cnt, cnt), key
         assert ub.size > 0
+        n_checked += nh.size
+        t_checked += ub.size
+    print(f"\n{workload}: oracle ({sched} scheduler) agrees on {n_checked} reads / {t_checked} tuples out of {n_batches} batches + the strand-mixed sample, "
+          f"{time.time() - t0:.1f} s")
+    assert n_checked >= 50000 + S or n_batches < 10
     idx.close()
+
+
+@pytest.mark.parametrize("label,root_bins,child_bins", [("chopper_1024", 1024, 1024), ("root_4096", 4096, 128)])
+def test_gtdb_class_layout_leg_shapes_against_the_oracle(label, root_bins, child_bins):
+    """bench.py's `layouts` legs measure two more index shapes at the 113-GB footprint -- children as wide as the root (the reference's
+    layout step applies one t_max at every level) and a 4096-bin root; here 5 000 reads each are compared with the oracle tuple by
+    tuple (the third leg, strand-mixed reads, is a sample of the two class tests above)"""
+    import torch
+
+    import bench
+
+    free_hbm, _ = torch.cuda.mem_get_info(0)
+    if free_hbm < 160e9:
+        pytest.skip(f"needs 160 GB of free HBM, have {free_hbm/1e9:.0f}")
+    args = bench.parse_args(["--workload", "gtdb", "--reads", "5000", "--batches", "1", "--root-bins", str(root_bins), "--child-bins", str(child_bins)])
+    wl, idx, lay, batches, info = bench.build_workload(args, 0, 0, 1)
+    assert 95e9 < idx.data_bytes < 125e9 and wl["root_bins"] == root_bins and wl["child_bins"] == child_bins
+    bases, offs = batches[0]
+    sr = Searcher(idx, error_rate=args.error_rate)
+    res = sr.search_batch(bases, offs)
+    sr.close()
+    needed = {0} | {i for i, f in enumerate(lay["ixfs"]) if f.get("key_sets") or f["columns"]}
+    host = []
+    for i, f in enumerate(lay["ixfs"]):
+        nbytes = 3 * f["seg_len"] * f["stride"]
+        data = idx.download_ixf(i) if i in needed else np.empty(nbytes, dtype=np.uint8)    # untouched virtual memory
+        host.append(dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], data=data))
+    idx.close()
+    h = orc.Hixf(host, [f["next_ixf"] for f in lay["ixfs"]], [f["fname_idx"] for f in lay["ixfs"]])
+    nh, off, ub, cnt, _ = h.search_batch(bases, offs, err=args.error_rate, threads=min(32, os.cpu_count() or 8))
+    assert np.array_equal(res.n_hashes, nh) and np.array_equal(res.read_off, off)
+    assert np.array_equal(res.user_bin, ub) and np.array_equal(res.count, cnt)
+    assert ub.size > 5000                                                       # related strains: several tuples per read
+    print(f"\n{label}: oracle agrees on {nh.size} reads / {ub.size} tuples ({idx.n_ixf if False else len(host)} IXFs, {sum(1 for i in needed)} of them downloaded)")
 
 
 def test_refseq_class_ten_million_reads():
