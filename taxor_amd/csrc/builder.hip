@@ -43,6 +43,7 @@
 #include "ixf_arith.h"
 #include "kernels.h"
 #include "keyset.h"
+#include "tuning.h"
 
 #include <algorithm>
 #include <chrono>
@@ -440,7 +441,7 @@ struct Engine {
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = (size_t)8 << 30;
         free_half = (uint64_t)fr / 2;
         budget_bytes = std::min<uint64_t>(free_half, 3ull << 30);
-        if (const char *e = getenv("TAXOR_BUILD_SCRATCH_MB")) budget_bytes = std::min<uint64_t>(free_half, strtoull(e, nullptr, 10) << 20);   // (tests, sweeps)
+        if (const char *e = tune_env("TAXOR_BUILD_SCRATCH_MB")) budget_bytes = std::min<uint64_t>(free_half, strtoull(e, nullptr, 10) << 20);   // (tests, sweeps)
         return TAXOR_OK;
     }
 

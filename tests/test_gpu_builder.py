@@ -277,8 +277,9 @@ def test_bins_of_more_than_16M_keys_use_64_bit_state_words():
 
 
 def test_ixf_larger_than_the_scratch_is_built_in_chunks_of_its_bins(monkeypatch):
-    """TAXOR_BUILD_SCRATCH_MB=1: the budget is raised to what ONE bin needs, so this IXF of 150 bins goes through the engine a few bins
+    """TAXOR_TUNING=1 TAXOR_BUILD_SCRATCH_MB=1: the budget is raised to what ONE bin needs, so this IXF of 150 bins goes through the engine a few bins
     at a time; the hierarchy above it is built from its union as usual"""
+    monkeypatch.setenv("TAXOR_TUNING", "1")                  # (the knob sits behind the library's one gate, tuning.h)
     monkeypatch.setenv("TAXOR_BUILD_SCRATCH_MB", "1")
     nc, cb, kpb = 3, 150, 20000
     shapes, ub, counts = synth.full_hierarchy_shapes(nc, cb, kpb, slack=1.1)
