@@ -429,11 +429,12 @@ def build_cpu_reference(n_keys, salt):
 
 
 # algorithmic bytes one key insertion moves in builder.hip (32-bit state words; DESIGN.md section 4 derives the sum):
-#   key 8 B x 4 (count, round, assign, verify) + state word: 3 adds + 3 subs (4 B read + 4 B write each) + 1 load + the seed scan
-#   over 1.23 slots + claim bit (4 + 4) + list entry 8 B written and read for 1.12 listed rows + log 4 + 4 + round marks 2 B written
-#   per listed row, 3 x 2 B read + fingerprints: 2 read + 1 written + 3 verified + 1.23 cleared
-BUILD_BYTES_PER_INSERTION = 32 + 48 + 4 + 1.23 * 4 + 8 + 1.12 * 16 + 8 + 1.12 * 2 + 6 + 6 + 1.23
-BUILD_RMW_PER_INSERTION = 7          # 3 adds, 1 claim, 3 subs
+#   key 8 B x 4 (count, round, assign, verify) + state word: 3 adds + 2 subs (4 B read + 4 B written each), 1 load, the seed scan over
+#   1.23 slots + list entry 8 B written and read for 1.12 listed rows + log 4 + 4 + round marks: 2 B written per listed row, ~1 read
+#   + fingerprints: 2 read + 1 written + 3 verified + 1.23 cleared
+BUILD_BYTES_PER_INSERTION = 32 + 24 + 16 + 4 + 1.23 * 4 + 1.12 * 16 + 8 + 1.12 * 2 + 2 + 6 + 1.23
+BUILD_RMW_PER_INSERTION = 5          # 3 adds (k_count), 2 subs (k_round: the peeling row's own slot is not updated)
+BUILD_RANDOM_ACCESSES_PER_INSERTION = 12   # loads / stores that are not atomics: key x 3, state word, round marks ~2, fingerprints 6
 RMW_CEILING_G_PER_S = 27.1           # random 4-B atomics on a <= 256 MB set, any scope, returning or not (profiles/r06/atomics_bench.txt)
 
 
@@ -483,12 +484,15 @@ def build_mode(args):
                                   f"of {nc} merged bins of {cb * kpb} keys; every bin built; {ins // steps} insertions per step",
                       "timed_region": "keys resident in HBM (generated on the device): count -> seed scan -> peeling rounds -> clear -> assignment in reverse -> "
                                       "verification of every key, for every chunk of bins; duplicate-free union of each child's keys for the root (a hash set in HBM); scratch allocation inside; "
-                                      "the index shell's allocation outside",
+                                      "the index shell's allocation and the release of scratch afterwards outside",
                       "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "children": nc, "child_bins": cb, "keys_per_bin": kpb,
                       "insertions_per_step": ins // steps, "chunks_per_step": sts[-1]["chunks"], "rounds_max": max(s_["rounds_max"] for s_ in sts),
                       "reseeds": sum(s_["reseeds"] for s_ in sts), "scratch_bytes": max(s_["scratch_bytes"] for s_ in sts)},
            "stage_s_per_step": {"peel": round(sum(s_["seconds_peel"] for s_ in sts) / steps, 4), "assign_verify": round(sum(s_["seconds_assign"] for s_ in sts) / steps, 4),
-                                "unions": round(sum(s_["seconds_union"] for s_ in sts) / steps, 4), "total": round(secs / steps, 4), "wall": round(wall / steps, 4)},
+                                "unions": round(sum(s_["seconds_union"] for s_ in sts) / steps, 4), "total": round(secs / steps, 4),
+                                "release_after": round(sum(s_["seconds_release"] for s_ in sts) / steps, 4), "wall": round(wall / steps, 4),
+                                "note": "total = call -> last IXF built and verified; release_after = hipFree of keys, unions and scratch, outside `value`; wall also "
+                                        "holds the generation of the synthetic keys"},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                         "kernel": "k_count + k_round + k_assign + k_verify (builder.hip)",
                         "algorithmic_bytes_per_insertion": round(BUILD_BYTES_PER_INSERTION, 1),
@@ -496,10 +500,11 @@ def build_mode(args):
                                 "every one of its accesses is a random 1-8-byte access, and what the chip limits is their NUMBER -- see `rmw`",
                         "rmw": {"per_insertion": BUILD_RMW_PER_INSERTION, "achieved_G_per_s": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9, 2),
                                 "ceiling_G_per_s": RMW_CEILING_G_PER_S, "frac": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9 / RMW_CEILING_G_PER_S, 4),
+                                "random_loads_stores_per_insertion": BUILD_RANDOM_ACCESSES_PER_INSERTION,
                                 "note": "random atomic read-modify-writes per second against the chip's measured rate for them (profiles/r06/atomics_bench.txt: 27 G/s "
-                                        "up to 256 MB, 18-20 G/s beyond, whatever the scope, width or use of the return value); the builder also does ~11 random loads "
-                                        "and stores per insertion (54 G/s ceiling), so 7 RMW / 27 G/s + 11 / 54 G/s = 0.46 ns per insertion is the floor of this design: "
-                                        "2.2 G insertions/s"}}}
+                                        "up to 256 MB, 18-20 G/s beyond, whatever the scope, width or use of the return value); the builder also does ~12 random loads "
+                                        "and stores per insertion (54 G/s ceiling), so 5 RMW / 20-27 G/s + 12 / 54 G/s = 0.41-0.47 ns per insertion is the floor of this "
+                                        "design: 2.1-2.4 G insertions/s in the peeling + assignment kernels"}}}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = build_cpu_reference(args.build_cpu_keys, salt)
     idx.close()

@@ -74,7 +74,8 @@ typedef struct taxor_build_stats {
     double seconds_peel;      /* count + seed scan + rounds */
     double seconds_assign;    /* clearing, assignment in reverse, verification */
     double seconds_union;     /* duplicate-free unions of the merged bins' key sets */
-    double seconds_total;
+    double seconds_total;     /* from the call to the last IXF built and verified (key upload and scratch allocation inside) */
+    double seconds_release;   /* handing keys, unions and scratch back to the driver afterwards (not in seconds_total) */
 } taxor_build_stats;
 int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
                                  const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);

@@ -254,16 +254,17 @@ class Hixf:
         lib().orc_ixf_bulk_count(C.byref(self._ixf[i]), _p(h), h.size, _p(out))
         return out
 
-    def synth_keys_found(self, i, bin_, first, n, salt, sample_step=0, counts=None):
+    def synth_keys_found(self, i, bin_, first, n, salt, sample_step=0, counts=None, threads=0):
         """the synthetic keys first .. first+n-1 against column `bin_` of IXF i (bulk_count's rule on one column) -> number found;
         every sample_step-th key also through orc_ixf_bulk_count over all bins: counts (uint64[bins]) accumulates.
         Returns (found, sampled)."""
         sampled = C.c_uint64(0)
         L = lib()
         L.orc_ixf_synth_keys_found.restype = C.c_uint64
-        L.orc_ixf_synth_keys_found.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.orc_ixf_synth_keys_found.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+        threads = int(threads) if threads else min(32, len(os.sched_getaffinity(0)) or 8)
         found = L.orc_ixf_synth_keys_found(C.byref(self._ixf[i]), int(bin_), int(first), int(n), int(salt) & (2**64 - 1), int(sample_step),
-                                           _p(counts) if counts is not None else None, C.byref(sampled))
+                                           _p(counts) if counts is not None else None, C.byref(sampled), threads)
         return int(found), int(sampled.value)
 
     def bulk_contains(self, hashes, thr):

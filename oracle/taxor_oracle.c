@@ -453,10 +453,11 @@ void orc_synth_keys(uint64_t first, uint64_t n, uint64_t salt, uint64_t *out)
 }
 
 uint64_t orc_ixf_synth_keys_found(const orc_ixf *f, uint64_t bin, uint64_t first, uint64_t n, uint64_t salt, uint64_t sample_step,
-                                  uint64_t *counts, uint64_t *sampled)
+                                  uint64_t *counts, uint64_t *sampled, int threads)
 {
     uint64_t found = 0, n_sampled = 0;
-#pragma omp parallel reduction(+ : found, n_sampled)
+    if (threads < 1) threads = 1;
+#pragma omp parallel num_threads(threads) reduction(+ : found, n_sampled)
     {
         uint32_t *mine = counts ? (uint32_t *)calloc(f->bins ? f->bins : 1, sizeof(uint32_t)) : NULL;
         uint32_t *one = counts ? (uint32_t *)malloc((f->bins ? f->bins : 1) * sizeof(uint32_t)) : NULL;

@@ -118,10 +118,10 @@ void orc_ixf_bulk_count(const orc_ixf *f, const uint64_t *hashes, size_t n, uint
 
 /* Checker of built filters: the synthetic keys first .. first + n - 1 (key i = splitmix64 finaliser of i + salt) looked up in
  * column `bin` of f with bulk_count's rule -> number found (n = none missing); every sample_step-th key also through
- * orc_ixf_bulk_count over all bins (counts[bins] accumulates, *sampled += keys that did).  OpenMP over the keys. */
+ * orc_ixf_bulk_count over all bins (counts[bins] accumulates, *sampled += keys that did).  OpenMP over the keys, `threads` of them. */
 void orc_synth_keys(uint64_t first, uint64_t n, uint64_t salt, uint64_t *out);
 uint64_t orc_ixf_synth_keys_found(const orc_ixf *f, uint64_t bin, uint64_t first, uint64_t n, uint64_t salt, uint64_t sample_step,
-                                  uint64_t *counts, uint64_t *sampled);
+                                  uint64_t *counts, uint64_t *sampled, int threads);
 
 /* ---- hierarchical IXF -------------------------------------------------------------------------- */
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DESIGN.md section 5's table from ONE bench.py line (the headline and the `layouts` legs of the same invocation).
-usage: python profiles/design_table.py profiles/r05/bench_gtdb.json [--write]     (--write: replace the block between the
-<!-- BENCH-TABLE --> markers of DESIGN.md)"""
+usage: python profiles/design_table.py profiles/r06/bench_gtdb.json [profiles/r06/bench_build.json] [--write]
+(--write: replace the block between the <!-- BENCH-TABLE --> markers of DESIGN.md; the second file adds the builder's line)"""
 import json
 import os
 import re
@@ -14,7 +14,7 @@ c, r = j["config"], j["roofline"]
 lv = r.get("levels", [])
 gc = r.get("gather_ceiling", {})
 out = []
-out.append(f"Source: `{os.path.relpath(path, ROOT)}` — one `python bench.py` invocation ({j['steps']} steps, {j['warmup']} warm-up; the driver's own run is `BENCH_r05.json`).")
+out.append(f"Source: `{os.path.relpath(path, ROOT)}` — one `python bench.py` invocation ({j['steps']} steps, {j['warmup']} warm-up; the driver's own run is `BENCH_r06.json`).")
 out.append("")
 out.append("| leg (same invocation) | index | reads | Mbp/s | `frac` | other fractions | work per read |")
 out.append("|---|---|---|---|---|---|---|")
@@ -49,7 +49,22 @@ if gc:
 if r.get("traffic") is not None:
     out.append(f"Memory side (live `rocprofv3 --pmc` passes in the same invocation): {r['traffic'] / 1e9:.2f} GB per launch = {r.get('traffic_GBps', 0):,.0f} GB/s "
                f"({r.get('traffic_over_requested')} × requested, {r.get('traffic_over_line128')} × the 128-B lines touched); average launch {r['avg_launch_ms']} ms "
-               f"(rocprofv3 kernel trace of the same command: `profiles/r05/gtdb_kernel_stats.csv`).")
+               f"(rocprofv3 kernel trace of the round-5 command: `profiles/r05/gtdb_kernel_stats.csv`; the search kernels are unchanged in round 6).")
+extra = [a for a in sys.argv[2:] if not a.startswith("--")]
+if extra:
+    b = json.loads([l for l in open(extra[0]) if l.startswith("{")][-1])
+    bc, br, bs = b["config"], b["roofline"], b["stage_s_per_step"]
+    cbb = b.get("cpu_baseline") or {}
+    out.append("")
+    out.append(f"Index construction (`{os.path.relpath(extra[0], ROOT)}`, `python bench.py --mode build`, {b['steps']} steps = whole builds, {b['warmup']} warm-up): "
+               f"**{b['value'] / 1e9:.2f} G key insertions/s** -- {bc['insertions_per_step'] / 1e9:.2f} G insertions per build of {bc['index_bytes'] / 1e9:.1f} GB "
+               f"({bc['children']} children x {bc['child_bins']} bins x {bc['keys_per_bin']} keys under a root of merged bins, every bin built) in {bs['total']:.2f} s: "
+               f"peel {bs['peel']:.2f} s, assign + verify {bs['assign_verify']:.2f} s, unions {bs['unions']:.2f} s; {bc['chunks_per_step']} chunks of <= 3 GB scratch, "
+               f"{bc['rounds_max']} rounds at most, {bc['reseeds']} reseeds.  `roofline.frac` {br['frac']} of HBM bytes ({br['algorithmic_bytes_per_insertion']} B per insertion) -- not its bound; "
+               f"`rmw`: {br['rmw']['achieved_G_per_s']} G random read-modify-writes/s = {br['rmw']['frac']} of the measured 27 G/s over the WHOLE job"
+               + (f"; reference `AddAll` on one core: {cbb['value'] / 1e6:.1f} M insertions/s ({b['value'] / cbb['value']:.0f}x)" if cbb else "")
+               + ".  Longest builder launch in the `rocprofv3 --kernel-trace --stats` of the same command: 3.9 ms (`k_set_insert`; `k_count` 2.5, `k_round` 2.3; "
+                 "`profiles/r06/build_kernel_stats.csv`).")
 text = "\n".join(out)
 print(text)
 if "--write" in sys.argv:

@@ -263,8 +263,8 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_upload_relayout
 static bool view_is_search_layout(const taxor_hixf_view *v)
 {
     if (taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_ROWS || (v->ixf_layout & taxor::IXF_ROWS_POSITION_MAJOR)) return false;
-    for (uint64_t i = 0; i < v->n_ixf; ++i)
-        if (v->ixf[i].src_stride != 0 && v->ixf[i].src_stride != v->ixf[i].stride) return false;
+    for (uint64_t i = 0; i < v->n_ixf; ++i)       // (the pitch a CODE names counts too: 0x200 "unpadded" with src_stride left 0 is not the search layout)
+        if (taxor::ixf_src_pitch(v->ixf_layout, v->ixf[i].src_stride, v->ixf[i].stride, v->ixf[i].bins) != v->ixf[i].stride) return false;
     return true;
 }
 
@@ -455,9 +455,12 @@ static int index_create_impl(const taxor_hixf_view *v, int device, bool upload, 
                         (unsigned long long)i, (unsigned long long)f.bins, (unsigned long long)f.stride,
                         (unsigned long long)f.seg_len);
         }
-        if (f.src_stride != 0 && f.src_stride < f.bins && taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_BIT_SLICED) {
+        const uint64_t src_pitch = taxor::ixf_src_pitch(v->ixf_layout, f.src_stride, f.stride, f.bins);
+        if (src_pitch < f.bins && taxor::ixf_layout_kind(v->ixf_layout) != taxor::IXF_KIND_BIT_SLICED) {
             delete idx;
-            return fail(TAXOR_E_ARG, "index_create: IXF %llu: source pitch %llu below its %llu bins", (unsigned long long)i, (unsigned long long)f.src_stride,
+            if (src_pitch == 0)
+                return fail(TAXOR_E_ARG, "index_create: IXF %llu: the layout code names the record's stored pitch but src_stride is 0", (unsigned long long)i);
+            return fail(TAXOR_E_ARG, "index_create: IXF %llu: source pitch %llu below its %llu bins", (unsigned long long)i, (unsigned long long)src_pitch,
                         (unsigned long long)f.bins);
         }
         if (3 * f.seg_len >= (1ull << 32) || f.stride > (1u << 20)) {

@@ -851,9 +851,12 @@ static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *ke
     Engine eng;
     rc = eng.open(device);
     if (rc == TAXOR_OK) rc = build_plans(eng, idx, plans);
-    if (d_own) (void)hipFree(d_own);
-    if (rc != TAXOR_OK) return rc;
     eng.stats.seconds_total = now_s() - t0;
+    const double t_rel = now_s();
+    if (d_own) (void)hipFree(d_own);
+    eng.release();
+    eng.stats.seconds_release = now_s() - t_rel;
+    if (rc != TAXOR_OK) return rc;
     if (seed_out) *seed_out = p.seed;
     if (rounds_out) *rounds_out = eng.stats.rounds_max;
     if (stats_out) *stats_out = eng.stats;
@@ -1015,10 +1018,15 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         }
         eng.stats.seconds_union += now_s() - tu;
     }
+    // the job is done here; handing tens of GB of keys, unions and scratch back to the driver is timed apart (hipFree of that much
+    // takes anything between milliseconds and over a second, whatever was done with the memory)
+    eng.stats.seconds_total = now_s() - t0;
+    const double t_rel = now_s();
     unioner.release();
     cleanup();
+    eng.release();
+    eng.stats.seconds_release = now_s() - t_rel;
     if (rc != TAXOR_OK) return rc;
-    eng.stats.seconds_total = now_s() - t0;
     if (rounds_out) *rounds_out = eng.stats.rounds_max;
     if (stats_out) *stats_out = eng.stats;
     return TAXOR_OK;

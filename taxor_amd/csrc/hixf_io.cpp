@@ -101,6 +101,7 @@ struct taxor_hixf {
     std::vector<taxor_species> species;
     std::vector<const char *> filenames;
     taxor_hixf_meta meta{};
+    bool pitch_overridden = false;                         // finish_ixfs: the records' stride scalar was contradicted by their lengths
     std::map<uint64_t, uint64_t> user_bin_index;           // user_bin -> first species index (taxor_search.cpp:172-178)
     // the per-species parts of a hit line (taxor_search.cpp:287-305), rendered once: "ACCESSION\tNAME\tTAXID\tREF_LEN\t" and
     // "TAX_STR\tTAX_ID_STR\n"; and user bin -> species index as a flat table for the user bins the index can report
@@ -313,7 +314,18 @@ std::string finish_ixfs(const taxor_ixf_schema &sc, taxor_hixf *h)
         for (uint32_t r : rules) {
             std::string e;
             for (size_t i = 0; i < h->ixf.size() && e.empty(); ++i) e = apply_layout(h, i, code | r);
-            if (e.empty()) { h->view.ixf_layout = code | r; return ""; }
+            if (e.empty()) {
+                h->view.ixf_layout = code | r;
+                // the record carries a stride scalar and the array lengths contradict it: the file loads under a pitch its own scalar
+                // does not name.  Said out loud and remembered (meta.foreign_schema), not dropped -- a file of this library's own
+                // schema that arrives here is damaged or was written by something else
+                if (sc.idx_stride >= 0 && r != taxor::IXF_PITCH_STORED) {
+                    h->pitch_overridden = true;
+                    fprintf(stderr, "[TAXOR SEARCH WARNING] the stored row pitch of the IXF records contradicts their array lengths (%s); loaded with the pitch %s\n",
+                            first_err.c_str(), r == taxor::IXF_PITCH_PADDED ? "bins padded to 64" : "exactly bins");
+                }
+                return "";
+            }
             if (first_err.empty()) first_err = e;
         }
         return first_err;
@@ -439,7 +451,7 @@ extern "C" int taxor_hixf_load_schema(const char *path, const taxor_ixf_schema *
         taxor_ixf_schema_default(&own);
         (*out)->meta.foreign_schema = schema->n_before != own.n_before || schema->n_after != own.n_after || schema->idx_bins != own.idx_bins ||
                                       schema->idx_stride != own.idx_stride || schema->idx_seg_len != own.idx_seg_len || schema->idx_seed != own.idx_seed ||
-                                      (schema->len_unit > 1) || schema->skip_before_len || schema->skip_after_len;
+                                      (schema->len_unit > 1) || schema->skip_before_len || schema->skip_after_len || (*out)->pitch_overridden;
     }
     return rc;
 }
@@ -575,6 +587,7 @@ extern "C" int taxor_hixf_load(const char *path, taxor_hixf **out)
     taxor_ixf_schema_default(&sc);
     bool schema_problem = false;
     const int rc = load_with(path, sc, out, &schema_problem);
+    if (rc == TAXOR_OK && (*out)->pitch_overridden) (*out)->meta.foreign_schema = 1;      // own framing, but not this library's pitch: see finish_ixfs
     if (rc == TAXOR_OK || !schema_problem) return rc;
     // the records did not fit this library's schema: probe the file and retry with what it found
     taxor_ixf_schema probed;

@@ -39,6 +39,17 @@ TAXOR_LHD bool ixf_layout_valid(uint32_t code)
            (code & IXF_PITCH_MASK) != IXF_PITCH_MASK && !(ixf_layout_kind(code) == IXF_KIND_BIT_SLICED && (code & IXF_PITCH_MASK) != 0u);
 }
 
+// row pitch (kind 0) / columns stored (kind 1) of an IXF's SOURCE bytes: the view's explicit src_stride, else what the code's pitch
+// rule says -- `bins` (unpadded), the index's own stride (padded; the meaning of src_stride = 0 in a plain view), or 0 when the
+// rule names the record's stored scalar and none was handed over (the caller must refuse that)
+TAXOR_LHD uint64_t ixf_src_pitch(uint32_t code, uint64_t src_stride, uint64_t stride, uint64_t bins)
+{
+    if (src_stride) return src_stride;
+    if ((code & IXF_PITCH_MASK) == IXF_PITCH_BINS) return bins;
+    if ((code & IXF_PITCH_MASK) == IXF_PITCH_STORED) return 0;
+    return stride;
+}
+
 // the source's row index of search-layout row r (segment * seg_len + position)
 TAXOR_LHD uint64_t ixf_src_row(uint32_t code, uint64_t r, uint64_t seg_len)
 {

@@ -162,7 +162,7 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_upload_relayout
         if (taxor_index_ixf_info(idx, i, &x.dst, &x.stride, &x.seg_len, &x.bins, &device) != 0) return rfail(TAXOR_E_ARG, "index upload: view does not match the index");
         x.rows = 3 * x.seg_len;
         x.groups = (x.bins + 63) / 64;
-        x.pitch = kind == IXF_KIND_BIT_SLICED ? x.groups * 64 : (v->ixf[i].src_stride ? v->ixf[i].src_stride : x.stride);
+        x.pitch = kind == IXF_KIND_BIT_SLICED ? x.groups * 64 : ixf_src_pitch(v->ixf_layout, v->ixf[i].src_stride, x.stride, x.bins);
         if (x.pitch < x.bins) return rfail(TAXOR_E_ARG, "index upload: IXF " + std::to_string(i) + ": source pitch " + std::to_string(x.pitch) + " below its " + std::to_string(x.bins) + " bins");
         if (!v->source && !v->ixf[i].data) continue;
         if (kind == IXF_KIND_BIN_MAJOR) {

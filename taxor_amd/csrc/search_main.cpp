@@ -884,6 +884,12 @@ int main(int argc, char **argv)
             std::vector<taxor_ixf_variant> vs = variant_family(root, raw_len, view->ixf_layout);
             std::vector<uint64_t> s_off, s_hs;
             cap_hash_lists(hoff, hs, n_lists, 160, s_off, s_hs);
+            // the scan copies the root's RAW bytes to the device in one piece (tens of GB under a 4096-bin root): the resident index
+            // has answered everything it was needed for, so it goes first instead of sitting beside that copy
+            taxor_gpu_searcher_destroy(sr);
+            taxor_gpu_index_destroy(gi);
+            sr = nullptr;
+            gi = nullptr;
             std::vector<float> ratio(vs.size() * n_lists);
             if (taxor_gpu_ixf_variant_scan(device, root.data, raw_len, root.bins, vs.data(), (uint32_t)vs.size(), s_hs.data(), s_off.data(), n_lists, ratio.data()) != TAXOR_OK)
                 die(taxor_gpu_last_error());
@@ -918,8 +924,8 @@ int main(int argc, char **argv)
                 printf("no variant answers: the key hash (wyhash / minimiser value) or the genome is not what the index holds\n");
             }
         }
-        taxor_gpu_searcher_destroy(sr);
-        taxor_gpu_index_destroy(gi);
+        if (sr) taxor_gpu_searcher_destroy(sr);
+        if (gi) taxor_gpu_index_destroy(gi);
         taxor_hixf_free(h);
         return pass ? 0 : 2;
     }

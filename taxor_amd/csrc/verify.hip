@@ -81,6 +81,11 @@ extern "C" int taxor_gpu_ixf_variant_scan(int device, const uint8_t *raw, uint64
     for (uint32_t i = 0; i < n_variants; ++i)
         if (variants[i].seg_len == 0 || variants[i].stride == 0 || !ixf_layout_valid(variants[i].layout))
             return vfail(TAXOR_E_ARG, "ixf_variant_scan: variant with zero segment length or stride, or an unknown layout");
+    // the kernel's "does this shape fit the raw bytes" test multiplies rows by the pitch in 64 bits: bound both here so that it cannot wrap
+    // (an index cannot hold more than 2^32 rows or rows wider than 2^20 bytes either, api.hip index_create)
+    for (uint32_t i = 0; i < n_variants; ++i)
+        if (variants[i].seg_len > (1ull << 31) || variants[i].stride > (1ull << 20))
+            return vfail(TAXOR_E_ARG, "ixf_variant_scan: variant " + std::to_string(i) + " with a segment length above 2^31 or a pitch above 2^20");
     if (n_lists > 65535 || n_variants > 65535 || bins >= (1ull << 32)) return vfail(TAXOR_E_ARG, "ixf_variant_scan: more than 65535 lists or variants");
     const uint64_t nh = hash_off[n_lists];
     uint8_t *d_raw = nullptr;
