@@ -129,7 +129,7 @@ def parse_args(argv=None):
                          "--use-syncmer, the reference's default build mode (every canonical 20-mer, k-mer threshold model); minimiser = "
                          "the same with window 32 (FracMinHash model).  kmer / minimiser run on the viral-class footprint with 5-kb reads.  "
                          "build = GPU construction of a hierarchy (SURVEY 8(f) #3): a step is one whole build, the line carries key insertions/s")
-    ap.add_argument("--build-children", type=int, default=48, help="--mode build: child IXFs under the root")
+    ap.add_argument("--build-children", type=int, default=64, help="--mode build: child IXFs under the root")
     ap.add_argument("--build-child-bins", type=int, default=128)
     ap.add_argument("--build-keys-per-bin", type=int, default=422000, help="--mode build: keys per leaf bin (default: the leaf size of the gtdb workload)")
     ap.add_argument("--build-cpu-keys", type=int, default=200000,

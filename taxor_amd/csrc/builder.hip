@@ -498,7 +498,8 @@ struct Engine {
 
     // construct the columns of `jobs` (key_base / slot_base are filled in here; every job has keys; jobs of one group are
     // adjacent).  group_ok[g] = 0: a bin of group g did not peel under its seed, its columns are untouched.
-    // group_full[g] = 1: the jobs of group g are all the bins of its IXF (the whole array may be cleared at once).
+    // group_full[g] = 1: the jobs of group g are all the bins of its IXF (the whole array is cleared at once); 2: the caller has
+    // cleared the array already (an IXF built in several chunks all of whose bins have keys); 0: column by column.
     int run(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, const std::vector<uint8_t> &group_full)
     {
         group_ok.assign(n_groups, 1);
@@ -615,8 +616,8 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
             while (j1 < jobs.size() && jobs[j1].group == jobs[j0].group) ++j1;
             const uint32_t g = jobs[j0].group;
             if (group_ok[g]) {
-                if (group_full[g]) E_TRY(hipMemsetAsync(jobs[j0].data, 0, group_rows[g] * jobs[j0].stride, st));
-                else {
+                if (group_full[g] == 1) E_TRY(hipMemsetAsync(jobs[j0].data, 0, group_rows[g] * jobs[j0].stride, st));
+                else if (group_full[g] == 0) {
                     const uint64_t total = group_rows[g] * (j1 - j0);
                     hipLaunchKernelGGL(k_zero_columns, dim3((uint32_t)std::min<uint64_t>(4096, (total + BB - 1) / BB)), dim3(BB), 0, st, d_jobs,
                                        (uint32_t)j0, (uint32_t)(j1 - j0), group_rows[g]);
@@ -713,8 +714,10 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             const uint64_t per_bin = 3 * p.seg_len;
             if (per_bin > budget) return bfail(TAXOR_E_NOMEM, "build: one bin of IXF " + std::to_string(p.ixf) + " does not fit the peeling scratch");
             bool built = false;
+            const bool all_bins = p.n_with_keys == p.bins;
             while (!built) {
                 built = true;
+                if (all_bins && hipMemsetAsync(p.data, 0, 3 * p.seg_len * p.stride, eng.st) != hipSuccess) return bfail(TAXOR_E_HIP, "build: clearing an IXF failed");
                 for (uint64_t b0 = 0; b0 < p.bins && built;) {
                     uint64_t b1 = b0, s = 0, k = 0;
                     while (b1 < p.bins && (p.n[b1] == 0 || (s + per_bin <= budget && k + p.n[b1] < (1ull << 32)))) {
@@ -723,7 +726,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
                     }
                     jobs.clear();
                     add_jobs(p, 0, b0, b1, jobs);
-                    full.assign(1, 0);
+                    full.assign(1, all_bins ? 2 : 0);
                     const int rc = eng.run(jobs, 1, ok, full);
                     if (rc != TAXOR_OK) return rc;
                     if (!ok[0]) built = false;
