@@ -88,8 +88,44 @@ def run_trial(seed, verbose=False):
         for f in host:
             raw, pitch = to_source_layout(f, layout)
             device_side.append(dict(f, data=raw, src_stride=pitch, stride=(f["bins"] + 63) // 64 * 64))
-    idx = GpuIndex(device_side, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith, layout=layout)
-    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
+    # one trial in three of those in the search layout: the index is CONSTRUCTED ON THE GPU from the leaf key sets alone
+    # (taxor_gpu_index_build_hixf: all IXFs of a level in shared chunks, merged bins = unions computed on the device, an IXF that
+    # does not peel redone under a redrawn seed), read back, and the oracle works on those bytes -- after checking that every leaf
+    # key is found in its own bin and in the merged bin of every ancestor.  A generator of its own again.
+    brng = np.random.default_rng(seed ^ 0xB111D)
+    gpu_built = False
+    if layout == 0 and brng.random() < 0.34:
+        from taxor_amd._lib import TaxorError
+        shapes = [dict(bins=f["bins"], stride=f["stride"], seg_len=f["seg_len"], seed=f["seed"], next_ixf=f["next_ixf"], fname_idx=f["fname_idx"], data=None)
+                  for f in lay["ixfs"]]
+        idx = GpuIndex(shapes, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith)
+        for i, f in enumerate(lay["ixfs"]):
+            idx.fill_random(i, f["fill_seed"])
+        leaf = {(i, b): keys for i, f in enumerate(lay["ixfs"]) for b, keys in f["leaf_keys"].items()}
+        try:
+            idx.build_hixf(leaf, seed0=int(brng.integers(1, 2**62)))
+        except TaxorError as e:
+            idx.close()
+            if "no seed peeled" not in str(e):
+                raise
+            # small full bins: a hundred of them under ONE seed may not peel in 32 seeds (the reference's rule)
+            return True, dict(seed=seed, void="the GPU builder found no seed for an IXF of small full bins"), 0
+        host = [dict(s_, seed=idx.ixf_seed(i), data=idx.download_ixf(i)) for i, s_ in enumerate(shapes)]
+        h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
+        parent = {int(f["next_ixf"][b]): (i, b) for i, f in enumerate(host) for b in range(f["bins"]) if f["fname_idx"][b] == -1}
+        for (i, b), keys in leaf.items():
+            node, at = i, b
+            while True:
+                if h.ixf_bulk_count(node, keys)[at] != len(keys):
+                    idx.close()
+                    return False, dict(seed=seed, gpu_built=True, missing=f"keys of leaf ({i},{b}) in bin {at} of IXF {node}"), 0
+                if node not in parent:
+                    break
+                node, at = parent[node]
+        gpu_built = True
+    else:
+        idx = GpuIndex(device_side, lay["n_user_bins"], k=k, s=s, t=t, use_syncmer=syncmer, window_size=(win or k), scaling=scaling, arith=arith, layout=layout)
+        h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host], arith=arith)
     n_syn = int(rng.integers(20, 200))
     bases, offs, origin = synth.synth_reads(g, go, n_syn, int(rng.integers(200, 4000)), error_rate=float(rng.choice([0.0, 0.01, 0.03, 0.08])),
                                             frac_random=0.1, seed=int(rng.integers(1, 2**31)))
@@ -110,7 +146,7 @@ def run_trial(seed, verbose=False):
     err = float(rng.choice([0.0, 0.01, 0.04, 0.1, 0.2])) if syncmer else float(rng.choice([0.01, 0.04, 0.1, 0.3]))
     sub = int(rng.choice([0, 1, 7, 64]))
     cfg = dict(seed=seed, syncmer=syncmer, k=k, s=s, t=t, window=win, scaling=scaling, n_ixf=len(host), depth=lay["depth"],
-               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith, layout=layout)
+               bins=[f["bins"] for f in host][:6], heavy=bool(heavy), reads=len(reads), pct=pct, err=err, sub=sub, arith=arith, layout=layout, gpu_built=gpu_built)
     if verbose:
         print(cfg, flush=True)
     sr = Searcher(idx, error_rate=err, percentage=pct, sub_batch_reads=sub, group_always=group_always,
