@@ -476,6 +476,8 @@ def build_mode(args):
             raise SystemExit("PARITY FAILURE: a built bin does not hold its keys")
     sr.close()
     kern_s = sum(s_["seconds_peel"] + s_["seconds_assign"] for s_ in sts)
+    t_count = max(1e-9, sum(s_["seconds_count"] for s_ in sts))
+    t_rounds = max(1e-9, sum(s_["seconds_rounds"] for s_ in sts))
     achieved = BUILD_BYTES_PER_INSERTION * ins / kern_s / 1e9
     out = {"metric": "key insertions/s (GPU IXF/HIXF construction, SURVEY 8(f) #3)", "value": round(value, 1), "unit": "key insertions/s",
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(secs / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -501,6 +503,13 @@ def build_mode(args):
                         "rmw": {"per_insertion": BUILD_RMW_PER_INSERTION, "achieved_G_per_s": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9, 2),
                                 "ceiling_G_per_s": RMW_CEILING_G_PER_S, "frac": round(BUILD_RMW_PER_INSERTION * ins / kern_s / 1e9 / RMW_CEILING_G_PER_S, 4),
                                 "random_loads_stores_per_insertion": BUILD_RANDOM_ACCESSES_PER_INSERTION,
+                                "kernels": [
+                                    {"kernel": "k_count", "rmw_per_insertion": 3, "seconds_per_step": round(t_count / steps, 4),
+                                     "achieved_G_per_s": round(3 * ins / t_count / 1e9, 2), "frac": round(3 * ins / t_count / 1e9 / RMW_CEILING_G_PER_S, 4)},
+                                    {"kernel": "k_seed + k_round", "rmw_per_insertion": 2, "seconds_per_step": round(t_rounds / steps, 4),
+                                     "achieved_G_per_s": round(2 * ins / t_rounds / 1e9, 2), "frac": round(2 * ins / t_rounds / 1e9 / RMW_CEILING_G_PER_S, 4),
+                                     "note": "plus ~4 random loads / stores per insertion (state word, key, round marks) and the list traffic"}],
+                                "kernels_note": "HIP events on the builder's stream inside the library (taxor_build_stats::seconds_count, seconds_rounds), summed over the chunks",
                                 "note": "random atomic read-modify-writes per second against the chip's measured rate for them (profiles/r06/atomics_bench.txt: 27 G/s "
                                         "up to 256 MB, 18-20 G/s beyond, whatever the scope, width or use of the return value); the builder also does ~12 random loads "
                                         "and stores per insertion (54 G/s ceiling), so 5 RMW / 20-27 G/s + 12 / 54 G/s = 0.41-0.47 ns per insertion is the floor of this "

@@ -76,6 +76,8 @@ typedef struct taxor_build_stats {
     double seconds_union;     /* duplicate-free unions of the merged bins' key sets */
     double seconds_total;     /* from the call to the last IXF built and verified (key upload and scratch allocation inside) */
     double seconds_release;   /* handing keys, unions and scratch back to the driver afterwards (not in seconds_total) */
+    double seconds_count;     /* GPU time of k_count (3 atomic adds per key), HIP events on the builder's stream */
+    double seconds_rounds;    /* GPU time of the seed scan and the peeling rounds (2 atomic subs per key), HIP events */
 } taxor_build_stats;
 int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
                                  const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);

@@ -400,6 +400,7 @@ struct Engine {
     int device = 0;
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev_t[3] = {nullptr, nullptr, nullptr};      // timing: before k_count, after it, after the last round
     void *d_w = nullptr;
     uint64_t *d_list = nullptr, *d_job_peeled = nullptr;
     uint32_t *d_log = nullptr;
@@ -423,6 +424,7 @@ struct Engine {
         if (h_counts) (void)hipHostFree(h_counts);
         h_round_end = nullptr; h_counts = nullptr;
         for (auto &e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        for (auto &e : ev_t) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (st) (void)hipStreamDestroy(st);
         st = nullptr;
         cap_slots = cap_jobs = w_bytes = 0;
@@ -434,6 +436,7 @@ struct Engine {
         E_TRY(hipSetDevice(device));
         E_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (auto &e : ev) E_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : ev_t) E_TRY(hipEventCreate(&e));
         E_TRY(hipHostMalloc((void **)&h_round_end, (MAX_ROUNDS + 2) * sizeof(uint32_t), hipHostMallocDefault));
         E_TRY(hipHostMalloc((void **)&h_counts, 2 * sizeof(unsigned long long), hipHostMallocDefault));
         E_TRY(hipMalloc((void **)&d_ctl, sizeof(Ctl)));
@@ -548,7 +551,9 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     E_TRY(hipMemsetAsync(d_pushed, 0xFF, n_slots * 2, st));
     E_TRY(hipMemsetAsync(d_ctl, 0, sizeof(Ctl), st));
     const uint32_t grid_keys = (uint32_t)((n_keys + KEYS_PER_BLOCK - 1) / KEYS_PER_BLOCK);
+    E_TRY(hipEventRecord(ev_t[0], st));
     for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_count<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
+    E_TRY(hipEventRecord(ev_t[1], st));
     const uint32_t grid_slots = (uint32_t)((n_slots + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK);
     for (uint32_t b = 0; b < grid_slots; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_seed<WT>), dim3(std::min(SLICE_BLOCKS, grid_slots - b)), dim3(BB), 0, st, a, b, grid_slots);
     // rounds: two batches ahead of the host.  The grid follows the chunk's size (a small chunk's rounds are small)
@@ -571,6 +576,7 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
         const uint32_t lo = launched, hi = std::min(MAX_ROUNDS, launched + ROUND_BATCH);
         for (uint32_t t = lo; t < hi; ++t) hipLaunchKernelGGL((k_round<WT>), dim3(round_grid), dim3(BB), 0, st, a, t);
         launched = hi;
+        E_TRY(hipEventRecord(ev_t[2], st));          // (re-recorded after every batch: the last one stands)
         // the ends of rounds lo .. hi (round t's own end is written by the launch before it, hi's by the last one of this batch)
         E_TRY(hipMemcpyAsync(h_round_end + lo, &d_ctl->round_end[lo], (hi - lo + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         E_TRY(hipEventRecord(ev[slot], st));
@@ -587,6 +593,11 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     E_TRY(hipStreamSynchronize(st));
     E_TRY(hipGetLastError());
     stats.rounds_max = std::max(stats.rounds_max, rounds);
+    {   // the two kernels that carry the read-modify-writes, by HIP events on the builder's stream
+        float ms_count = 0.f, ms_rounds = 0.f;
+        if (hipEventElapsedTime(&ms_count, ev_t[0], ev_t[1]) == hipSuccess) stats.seconds_count += ms_count * 1e-3;
+        if (hipEventElapsedTime(&ms_rounds, ev_t[1], ev_t[2]) == hipSuccess) stats.seconds_rounds += ms_rounds * 1e-3;
+    }
     const double t1 = now_s();
     stats.seconds_peel += t1 - t0;
 

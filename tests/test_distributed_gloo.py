@@ -45,6 +45,12 @@ def _worker(rank, world, port, n_reads, q):
         g_off, g_ub, g_cnt, g_nh = out
         ok = (np.array_equal(g_off.numpy(), off) and np.array_equal(g_ub.numpy(), ub)
               and np.array_equal(g_cnt.numpy(), cnt) and np.array_equal(g_nh.numpy(), nh))
+        # what the exchange moved, as bench.py's `comm` object reports it: every rank's (reads, tuples) as received, and the payload
+        # bytes that came from the peers (the four arrays of every rank but this one)
+        spans = [td.shard_range(n_reads, r, world) for r in range(world)]
+        want_sizes = [(b - a, int(off[b] - off[a])) for a, b in spans]
+        want_bytes = sum((n + 1) * 8 + t * 8 + t * 4 + n * 4 for n, t in want_sizes[1:])
+        ok = ok and td.last_gather["sizes"] == want_sizes and td.last_gather["bytes_received"] == want_bytes
         q.put(ok)
     else:
         assert out is None

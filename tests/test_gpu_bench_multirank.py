@@ -67,6 +67,17 @@ def test_three_ranks_weak_scaling_gathers_every_shard(tmp_path):
     assert int(r3["read_off"][-1]) == r3["user_bin"].size > t
     # weak scaling: three times the bases per step
     assert abs(j3["value"] * j3["ms_per_step"] / (j1["value"] * j1["ms_per_step"]) - 3.0) < 6e-2
+    # the comm object is written from what the exchange moved: three ranks' reads arrived, two of them over the wire, and the
+    # strong-scaling leg's gathered CSR (three shards of one batch) hashes to what rank 0 computes alone
+    cm = j3["comm"]
+    assert cm["backend"] == "gloo" and cm["world"] == 3 and cm["ranks_in_last_gather"] == [0, 1, 2] and cm["rccl_version"] is None
+    assert [x[0] for x in cm["reads_tuples_per_rank_last_gather"]] == [n, n, n]
+    assert cm["gather_bytes_per_step"] > 2 * 12 * n and len(cm["sent_bytes_per_rank_per_step"]) == 3 and cm["gather_ms_per_step"] > 0
+    pr_ms = cm["ms_per_step_per_rank"]
+    assert len(pr_ms["all"]) == 3 and 0 < pr_ms["min"] <= pr_ms["rank0"] <= pr_ms["max"]
+    sl = cm["strong_leg"]
+    assert sl["equal"] and sl["reads"] == n and sl["tuples"] > 0
+    assert "comm" not in j1
 
 
 def test_eight_ranks_on_one_gpu(tmp_path):
@@ -200,5 +211,9 @@ def test_build_mode_line():
     assert j["config"]["insertions_per_step"] == 2 * 6 * 64 * 60000 and "every bin built" in j["config"]["workload"] and "keys resident in HBM" in j["config"]["timed_region"]
     r = j["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 0.2 and r["algorithmic_bytes_per_insertion"] > 100 and r["rmw"]["per_insertion"] == 5 and 0 < r["rmw"]["frac"] < 1.2
+    kn = {k["kernel"]: k for k in r["rmw"]["kernels"]}          # the two kernels that carry the read-modify-writes, timed by HIP events in the library
+    assert kn["k_count"]["rmw_per_insertion"] == 3 and 0.2 < kn["k_count"]["frac"] < 1.2 and kn["k_seed + k_round"]["rmw_per_insertion"] == 2
+    assert 0 < kn["k_count"]["seconds_per_step"] < j["stage_s_per_step"]["peel"] and 0 < kn["k_seed + k_round"]["seconds_per_step"] < j["stage_s_per_step"]["peel"]
+    assert j["stage_s_per_step"]["release_after"] >= 0
     cb = j["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["cores"] == 1 and 1e6 < cb["value"] < j["value"]
