@@ -490,6 +490,10 @@ def build_mode(args):
                       "index_bytes": idx.data_bytes, "n_ixf": idx.n_ixf, "children": nc, "child_bins": cb, "keys_per_bin": kpb,
                       "insertions_per_step": ins // steps, "chunks_per_step": sts[-1]["chunks"], "rounds_max": max(s_["rounds_max"] for s_ in sts),
                       "reseeds": sum(s_["reseeds"] for s_ in sts), "scratch_bytes": max(s_["scratch_bytes"] for s_ in sts)},
+           "value_median_step": round(float(np.median([s_["keys_inserted"] / s_["seconds_total"] for s_ in sts])), 1),
+           "step_seconds": [round(s_["seconds_total"], 4) for s_ in sts],
+           "step_note": "`value` = all insertions / all step seconds (the contract); value_median_step = the median step's rate.  A build allocates tens of GB (keys' unions) "
+                        "and now and then the driver takes seconds over such a hipMalloc and stalls the queue meanwhile -- such a step is in `value`, not in the median",
            "stage_s_per_step": {"peel": round(sum(s_["seconds_peel"] for s_ in sts) / steps, 4), "assign_verify": round(sum(s_["seconds_assign"] for s_ in sts) / steps, 4),
                                 "unions": round(sum(s_["seconds_union"] for s_ in sts) / steps, 4), "total": round(secs / steps, 4),
                                 "release_after": round(sum(s_["seconds_release"] for s_ in sts) / steps, 4), "wall": round(wall / steps, 4),

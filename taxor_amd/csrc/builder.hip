@@ -49,7 +49,6 @@
 #include <chrono>
 #include <cstdlib>
 #include <string>
-#include <thread>
 #include <vector>
 
 using namespace taxor;
@@ -71,8 +70,10 @@ constexpr uint32_t SLICE_BLOCKS = 8192;    // blocks per launch of the key / slo
 
 // one technical bin to construct
 struct BinJob {
-    const uint64_t *keys;   // device: the bin's keys (distinct)
-    uint64_t n_keys;
+    const uint64_t *keys;   // device: the bin's keys (distinct among those that count)
+    const uint8_t *keep;    // one byte per key, 0 = this key does not count (a duplicate inside a merged bin's key range); nullptr: all count
+    uint64_t n_keys;        // length of the key range (a key's index is its position in it)
+    uint64_t n_kept;        // keys that count
     uint64_t key_base;      // keys of the chunk's jobs before this one
     uint64_t slot_base;     // slots (3 * seg_len each) of the chunk's jobs before this one
     uint8_t *data;          // fingerprint array of the job's IXF
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
     for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         const uint64_t k = g - J.key_base;
+        if (J.keep && !ldg8(J.keep + k)) continue;
         const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
         const WT d = w_delta<WT>(k);
 #pragma unroll
@@ -222,10 +224,18 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
     __shared__ uint64_t stage[2 * ROUND_ITER * BB];
     __shared__ uint32_t stage_n, gbase, claimed_blk;
     const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
+    const uint32_t step = (uint32_t)ROUND_ITER * BB;
+    // Only blocks that have entries take part in the round's ticket (one returning atomic on ONE word each, ~13 ns: 1024 tickets
+    // would be the whole cost of a plateau round of a few ten thousand entries).  A launch behind the last round finds an empty
+    // range: the list cannot have grown, so its end is recorded as it is, without a ticket.
+    const uint32_t n_work = (uint32_t)min((uint64_t)gridDim.x, ((uint64_t)(hi - lo) + step - 1) / step);
+    if (blockIdx.x >= n_work) {
+        if (n_work == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->round_end[t + 2] = hi;
+        return;
+    }
     if (threadIdx.x == 0) { stage_n = 0; claimed_blk = 0; }
     __syncthreads();
     uint32_t claimed = 0;
-    const uint32_t step = (uint32_t)ROUND_ITER * BB;
     for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * step; base < hi; base += (uint64_t)gridDim.x * step) {
 #pragma unroll 1
         for (int it = 0; it < ROUND_ITER; ++it) {
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
     __syncthreads();
     if (threadIdx.x == 0) {
         if (claimed_blk) atomicAdd(&a.ctl->peeled, (unsigned long long)claimed_blk);
-        finish_launch(a.ctl, t + 1, gridDim.x);
+        finish_launch(a.ctl, t + 1, n_work);
     }
 }
 
@@ -333,6 +343,7 @@ __global__ __launch_bounds__(BB) void k_verify(const Peel<WT> a, uint32_t block0
     for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         if (a.skip && a.skip[J.group]) continue;
+        if (J.keep && !ldg8(J.keep + (g - J.key_base))) continue;
         const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + (g - J.key_base)), J.seed, J.seg_len, J.arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
@@ -517,7 +528,7 @@ struct Engine {
             ns += 3ull * j.seg_len;
             wide |= j.n_keys >= (1ull << 24);
             group_rows[j.group] = 3ull * j.seg_len;
-            if (j.n_keys > 3ull * j.seg_len) return bfail(TAXOR_E_ARG, "build: a bin holds more keys than its IXF has rows");
+            if (j.n_kept > 3ull * j.seg_len) return bfail(TAXOR_E_ARG, "build: a bin holds more keys than its IXF has rows");
             if (j.n_keys >= 0xFFFFFFFFull) return bfail(TAXOR_E_ARG, "build: more than 2^32 - 2 keys in one bin");
         }
         if (ns >= 0xFFFFFFF8ull || jobs.size() >= (1ull << 31)) return bfail(TAXOR_E_INTERNAL, "build: chunk too large");
@@ -603,14 +614,16 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
 
     // which IXFs fell short?
     uint32_t n_failed = 0;
-    if (h_counts[0] != n_keys) {
+    uint64_t n_expected = 0;
+    for (const auto &j : jobs) n_expected += j.n_kept;
+    if (h_counts[0] != n_expected) {
         E_TRY(hipMemsetAsync(d_job_peeled, 0, jobs.size() * 8, st));
         hipLaunchKernelGGL(k_job_peeled, dim3(1024), dim3(BB), 0, st, d_list, d_log, h_round_end[rounds], (unsigned long long *)d_job_peeled);
         std::vector<uint64_t> got(jobs.size());
         E_TRY(hipMemcpyAsync(got.data(), d_job_peeled, jobs.size() * 8, hipMemcpyDeviceToHost, st));
         E_TRY(hipStreamSynchronize(st));
         for (size_t j = 0; j < jobs.size(); ++j)
-            if (got[j] != jobs[j].n_keys) group_ok[jobs[j].group] = 0;
+            if (got[j] != jobs[j].n_kept) group_ok[jobs[j].group] = 0;
         for (uint32_t g = 0; g < n_groups; ++g) n_failed += !group_ok[g];
         if (!n_failed) return bfail(TAXOR_E_INTERNAL, "build: peeled keys fall short but every bin is complete");
         std::vector<uint8_t> skip(n_groups);
@@ -655,7 +668,7 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
             return bfail(TAXOR_E_INTERNAL, "build: " + std::to_string(h_counts[1]) + " keys do not match their own columns after construction");
     }
     for (const auto &j : jobs)
-        if (group_ok[j.group]) stats.keys_inserted += j.n_keys;
+        if (group_ok[j.group]) stats.keys_inserted += j.n_kept;
     stats.seconds_assign += now_s() - t1;
     return TAXOR_OK;
 }
@@ -667,7 +680,8 @@ struct IxfPlan {
     uint64_t stride = 0, seg_len = 0, bins = 0;
     uint64_t seed = 0;
     std::vector<const uint64_t *> keys;      // per bin (device)
-    std::vector<uint64_t> n;                 // per bin
+    std::vector<const uint8_t *> keep;       // per bin: marks of the keys that count (nullptr: all of them)
+    std::vector<uint64_t> n, kept;           // per bin: length of the key range, keys that count
     uint64_t total = 0, max_bin = 0, n_with_keys = 0;
     int attempts = 0;
 };
@@ -687,7 +701,9 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             if (!p.n[b]) continue;
             BinJob j{};
             j.keys = p.keys[b];
+            j.keep = p.keep[b];
             j.n_keys = p.n[b];
+            j.n_kept = p.kept[b];
             j.data = p.data;
             j.stride = p.stride;
             j.seed = p.seed;
@@ -775,7 +791,9 @@ int plan_ixf(taxor_gpu_index *idx, uint64_t ixf, IxfPlan &p, int *device)
     if (taxor_index_ixf_info(idx, ixf, &p.data, &p.stride, &p.seg_len, &p.bins, device)) return bfail(TAXOR_E_ARG, "build: bad index / IXF id");
     p.ixf = ixf;
     p.keys.assign(p.bins, nullptr);
+    p.keep.assign(p.bins, nullptr);
     p.n.assign(p.bins, 0);
+    p.kept.assign(p.bins, 0);
     return TAXOR_OK;
 }
 
@@ -858,7 +876,7 @@ static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *ke
     }
     for (uint64_t b = 0; b < p.bins; ++b) {
         p.keys[b] = d_keys + (key_off[b] - key_off[0]);
-        p.n[b] = key_off[b + 1] - key_off[b];
+        p.n[b] = p.kept[b] = key_off[b + 1] - key_off[b];
     }
     plan_totals(p);
     p.seed = seed0;
@@ -949,89 +967,99 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
     Engine eng;
     int rc = eng.open(device);
     if (rc != TAXOR_OK) { cleanup(); return rc; }
-    struct Union { const uint64_t *p = nullptr; uint64_t n = 0; };
+    // What a merged bin of the level above holds: the keys of everything in this IXF, each once.  For an IXF whose bins are all
+    // leaves that is its OWN key range in the caller's array plus one byte per key ("counts" / "a duplicate of an earlier one"):
+    // nothing is copied, and the marks are an eighth of the keys (a class-scale level's unions were a 27-GB hipMalloc, half a second
+    // of the driver's time on a good day).  An IXF with merged bins of its own (deeper hierarchies) gets its union materialised.
+    struct Union { const uint64_t *p = nullptr; const uint8_t *keep = nullptr; uint64_t n = 0, kept = 0; };
     std::vector<Union> uni(n_ixf);
     KeyUnion unioner;
+    std::vector<void *> marks;                 // per level: the mark bytes; the materialised unions are in `arenas`
+    auto free_level = [&](size_t lvl) {
+        if (lvl < arenas.size() && arenas[lvl]) { (void)hipFree(arenas[lvl]); arenas[lvl] = nullptr; }
+        if (lvl < marks.size() && marks[lvl]) { (void)hipFree(marks[lvl]); marks[lvl] = nullptr; }
+    };
     for (int d = max_depth; d >= 0 && rc == TAXOR_OK; --d) {
         std::vector<IxfPlan> level;
         std::vector<uint64_t> ids;
-        uint64_t level_keys = 0, level_max = 0;
+        uint64_t mark_bytes = 0, arena_keys = 0, concat_max = 0;
+        std::vector<uint8_t> leaf_only(n_ixf, 0);
         for (uint64_t i = 0; i < n_ixf; ++i) {
             if (depth[i] != d) continue;
             IxfPlan &p = plan[i];
+            bool only_leaves = true;
             for (uint64_t b = 0; b < p.bins; ++b) {
                 const uint64_t g = bin_base[i] + b;
                 if (binfo[g] & BINFO_MERGED) {
                     const Union &u = uni[binfo[g] & 0x3FFFFFFFu];
                     p.keys[b] = u.p;
+                    p.keep[b] = u.keep;
                     p.n[b] = u.n;
+                    p.kept[b] = u.kept;
+                    only_leaves = false;
                 } else {
                     p.keys[b] = d_keys ? d_keys + (key_off[g] - key_off[0]) : nullptr;
-                    p.n[b] = key_off[g + 1] - key_off[g];
+                    p.keep[b] = nullptr;
+                    p.n[b] = p.kept[b] = key_off[g + 1] - key_off[g];
                 }
             }
             plan_totals(p);
-            level_keys += p.total;
-            level_max = std::max(level_max, p.total);
+            leaf_only[i] = only_leaves;
+            if (only_leaves) mark_bytes += p.total;
+            else { arena_keys += p.total; concat_max = std::max(concat_max, p.total); }
             ids.push_back(i);
         }
         for (uint64_t i : ids) level.push_back(plan[i]);
-        // the arena the unions of this level go to: tens of GB at class scale, and hipMalloc of that much is half a second of
-        // page-table work on the host -- done by a thread of its own while the level's bins are peeled
-        uint64_t *arena = nullptr;
-        hipError_t arena_err = hipSuccess;
-        std::thread arena_thread;
-        if (d > 0 && level_keys)
-            arena_thread = std::thread([&arena, &arena_err, level_keys, device] {
-                arena_err = hipSetDevice(device);
-                if (arena_err == hipSuccess) arena_err = hipMalloc((void **)&arena, level_keys * 8);
-            });
         rc = build_plans(eng, idx, level);
-        if (arena_thread.joinable()) arena_thread.join();
-        arenas.push_back(arena);
+        arenas.push_back(nullptr);
+        marks.push_back(nullptr);
         if (rc != TAXOR_OK) break;
         for (size_t q = 0; q < ids.size(); ++q) plan[ids[q]].seed = level[q].seed;
         if (d == 0) break;
-        // what the level above inserts into its merged bins: the duplicate-free union of every IXF of this level
+        // what the level above inserts into its merged bins
         const double tu = now_s();
-        uint64_t *concat = nullptr;
-        if (level_keys && (arena_err != hipSuccess || !arena)) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
-        uint64_t used = 0;
+        uint64_t *arena = nullptr, *concat = nullptr;
+        uint8_t *mark = nullptr;
+        if (mark_bytes && hipMalloc((void **)&mark, mark_bytes) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the duplicate marks of one level"); break; }
+        marks.back() = mark;
+        if (arena_keys && hipMalloc((void **)&arena, arena_keys * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
+        arenas.back() = arena;
+        uint64_t used = 0, marked = 0;
         for (uint64_t i : ids) {
             IxfPlan &p = plan[i];
             if (!p.total) continue;
             if (p.total >= 0xFFFFFFFFull) { rc = bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 - 2 keys below one merged bin"); break; }
-            // the IXF's keys in one piece: its leaf bins are adjacent in the caller's array; with merged bins among them, gathered
-            const uint64_t *src = nullptr;
-            bool contiguous = true;
-            for (uint64_t b = 0; b < p.bins; ++b)
-                if (p.n[b] && (binfo[bin_base[i] + b] & BINFO_MERGED)) contiguous = false;
-            if (contiguous) src = d_keys + (key_off[bin_base[i]] - key_off[0]);
-            else {
-                if (!concat && hipMalloc((void **)&concat, level_max * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys of one IXF"); break; }
-                uint64_t o = 0;
-                for (uint64_t b = 0; b < p.bins; ++b) {
-                    if (p.n[b] && hipMemcpyAsync(concat + o, p.keys[b], p.n[b] * 8, hipMemcpyDeviceToDevice, eng.st) != hipSuccess) rc = bfail(TAXOR_E_HIP, "build_hixf: device copy failed");
-                    o += p.n[b];
-                }
-                if (rc != TAXOR_OK) break;
-                src = concat;
+            if (leaf_only[i]) {
+                // its leaf bins are adjacent in the caller's array: the range itself, with marks
+                const uint64_t *src = d_keys + (key_off[bin_base[i]] - key_off[0]);
+                uint64_t kept = 0;
+                const hipError_t e = unioner.mark(src, p.total, mark + marked, &kept, eng.st);
+                if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
+                uni[i] = Union{src, kept == p.total ? nullptr : mark + marked, p.total, kept};
+                marked += p.total;
+                continue;
             }
+            // bins of several kinds: everything gathered (a child's range goes in WITH its duplicates: the set drops them again)
+            if (!concat && hipMalloc((void **)&concat, concat_max * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys of one IXF"); break; }
+            uint64_t o = 0;
+            for (uint64_t b = 0; b < p.bins; ++b) {
+                if (p.n[b] && hipMemcpyAsync(concat + o, p.keys[b], p.n[b] * 8, hipMemcpyDeviceToDevice, eng.st) != hipSuccess) rc = bfail(TAXOR_E_HIP, "build_hixf: device copy failed");
+                o += p.n[b];
+            }
+            if (rc != TAXOR_OK) break;
             uint64_t n_out = 0;
-            const hipError_t e = unioner.unique(src, p.total, arena + used, &n_out, eng.st);
+            const hipError_t e = unioner.unique(concat, p.total, arena + used, &n_out, eng.st);
             if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
-            uni[i].p = arena + used;
-            uni[i].n = n_out;
+            uni[i] = Union{arena + used, nullptr, n_out, n_out};
             used += n_out;
         }
         if (concat) (void)hipFree(concat);
         // the unions of the level below are not needed any more
-        if (arenas.size() >= 2 && arenas[arenas.size() - 2]) {
-            (void)hipFree(arenas[arenas.size() - 2]);
-            arenas[arenas.size() - 2] = nullptr;
-        }
+        if (arenas.size() >= 2) free_level(arenas.size() - 2);
         eng.stats.seconds_union += now_s() - tu;
     }
+    for (size_t l = 0; l < marks.size(); ++l)
+        if (marks[l]) { (void)hipFree(marks[l]); marks[l] = nullptr; }
     // the job is done here; handing tens of GB of keys, unions and scratch back to the driver is timed apart (hipFree of that much
     // takes anything between milliseconds and over a second, whatever was done with the memory)
     eng.stats.seconds_total = now_s() - t0;

@@ -16,6 +16,11 @@ struct KeyUnion {
     void release();
     // d_out (room for n keys) receives the distinct keys of d_in[0, n) in no particular order, *n_out their number.  Waits for `st`.
     hipError_t unique(const uint64_t *d_in, uint64_t n, uint64_t *d_out, uint64_t *n_out, hipStream_t st);
+    // nothing is copied: d_keep[i] = 1 for one occurrence of every distinct key of d_in[0, n), 0 for its duplicates; *n_kept = the ones.
+    hipError_t mark(const uint64_t *d_in, uint64_t n, uint8_t *d_keep, uint64_t *n_kept, hipStream_t st);
+private:
+    hipError_t prepare(uint64_t n, uint64_t *entries, hipStream_t st);
+public:
 };
 
 }
