@@ -49,7 +49,7 @@ if gc:
 if r.get("traffic") is not None:
     out.append(f"Memory side (live `rocprofv3 --pmc` passes in the same invocation): {r['traffic'] / 1e9:.2f} GB per launch = {r.get('traffic_GBps', 0):,.0f} GB/s "
                f"({r.get('traffic_over_requested')} × requested, {r.get('traffic_over_line128')} × the 128-B lines touched); average launch {r['avg_launch_ms']} ms "
-               f"(rocprofv3 kernel trace of the round-5 command: `profiles/r05/gtdb_kernel_stats.csv`; the search kernels are unchanged in round 6).")
+               f"(rocprofv3 `--kernel-trace --stats` of the same command without the legs: `profiles/r06/gtdb_kernel_stats.csv`, `k_query_level<true,2,...>` average in its first row).")
 extra = [a for a in sys.argv[2:] if not a.startswith("--")]
 if extra:
     b = json.loads([l for l in open(extra[0]) if l.startswith("{")][-1])
@@ -61,10 +61,11 @@ if extra:
                f"({bc['children']} children x {bc['child_bins']} bins x {bc['keys_per_bin']} keys under a root of merged bins, every bin built) in {bs['total']:.2f} s: "
                f"peel {bs['peel']:.2f} s, assign + verify {bs['assign_verify']:.2f} s, unions {bs['unions']:.2f} s; {bc['chunks_per_step']} chunks of <= 3 GB scratch, "
                f"{bc['rounds_max']} rounds at most, {bc['reseeds']} reseeds.  `roofline.frac` {br['frac']} of HBM bytes ({br['algorithmic_bytes_per_insertion']} B per insertion) -- not its bound; "
-               f"`rmw`: {br['rmw']['achieved_G_per_s']} G random read-modify-writes/s = {br['rmw']['frac']} of the measured 27 G/s over the WHOLE job"
+               f"`rmw`: {br['rmw']['achieved_G_per_s']} G random read-modify-writes/s = {br['rmw']['frac']} of the measured 27 G/s averaged over peel + assign + verify"
                + (f"; reference `AddAll` on one core: {cbb['value'] / 1e6:.1f} M insertions/s ({b['value'] / cbb['value']:.0f}x)" if cbb else "")
-               + ".  Longest builder launch in the `rocprofv3 --kernel-trace --stats` of the same command: 3.9 ms (`k_set_insert`; `k_count` 2.5, `k_round` 2.3; "
-                 "`profiles/r06/build_kernel_stats.csv`).")
+               + ".  Per kernel (HIP events inside the library): " + "; ".join(f"`{k['kernel']}` {k['achieved_G_per_s']} G RMW/s = {k['frac']} of the ceiling" for k in br['rmw'].get('kernels', []))
+               + ".  Longest builder launch in the `rocprofv3 --kernel-trace --stats` of the same command: 4.0 ms (`k_set_mark`; `k_count` 2.5, `k_round` 2.3; "
+                 "`profiles/r06/build_kernel_stats.csv`); one counter pass: `profiles/r06/build_pmc.txt`.")
 text = "\n".join(out)
 print(text)
 if "--write" in sys.argv:

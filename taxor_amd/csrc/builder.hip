@@ -815,7 +815,10 @@ extern "C" int taxor_gpu_synth_keys(int device, uint64_t *d_out, uint64_t first,
 {
     if (!d_out && n) return bfail(TAXOR_E_ARG, "synth_keys: null output");
     if (hipSetDevice(device) != hipSuccess) return bfail(TAXOR_E_HIP, "synth_keys: hipSetDevice failed");
-    if (n) hipLaunchKernelGGL(k_synth_keys, dim3((uint32_t)std::min<uint64_t>(8192, (n + BB - 1) / BB)), dim3(BB), 0, nullptr, d_out, first, n, salt);
+    for (uint64_t o = 0; o < n; o += (1ull << 30)) {          // (a billion keys per launch: ~1.5 ms)
+        const uint64_t m = std::min<uint64_t>(1ull << 30, n - o);
+        hipLaunchKernelGGL(k_synth_keys, dim3((uint32_t)std::min<uint64_t>(8192, (m + BB - 1) / BB)), dim3(BB), 0, nullptr, d_out + o, first + o, m, salt);
+    }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bfail(TAXOR_E_HIP, "synth_keys: kernel failed");
     return TAXOR_OK;
 }
