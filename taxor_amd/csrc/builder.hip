@@ -21,8 +21,9 @@
 //             choice does not depend on any race.  The peeling row logs the key's index at its list position and removes the
 //             key from its OTHER two rows (its own slot is never looked at again); a row whose degree drops 2 -> 1 is appended
 //             for round t+1 (it can never be appended twice).  Two read-modify-writes per key.  Appends: collected in LDS, one
-//             returning atomic per block and 1024 entries.  The last block to finish a round (ticket counter) records where
-//             the list ends -- one launch per round, no launch in between, no flags to set or retire             (k_round)
+//             returning atomic per block and 1024 entries.  The last WORKING block to finish a round (ticket counter; blocks
+//             without entries leave at once) records where the list ends -- one launch per round, no launch in between, no
+//             flags to set or retire                                                                              (k_round)
 //   stop    : rounds are enqueued 32 at a time, two batches ahead of the host, which looks at the recorded ends of a batch
 //             only when the next one is already queued: no device-to-host copy per round, the device never waits for the host.
 //             Launches behind the last round find an empty range and return.
@@ -37,8 +38,10 @@
 // A bin that does not peel (its logged keys fall short) re-seeds ITS IXF only; the other IXFs of the chunk are
 // finished, the failed one goes into the next chunk with a redrawn seed, like construct_ixf.cpp:100-108.
 //
-// taxor_gpu_index_build_hixf* builds a whole hierarchy level by level from the leaves up: the keys stay on the device, a merged
-// bin's key set is the duplicate-free union of everything in its child IXF (keyset.hip: a hash set in HBM), all IXFs of a level share chunks.
+// taxor_gpu_index_build_hixf* builds a whole hierarchy level by level from the leaves up: the keys stay on the device, all IXFs of
+// a level share chunks, and a merged bin's key set is the duplicate-free union of everything in its child IXF (keyset.hip: a hash
+// set in HBM) -- for a child of leaf bins not a copy but the child's OWN key range plus one mark byte per key (BinJob::keep: the
+// kernels skip unmarked keys), so that a level's unions cost an eighth of its keys in memory instead of all of them again.
 #include "../../include/taxor_gpu_tools.h"
 #include "ixf_arith.h"
 #include "kernels.h"
@@ -222,7 +225,7 @@ template <typename WT>
 __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
 {
     __shared__ uint64_t stage[2 * ROUND_ITER * BB];
-    __shared__ uint32_t stage_n, gbase, claimed_blk;
+    __shared__ uint32_t stage_n, gbase, peeled_blk;
     const uint32_t lo = a.ctl->round_end[t], hi = a.ctl->round_end[t + 1];
     const uint32_t step = (uint32_t)ROUND_ITER * BB;
     // Only blocks that have entries take part in the round's ticket (one returning atomic on ONE word each, ~13 ns: 1024 tickets
@@ -233,9 +236,9 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
         if (n_work == 0 && blockIdx.x == 0 && threadIdx.x == 0) a.ctl->round_end[t + 2] = hi;
         return;
     }
-    if (threadIdx.x == 0) { stage_n = 0; claimed_blk = 0; }
+    if (threadIdx.x == 0) { stage_n = 0; peeled_blk = 0; }
     __syncthreads();
-    uint32_t claimed = 0;
+    uint32_t peeled = 0;
     for (uint64_t base = (uint64_t)lo + (uint64_t)blockIdx.x * step; base < hi; base += (uint64_t)gridDim.x * step) {
 #pragma unroll 1
         for (int it = 0; it < ROUND_ITER; ++it) {
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
                     if (own == 2 && mine && a.pushed[J.slot_base + p.row[1]] == (uint16_t)t) mine = false;
                     if (mine) {
                         logged = (uint32_t)k;
-                        ++claimed;
+                        ++peeled;
                         const WT d = w_delta<WT>(k);
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
@@ -280,10 +283,10 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
         }
         stage_flush(stage, &stage_n, &gbase, a.list, &a.ctl->list_n);
     }
-    if (claimed) atomicAdd(&claimed_blk, claimed);
+    if (peeled) atomicAdd(&peeled_blk, peeled);
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (claimed_blk) atomicAdd(&a.ctl->peeled, (unsigned long long)claimed_blk);
+        if (peeled_blk) atomicAdd(&a.ctl->peeled, (unsigned long long)peeled_blk);
         finish_launch(a.ctl, t + 1, n_work);
     }
 }
@@ -744,6 +747,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             const bool all_bins = p.n_with_keys == p.bins;
             while (!built) {
                 built = true;
+                const uint64_t inserted_before = eng.stats.keys_inserted;      // (an attempt that is thrown away does not count)
                 if (all_bins && hipMemsetAsync(p.data, 0, 3 * p.seg_len * p.stride, eng.st) != hipSuccess) return bfail(TAXOR_E_HIP, "build: clearing an IXF failed");
                 for (uint64_t b0 = 0; b0 < p.bins && built;) {
                     uint64_t b1 = b0, s = 0, k = 0;
@@ -760,6 +764,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
                     b0 = b1;
                 }
                 if (!built) {
+                    eng.stats.keys_inserted = inserted_before;
                     if (++p.attempts >= 32) return bfail(TAXOR_E_INTERNAL, "build: no seed peeled every bin of IXF " + std::to_string(p.ixf) + " in 32 attempts (duplicate keys inside a bin?)");
                     p.seed = next_seed(p.seed);
                 }

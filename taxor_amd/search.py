@@ -81,7 +81,8 @@ def _results(res: _lib.Results, copy=True) -> SearchResults:
 def source_bytes(layout, f):
     """bytes a source holds for IXF dict f under layout code `layout` (taxor_amd/csrc/ixf_layout.h ixf_src_bytes)"""
     rows, kind = 3 * f["seg_len"], int(layout) & 0xFF
-    pitch = int(f.get("src_stride", 0)) or f["stride"]
+    # (ixf_layout.h ixf_src_pitch: the explicit pitch, else what the code's pitch rule names -- `bins` when unpadded, the index's stride otherwise)
+    pitch = int(f.get("src_stride", 0)) or (f["bins"] if (int(layout) & 0x600) == _lib.LAYOUT_PITCH_BINS else f["stride"])
     if kind == _lib.LAYOUT_BIT_SLICED:
         return rows * ((f["bins"] + 63) // 64) * 64
     return rows * pitch

@@ -82,3 +82,21 @@ def test_a_layout_that_contradicts_the_view_is_refused():
         GpuIndex([dict(f, data=np.zeros(60 * 64, np.uint8), src_stride=64)], 100, layout=_lib.LAYOUT_BIN_MAJOR | _lib.LAYOUT_PITCH_BINS)   # 64 columns for 100 bins
     with pytest.raises(_lib.TaxorError):
         GpuIndex([f], 100, layout=0x003)
+
+
+def test_the_pitch_a_layout_code_names_counts_when_src_stride_is_left_zero():
+    """a C-ABI caller who passes the code `taxor pin` prints -- 0x200, rows at exactly `bins` bytes -- but leaves
+    taxor_ixf_view::src_stride 0 used to get the bytes uploaded as they lie (wrong answers, no error).  The pitch rule of the code
+    now counts: unpadded -> bins; padded / none -> the index's own stride; "the record's stored scalar" without a scalar is refused."""
+    rng = np.random.default_rng(11)
+    for bins, seg in [(100, 37), (65, 50), (130, 21)]:
+        f = _random_ixf(rng, bins, seg)
+        for code in (_lib.LAYOUT_ROWS | _lib.LAYOUT_PITCH_BINS, _lib.LAYOUT_BIN_MAJOR | _lib.LAYOUT_PITCH_BINS,
+                     _lib.LAYOUT_ROWS | _lib.LAYOUT_POSITION_MAJOR | _lib.LAYOUT_PITCH_BINS):
+            raw, pitch = to_source_layout(f, code)
+            assert pitch == bins
+            idx = GpuIndex([dict(f, data=raw, src_stride=0)], bins, layout=code)          # src_stride left 0: the code says "bins"
+            assert np.array_equal(idx.download_ixf(0), f["data"]), (describe_layout(code), bins, seg)
+            idx.close()
+        with pytest.raises(_lib.TaxorError):
+            GpuIndex([dict(f, data=f["data"], src_stride=0)], bins, layout=_lib.LAYOUT_ROWS | _lib.LAYOUT_PITCH_STORED)
