@@ -460,7 +460,7 @@ def build_mode(args):
         if i >= warmup:
             sts.append(st)
         log(f"build {i}: {st['keys_inserted'] / st['seconds_total'] / 1e9:.3f} G insertions/s ({st['seconds_total']:.3f} s; peel {st['seconds_peel']:.3f}, "
-            f"assign+verify {st['seconds_assign']:.3f}, unions {st['seconds_union']:.3f}; {st['chunks']} chunks, {st['rounds_max']} rounds, {st['reseeds']} reseeds)")
+            f"assign+verify {st['seconds_assign']:.3f}, unions {st['seconds_union']:.3f}, scratch alloc {st['seconds_alloc']:.3f}; {st['chunks']} chunks, {st['rounds_max']} rounds, {st['reseeds']} reseeds)")
     ins = sum(s_["keys_inserted"] for s_ in sts)
     secs = sum(s_["seconds_total"] for s_ in sts)
     wall = sum(s_["wall_s"] for s_ in sts)
@@ -475,6 +475,34 @@ def build_mode(args):
         if own[b] != keys.size or up[c - 1] != keys.size:
             raise SystemExit("PARITY FAILURE: a built bin does not hold its keys")
     sr.close()
+    # the same from keys in HOST memory, as a binding has them (construct_ixf.cpp reads the bins' hashes from temp files): PCIe inside,
+    # never `value`.  A smaller hierarchy (<= 16 children: 7 GB of keys), two builds.
+    import ctypes as C
+    host_fed = None
+    if not args.no_dropin:
+        from taxor_amd import _lib
+        nc_h = min(nc, 16)
+        shapes_h, ub_h, counts_h = synth.full_hierarchy_shapes(nc_h, cb, kpb)
+        off_h = np.zeros(counts_h.size + 1, dtype=np.uint64)
+        np.cumsum(counts_h, out=off_h[1:])
+        n_h = int(off_h[-1])
+        L = _lib.lib()
+        d_tmp = C.c_void_p()
+        _lib.check(L.taxor_gpu_malloc(0, n_h * 8, C.byref(d_tmp)))
+        _lib.check(L.taxor_gpu_synth_keys(0, d_tmp, 0, n_h, salt + 1))
+        hkeys = np.empty(n_h, dtype=np.uint64)
+        _lib.check(L.taxor_gpu_memcpy_to_host(hkeys.ctypes.data_as(C.c_void_p), d_tmp, n_h * 8))
+        L.taxor_gpu_free(d_tmp)
+        idx_h = GpuIndex(shapes_h, ub_h)
+        hs = [idx_h.build_hixf_host_keys(hkeys, off_h, seed0=77 + i) for i in range(2)][-1]
+        idx_h.close()
+        del hkeys
+        host_fed = {"value": round(hs["keys_inserted"] / hs["seconds_total"], 1), "unit": "key insertions/s", "children": nc_h, "insertions": int(hs["keys_inserted"]),
+                    "seconds_total": round(hs["seconds_total"], 4), "seconds_upload": round(hs["seconds_upload"], 4),
+                    "upload_GBps": round(n_h * 8 / max(1e-9, hs["seconds_upload"]) / 1e9, 1),
+                    "note": "taxor_gpu_index_build_hixf_ex with the keys in pageable host memory: allocation + upload (4 threads through page-locked staging) + build; "
+                            "the second of two builds"}
+        log(f"host-fed build: {host_fed['value'] / 1e9:.3f} G insertions/s ({host_fed['seconds_total']:.3f} s of which upload {host_fed['seconds_upload']:.3f} s = {host_fed['upload_GBps']} GB/s)")
     kern_s = sum(s_["seconds_peel"] + s_["seconds_assign"] for s_ in sts)
     t_count = max(1e-9, sum(s_["seconds_count"] for s_ in sts))
     t_rounds = max(1e-9, sum(s_["seconds_rounds"] for s_ in sts))
@@ -518,6 +546,9 @@ def build_mode(args):
                                         "up to 256 MB, 18-20 G/s beyond, whatever the scope, width or use of the return value); the builder also does ~12 random loads "
                                         "and stores per insertion (54 G/s ceiling), so 5 RMW / 20-27 G/s + 12 / 54 G/s = 0.41-0.47 ns per insertion is the floor of this "
                                         "design: 2.1-2.4 G insertions/s in the peeling + assignment kernels"}}}
+    if host_fed is not None:
+        out["pcie_inclusive"] = host_fed
+        out["value_host_fed"] = host_fed["value"]
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = build_cpu_reference(args.build_cpu_keys, salt)
     idx.close()

@@ -51,7 +51,9 @@ int taxor_gpu_index_download_ixf(const taxor_gpu_index *idx, uint64_t ixf, uint8
  * at once in synchronous rounds (taxor_amd/csrc/builder.hip); if a bin does not peel the IXF is re-seeded and rebuilt,
  * like the reference.  On success the IXF carries *seed_out (also written into the resident index); *rounds_out =
  * peeling rounds of the slowest chunk.  The columns are a function of (keys, seed) alone: two builds are byte-identical.
- * Every key is looked up in the finished columns before the call returns.  The index must not be searched meanwhile. */
+ * Every key is looked up in the finished columns before the call returns.  The index must not be searched meanwhile.  The
+ * builder's scratch (peeling state of one chunk, <= 3 GB unless one bin needs more; the union table; mark bytes) stays with the
+ * index for its next build and is released by taxor_gpu_index_destroy. */
 int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, const uint64_t *key_off,
                               uint64_t seed0, uint64_t *seed_out, uint32_t *rounds_out);
 /* The whole hierarchy at once (the back end of hierarchical_build.cpp:27-236): key_off[total_bins + 1] indexes `keys`
@@ -78,6 +80,8 @@ typedef struct taxor_build_stats {
     double seconds_release;   /* handing keys, unions and scratch back to the driver afterwards (not in seconds_total) */
     double seconds_count;     /* GPU time of k_count (3 atomic adds per key), HIP events on the builder's stream */
     double seconds_rounds;    /* GPU time of the seed scan and the peeling rounds (2 atomic subs per key), HIP events */
+    double seconds_upload;    /* keys from host memory to the device (allocation + copy; 0 when they were there already); in seconds_total */
+    double seconds_alloc;     /* hipMalloc / hipFree of the peeling scratch (in seconds_total; the driver's time, erratic for GB-sized blocks) */
 } taxor_build_stats;
 int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
                                  const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);

@@ -110,7 +110,8 @@ class BuildStats(C.Structure):
     _fields_ = [("keys_inserted", C.c_uint64), ("scratch_bytes", C.c_uint64), ("rounds_max", C.c_uint32), ("reseeds", C.c_uint32),
                 ("chunks", C.c_uint32), ("reserved", C.c_uint32), ("seconds_peel", C.c_double), ("seconds_assign", C.c_double),
                 ("seconds_union", C.c_double), ("seconds_total", C.c_double), ("seconds_release", C.c_double),
-                ("seconds_count", C.c_double), ("seconds_rounds", C.c_double)]
+                ("seconds_count", C.c_double), ("seconds_rounds", C.c_double), ("seconds_upload", C.c_double),
+                ("seconds_alloc", C.c_double)]
 
 
 SIGNATURES = {

@@ -95,6 +95,10 @@ struct taxor_gpu_index {
     // part j when the row is cut into root_pmax parts (every boundary is a unit boundary at which a bin run ends)
     uint32_t root_pmax = 1;
     uint16_t root_cut[9] = {};
+    // the builder's scratch (builder.hip: peeling state, union table, mark bytes), kept from one build of this index to the next --
+    // hipMalloc / hipFree of GB-sized blocks takes the driver anything between nothing and a second -- and released with the index
+    void *build_ctx = nullptr;
+    void (*build_ctx_free)(void *) = nullptr;
 };
 
 struct SubBatch {
@@ -648,10 +652,22 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_slab(taxor_gpu_
     return 0;
 }
 
+// library-internal (builder.hip): the builder's per-index context
+extern "C" __attribute__((visibility("hidden"))) void *taxor_index_build_ctx(taxor_gpu_index *idx) { return idx ? idx->build_ctx : nullptr; }
+extern "C" __attribute__((visibility("hidden"))) void taxor_index_set_build_ctx(taxor_gpu_index *idx, void *ctx, void (*free_fn)(void *))
+{
+    if (!idx) return;
+    if (idx->build_ctx && idx->build_ctx_free && idx->build_ctx != ctx) idx->build_ctx_free(idx->build_ctx);
+    idx->build_ctx = ctx;
+    idx->build_ctx_free = free_fn;
+}
+
 extern "C" void taxor_gpu_index_destroy(taxor_gpu_index *idx)
 {
     if (!idx) return;
     (void)hipSetDevice(idx->device);
+    if (idx->build_ctx && idx->build_ctx_free) idx->build_ctx_free(idx->build_ctx);
+    idx->build_ctx = nullptr;
     if (idx->d_slab) (void)hipFree(idx->d_slab);
     if (idx->d_ixf) (void)hipFree(idx->d_ixf);
     if (idx->d_binfo) (void)hipFree(idx->d_binfo);

@@ -49,9 +49,13 @@
 #include "tuning.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace taxor;
@@ -400,6 +404,8 @@ extern "C" __attribute__((visibility("hidden"))) int taxor_index_set_seed(taxor_
 extern "C" __attribute__((visibility("hidden"))) uint32_t taxor_index_arith(const taxor_gpu_index *idx);
 extern "C" __attribute__((visibility("hidden"))) int taxor_index_tree(taxor_gpu_index *idx, uint64_t *n_ixf, const uint32_t **bin_base,
                                                                       const uint32_t **binfo);
+extern "C" __attribute__((visibility("hidden"))) void *taxor_index_build_ctx(taxor_gpu_index *idx);
+extern "C" __attribute__((visibility("hidden"))) void taxor_index_set_build_ctx(taxor_gpu_index *idx, void *ctx, void (*free_fn)(void *));
 
 namespace {
 
@@ -446,6 +452,9 @@ struct Engine {
 
     int open(int dev)
     {
+        const double ta = now_s();
+        struct Acc { double &s; double t0; ~Acc() { s += now_s() - t0; } } acc{stats.seconds_alloc, ta};
+        if (st) { E_TRY(hipSetDevice(device)); return TAXOR_OK; }      // kept from an earlier build of the same index
         device = dev;
         E_TRY(hipSetDevice(device));
         E_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -477,6 +486,8 @@ struct Engine {
 
     int ensure(uint64_t slots, uint64_t jobs, bool wide)
     {
+        const double ta = now_s();
+        struct Acc { double &s; double t0; ~Acc() { s += now_s() - t0; } } acc{stats.seconds_alloc, ta};
         const uint64_t wb = slots * (wide ? 8 : 4);
         if (wb > w_bytes) {
             if (d_w) (void)hipFree(d_w);
@@ -812,6 +823,47 @@ void plan_totals(IxfPlan &p)
     }
 }
 
+// What a build keeps with its index for the next one (released by taxor_gpu_index_destroy): the peeling scratch, the union table
+// and two buffers of mark bytes (the marks of the level below are read while those of this level are written).
+struct BuildCtx {
+    std::mutex mu;             // one build of an index at a time
+    Engine eng;
+    KeyUnion unioner;
+    uint8_t *mark[2] = {nullptr, nullptr};
+    uint64_t mark_cap[2] = {0, 0};
+    ~BuildCtx()
+    {
+        for (auto *m : mark)
+            if (m) (void)hipFree(m);
+    }
+    // mark buffer `which` with room for n bytes
+    uint8_t *marks(int which, uint64_t n)
+    {
+        if (n > mark_cap[which]) {
+            const double ta = now_s();
+            if (mark[which]) (void)hipFree(mark[which]);
+            mark[which] = nullptr;
+            mark_cap[which] = 0;
+            if (hipMalloc((void **)&mark[which], n) != hipSuccess) return nullptr;
+            mark_cap[which] = n;
+            eng.stats.seconds_alloc += now_s() - ta;
+        }
+        return mark[which];
+    }
+};
+
+void build_ctx_free(void *p) { delete static_cast<BuildCtx *>(p); }
+
+BuildCtx *build_ctx_of(taxor_gpu_index *idx)
+{
+    auto *c = static_cast<BuildCtx *>(taxor_index_build_ctx(idx));
+    if (!c) {
+        c = new BuildCtx;
+        taxor_index_set_build_ctx(idx, c, build_ctx_free);
+    }
+    return c;
+}
+
 } // namespace
 
 extern "C" uint64_t taxor_synth_key(uint64_t i, uint64_t salt) { return synth_key(i, salt); }
@@ -852,6 +904,53 @@ extern "C" int taxor_gpu_memcpy_to_host(void *dst, const void *d_src, uint64_t b
     return hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? TAXOR_OK : bfail(TAXOR_E_HIP, "taxor_gpu_memcpy_to_host failed");
 }
 
+// Keys from pageable host memory to the device.  One hipMemcpy of tens of GB goes through the runtime's own staging at ~10 GB/s; a
+// binding has the hashes in host vectors (construct_ixf.cpp:82,123 reads them from temp files), so the upload is part of its build.
+// Four threads, two page-locked 16-MB buffers and a stream each, pieces off a shared cursor -- the shape of the index upload
+// (api.hip index_upload).  Small arrays take the plain copy.
+static hipError_t upload_keys(int device, uint64_t *d_dst, const uint64_t *src, uint64_t n_keys)
+{
+    const uint64_t bytes = n_keys * 8, piece = 16ull << 20;
+    if (bytes < (256ull << 20)) return hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice);
+    const int n_threads = 4;
+    std::atomic<uint64_t> cursor{0};
+    std::atomic<int> err{(int)hipSuccess};
+    auto worker = [&] {
+        hipStream_t st = nullptr;
+        void *buf[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            e = hipHostMalloc(&buf[k], piece, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[k], hipEventDisableTiming);
+        }
+        bool used[2] = {false, false};
+        for (int k = 0; e == hipSuccess && err.load() == (int)hipSuccess; k ^= 1) {
+            const uint64_t off = cursor.fetch_add(piece);
+            if (off >= bytes) break;
+            const uint64_t len = std::min(piece, bytes - off);
+            if (used[k]) e = hipEventSynchronize(done[k]);           // the copy that last read this buffer has finished
+            if (e != hipSuccess) break;
+            memcpy(buf[k], (const char *)src + off, len);
+            e = hipMemcpyAsync((char *)d_dst + off, buf[k], len, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(done[k], st);
+            used[k] = true;
+        }
+        if (st && e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) err.store((int)e);
+        for (int k = 0; k < 2; ++k) {
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            if (buf[k]) (void)hipHostFree(buf[k]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+    for (auto &t : th) t.join();
+    return (hipError_t)err.load();
+}
+
 // keys: the bins' key lists concatenated, on the host or (keys_on_device) on the index's device
 static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device, const uint64_t *key_off, uint64_t seed0,
                           uint64_t *seed_out, uint32_t *rounds_out, taxor_build_stats *stats_out)
@@ -876,7 +975,7 @@ static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *ke
     const uint64_t *d_keys = keys + key_off[0];
     if (!keys_on_device) {
         if (hipMalloc((void **)&d_own, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_ixf: no device memory for the keys");
-        if (hipMemcpy(d_own, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        if (upload_keys(device, d_own, keys + key_off[0], total) != hipSuccess) {
             (void)hipFree(d_own);
             return bfail(TAXOR_E_HIP, "build_ixf: key upload failed");
         }
@@ -888,13 +987,15 @@ static int build_ixf_impl(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *ke
     }
     plan_totals(p);
     p.seed = seed0;
-    Engine eng;
+    BuildCtx *ctx = build_ctx_of(idx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Engine &eng = ctx->eng;
+    eng.stats = taxor_build_stats{};
     rc = eng.open(device);
     if (rc == TAXOR_OK) rc = build_plans(eng, idx, plans);
     eng.stats.seconds_total = now_s() - t0;
     const double t_rel = now_s();
     if (d_own) (void)hipFree(d_own);
-    eng.release();
     eng.stats.seconds_release = now_s() - t_rel;
     if (rc != TAXOR_OK) return rc;
     if (seed_out) *seed_out = p.seed;
@@ -964,15 +1065,22 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         for (auto *p : arenas)
             if (p) (void)hipFree(p);
     };
+    double t_upload = 0.0;
     if (total && !keys_on_device) {
+        const double tu0 = now_s();
         if (hipMalloc((void **)&d_leaf, total * 8) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys");
-        if (hipMemcpy(d_leaf, keys + key_off[0], total * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        if (upload_keys(device, d_leaf, keys + key_off[0], total) != hipSuccess) {
             cleanup();
             return bfail(TAXOR_E_HIP, "build_hixf: key upload failed");
         }
         d_keys = d_leaf;
+        t_upload = now_s() - tu0;
     }
-    Engine eng;
+    BuildCtx *ctx = build_ctx_of(idx);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    Engine &eng = ctx->eng;
+    eng.stats = taxor_build_stats{};
+    eng.stats.seconds_upload = t_upload;
     int rc = eng.open(device);
     if (rc != TAXOR_OK) { cleanup(); return rc; }
     // What a merged bin of the level above holds: the keys of everything in this IXF, each once.  For an IXF whose bins are all
@@ -981,11 +1089,9 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
     // of the driver's time on a good day).  An IXF with merged bins of its own (deeper hierarchies) gets its union materialised.
     struct Union { const uint64_t *p = nullptr; const uint8_t *keep = nullptr; uint64_t n = 0, kept = 0; };
     std::vector<Union> uni(n_ixf);
-    KeyUnion unioner;
-    std::vector<void *> marks;                 // per level: the mark bytes; the materialised unions are in `arenas`
-    auto free_level = [&](size_t lvl) {
+    KeyUnion &unioner = ctx->unioner;
+    auto free_level = [&](size_t lvl) {        // (the mark bytes are the context's, two buffers taken in turn by the levels)
         if (lvl < arenas.size() && arenas[lvl]) { (void)hipFree(arenas[lvl]); arenas[lvl] = nullptr; }
-        if (lvl < marks.size() && marks[lvl]) { (void)hipFree(marks[lvl]); marks[lvl] = nullptr; }
     };
     for (int d = max_depth; d >= 0 && rc == TAXOR_OK; --d) {
         std::vector<IxfPlan> level;
@@ -1020,7 +1126,6 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         for (uint64_t i : ids) level.push_back(plan[i]);
         rc = build_plans(eng, idx, level);
         arenas.push_back(nullptr);
-        marks.push_back(nullptr);
         if (rc != TAXOR_OK) break;
         for (size_t q = 0; q < ids.size(); ++q) plan[ids[q]].seed = level[q].seed;
         if (d == 0) break;
@@ -1028,8 +1133,7 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         const double tu = now_s();
         uint64_t *arena = nullptr, *concat = nullptr;
         uint8_t *mark = nullptr;
-        if (mark_bytes && hipMalloc((void **)&mark, mark_bytes) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the duplicate marks of one level"); break; }
-        marks.back() = mark;
+        if (mark_bytes && !(mark = ctx->marks(d & 1, mark_bytes))) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the duplicate marks of one level"); break; }
         if (arena_keys && hipMalloc((void **)&arena, arena_keys * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the key unions of one level"); break; }
         arenas.back() = arena;
         uint64_t used = 0, marked = 0;
@@ -1066,15 +1170,11 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         if (arenas.size() >= 2) free_level(arenas.size() - 2);
         eng.stats.seconds_union += now_s() - tu;
     }
-    for (size_t l = 0; l < marks.size(); ++l)
-        if (marks[l]) { (void)hipFree(marks[l]); marks[l] = nullptr; }
     // the job is done here; handing tens of GB of keys, unions and scratch back to the driver is timed apart (hipFree of that much
     // takes anything between milliseconds and over a second, whatever was done with the memory)
     eng.stats.seconds_total = now_s() - t0;
     const double t_rel = now_s();
-    unioner.release();
     cleanup();
-    eng.release();
     eng.stats.seconds_release = now_s() - t_rel;
     if (rc != TAXOR_OK) return rc;
     if (rounds_out) *rounds_out = eng.stats.rounds_max;

@@ -253,6 +253,15 @@ class GpuIndex:
             L.taxor_gpu_free(d_keys)
         return {k: getattr(st, k) for k, _ in _lib.BuildStats._fields_ if k != "reserved"}, off
 
+    def build_hixf_host_keys(self, keys, off, seed0=1):
+        """GPU construction of the whole hierarchy from keys in HOST memory (what a binding has): keys = uint64 array, off[total_bins + 1]
+        per technical bin in index bin order (merged bins: empty).  Returns the run's figures (upload inside seconds_total)."""
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        o = np.ascontiguousarray(off, dtype=np.uint64)
+        st = _lib.BuildStats()
+        check(_lib.lib().taxor_gpu_index_build_hixf_ex(self._h, _p(k) if k.size else None, 0, _p(o), int(seed0), C.byref(st)))
+        return {kk: getattr(st, kk) for kk, _ in _lib.BuildStats._fields_ if kk != "reserved"}
+
     def ixf_seed(self, ixf):
         return int(_lib.lib().taxor_gpu_index_ixf_seed(self._h, ixf))
 

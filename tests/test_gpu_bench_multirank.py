@@ -219,6 +219,9 @@ def test_build_mode_line():
     kn = {k["kernel"]: k for k in r["rmw"]["kernels"]}          # the two kernels that carry the read-modify-writes, timed by HIP events in the library
     assert kn["k_count"]["rmw_per_insertion"] == 3 and 0.2 < kn["k_count"]["frac"] < 1.2 and kn["k_seed + k_round"]["rmw_per_insertion"] == 2
     assert 0 < kn["k_count"]["seconds_per_step"] < j["stage_s_per_step"]["peel"] and 0 < kn["k_seed + k_round"]["seconds_per_step"] < j["stage_s_per_step"]["peel"]
-    assert j["stage_s_per_step"]["release_after"] >= 0
+    assert j["stage_s_per_step"]["release_after"] >= 0 and j["value_median_step"] > 2e8 and len(j["step_seconds"]) == 2
+    # the same from keys in host memory (what a binding has): upload inside, never `value`
+    pi = j["pcie_inclusive"]
+    assert j["value_host_fed"] == pi["value"] > 1e8 and 0 < pi["seconds_upload"] < pi["seconds_total"] and pi["upload_GBps"] > 1
     cb = j["cpu_baseline"]
     assert cb["kind"] == "reference" and cb["cores"] == 1 and 1e6 < cb["value"] < j["value"]
