@@ -62,7 +62,11 @@ import numpy as np
 # the HIP runtime maps streams onto this many hardware queues per device (default 4) and streams that share one run in
 # submission order; a searcher's copy / hashing / query streams must not (taxor_amd/csrc/api.hip, runtime_env_once).  Set
 # before torch brings the runtime up; a value the user exported wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A rank of a distributed run also carries torch's and RCCL's streams: with 8 queues the searchers' streams then share queues with
+# each other (measured: forced one-rank RCCL run 4.8 % behind the plain run with 2 resident batches, 1.6 % with 8; with 24 queues
+# 0.7 % / 0.6 % -- profiles/r06/hw_queues_dist.txt; 32 and more lose a third, api.hip).
+_DIST = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TAXOR_BENCH_FORCE_DIST") == "1"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if _DIST else "8")
 # several ranks on one node: this pool's host driver shares device memory between processes through dmabuf only, and
 # RCCL's intra-node transport fails with `hipIpcGetMemHandle: invalid argument` under the legacy mode (exported on the
 # boxes already; set here too so that a hand-built environment does not lose it)
@@ -650,12 +654,13 @@ def main():
 
     from taxor_amd import distributed as td
     gathered = {}
-    comm_acc = {"ms": 0.0, "n": 0, "bytes": 0, "sent": 0}
+    comm_acc = {"ms": 0.0, "n": 0, "bytes": 0, "sent": 0, "events": [], "export_host_ms": 0.0, "gather_host_ms": 0.0}
 
     def gather_results(sr):
         """per-read results of every rank -> rank 0 over RCCL (point-to-point, one xGMI link per peer)"""
         if not dist_on:
             return
+        t_x = time.perf_counter()
         nr, nt = sr.result_sizes()
         dev = torch.device("cuda", local_rank)
         ro = torch.empty(nr + 1, dtype=torch.int64, device=dev)
@@ -671,11 +676,12 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         t_g = time.perf_counter()
+        comm_acc["export_host_ms"] += (t_g - t_x) * 1e3
         gathered["last"] = td.gather_csr(ro, ub, ct, nh, dst=0)
+        comm_acc["gather_host_ms"] += (time.perf_counter() - t_g) * 1e3
         if backend == "nccl":
             e1.record()
-            e1.synchronize()
-            comm_acc["ms"] += e0.elapsed_time(e1)
+            comm_acc["events"].append((e0, e1))        # read after the timed loop's final synchronize: no host sync per step for the clock
         else:
             comm_acc["ms"] += (time.perf_counter() - t_g) * 1e3
         comm_acc["n"] += 1
@@ -698,7 +704,7 @@ def main():
         t0 = time.perf_counter()
         acc = dict(q_ms=0.0, q_bytes=0.0, q_touched=0.0, launches=0, bases=0, sync_ms=0.0, query_ms=0.0, fin_ms=0.0, total_ms=0.0,
                    hashes=0, tuples=0, work=0, reads=0, alg=0, lvl_ms=[0.0] * 8, lvl_bytes=[0] * 8, lvl_rows=[0] * 8, lvl_sparse=[0] * 8)
-        comm_acc.update(ms=0.0, n=0, bytes=0, sent=0)
+        comm_acc.update(ms=0.0, n=0, bytes=0, sent=0, events=[], export_host_ms=0.0, gather_host_ms=0.0)
         acc["local_s"] = 0.0
         for i in range(steps):
             t_s = time.perf_counter()
@@ -727,6 +733,7 @@ def main():
         if dist_on:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        comm_acc["ms"] += sum(a_.elapsed_time(b_) for a_, b_ in comm_acc["events"])
         if dist_on:
             dev_t = torch.device("cuda", local_rank) if backend == "nccl" else "cpu"
             tt = torch.tensor([elapsed, float(acc["bases"])], dtype=torch.float64, device=dev_t)
@@ -741,6 +748,8 @@ def main():
             acc["per_rank_gather_ms"] = [float(v[1]) for v in all_t]
             acc["per_rank_sent_bytes"] = [float(v[2]) for v in all_t]
             acc["gather_bytes_received"] = comm_acc["bytes"] / max(1, comm_acc["n"])
+            acc["export_host_ms"] = comm_acc["export_host_ms"] / max(1, comm_acc["n"])
+            acc["gather_host_ms"] = comm_acc["gather_host_ms"] / max(1, comm_acc["n"])
             acc["gather_sizes"] = list(td.last_gather["sizes"])
         else:
             acc["all_bases"] = float(acc["bases"])
@@ -1045,11 +1054,14 @@ def main():
             prm = acc.get("per_rank_ms", [])
             out["comm"] = {"backend": "nccl (RCCL)" if backend == "nccl" else backend,
                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None,
-                           "world": dist.get_world_size(),
+                           "world": dist.get_world_size(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                            "ranks_in_last_gather": [p_ for p_, (n_, _t) in enumerate(sizes) if n_ > 0],
                            "reads_tuples_per_rank_last_gather": [[int(n_), int(t_)] for n_, t_ in sizes],
                            "gather_bytes_per_step": round(acc.get("gather_bytes_received", 0.0), 1),
                            "gather_ms_per_step": round(acc.get("per_rank_gather_ms", [0.0])[0], 4),
+                           "host_ms_per_step": {"export_to_torch": round(acc.get("export_host_ms", 0.0), 4), "gather_csr": round(acc.get("gather_host_ms", 0.0), 4),
+                                                "note": "rank 0's wall clock inside a step for the hand-off: result sizes + four torch.empty + the D2D export of the CSR; "
+                                                        "gather_csr (all_gather of the sizes + the point-to-point exchange)"},
                            "sent_bytes_per_rank_per_step": [round(v, 1) for v in acc.get("per_rank_sent_bytes", [])],
                            "ms_per_step_per_rank": {"min": round(min(prm), 3) if prm else None, "max": round(max(prm), 3) if prm else None,
                                                     "rank0": round(prm[0], 3) if prm else None, "all": [round(v, 3) for v in prm]},

@@ -159,9 +159,17 @@ def test_forced_single_rank_rccl_run_equals_the_plain_run(tmp_path):
     solo-then-concurrent host-fed block, destroy_process_group -- launched through torch.distributed.run like the driver
     launches N ranks.  What one GPU can execute of the 8-GPU run is executed here; the line must agree with the plain N = 1 run
     (that is also the SCALE N=1 == BENCH check), the gathered CSR must be the plain run's, and host_fed_scaling must be ~1."""
-    common = ["bench.py", "--gpus", "1", "--workload", "refseq", "--steps", "12", "--warmup", "3", "--batches", "2",
+    # the headline workload itself (GTDB-class, 50-ms steps): what the forced run adds per step -- the export of the four result arrays, an
+    # all_gather of two words, one event synchronisation -- is ~0.1 ms; on a 33-ms RefSeq-class step the same run came out 2-6 % apart
+    # from box to box, which says more about RCCL's proxy thread on a 16-CPU quota than about this code path
+    import torch
+    if torch.cuda.mem_get_info(0)[0] < 160e9:
+        pytest.skip("needs 160 GB of free HBM")
+    common = ["bench.py", "--gpus", "1", "--workload", "gtdb", "--steps", "8", "--warmup", "2", "--batches", "2",
               "--traffic", "none", "--no-cpu-baseline", "--no-unpruned", "--no-ceiling", "--no-e04", "--no-layouts", "--sustained-reads", "2000000"]
-    env = {k: v for k, v in os.environ.items() if k not in ("TAXOR_BENCH_BACKEND", "TAXOR_BENCH_SAME_GPU")}
+    # (GPU_MAX_HW_QUEUES: conftest.py exports 8 for the test session; bench.py must choose for itself like under the driver -- 8 for the
+    # plain run, 24 for a rank of a distributed one, whose torch / RCCL streams would otherwise push the searchers' streams onto shared queues)
+    env = {k: v for k, v in os.environ.items() if k not in ("TAXOR_BENCH_BACKEND", "TAXOR_BENCH_SAME_GPU", "GPU_MAX_HW_QUEUES")}
     env["MASTER_ADDR"] = "127.0.0.1"
 
     def run(cmd, env, dump):
@@ -189,6 +197,7 @@ def test_forced_single_rank_rccl_run_equals_the_plain_run(tmp_path):
     cm = forced["comm"]
     assert "comm" not in plain
     assert cm["backend"] == "nccl (RCCL)" and cm["world"] == 1 and cm["rccl_version"] and cm["ranks_in_last_gather"] == [0]
+    assert cm["gpu_max_hw_queues"] == "24" and cm["host_ms_per_step"]["export_to_torch"] < 1.0 and cm["host_ms_per_step"]["gather_csr"] < 1.0
     assert cm["reads_tuples_per_rank_last_gather"][0][0] == forced["config"]["reads_per_gpu"] and cm["reads_tuples_per_rank_last_gather"][0][1] > 0
     assert cm["gather_bytes_per_step"] == 0 and cm["gather_ms_per_step"] > 0 and cm["sent_bytes_per_rank_per_step"][0] > 1e6
     pr_ms = cm["ms_per_step_per_rank"]
