@@ -449,6 +449,8 @@ def build_mode(args):
     from taxor_amd import GpuIndex, Searcher, synth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
+        raise SystemExit("--mode build is a single-GPU line: index construction does not shard across devices here (an index is built once and replicated)")
     nc, cb, kpb = args.build_children, args.build_child_bins, args.build_keys_per_bin
     shapes, ub, counts = synth.full_hierarchy_shapes(nc, cb, kpb)
     salt = synth.DEFAULT_SEED
