@@ -766,7 +766,13 @@ int main(int argc, char **argv)
     // while the process is still single-threaded: the HIP runtime's hardware-queue count (taxor_amd/csrc/api.hip,
     // runtime_env_once -- the library would set it at its first call, by which time this host has threads that read the
     // environment)
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // A process that will also hold an RCCL communicator (--gpus a,b,... or --gather rccl) asks for 16: RCCL's own streams otherwise
+    // push the searchers' streams onto shared queues (21.5 -> 23.7 Gbp/s in the one-device experiment, docs/EXPERIMENTS.md section 4;
+    // bench.py's ranks: profiles/r06/hw_queues_dist.txt).  A value the user exported wins.
+    bool with_comm = false;
+    for (int i = 1; i + 1 < argc; ++i)
+        if ((strcmp(argv[i], "--gpus") == 0 && strchr(argv[i + 1], ',')) || (strcmp(argv[i], "--gather") == 0 && strcmp(argv[i + 1], "rccl") == 0)) with_comm = true;
+    setenv("GPU_MAX_HW_QUEUES", with_comm ? "16" : "8", 0);
     if (const char *e = tune_env("TAXOR_CLI_NT")) fastx::stream_stores() = atoi(e) != 0;
     if (const char *e = tune_env("TAXOR_CLI_RDBUF_KB")) fastx::range_buffer_bytes() = (size_t)std::max(64, atoi(e)) << 10;
     int a = 1;
