@@ -1103,6 +1103,7 @@ def main():
                     fh.write(json.dumps(out) + "\n")
             except OSError:
                 pass
+            info["lay"], info["leg_batches"] = lay, batches[:2]
             out["layouts"] = layout_legs(args, idx, info, searchers, timed, local_rank, out)     # (never raises: a leg that fails is reported as such)
             idx = None
         print(json.dumps(out), flush=True)
@@ -1155,6 +1156,12 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
 
     shape = {"root_bins": out["config"]["root_bins"], "child_bins": out["config"]["child_bins"], "index_bytes": out["config"]["index_bytes"],
              "n_ixf": out["config"]["n_ixf"], "depth": out["config"]["depth"]}
+    # the random-filled headline index with two of its own batches, measured like every leg: what exact_fill (below) is held against
+    twin = None
+    try:
+        twin = measure(idx, info["leg_batches"], "headline_2_batches", "the headline index, its first two batches, 3 steps", dict(shape, frac_reverse=args.frac_reverse))
+    except Exception as e:
+        log(f"twin measurement failed: {type(e).__name__}: {e}")
     # (a) the headline index, reads from both strands
     both = []
     for b in range(2):
@@ -1190,69 +1197,40 @@ def layout_legs(args, idx, info, searchers, timed, local_rank, out):
             log(f"layout leg {label} failed: {type(e).__name__}: {e}")
         if idx2 is not None:
             idx2.close()
-    # (d) every bin a real filter: the headline's SHAPE at a size whose keys fit HBM, against its twin with random-filled decoys
+    # (d) every bin a real filter: the headline's own layout and reads, against the random-filled headline index measured the same way
     try:
-        legs.append(exact_fill_leg(args, measure, local_rank, ncpu))
+        if twin is None:
+            raise RuntimeError("the random-filled twin was not measured")
+        legs.append(exact_fill_leg(args, measure, local_rank, info, twin))
     except Exception as e:
         legs.append({"layout": "exact_fill", "error": f"{type(e).__name__}: {e}"})
         log(f"layout leg exact_fill failed: {type(e).__name__}: {e}")
     return legs
 
 
-EXACT_FILL_KEYS = {"gtdb": 4.5e9, "refseq": 1.5e9, "viral": 1.5e8, "tiny": 2e6}
-
-
-def exact_fill_leg(args, measure, local_rank, ncpu):
-    """`layouts` leg exact_fill: an index of the headline's shape -- root and child widths, number of children, the
-    depth-3 chain, the planted families -- in which EVERY bin is a real XOR filter built by taxor_gpu_index_build_hixf_ex (decoy
-    leaf bins filled to 90 % of capacity with synthetic keys, merged bins holding the union of their child), searched with the same reads
-    as its twin whose decoy bins are seeded random bytes (what the headline index is made of).  The keys of a 113-GB index
-    (7e10) do not fit one GPU next to it, so both twins are smaller: leaf bins of ~35 k keys instead of 422 k."""
-    from taxor_amd import GpuIndex, Searcher, synth
-    wl = dict(WORKLOADS[args.workload])
-    root_bins = args.root_bins or wl["root_bins"]
-    child_bins = args.child_bins or wl["child_bins"]
-    n_children = min(wl["n_children"], root_bins - 8)
-    fam_size = max(2, min(args.family_size, wl["genomes"]))
-    n_genomes = (wl["genomes"] // fam_size) * fam_size
-    read_len = args.read_len or wl["read_len"]
-    n_reads = args.reads or wl["reads"]
-    k, s_, t = 22, 12, 5
-    cap = int(EXACT_FILL_KEYS[args.workload] / ((n_children + 1) * child_bins))
-    genome_len = max(4 * read_len, int(cap * 11.0))                    # ~1 syncmer per 11.5 bases: the largest genome just fits a leaf bin
+def exact_fill_leg(args, measure, local_rank, info, twin):
+    """`layouts` leg exact_fill: the HEADLINE'S OWN layout -- same bins, same planted genomes, same size -- built once more
+    with EVERY bin a real XOR filter (taxor_gpu_index_build_hixf_gen): the planted bins from their genomes' hashes, every decoy leaf bin from
+    generated keys (no key memory: a 113-GB index holds 7e10 keys, 560 GB if they had to be resident), merged bins from the union of their
+    child; searched with the headline's own first two batches and held against the random-filled headline index measured the same way
+    (`twin`: 2 batches, 3 steps, before the headline index was released)."""
+    from taxor_amd import synth
+    lay, batches = info["lay"], info["leg_batches"]
     t0 = time.time()
-    g, go, family = synth.family_genomes(n_genomes // fam_size, fam_size, genome_len, seed=synth.DEFAULT_SEED + 7)
-    dummy = GpuIndex([dict(bins=64, stride=64, seg_len=16, seed=1, next_ixf=np.zeros(64, np.int64), fname_idx=np.arange(64), data=np.zeros(3 * 16 * 64, np.uint8))],
-                     64, k, s_, t, device=local_rank)
-    hs = Searcher(dummy, ratio=0.5)
-    hoff, hashes = hs.seq_to_syncmers(g, go)
-    hs.close()
-    dummy.close()
-    planted = [hashes[int(hoff[i]):int(hoff[i + 1])] for i in range(n_genomes)]
-    child_cap = max(len(p) for p in planted) + 64
-    lay = synth.make_family_layout(planted, family, root_bins=root_bins, child_bins=child_bins, n_children=n_children, spread=4,
-                                   root_max_elems=child_bins * child_cap, child_max_elems=child_cap, seed=synth.DEFAULT_SEED, build="gpu")
-    batches = []
-    for b in range(2):
-        bb, oo, _ = synth.synth_reads(g, go, n_reads, read_len, error_rate=args.read_error, frac_random=0.1, seed=synth.DEFAULT_SEED + 91000 + b, threads=ncpu)
-        batches.append((np.ascontiguousarray(bb), np.ascontiguousarray(oo)))
-    idx_e, st = synth.exact_fill_index(lay, device=local_rank)
+    idx_e, st = synth.exact_fill_index(lay, device=local_rank, fill_frac=0.95)
     log(f"exact-fill index: {idx_e.data_bytes/1e9:.2f} GB, {idx_e.n_ixf} IXFs, {st['keys_inserted']/1e9:.2f} G insertions in {st['seconds_total']:.2f} s "
-        f"({st['keys_inserted']/st['seconds_total']/1e9:.2f} G/s), {time.time()-t0:.1f}s")
-    shape = {"root_bins": root_bins, "child_bins": child_bins, "index_bytes": idx_e.data_bytes, "n_ixf": idx_e.n_ixf, "depth": idx_e.depth, "frac_reverse": 0.0,
-             "leaf_capacity_keys": child_cap}
+        f"({st['keys_inserted']/st['seconds_total']/1e9:.2f} G/s; {st['chunks']} chunks, {st['reseeds']} IXFs redone), {time.time()-t0:.1f}s")
+    shape = {"root_bins": lay["ixfs"][0]["bins"], "child_bins": lay["ixfs"][1]["bins"] if len(lay["ixfs"]) > 1 else None, "index_bytes": idx_e.data_bytes,
+             "n_ixf": idx_e.n_ixf, "depth": idx_e.depth, "frac_reverse": args.frac_reverse}
     try:
-        leg = measure(idx_e, batches, "exact_fill", "the headline's shape with EVERY bin a real filter (decoy leaf bins filled to 90 % of capacity with synthetic keys, merged "
-                      "bins = union of their child, all constructed on the GPU), smaller than the headline because 7e10 keys do not fit next to a 113-GB index", shape)
+        leg = measure(idx_e, batches, "exact_fill", "the headline's own layout at full size with EVERY bin a real filter: planted bins from their genomes, decoy leaf bins from "
+                      "generated keys (up to 95 % of capacity, less where the root's bin bounds the union of a child), merged bins = union of their child, all constructed "
+                      "on the GPU; the headline's own reads", shape)
     finally:
         idx_e.close()
     leg["build"] = {"insertions": int(st["keys_inserted"]), "seconds": round(st["seconds_total"], 3), "insertions_per_s": round(st["keys_inserted"] / st["seconds_total"], 1),
-                    "chunks": int(st["chunks"]), "rounds_max": int(st["rounds_max"]), "reseeds": int(st["reseeds"])}
-    idx_r = synth.device_index(lay, k, s_, t, device=local_rank)        # the twin: same shape and planted columns, decoy bins of seeded random bytes
-    try:
-        twin = measure(idx_r, batches, "exact_fill_twin", "the same layout with random-filled decoy bins, like the headline index", dict(shape, index_bytes=idx_r.data_bytes))
-    finally:
-        idx_r.close()
+                    "chunks": int(st["chunks"]), "rounds_max": int(st["rounds_max"]), "reseeds": int(st["reseeds"]), "scratch_bytes": int(st["scratch_bytes"]),
+                    "note": "decoy keys are generated by the kernels (synth_key of a running index), not read: not the builder's bench line (bench.py --mode build)"}
     leg["random_fill_twin"] = {kk: twin[kk] for kk in ("value", "frac", "algorithmic_frac", "tuples_per_read", "work_items_per_read", "hashes_per_read")}
     leg["value_over_random_fill_twin"] = round(leg["value"] / twin["value"], 4)
     leg["within_3_percent"] = bool(abs(leg["value"] / twin["value"] - 1.0) < 0.03)

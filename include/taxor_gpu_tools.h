@@ -87,6 +87,14 @@ int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint6
                                  const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);
 int taxor_gpu_index_build_hixf_ex(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off,
                                   uint64_t seed0, taxor_build_stats *stats);
+/* The same with GENERATED keys for some leaf bins: bin g (index bin order) holds gen_count[g] keys synth_key(gen_first[g] + k, gen_salt),
+ * k < gen_count[g], instead of keys from `keys` (its key_off range is then empty).  Generated keys need no memory -- the kernels
+ * compute them -- and a merged bin above an IXF of generated bins with consecutive index ranges is itself such a range, so an
+ * index far larger than its keys would be (a 113-GB GTDB-class index has 7e10 of them: 560 GB) can be built with EVERY bin a
+ * real filter.  Bins with real keys (planted genomes) and generated decoys mix freely. */
+int taxor_gpu_index_build_hixf_gen(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off,
+                                   const uint64_t *gen_first, const uint64_t *gen_count, uint64_t gen_salt, uint64_t seed0,
+                                   taxor_build_stats *stats);
 /* Synthetic key sets for the build bench and tests: key i = a bijection of (i + salt) (distinct without a table);
  * taxor_gpu_synth_keys writes keys first .. first + n - 1 to the DEVICE array d_out, taxor_synth_key is the same
  * function on the host.  taxor_gpu_malloc / _free / _memcpy_to_host / _from_host: plain device memory for such arrays. */

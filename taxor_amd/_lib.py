@@ -121,6 +121,7 @@ SIGNATURES = {
     "taxor_gpu_index_build_hixf": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.c_uint32)]),
     "taxor_gpu_index_build_ixf_ex": (C.c_int, [_P, C.c_uint64, _P, C.c_int, _P, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(BuildStats)]),
     "taxor_gpu_index_build_hixf_ex": (C.c_int, [_P, _P, C.c_int, _P, C.c_uint64, C.POINTER(BuildStats)]),
+    "taxor_gpu_index_build_hixf_gen": (C.c_int, [_P, _P, C.c_int, _P, _P, _P, C.c_uint64, C.c_uint64, C.POINTER(BuildStats)]),
     "taxor_synth_key": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "taxor_gpu_synth_keys": (C.c_int, [C.c_int, _P, C.c_uint64, C.c_uint64, C.c_uint64]),
     "taxor_gpu_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(_P)]),

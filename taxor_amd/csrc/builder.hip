@@ -77,7 +77,7 @@ constexpr uint32_t SLICE_BLOCKS = 8192;    // blocks per launch of the key / slo
 
 // one technical bin to construct
 struct BinJob {
-    const uint64_t *keys;   // device: the bin's keys (distinct among those that count)
+    const uint64_t *keys;   // device: the bin's keys (distinct among those that count); nullptr: GENERATED keys, key k = synth_key(gen_first + k, gen_salt)
     const uint8_t *keep;    // one byte per key, 0 = this key does not count (a duplicate inside a merged bin's key range); nullptr: all count
     uint64_t n_keys;        // length of the key range (a key's index is its position in it)
     uint64_t n_kept;        // keys that count
@@ -90,6 +90,8 @@ struct BinJob {
     uint32_t arith;         // arithmetic code of the index (ixf_arith.h)
     uint32_t bin;           // column
     uint32_t group;         // the chunk's IXF this bin belongs to: seed and failure are per IXF
+    uint64_t gen_first;     // generated keys (keys == nullptr): index of the bin's first key in the synthetic key sequence ...
+    uint64_t gen_salt;      // ... and its salt (ixf_arith.h synth_key: a bijection of the index, so the keys are distinct and need no memory)
 };
 
 // control block of a chunk; hot words on lines of their own
@@ -134,6 +136,8 @@ __device__ __forceinline__ uint64_t ldg64(const uint64_t *p) { return *(const ui
 __device__ __forceinline__ uint8_t ldg8(const uint8_t *p) { return *(const uint8_t __attribute__((address_space(1))) *)(uintptr_t)p; }
 __device__ __forceinline__ void stg8(uint8_t *p, uint8_t v) { *(uint8_t __attribute__((address_space(1))) *)(uintptr_t)p = v; }
 
+__device__ __forceinline__ uint64_t job_key(const BinJob &J, uint64_t k) { return J.keys ? ldg64(J.keys + k) : synth_key(J.gen_first + k, J.gen_salt); }
+
 template <typename WT>
 __device__ __forceinline__ WT w_delta(uint64_t idx) { return (WT)((WT)idx << 8) + (WT)1; }
 
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         const uint64_t k = g - J.key_base;
         if (J.keep && !ldg8(J.keep + k)) continue;
-        const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
+        const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
         const WT d = w_delta<WT>(k);
 #pragma unroll
         for (int j = 0; j < 3; ++j) __hip_atomic_fetch_add(&a.w[J.slot_base + p.row[j]], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
                 uint32_t logged = DEAD;
                 const uint64_t k = (uint64_t)(w >> 8);
                 if ((w & (WT)0xFF) == (WT)1 && k < J.n_keys) {
-                    const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
+                    const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
                     // the key's lowest-segment row that is listed for this round peels it; this row, unless a lower one carries the mark
                     const int own = row == p.row[0] ? 0 : row == p.row[1] ? 1 : 2;
                     bool mine = true;
@@ -304,7 +308,7 @@ __device__ __forceinline__ void assign_entry(const Peel<WT> &a, uint64_t i)
     const uint64_t e = a.list[i];
     const BinJob &J = a.jobs[(uint32_t)(e >> 32)];
     if (a.skip && a.skip[J.group]) return;
-    const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + k), J.seed, J.seg_len, J.arith);
+    const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
     const uint32_t row = (uint32_t)e;
     const int fr = row == p.row[0] ? 0 : row == p.row[1] ? 1 : 2;
     uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(BB) void k_verify(const Peel<WT> a, uint32_t block0
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
         if (a.skip && a.skip[J.group]) continue;
         if (J.keep && !ldg8(J.keep + (g - J.key_base))) continue;
-        const ixf_probe p = ixf_probe_key_arith(ldg64(J.keys + (g - J.key_base)), J.seed, J.seg_len, J.arith);
+        const ixf_probe p = ixf_probe_key_arith(job_key(J, g - J.key_base), J.seed, J.seg_len, J.arith);
         uint8_t v = (uint8_t)(p.fp4 & 0xFFu);
 #pragma unroll
         for (int j = 0; j < 3; ++j) v ^= ldg8(J.data + ((uint64_t)p.row[j] * J.stride + J.bin));
@@ -696,9 +700,13 @@ struct IxfPlan {
     std::vector<const uint64_t *> keys;      // per bin (device)
     std::vector<const uint8_t *> keep;       // per bin: marks of the keys that count (nullptr: all of them)
     std::vector<uint64_t> n, kept;           // per bin: length of the key range, keys that count
+    std::vector<uint64_t> gen_first;         // per bin: NO_GEN, or the first index of a GENERATED key range (then keys[b] is nullptr)
+    uint64_t gen_salt = 0;
     uint64_t total = 0, max_bin = 0, n_with_keys = 0;
     int attempts = 0;
 };
+
+constexpr uint64_t NO_GEN = ~0ull;
 
 uint64_t next_seed(uint64_t s) { return s * 6364136223846793005ull + 1442695040888963407ull; }
 
@@ -715,6 +723,8 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             if (!p.n[b]) continue;
             BinJob j{};
             j.keys = p.keys[b];
+            j.gen_first = p.gen_first[b] == NO_GEN ? 0 : p.gen_first[b];
+            j.gen_salt = p.gen_salt;
             j.keep = p.keep[b];
             j.n_keys = p.n[b];
             j.n_kept = p.kept[b];
@@ -810,6 +820,7 @@ int plan_ixf(taxor_gpu_index *idx, uint64_t ixf, IxfPlan &p, int *device)
     p.keep.assign(p.bins, nullptr);
     p.n.assign(p.bins, 0);
     p.kept.assign(p.bins, 0);
+    p.gen_first.assign(p.bins, NO_GEN);
     return TAXOR_OK;
 }
 
@@ -1010,8 +1021,11 @@ extern "C" int taxor_gpu_index_build_ixf(taxor_gpu_index *idx, uint64_t ixf, con
     return build_ixf_impl(idx, ixf, keys, 0, key_off, seed0, seed_out, rounds_out, nullptr);
 }
 
+// gen_first / gen_count [total_bins] (both or neither): technical bin g holds gen_count[g] GENERATED keys, synth_key(gen_first[g] + k,
+// gen_salt), instead of keys from `keys` (its key_off range must then be empty)
 static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off, uint64_t seed0,
-                           uint32_t *rounds_out, taxor_build_stats *stats_out)
+                           uint32_t *rounds_out, taxor_build_stats *stats_out, const uint64_t *gen_first = nullptr, const uint64_t *gen_count = nullptr,
+                           uint64_t gen_salt = 0)
 {
     uint64_t n_ixf = 0;
     const uint32_t *bin_base = nullptr, *binfo = nullptr;
@@ -1027,9 +1041,13 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
     const uint64_t total_bins = bin_base[n_ixf];
     for (uint64_t g = 0; g < total_bins; ++g) {
         if (key_off[g + 1] < key_off[g]) return bfail(TAXOR_E_ARG, "build_hixf: key_off not monotone");
-        if ((binfo[g] & BINFO_MERGED) && key_off[g + 1] != key_off[g])
+        if ((binfo[g] & BINFO_MERGED) && (key_off[g + 1] != key_off[g] || (gen_count && gen_count[g])))
             return bfail(TAXOR_E_ARG, "build_hixf: a merged bin must not bring keys of its own (they come from its child)");
+        if (gen_count && gen_count[g] && key_off[g + 1] != key_off[g])
+            return bfail(TAXOR_E_ARG, "build_hixf: a bin brings its keys OR has them generated, not both");
+        if (gen_count && gen_count[g] >= 0xFFFFFFFFull) return bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 - 2 generated keys in one bin");
     }
+    if ((gen_first == nullptr) != (gen_count == nullptr)) return bfail(TAXOR_E_ARG, "build_hixf: gen_first and gen_count come together");
     const uint64_t total = key_off[total_bins] - key_off[0];
     if (total && !keys) return bfail(TAXOR_E_ARG, "build_hixf: null keys");
     if (rounds_out) *rounds_out = 0;
@@ -1087,7 +1105,7 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
     // leaves that is its OWN key range in the caller's array plus one byte per key ("counts" / "a duplicate of an earlier one"):
     // nothing is copied, and the marks are an eighth of the keys (a class-scale level's unions were a 27-GB hipMalloc, half a second
     // of the driver's time on a good day).  An IXF with merged bins of its own (deeper hierarchies) gets its union materialised.
-    struct Union { const uint64_t *p = nullptr; const uint8_t *keep = nullptr; uint64_t n = 0, kept = 0; };
+    struct Union { const uint64_t *p = nullptr; const uint8_t *keep = nullptr; uint64_t n = 0, kept = 0, gen_first = NO_GEN; };
     std::vector<Union> uni(n_ixf);
     KeyUnion &unioner = ctx->unioner;
     auto free_level = [&](size_t lvl) {        // (the mark bytes are the context's, two buffers taken in turn by the levels)
@@ -1097,30 +1115,45 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
         std::vector<IxfPlan> level;
         std::vector<uint64_t> ids;
         uint64_t mark_bytes = 0, arena_keys = 0, concat_max = 0;
-        std::vector<uint8_t> leaf_only(n_ixf, 0);
+        std::vector<uint8_t> leaf_only(n_ixf, 0);     // (kind of every IXF's union, see below)
         for (uint64_t i = 0; i < n_ixf; ++i) {
             if (depth[i] != d) continue;
             IxfPlan &p = plan[i];
-            bool only_leaves = true;
+            p.gen_salt = gen_salt;
+            // kind of its union: 0 = its own key range with marks (all bins leaves with keys from `keys`), 1 = materialised (merged bins of its
+            // own, or leaves of both kinds), 2 = a generated range (all bins leaves with generated keys whose index ranges follow one another)
+            bool only_leaves = true, any_gen = false, any_ptr = false, gen_run = true;
+            uint64_t run_next = NO_GEN;
             for (uint64_t b = 0; b < p.bins; ++b) {
                 const uint64_t g = bin_base[i] + b;
+                p.gen_first[b] = NO_GEN;
                 if (binfo[g] & BINFO_MERGED) {
                     const Union &u = uni[binfo[g] & 0x3FFFFFFFu];
                     p.keys[b] = u.p;
                     p.keep[b] = u.keep;
                     p.n[b] = u.n;
                     p.kept[b] = u.kept;
+                    p.gen_first[b] = u.gen_first;
                     only_leaves = false;
+                } else if (gen_count && gen_count[g]) {
+                    p.keys[b] = nullptr;
+                    p.keep[b] = nullptr;
+                    p.n[b] = p.kept[b] = gen_count[g];
+                    p.gen_first[b] = gen_first[g];
+                    any_gen = true;
+                    if (run_next != NO_GEN && gen_first[g] != run_next) gen_run = false;
+                    run_next = gen_first[g] + gen_count[g];
                 } else {
                     p.keys[b] = d_keys ? d_keys + (key_off[g] - key_off[0]) : nullptr;
                     p.keep[b] = nullptr;
                     p.n[b] = p.kept[b] = key_off[g + 1] - key_off[g];
+                    any_ptr |= p.n[b] != 0;
                 }
             }
             plan_totals(p);
-            leaf_only[i] = only_leaves;
-            if (only_leaves) mark_bytes += p.total;
-            else { arena_keys += p.total; concat_max = std::max(concat_max, p.total); }
+            leaf_only[i] = !only_leaves || (any_gen && (any_ptr || !gen_run)) ? 1 : any_gen ? 2 : 0;
+            if (leaf_only[i] == 0) mark_bytes += p.total;
+            else if (leaf_only[i] == 1) { arena_keys += p.total; concat_max = std::max(concat_max, p.total); }
             ids.push_back(i);
         }
         for (uint64_t i : ids) level.push_back(plan[i]);
@@ -1141,13 +1174,24 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
             IxfPlan &p = plan[i];
             if (!p.total) continue;
             if (p.total >= 0xFFFFFFFFull) { rc = bfail(TAXOR_E_ARG, "build_hixf: more than 2^32 - 2 keys below one merged bin"); break; }
-            if (leaf_only[i]) {
+            if (leaf_only[i] == 2) {
+                // generated keys of consecutive indices: their union is the range of indices itself (a bijection: no duplicates, no memory)
+                uint64_t first = NO_GEN;
+                for (uint64_t b = 0; b < p.bins && first == NO_GEN; ++b)
+                    if (p.n[b]) first = p.gen_first[b];
+                Union u;
+                u.n = u.kept = p.total;
+                u.gen_first = first;
+                uni[i] = u;
+                continue;
+            }
+            if (leaf_only[i] == 0) {
                 // its leaf bins are adjacent in the caller's array: the range itself, with marks
                 const uint64_t *src = d_keys + (key_off[bin_base[i]] - key_off[0]);
                 uint64_t kept = 0;
                 const hipError_t e = unioner.mark(src, p.total, mark + marked, &kept, eng.st);
                 if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
-                uni[i] = Union{src, kept == p.total ? nullptr : mark + marked, p.total, kept};
+                uni[i] = Union{src, kept == p.total ? nullptr : mark + marked, p.total, kept, NO_GEN};
                 marked += p.total;
                 continue;
             }
@@ -1155,14 +1199,16 @@ static int build_hixf_impl(taxor_gpu_index *idx, const uint64_t *keys, int keys_
             if (!concat && hipMalloc((void **)&concat, concat_max * 8) != hipSuccess) { rc = bfail(TAXOR_E_NOMEM, "build_hixf: no device memory for the keys of one IXF"); break; }
             uint64_t o = 0;
             for (uint64_t b = 0; b < p.bins; ++b) {
-                if (p.n[b] && hipMemcpyAsync(concat + o, p.keys[b], p.n[b] * 8, hipMemcpyDeviceToDevice, eng.st) != hipSuccess) rc = bfail(TAXOR_E_HIP, "build_hixf: device copy failed");
+                if (p.n[b] && p.gen_first[b] != NO_GEN)       // generated keys are written out for the set
+                    hipLaunchKernelGGL(k_synth_keys, dim3((uint32_t)std::min<uint64_t>(8192, (p.n[b] + BB - 1) / BB)), dim3(BB), 0, eng.st, concat + o, p.gen_first[b], p.n[b], gen_salt);
+                else if (p.n[b] && hipMemcpyAsync(concat + o, p.keys[b], p.n[b] * 8, hipMemcpyDeviceToDevice, eng.st) != hipSuccess) rc = bfail(TAXOR_E_HIP, "build_hixf: device copy failed");
                 o += p.n[b];
             }
             if (rc != TAXOR_OK) break;
             uint64_t n_out = 0;
             const hipError_t e = unioner.unique(concat, p.total, arena + used, &n_out, eng.st);
             if (e != hipSuccess) { rc = bfail(TAXOR_E_HIP, std::string("build_hixf: key union failed: ") + hipGetErrorString(e)); break; }
-            uni[i] = Union{arena + used, nullptr, n_out, n_out};
+            uni[i] = Union{arena + used, nullptr, n_out, n_out, NO_GEN};
             used += n_out;
         }
         if (concat) (void)hipFree(concat);
@@ -1198,4 +1244,10 @@ extern "C" int taxor_gpu_index_build_hixf_ex(taxor_gpu_index *idx, const uint64_
                                              taxor_build_stats *stats)
 {
     return build_hixf_impl(idx, keys, keys_on_device, key_off, seed0, nullptr, stats);
+}
+
+extern "C" int taxor_gpu_index_build_hixf_gen(taxor_gpu_index *idx, const uint64_t *keys, int keys_on_device, const uint64_t *key_off,
+                                              const uint64_t *gen_first, const uint64_t *gen_count, uint64_t gen_salt, uint64_t seed0, taxor_build_stats *stats)
+{
+    return build_hixf_impl(idx, keys, keys_on_device, key_off, seed0, nullptr, stats, gen_first, gen_count, gen_salt);
 }

@@ -88,7 +88,8 @@ def capacity_of(seg_len):
 def exact_fill_index(layout, salt=DEFAULT_SEED, k=22, s=12, t=5, device=0, seed0=7, fill_frac=0.9):
     """An index of the layout's shape in which EVERY bin is a real filter: planted leaf bins hold their genomes' hashes, every
     other leaf bin is filled with synthetic keys (synth_key(running index, salt), generated on the device) to fill_frac of its
-    IXF's capacity, merged bins receive the union of their child -- all of it constructed by taxor_gpu_index_build_hixf_ex.
+    IXF's capacity, merged bins receive the union of their child -- all of it constructed by taxor_gpu_index_build_hixf_gen (the decoys'
+    keys are generated inside the kernels: no key memory, so the index may be of class scale).
     fill_frac < 1: an IXF's capacity is that of its LARGEST bin, the others are smaller in any real index; and a bin of a few
     ten thousand keys filled to exactly 1/1.23 of its rows fails to peel under a given seed every so often (the margin to the
     peeling threshold, 0.7 %, is about its own finite-size fluctuation), which a hundred such bins under ONE seed -- the
@@ -124,21 +125,24 @@ def exact_fill_index(layout, salt=DEFAULT_SEED, k=22, s=12, t=5, device=0, seed0
                 counts.append(len(f["key_sets"][b]))
             else:
                 counts.append(fill)
-    off = np.zeros(len(counts) + 1, dtype=np.uint64)
-    np.cumsum(np.array(counts, dtype=np.uint64), out=off[1:])
-    total = int(off[-1])
-    d_keys = C.c_void_p()
-    _lib.check(L.taxor_gpu_malloc(device, total * 8, C.byref(d_keys)))
-    try:
-        # decoys: one sweep over everything (the planted ranges are overwritten below), so that every synthetic key is distinct
-        _lib.check(L.taxor_gpu_synth_keys(device, d_keys, 0, total, int(salt)))
-        for g, keys in planted:
-            kk = np.ascontiguousarray(keys, dtype=np.uint64)
-            _lib.check(L.taxor_gpu_memcpy_from_host(C.c_void_p(d_keys.value + int(off[g]) * 8), _p(kk), kk.size * 8))
-        st = _lib.BuildStats()
-        _lib.check(L.taxor_gpu_index_build_hixf_ex(idx._h, d_keys, 1, _p(off), int(seed0), C.byref(st)))
-    finally:
-        L.taxor_gpu_free(d_keys)
+    # planted bins bring their keys (host arrays, a few hundred MB at most); decoy bins have theirs GENERATED on the device from a running
+    # index -- no key memory at all, so the index may be far larger than its keys would be (taxor_gpu_index_build_hixf_gen)
+    n_bins = len(counts)
+    is_planted = np.zeros(n_bins, dtype=bool)
+    for g, _ in planted:
+        is_planted[g] = True
+    cnt = np.array(counts, dtype=np.uint64)
+    real = np.where(is_planted, cnt, np.uint64(0)).astype(np.uint64)
+    gen_count = np.where(is_planted, np.uint64(0), cnt).astype(np.uint64)
+    gen_first = np.zeros(n_bins, dtype=np.uint64)
+    np.cumsum(gen_count[:-1], out=gen_first[1:])
+    off = np.zeros(n_bins + 1, dtype=np.uint64)
+    np.cumsum(real, out=off[1:])
+    keys = np.concatenate([np.ascontiguousarray(k_, dtype=np.uint64) for _, k_ in planted]) if planted else np.zeros(0, np.uint64)
+    assert keys.size == int(off[-1])
+    st = _lib.BuildStats()
+    _lib.check(L.taxor_gpu_index_build_hixf_gen(idx._h, _p(keys) if keys.size else None, 0, _p(off), _p(gen_first), _p(gen_count), int(salt) & (2**64 - 1),
+                                                int(seed0), C.byref(st)))
     for i, f in enumerate(fs):
         f["seed"] = idx.ixf_seed(i)
     return idx, {kk: getattr(st, kk) for kk, _ in _lib.BuildStats._fields_ if kk != "reserved"}

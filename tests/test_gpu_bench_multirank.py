@@ -124,6 +124,7 @@ def test_bench_line_says_what_the_workload_is_and_carries_the_layout_legs():
     # every bin a real filter (built on the GPU) against its random-filled twin: same shape, same reads, same rate
     ex = legs.pop("exact_fill")
     assert ex["root_bins"] == c["root_bins"] and ex["child_bins"] == c["child_bins"] and ex["depth"] == c["depth"]
+    assert ex["index_bytes"] == c["index_bytes"] and ex["n_ixf"] == c["n_ixf"]                      # the headline's own layout, at full size
     assert ex["build"]["insertions"] > 1e8 and ex["build"]["insertions_per_s"] > 2e8 and ex["build"]["reseeds"] < ex["n_ixf"]
     assert ex["tuples_per_read"] > 0.5 and abs(ex["tuples_per_read"] / ex["random_fill_twin"]["tuples_per_read"] - 1) < 0.05
     assert ex["hashes_per_read"] == ex["random_fill_twin"]["hashes_per_read"]

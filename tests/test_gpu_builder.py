@@ -326,3 +326,65 @@ def test_many_small_ixfs_share_chunks_and_only_a_failed_ixf_is_reseeded():
             assert sr.ixf_bulk_count(c, leaf[(c, b)])[b] == leaf[(c, b)].size
     sr.close()
     idx.close()
+
+
+def test_generated_keys_need_no_memory_and_mix_with_real_ones():
+    """taxor_gpu_index_build_hixf_gen: leaf bins whose keys are GENERATED by the kernels (synth_key of a running index) next to bins
+    that bring real keys.  A child of generated bins with consecutive index ranges hands its parent a generated range (nothing is
+    materialised); a child that mixes both kinds, or whose ranges leave a gap, gets its union written out.  Checked by the oracle:
+    every key of every leaf bin is found in its bin and in the root's merged bin above it."""
+    import ctypes as C
+    from taxor_amd import _lib
+    nc, cb, kpb, salt = 5, 8, 3000, 424242
+    shapes, ub, _ = synth.full_hierarchy_shapes(nc, cb, kpb, slack=1.5)
+    rb = shapes[0]["bins"]
+    n_bins = rb + nc * cb
+    rng = np.random.default_rng(77)
+    gen_first = np.zeros(n_bins, np.uint64)
+    gen_count = np.zeros(n_bins, np.uint64)
+    real = {}
+    nxt = 10**9                                             # running index of the generated keys
+    for c in range(1, nc + 1):
+        for b in range(cb):
+            g = rb + (c - 1) * cb + b
+            n = int(rng.integers(kpb // 2, kpb + 1))
+            kind = "gen"
+            if c == 2 and b == 3: kind = "real"             # a child that mixes both kinds
+            if c == 3: kind = "real"                        # a child of real keys only
+            if c == 5 and b == 4: kind = "empty"
+            if kind == "real":
+                real[g] = np.unique(rng.integers(1, 2**63, size=n, dtype=np.uint64))
+            elif kind == "gen":
+                if c == 4 and b == 5: nxt += 12345          # a gap in child 4's index ranges: no single generated range any more
+                gen_first[g], gen_count[g] = nxt, n
+                nxt += n
+    off = np.zeros(n_bins + 1, np.uint64)
+    for g, k in real.items():
+        off[g + 1] = k.size
+    off = np.cumsum(off).astype(np.uint64)
+    keys = np.concatenate([real[g] for g in sorted(real)])
+    idx = GpuIndex(shapes, ub)
+    for i in range(len(shapes)):
+        idx.fill_random(i, 5 + i)
+    st = _lib.BuildStats()
+    _lib.check(_lib.lib().taxor_gpu_index_build_hixf_gen(idx._h, keys.ctypes.data_as(C.c_void_p), 0, off.ctypes.data_as(C.c_void_p),
+                                                         gen_first.ctypes.data_as(C.c_void_p), gen_count.ctypes.data_as(C.c_void_p), salt, 9, C.byref(st)))
+    n_leaf = int(gen_count.sum()) + keys.size
+    assert st.keys_inserted == 2 * n_leaf
+    host = [dict(s, seed=idx.ixf_seed(i), data=idx.download_ixf(i)) for i, s in enumerate(shapes)]
+    h = orc.Hixf(host, [f["next_ixf"] for f in host], [f["fname_idx"] for f in host])
+    for c in range(1, nc + 1):
+        for b in range(cb):
+            g = rb + (c - 1) * cb + b
+            if gen_count[g]:
+                n = int(gen_count[g])
+                assert h.synth_keys_found(c, b, int(gen_first[g]), n, salt)[0] == n and h.synth_keys_found(0, c - 1, int(gen_first[g]), n, salt)[0] == n, (c, b)
+            elif g in real:
+                assert h.ixf_bulk_count(c, real[g])[b] == real[g].size and h.ixf_bulk_count(0, real[g])[c - 1] == real[g].size, (c, b)
+    # a bin may bring keys or have them generated, not both; merged bins neither
+    bad = gen_count.copy()
+    bad[sorted(real)[0]] = 5
+    with pytest.raises(TaxorError):
+        _lib.check(_lib.lib().taxor_gpu_index_build_hixf_gen(idx._h, keys.ctypes.data_as(C.c_void_p), 0, off.ctypes.data_as(C.c_void_p),
+                                                             gen_first.ctypes.data_as(C.c_void_p), bad.ctypes.data_as(C.c_void_p), salt, 9, C.byref(st)))
+    idx.close()
