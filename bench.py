@@ -466,7 +466,8 @@ def build_mode(args):
         if i >= warmup:
             sts.append(st)
         log(f"build {i}: {st['keys_inserted'] / st['seconds_total'] / 1e9:.3f} G insertions/s ({st['seconds_total']:.3f} s; peel {st['seconds_peel']:.3f}, "
-            f"assign+verify {st['seconds_assign']:.3f}, unions {st['seconds_union']:.3f}, scratch alloc {st['seconds_alloc']:.3f}; {st['chunks']} chunks, {st['rounds_max']} rounds, {st['reseeds']} reseeds)")
+            f"assign+verify {st['seconds_assign']:.3f}, unions {st['seconds_union']:.3f}, scratch alloc {st['seconds_alloc']:.3f}; count kernels {st['seconds_count']:.3f}, seed + rounds "
+            f"{st['seconds_rounds']:.3f}; {st['chunks']} chunks, {st['rounds_max']} rounds, {st['reseeds']} reseeds)")
     ins = sum(s_["keys_inserted"] for s_ in sts)
     secs = sum(s_["seconds_total"] for s_ in sts)
     wall = sum(s_["wall_s"] for s_ in sts)

@@ -92,7 +92,16 @@ struct BinJob {
     uint32_t group;         // the chunk's IXF this bin belongs to: seed and failure are per IXF
     uint64_t gen_first;     // generated keys (keys == nullptr): index of the bin's first key in the synthetic key sequence ...
     uint64_t gen_salt;      // ... and its salt (ixf_arith.h synth_key: a bijection of the index, so the keys are distinct and need no memory)
+    uint32_t lds_count;     // 1: the bin's degree words are built in LDS, range by range (k_count_lds), not by global atomics (k_count)
+    uint32_t reserved;
 };
+
+// one piece of k_count_lds' work: rows [row0, row0 + LDS_ROWS) of segment `seg` of job `job`
+struct CountItem {
+    uint32_t job, seg, row0;
+};
+constexpr uint32_t LDS_ROWS = 32768;       // 128 KB of 32-bit words: one block per CU
+constexpr int LDS_THREADS = 1024;
 
 // control block of a chunk; hot words on lines of their own
 struct Ctl {
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
     __syncthreads();
     for (uint64_t g = g0 + threadIdx.x; g < g1; g += BB) {
         const BinJob &J = a.jobs[job_in<true>(a.jobs, jr[0], jr[1], g)];
+        if (J.lds_count) continue;                         // built by k_count_lds
         const uint64_t k = g - J.key_base;
         if (J.keep && !ldg8(J.keep + k)) continue;
         const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
@@ -162,6 +172,34 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
 #pragma unroll
         for (int j = 0; j < 3; ++j) __hip_atomic_fetch_add(&a.w[J.slot_base + p.row[j]], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// The degree words of a bin of moderate size without a single global atomic: the rows of one segment are cut into ranges of 32 768
+// (128 KB of LDS), a block takes one range, runs over ALL keys of the bin, hashes each and adds those that fall into its range with
+// an LDS atomic, then writes the range out in one piece.  A key is read and hashed 3 x ceil(seg_len / 32768) times -- 15 times for a
+// GTDB-class leaf bin of 422 k keys -- which is streaming and arithmetic, and cheaper than three random read-modify-writes in HBM
+// (k_count: 27 G/s for the whole chip = 9 G keys/s; this: 19 G keys/s, bound by the hashing).  32-bit words only: a 54 M-key bin
+// would need 2 000 passes.
+__global__ __launch_bounds__(LDS_THREADS) void k_count_lds(const Peel<uint32_t> a, const CountItem *__restrict__ items)
+{
+    extern __shared__ uint32_t lds_w[];
+    const CountItem it = items[blockIdx.x];
+    const BinJob &J = a.jobs[it.job];
+    const uint32_t n_rows = min(LDS_ROWS, J.seg_len - it.row0);
+    for (uint32_t i = threadIdx.x; i < n_rows; i += LDS_THREADS) lds_w[i] = 0;
+    __syncthreads();
+    const uint32_t lo = it.seg * J.seg_len + it.row0;          // absolute row of the range's first row
+    // (what bounds this loop is its arithmetic -- the key's hash, fifteen times per key of a GTDB-class leaf bin; more loads in flight
+    //  per thread changed nothing, profiles/r06/build_lds_count.txt -- so only the ONE row this pass looks at is derived from the hash)
+    for (uint64_t k = threadIdx.x; k < J.n_keys; k += LDS_THREADS) {
+        if (J.keep && !ldg8(J.keep + k)) continue;
+        const uint64_t h = ixf_key_hash_arith(job_key(J, k), J.seed, J.arith);
+        const uint32_t r = (uint32_t)ixf_row_arith(h, (int)it.seg, J.seg_len, J.arith) - lo;     // (unsigned: rows below the range wrap to huge values)
+        if (r < n_rows) atomicAdd(&lds_w[r], w_delta<uint32_t>(k));
+    }
+    __syncthreads();
+    uint32_t *dst = a.w + J.slot_base + lo;
+    for (uint32_t i = threadIdx.x; i < n_rows; i += LDS_THREADS) dst[i] = lds_w[i];
 }
 
 // entries of one wave into the block's LDS stage: one LDS atomic per wave
@@ -430,6 +468,9 @@ struct Engine {
     uint32_t *d_log = nullptr;
     uint16_t *d_pushed = nullptr;
     uint8_t *d_skip = nullptr;
+    CountItem *d_items = nullptr;
+    uint64_t cap_items = 0;
+    bool lds_ready = false;
     Ctl *d_ctl = nullptr;
     BinJob *d_jobs = nullptr;
     uint32_t *h_round_end = nullptr;                   // page-locked
@@ -441,8 +482,10 @@ struct Engine {
 
     void release()
     {
-        for (void *p : {(void *)d_w, (void *)d_list, (void *)d_job_peeled, (void *)d_log, (void *)d_pushed, (void *)d_skip, (void *)d_ctl, (void *)d_jobs})
+        for (void *p : {(void *)d_w, (void *)d_list, (void *)d_job_peeled, (void *)d_log, (void *)d_pushed, (void *)d_skip, (void *)d_ctl, (void *)d_jobs, (void *)d_items})
             if (p) (void)hipFree(p);
+        d_items = nullptr;
+        cap_items = 0;
         d_w = nullptr; d_list = nullptr; d_job_peeled = nullptr; d_log = nullptr; d_pushed = nullptr; d_skip = nullptr; d_ctl = nullptr; d_jobs = nullptr;
         if (h_round_end) (void)hipHostFree(h_round_end);
         if (h_counts) (void)hipHostFree(h_counts);
@@ -528,6 +571,19 @@ struct Engine {
     int run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, uint64_t n_keys, uint64_t n_slots,
                   const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows);
 
+    static bool lds_count_enabled()
+    {
+        const char *e = tune_env("TAXOR_BUILD_LDS_COUNT");        // A/B: 0 = every bin through k_count's global atomics
+        return !(e && atoi(e) == 0);
+    }
+    // (sliced like the other sweeps: 2048 items, ~1 ms, per launch)
+    void launch_count_lds(const Peel<uint32_t> &a, size_t n_items)
+    {
+        for (size_t i0 = 0; i0 < n_items; i0 += 2048)
+            hipLaunchKernelGGL(k_count_lds, dim3((uint32_t)std::min<size_t>(2048, n_items - i0)), dim3(LDS_THREADS), LDS_ROWS * sizeof(uint32_t), st, a, d_items + i0);
+    }
+    void launch_count_lds(const Peel<uint64_t> &, size_t) {}      // (64-bit words: never)
+
     // construct the columns of `jobs` (key_base / slot_base are filled in here; every job has keys; jobs of one group are
     // adjacent).  group_ok[g] = 0: a bin of group g did not peel under its seed, its columns are untouched.
     // group_full[g] = 1: the jobs of group g are all the bins of its IXF (the whole array is cleared at once); 2: the caller has
@@ -575,13 +631,45 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     a.pushed = d_pushed;
     a.skip = nullptr;
     a.ctl = d_ctl;
+    // which bins get their degree words built in LDS (k_count_lds): 32-bit words, enough keys to be worth a block per range, few enough
+    // rows that a key is hashed a few dozen times at most
+    std::vector<CountItem> items;
+    if (sizeof(WT) == 4 && lds_count_enabled()) {
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            BinJob &J = jobs[j];
+            const uint32_t passes = (J.seg_len + LDS_ROWS - 1) / LDS_ROWS;
+            J.lds_count = (J.n_keys >= 16384 && passes <= 12) ? 1u : 0u;
+            if (J.lds_count)
+                for (uint32_t sgm = 0; sgm < 3; ++sgm)
+                    for (uint32_t r0 = 0; r0 < J.seg_len; r0 += LDS_ROWS) items.push_back(CountItem{(uint32_t)j, sgm, r0});
+        }
+    } else
+        for (auto &J : jobs) J.lds_count = 0;
+    if (!items.empty()) {
+        if (!lds_ready) {
+            E_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_count_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_ROWS * sizeof(uint32_t))));
+            lds_ready = true;
+        }
+        if (items.size() > cap_items) {
+            if (d_items) (void)hipFree(d_items);
+            d_items = nullptr;
+            cap_items = 0;
+            if (hipMalloc((void **)&d_items, (items.size() + items.size() / 4) * sizeof(CountItem)) != hipSuccess) return bfail(TAXOR_E_NOMEM, "build: no device memory for the count items");
+            cap_items = items.size() + items.size() / 4;
+        }
+        E_TRY(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(CountItem), hipMemcpyHostToDevice, st));
+    }
     E_TRY(hipMemcpyAsync(d_jobs, jobs.data(), jobs.size() * sizeof(BinJob), hipMemcpyHostToDevice, st));
     E_TRY(hipMemsetAsync(d_w, 0, n_slots * sizeof(WT), st));
     E_TRY(hipMemsetAsync(d_pushed, 0xFF, n_slots * 2, st));
     E_TRY(hipMemsetAsync(d_ctl, 0, sizeof(Ctl), st));
     const uint32_t grid_keys = (uint32_t)((n_keys + KEYS_PER_BLOCK - 1) / KEYS_PER_BLOCK);
     E_TRY(hipEventRecord(ev_t[0], st));
-    for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_count<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
+    if (items.size() != 0) launch_count_lds(a, items.size());
+    bool any_atomic = false;
+    for (const auto &J : jobs) any_atomic |= !J.lds_count;
+    if (any_atomic)
+        for (uint32_t b = 0; b < grid_keys; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_count<WT>), dim3(std::min(SLICE_BLOCKS, grid_keys - b)), dim3(BB), 0, st, a, b);
     E_TRY(hipEventRecord(ev_t[1], st));
     const uint32_t grid_slots = (uint32_t)((n_slots + SLOTS_PER_BLOCK - 1) / SLOTS_PER_BLOCK);
     for (uint32_t b = 0; b < grid_slots; b += SLICE_BLOCKS) hipLaunchKernelGGL((k_seed<WT>), dim3(std::min(SLICE_BLOCKS, grid_slots - b)), dim3(BB), 0, st, a, b, grid_slots);
