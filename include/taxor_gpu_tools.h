@@ -82,6 +82,7 @@ typedef struct taxor_build_stats {
     double seconds_rounds;    /* GPU time of the seed scan and the peeling rounds (2 atomic subs per key), HIP events */
     double seconds_upload;    /* keys from host memory to the device (allocation + copy; 0 when they were there already); in seconds_total */
     double seconds_alloc;     /* hipMalloc / hipFree of the peeling scratch (in seconds_total; the driver's time, erratic for GB-sized blocks) */
+    uint64_t keys_counted_in_lds; /* of keys_inserted: keys whose bin's degree words were built in LDS (no global atomic adds for them) */
 } taxor_build_stats;
 int taxor_gpu_index_build_ixf_ex(taxor_gpu_index *idx, uint64_t ixf, const uint64_t *keys, int keys_on_device,
                                  const uint64_t *key_off, uint64_t seed0, uint64_t *seed_out, taxor_build_stats *stats);

@@ -111,7 +111,7 @@ class BuildStats(C.Structure):
                 ("chunks", C.c_uint32), ("reserved", C.c_uint32), ("seconds_peel", C.c_double), ("seconds_assign", C.c_double),
                 ("seconds_union", C.c_double), ("seconds_total", C.c_double), ("seconds_release", C.c_double),
                 ("seconds_count", C.c_double), ("seconds_rounds", C.c_double), ("seconds_upload", C.c_double),
-                ("seconds_alloc", C.c_double)]
+                ("seconds_alloc", C.c_double), ("keys_counted_in_lds", C.c_uint64)]
 
 
 SIGNATURES = {

@@ -774,7 +774,10 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
             return bfail(TAXOR_E_INTERNAL, "build: " + std::to_string(h_counts[1]) + " keys do not match their own columns after construction");
     }
     for (const auto &j : jobs)
-        if (group_ok[j.group]) stats.keys_inserted += j.n_kept;
+        if (group_ok[j.group]) {
+            stats.keys_inserted += j.n_kept;
+            if (j.lds_count) stats.keys_counted_in_lds += j.n_kept;
+        }
     stats.seconds_assign += now_s() - t1;
     return TAXOR_OK;
 }
@@ -856,7 +859,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             const bool all_bins = p.n_with_keys == p.bins;
             while (!built) {
                 built = true;
-                const uint64_t inserted_before = eng.stats.keys_inserted;      // (an attempt that is thrown away does not count)
+                const uint64_t inserted_before = eng.stats.keys_inserted, lds_before = eng.stats.keys_counted_in_lds;      // (an attempt that is thrown away does not count)
                 if (all_bins && hipMemsetAsync(p.data, 0, 3 * p.seg_len * p.stride, eng.st) != hipSuccess) return bfail(TAXOR_E_HIP, "build: clearing an IXF failed");
                 for (uint64_t b0 = 0; b0 < p.bins && built;) {
                     uint64_t b1 = b0, s = 0, k = 0;
@@ -874,6 +877,7 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
                 }
                 if (!built) {
                     eng.stats.keys_inserted = inserted_before;
+                    eng.stats.keys_counted_in_lds = lds_before;
                     if (++p.attempts >= 32) return bfail(TAXOR_E_INTERNAL, "build: no seed peeled every bin of IXF " + std::to_string(p.ixf) + " in 32 attempts (duplicate keys inside a bin?)");
                     p.seed = next_seed(p.seed);
                 }

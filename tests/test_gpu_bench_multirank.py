@@ -225,10 +225,13 @@ def test_build_mode_line():
     assert j["unit"] == "key insertions/s" and j["value"] > 2e8 and j["steps"] == 2 and j["n_gpus"] == 1 and j["vs_baseline"] is None
     assert j["config"]["insertions_per_step"] == 2 * 6 * 64 * 60000 and "every bin built" in j["config"]["workload"] and "keys resident in HBM" in j["config"]["timed_region"]
     r = j["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] < 0.2 and r["algorithmic_bytes_per_insertion"] > 100 and r["rmw"]["per_insertion"] == 5 and 0 < r["rmw"]["frac"] < 1.2
-    kn = {k["kernel"]: k for k in r["rmw"]["kernels"]}          # the two kernels that carry the read-modify-writes, timed by HIP events in the library
-    assert kn["k_count"]["rmw_per_insertion"] == 3 and 0.2 < kn["k_count"]["frac"] < 1.2 and kn["k_seed + k_round"]["rmw_per_insertion"] == 2
-    assert 0 < kn["k_count"]["seconds_per_step"] < j["stage_s_per_step"]["peel"] and 0 < kn["k_seed + k_round"]["seconds_per_step"] < j["stage_s_per_step"]["peel"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 0.2 and r["algorithmic_bytes_per_insertion"] > 100 and r["rmw"]["per_insertion_by_design"] == 5
+    assert 2.0 <= r["rmw"]["per_insertion"] <= 5.0 and 0 < r["rmw"]["frac"] < 1.2
+    assert r["rmw"]["insertions_counted_in_lds"] == 6 * 64 * 60000           # the leaf bins (60 k keys, 32-bit words): degree words built in LDS
+    kn = {k["kernel"]: k for k in r["rmw"]["kernels"]}          # the kernels that carry the read-modify-writes, timed by HIP events in the library
+    kc = kn["k_count (+ k_count_lds)"]
+    assert kc["rmw_per_insertion"] == 3 and 0 < kc["frac"] < 1.2 and kc["keys_G_per_s"] > 1 and kn["k_seed + k_round"]["rmw_per_insertion"] == 2
+    assert 0 < kc["seconds_per_step"] < j["stage_s_per_step"]["peel"] and 0 < kn["k_seed + k_round"]["seconds_per_step"] < j["stage_s_per_step"]["peel"]
     assert j["stage_s_per_step"]["release_after"] >= 0 and j["value_median_step"] > 2e8 and len(j["step_seconds"]) == 2
     # the same from keys in host memory (what a binding has): upload inside, never `value`
     pi = j["pcie_inclusive"]
