@@ -165,7 +165,7 @@ SIGNATURES = {
     "taxor_gpu_gather_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(Results)]),
     "taxor_gpu_comm_info": (C.c_int, [_P, C.POINTER(CommStats)]),
     "taxor_gpu_comm_set_self_exchange": (C.c_int, [_P, C.c_int]),
-    # deflate chunks decoded on the device (inflate.hip; driven by the C++ reader, pgz.h)
+    # test and profiling entry points (include/taxor_gpu_tools.h)
     "taxor_gpu_phase_profile": (C.c_int, [_P, _P]),
     "taxor_gpu_syncmers": (C.c_int, [_P, _P, _P, C.c_uint64, C.POINTER(C.POINTER(C.c_uint64)),
                                      C.POINTER(C.POINTER(C.c_uint64))]),
