@@ -15,11 +15,13 @@ from taxor_amd import GpuIndex, Searcher, synth  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(20250523)
 t0 = time.time()
-n = ins = twice = reseeds = 0
+n = ins = twice = reseeds = in_lds = 0
 while time.time() - t0 < budget:
     nc = int(rng.integers(1, 12))
     cb = int(rng.choice([3, 17, 64, 100, 128]))
-    kpb = int(rng.choice([40, 900, 5000, 30000, 120000]))
+    kpb = int(rng.choice([40, 900, 5000, 30000, 120000, 420000, 1100000]))
+    if kpb > 120000:        # bins whose degree words are built in LDS in up to 12 passes per segment, and bins beyond that (global adds again)
+        cb = int(rng.choice([3, 17]))
     # all bins of an IXF must peel under ONE seed (the reference's rule): bins of 100 k keys may be full, a hundred bins of forty keys
     # need room (a 40-key bin at load 0.48 still fails under 2 % of the seeds)
     slack = 1.0 if kpb >= 100000 else 3.0 if kpb < 1000 else float(rng.choice([1.1, 1.3, 2.0]))
@@ -40,6 +42,7 @@ while time.time() - t0 < budget:
     assert st["keys_inserted"] == 2 * int(counts.sum()), (st, int(counts.sum()))
     ins += st["keys_inserted"]
     reseeds += st["reseeds"]
+    in_lds += st["keys_counted_in_lds"]
     sr = Searcher(idx, ratio=0.5)
     for _ in range(3):
         c, b = int(rng.integers(1, nc + 1)), int(rng.integers(0, cb))
@@ -62,5 +65,5 @@ while time.time() - t0 < budget:
         twice += 1
     idx.close()
     n += 1
-print(f"{n} hierarchies built ({ins / 1e9:.2f} G insertions, every key verified on the device; {reseeds} IXFs redone under a redrawn seed), "
+print(f"{n} hierarchies built ({ins / 1e9:.2f} G insertions, {in_lds / 1e9:.2f} G of them with degree words built in LDS, every key verified on the device; {reseeds} IXFs redone under a redrawn seed), "
       f"{twice} of them twice with identical bytes, {time.time() - t0:.0f} s")
