@@ -551,7 +551,7 @@ def build_mode(args):
                                      "achieved_G_per_s": round(3 * (ins - ins_lds) / t_count / 1e9, 2),
                                      "frac": round(3 * (ins - ins_lds) / t_count / 1e9 / RMW_CEILING_G_PER_S, 4),
                                      "keys_G_per_s": round(ins / t_count / 1e9, 2),
-                                     "note": "3 global atomic adds per key for the bins that go through k_count (>= 2^24 keys: 64-bit words; < 16 k keys); the others' "
+                                     "note": "3 global atomic adds per key for the bins that go through k_count (more than ~1 M keys -- too many LDS passes --, or < 16 k keys); the others' "
                                              "degree words are built in LDS by k_count_lds, in the same event bracket: achieved / frac count the global adds only"},
                                     {"kernel": "k_seed + k_round", "rmw_per_insertion": 2, "seconds_per_step": round(t_rounds / steps, 4),
                                      "achieved_G_per_s": round(2 * ins / t_rounds / 1e9, 2), "frac": round(2 * ins / t_rounds / 1e9 / RMW_CEILING_G_PER_S, 4),

@@ -6,7 +6,8 @@
   python profiles/build_pmc_table.py DIR/b_counter_collection.csv <keys per level>
 
 keys per level = leaf keys of the hierarchy (children x bins x keys per bin): every level inserts that many keys, the leaf level on
-32-bit state words, 54 M-key root bins on 64-bit words."""
+32-bit state words; 54 M-key root bins were on 64-bit words when `r06/build_pmc.txt` was taken and are on 32-bit words since
+(degree field of 6 bits, builder.hip `dbits`)."""
 import csv
 import re
 import sys

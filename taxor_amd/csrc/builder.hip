@@ -11,7 +11,8 @@
 //
 //   state   : ONE word per (bin,row) slot: degree in the low 8 bits, SUM of the incident keys' indices (position of the key in
 //             its bin) above it.  One atomic add inserts a key into a row, one atomic sub removes it; a slot of degree 1 holds
-//             the index of its only key.  32-bit words while every bin has < 2^24 keys, 64-bit words otherwise.
+//             the index of its only key.  32-bit words while every bin has < 2^26 keys (degree in 8 bits below 2^24 keys, in 6
+//             beyond: the sum is kept modulo what is left, which is exact once one key remains), 64-bit words otherwise.
 //   count   : 3 adds per key                                                                                 (k_count)
 //   seed    : slots of degree 1 -> work list, one list append per BLOCK (entries collected in LDS)            (k_seed)
 //   round t : the list is append-only; round t is its entries [end[t], end[t+1]), and every listed slot remembers the round it
@@ -100,6 +101,7 @@ struct BinJob {
 struct CountItem {
     uint32_t job, seg, row0;
 };
+constexpr uint64_t WIDE_KEYS = 1ull << 26;   // a bin of this many keys needs 64-bit state words
 constexpr uint32_t LDS_ROWS = 32768;       // 128 KB of 32-bit words: one block per CU
 constexpr int LDS_THREADS = 1024;
 
@@ -126,6 +128,7 @@ struct Peel {
     uint16_t *pushed;    // [n_slots] the round a slot was listed for, 0xFFFF = never
     const uint8_t *skip; // per group: 1 = not peeled under this seed, leave its columns alone (nullptr: none)
     Ctl *ctl;
+    uint32_t dbits;      // width of a state word's degree field: 8, or 6 when a bin of the chunk has 2^24 .. 2^26 - 1 keys (32-bit words)
 };
 
 // last job whose first key (slot) is <= g, searched inside [lo, hi]
@@ -147,8 +150,12 @@ __device__ __forceinline__ void stg8(uint8_t *p, uint8_t v) { *(uint8_t __attrib
 
 __device__ __forceinline__ uint64_t job_key(const BinJob &J, uint64_t k) { return J.keys ? ldg64(J.keys + k) : synth_key(J.gen_first + k, J.gen_salt); }
 
+// A slot of degree >= 2^dbits would carry into the sum: with distinct keys that is a 1e-60 event at 6 bits (mean degree 2.4), and a
+// wrong peel it led to would be caught by k_verify (the IXF is redone under another seed).
 template <typename WT>
-__device__ __forceinline__ WT w_delta(uint64_t idx) { return (WT)((WT)idx << 8) + (WT)1; }
+__device__ __forceinline__ WT w_delta(uint64_t idx, uint32_t dbits) { return (WT)((WT)idx << dbits) + (WT)1; }
+template <typename WT>
+__device__ __forceinline__ WT w_degree(WT w, uint32_t dbits) { return w & (WT)(((WT)1 << dbits) - (WT)1); }
 
 // (k_count, k_seed, k_verify are launched in slices of SLICE_BLOCKS blocks: block0 = first block of the slice)
 template <typename WT>
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(BB) void k_count(const Peel<WT> a, uint32_t block0)
         const uint64_t k = g - J.key_base;
         if (J.keep && !ldg8(J.keep + k)) continue;
         const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
-        const WT d = w_delta<WT>(k);
+        const WT d = w_delta<WT>(k, a.dbits);
 #pragma unroll
         for (int j = 0; j < 3; ++j) __hip_atomic_fetch_add(&a.w[J.slot_base + p.row[j]], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(LDS_THREADS) void k_count_lds(const Peel<uint32_t> 
         if (J.keep && !ldg8(J.keep + k)) continue;
         const uint64_t h = ixf_key_hash_arith(job_key(J, k), J.seed, J.arith);
         const uint32_t r = (uint32_t)ixf_row_arith(h, (int)it.seg, J.seg_len, J.arith) - lo;     // (unsigned: rows below the range wrap to huge values)
-        if (r < n_rows) atomicAdd(&lds_w[r], w_delta<uint32_t>(k));
+        if (r < n_rows) atomicAdd(&lds_w[r], w_delta<uint32_t>(k, a.dbits));
     }
     __syncthreads();
     uint32_t *dst = a.w + J.slot_base + lo;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(BB) void k_seed(const Peel<WT> a, uint32_t block0, 
     for (uint64_t s = s0 + threadIdx.x; s < s0 + SLOTS_PER_BLOCK; s += BB) {      // (uniform trip count: stage_push is a wave operation)
         bool single = false;
         uint64_t e = 0;
-        if (s < s1 && (a.w[s] & (WT)0xFF) == (WT)1) {
+        if (s < s1 && w_degree<WT>(a.w[s], a.dbits) == (WT)1) {
             const uint32_t j = job_in<false>(a.jobs, jr[0], jr[1], s);
             e = ((uint64_t)j << 32) | (uint64_t)(s - a.jobs[j].slot_base);
             a.pushed[s] = 0;
@@ -297,8 +304,8 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
                 const BinJob &J = a.jobs[job];
                 const WT w = __hip_atomic_load(&a.w[J.slot_base + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 uint32_t logged = DEAD;
-                const uint64_t k = (uint64_t)(w >> 8);
-                if ((w & (WT)0xFF) == (WT)1 && k < J.n_keys) {
+                const uint64_t k = (uint64_t)(w >> a.dbits);
+                if (w_degree<WT>(w, a.dbits) == (WT)1 && k < J.n_keys) {
                     const ixf_probe p = ixf_probe_key_arith(job_key(J, k), J.seed, J.seg_len, J.arith);
                     // the key's lowest-segment row that is listed for this round peels it; this row, unless a lower one carries the mark
                     const int own = row == p.row[0] ? 0 : row == p.row[1] ? 1 : 2;
@@ -308,13 +315,13 @@ __global__ __launch_bounds__(BB) void k_round(const Peel<WT> a, uint32_t t)
                     if (mine) {
                         logged = (uint32_t)k;
                         ++peeled;
-                        const WT d = w_delta<WT>(k);
+                        const WT d = w_delta<WT>(k, a.dbits);
 #pragma unroll
                         for (int j = 0; j < 3; ++j) {
                             if (j == own) continue;                 // (this slot is listed once, here, and holds no other key: never read again)
                             const uint64_t s = J.slot_base + p.row[j];
                             const WT old = __hip_atomic_fetch_sub(&a.w[s], d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((old & (WT)0xFF) == (WT)2) {
+                            if (w_degree<WT>(old, a.dbits) == (WT)2) {
                                 a.pushed[s] = (uint16_t)(t + 1);
                                 push[j] = true;
                                 ent[j] = ((uint64_t)job << 32) | p.row[j];
@@ -569,7 +576,7 @@ struct Engine {
 
     template <typename WT>
     int run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, uint64_t n_keys, uint64_t n_slots,
-                  const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows);
+                  const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows, uint32_t dbits);
 
     static bool lds_count_enabled()
     {
@@ -594,13 +601,15 @@ struct Engine {
         if (jobs.empty()) return TAXOR_OK;
         uint64_t nk = 0, ns = 0;
         bool wide = false;
+        uint64_t max_keys = 0;
         std::vector<uint64_t> group_rows(n_groups, 0);
         for (auto &j : jobs) {
             j.key_base = nk;
             j.slot_base = ns;
             nk += j.n_keys;
             ns += 3ull * j.seg_len;
-            wide |= j.n_keys >= (1ull << 24);
+            wide |= j.n_keys >= WIDE_KEYS;
+            max_keys = std::max<uint64_t>(max_keys, j.n_keys);
             group_rows[j.group] = 3ull * j.seg_len;
             if (j.n_kept > 3ull * j.seg_len) return bfail(TAXOR_E_ARG, "build: a bin holds more keys than its IXF has rows");
             if (j.n_keys >= 0xFFFFFFFFull) return bfail(TAXOR_E_ARG, "build: more than 2^32 - 2 keys in one bin");
@@ -610,14 +619,15 @@ struct Engine {
         const int rc = ensure(ns, jobs.size(), wide);
         if (rc != TAXOR_OK) return rc;
         ++stats.chunks;
-        return wide ? run_typed<uint64_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows)
-                    : run_typed<uint32_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows);
+        const uint32_t dbits = (!wide && max_keys >= (1ull << 24)) ? 6u : 8u;
+        return wide ? run_typed<uint64_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows, dbits)
+                    : run_typed<uint32_t>(jobs, n_groups, group_ok, nk, ns, group_full, group_rows, dbits);
     }
 };
 
 template <typename WT>
 int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<uint8_t> &group_ok, uint64_t n_keys, uint64_t n_slots,
-                      const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows)
+                      const std::vector<uint8_t> &group_full, const std::vector<uint64_t> &group_rows, uint32_t dbits)
 {
     const double t0 = now_s();
     Peel<WT> a{};
@@ -631,6 +641,7 @@ int Engine::run_typed(std::vector<BinJob> &jobs, uint32_t n_groups, std::vector<
     a.pushed = d_pushed;
     a.skip = nullptr;
     a.ctl = d_ctl;
+    a.dbits = dbits;
     // which bins get their degree words built in LDS (k_count_lds): 32-bit words, enough keys to be worth a block per range, few enough
     // rows that a key is hashed a few dozen times at most
     std::vector<CountItem> items;
@@ -829,14 +840,14 @@ int build_plans(Engine &eng, taxor_gpu_index *idx, std::vector<IxfPlan> &plans)
             jobs.push_back(j);
         }
     };
-    for (size_t q : todo) eng.fit_bin(3 * plans[q].seg_len, plans[q].max_bin >= (1ull << 24));
+    for (size_t q : todo) eng.fit_bin(3 * plans[q].seg_len, plans[q].max_bin >= WIDE_KEYS);
     while (!todo.empty()) {
         std::vector<BinJob> jobs;
         std::vector<size_t> members;
         std::vector<uint8_t> full, ok;
         uint64_t slots = 0, keys = 0;
         bool wide = false;
-        for (size_t q : todo) wide |= plans[q].max_bin >= (1ull << 24);
+        for (size_t q : todo) wide |= plans[q].max_bin >= WIDE_KEYS;
         const uint64_t budget = eng.slot_budget(wide);
         size_t taken = 0;
         for (; taken < todo.size(); ++taken) {

@@ -258,14 +258,20 @@ def test_two_builds_are_byte_identical():
     assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][1], got[2][1])
 
 
-def test_bins_of_more_than_16M_keys_use_64_bit_state_words():
-    """a bin of >= 2^24 keys (a merged bin high in a large hierarchy): the degree | index-sum words are 64 bits wide"""
-    n = (1 << 24) + 12345
+@pytest.mark.parametrize("n", [(1 << 24) + 12345, (1 << 26) + 777])
+def test_bins_of_more_than_16M_keys(n):
+    """a merged bin high in a large hierarchy: with 2^24 .. 2^26 - 1 keys its degree | index-sum words stay 32 bits wide with the degree in 6 bits
+    (the sum modulo 2^26 is the last key's index), from 2^26 keys on they are 64 bits wide"""
     keys = synth.synth_keys_host(0, n, 5)
     bins = 3
-    ixf, idx = _empty_index(bins, n)
+    stride, seg = 64, synth.seg_len_for(n)
+    ixf = dict(bins=bins, stride=stride, seg_len=seg, seed=1, next_ixf=np.zeros(bins, np.int64), fname_idx=np.arange(bins),
+               data=np.zeros(3 * seg * stride, dtype=np.uint8))
+    idx = GpuIndex([ixf], bins)
     seed, rounds = idx.build_ixf(0, {1: keys, 2: keys[:1000]}, seed0=4)
+    del keys
     after = idx.download_ixf(0)
+    idx.close()
     h = orc.Hixf([dict(ixf, seed=seed, data=after)], [ixf["next_ixf"]], [ixf["fname_idx"]])
     found, _ = h.synth_keys_found(0, 1, 0, n, 5)
     assert found == n
@@ -273,7 +279,6 @@ def test_bins_of_more_than_16M_keys_use_64_bit_state_words():
     assert found == 1000
     found, _ = h.synth_keys_found(0, 2, 1000, 200000, 5)                  # non-members of bin 2
     assert abs(found / 200000 - 1 / 256) < 0.001
-    idx.close()
 
 
 def test_ixf_larger_than_the_scratch_is_built_in_chunks_of_its_bins(monkeypatch):
