@@ -65,7 +65,7 @@ if extra:
                + (f"; reference `AddAll` on one core: {cbb['value'] / 1e6:.1f} M insertions/s ({b['value'] / cbb['value']:.0f}x)" if cbb else "")
                + (f"; from keys in host memory (upload at {b['pcie_inclusive']['upload_GBps']} GB/s inside, never `value`): {b['value_host_fed'] / 1e9:.2f} G insertions/s" if 'pcie_inclusive' in b else "")
                + ".  Per kernel (HIP events inside the library): " + "; ".join(f"`{k['kernel']}` {k['achieved_G_per_s']} G RMW/s = {k['frac']} of the ceiling" for k in br['rmw'].get('kernels', []))
-               + ".  Longest builder launch in the `rocprofv3 --kernel-trace --stats` of the same command: 3.9 ms (`k_set_mark`; `k_count` 3.2, `k_count_lds` 2.5, `k_round` 2.2; "
+               + ".  Longest builder launch in the `rocprofv3 --kernel-trace --stats` of the same command: 3.2 ms (`k_assign`; `k_count_lds` 2.5, `k_round` 2.5, `k_count` 2.0, `k_set_mark` 1.3; "
                  "`profiles/r06/build_kernel_stats.csv`); one counter pass: `profiles/r06/build_pmc.txt`.")
 text = "\n".join(out)
 print(text)

@@ -19,6 +19,7 @@ namespace {
 constexpr int KB = 256;
 constexpr uint64_t EMPTY = ~0ull;
 constexpr uint32_t ENTRIES_PER_BLOCK = 4096;
+constexpr uint64_t LAUNCH_KEYS = 1ull << 24;     // keys per k_set_insert / k_set_mark launch
 
 __device__ __forceinline__ uint64_t slot_hash(uint64_t k)
 {
@@ -142,7 +143,10 @@ hipError_t KeyUnion::mark(const uint64_t *d_in, uint64_t n, uint8_t *d_keep, uin
     uint64_t entries = 0;
     hipError_t e = prepare(n, &entries, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_set_mark, dim3((uint32_t)std::min<uint64_t>(8192, (n + KB - 1) / KB)), dim3(KB), 0, st, d_in, n, table, entries - 1, d_keep, d_ctl);
+    for (uint64_t i0 = 0; i0 < n; i0 += LAUNCH_KEYS) {            // (launches of ~1.5 ms whatever the child's size)
+        const uint64_t m = std::min<uint64_t>(LAUNCH_KEYS, n - i0);
+        hipLaunchKernelGGL(k_set_mark, dim3((uint32_t)std::min<uint64_t>(8192, (m + KB - 1) / KB)), dim3(KB), 0, st, d_in + i0, m, table, entries - 1, d_keep + i0, d_ctl);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_ctl, d_ctl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -158,7 +162,10 @@ hipError_t KeyUnion::unique(const uint64_t *d_in, uint64_t n, uint64_t *d_out, u
     uint64_t entries = 0;
     hipError_t e = prepare(n, &entries, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_set_insert, dim3((uint32_t)std::min<uint64_t>(8192, (n + KB - 1) / KB)), dim3(KB), 0, st, d_in, n, table, entries - 1, d_ctl);
+    for (uint64_t i0 = 0; i0 < n; i0 += LAUNCH_KEYS) {
+        const uint64_t m = std::min<uint64_t>(LAUNCH_KEYS, n - i0);
+        hipLaunchKernelGGL(k_set_insert, dim3((uint32_t)std::min<uint64_t>(8192, (m + KB - 1) / KB)), dim3(KB), 0, st, d_in + i0, m, table, entries - 1, d_ctl);
+    }
     hipLaunchKernelGGL(k_set_compact, dim3((uint32_t)((entries + ENTRIES_PER_BLOCK - 1) / ENTRIES_PER_BLOCK)), dim3(KB), 0, st, table, entries, d_out, d_ctl);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_ctl, d_ctl, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
